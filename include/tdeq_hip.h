@@ -1,0 +1,146 @@
+/*
+ * tdeq_hip.h — C-ABI of libtdeq_hip.so, the MI355X (gfx950) explicit Runge–Kutta hot path.
+ *
+ * The reference (rtqichen/torchdiffeq v0.2.5) has no native boundary: every function below replaces a
+ * group of eager ATen calls inside one reference Python function (cited per entry point as
+ * torchdiffeq/_impl/<file>:<lines>).  The host solver (torchdiffeq_amd/solvers.py) is the only caller.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross the boundary.
+ *   - every entry point returns an int: 0 on success, a hipError_t (>0) from the launch, or a
+ *     TDEQ_E* (<0) for argument errors.  Nothing throws or aborts across the ABI.
+ *   - all device buffers are BORROWED: owned by the caller, contiguous, kept alive until the stream
+ *     reaches the launch.  No allocation, no hipDeviceSynchronize, no global mutable state.
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - `dtype`: TDEQ_F32 or TDEQ_F64 = element type T of every state-sized buffer.
+ *   - coefficient arithmetic follows the reference's rounding: c_j = fl_T(fl_T(coef_j) * fl_T(dt)),
+ *     products and sums in T, no FMA contraction (rk_common.py:79,89,201-205; interp.py:17-21).
+ *   - `dt` may be negative: a solve in decreasing time passes sign*dt and keeps the raw func outputs
+ *     in k_j, which is bit-identical to the reference's `_ReverseFunc(mul=-1)` wrapper (misc.py:158-165).
+ *   - host arrays (`k`, `coef`, segment tables) are read during the call and copied into the kernel
+ *     argument block; they need not outlive the call.
+ *   - state buffers whose address is 16-byte aligned take the 16 B/lane vector path; otherwise a
+ *     scalar path is used (same results).
+ *
+ * Segments.  A state vector may consist of several logical segments (tuple states, the adjoint's
+ * [y | adj_y | params | vjp_t]).  Segment s starts at element chunk_start[s]*chunk and holds numel[s]
+ * valid elements; the space up to the next segment start is padding that the norm kernels ignore.
+ * `chunk` (elements) must be a multiple of TDEQ_CHUNK_QUANTUM.  n_seg==1 with chunk_start={0}
+ * is the plain unpadded tensor case.
+ */
+#ifndef TDEQ_HIP_H
+#define TDEQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDEQ_ABI_VERSION 1
+#define TDEQ_F32 0
+#define TDEQ_F64 1
+#define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
+#define TDEQ_MAX_SEGMENTS 4096
+#define TDEQ_INLINE_SEGMENTS 16  /* segment tables up to this size travel in the kernel arguments */
+#define TDEQ_CHUNK_QUANTUM 1024
+
+#define TDEQ_EINVAL (-1)       /* bad argument (null pointer, n_terms out of range, bad dtype ...) */
+#define TDEQ_EWORKSPACE (-2)   /* workspace too small */
+
+/* Segment table entry (host memory, passed to the norm entry points). */
+typedef struct tdeq_segment {
+    int64_t chunk_start;   /* first chunk of the segment                        */
+    int64_t numel;         /* valid elements in the segment                     */
+    double rtol;           /* per-segment tolerances (misc.py:115-123 tuple tol) */
+    double atol;
+} tdeq_segment;
+
+/* ABI version of the loaded library (== TDEQ_ABI_VERSION). */
+int tdeq_abi_version(void);
+
+/* Bytes of device workspace the norm entry points need for a state of n_chunks chunks. */
+size_t tdeq_workspace_bytes(int64_t n_chunks);
+
+/*
+ * Stage accumulate:  out = y0 + sum_j c_j * k_j ,  c_j = fl_T(fl_T(coef_j) * fl_T(dt)).
+ * Replaces `yi = y0 + torch.sum(k[..., :i+1] * (beta_i * dt), dim=-1)` (rk_common.py:79), the
+ * non-FSAL solution combine (rk_common.py:83-85) and `y1 = y0 + h0 * f0` of the initial-step
+ * heuristic (misc.py:65).  Structural zeros of the tableau row are skipped by the caller.
+ * 1 <= n_terms <= TDEQ_MAX_TERMS.  `out` may alias nothing it reads.
+ */
+int tdeq_stage_combine(void* out, const void* y0, const void* const* k, const double* coef,
+                       int n_terms, double dt, int64_t n, int dtype, void* stream);
+
+/*
+ * Embedded error estimate + tolerance scaling + per-segment sum of squares, fused:
+ *   err = sum_j fl_T(coef_j*dt) * k_j                       (rk_common.py:89)
+ *   tol = atol + rtol * max(|y0|, |y1|)                      (misc.py:81)
+ *   out_sumsq[s]  = sum over segment s of (err/tol)^2        (misc.py:22-23, 30-33, 82; fp64 accumulate)
+ *   out_nonfinite[s] = number of non-finite elements of y0/y1 seen in segment s (rk_common.py:287)
+ * The caller finishes sqrt(sumsq/numel) and the max over segments on the host.
+ * `out_sumsq` / `out_nonfinite` (n_seg doubles each) may be device memory or pinned host memory.
+ * `scaled_out` (optional, may be NULL): if given, err/tol is also stored per element (padding of a
+ * segmented layout zero-filled) so that a user-supplied norm callable can reduce it.
+ * `segs` is the host segment table; for n_seg > TDEQ_INLINE_SEGMENTS the caller also passes
+ * `segs_dev`, a device copy of the same n_seg records (made once per solve), else it may be NULL.
+ */
+int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void* const* k,
+                    const double* coef, int n_terms, double dt, const tdeq_segment* segs,
+                    const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
+                    double* out_sumsq, double* out_nonfinite, void* workspace,
+                    size_t workspace_bytes, int dtype, void* stream);
+
+/*
+ * Initial-step norms (Hairer II.4 as in misc.py:36-77), scale = atol + |y0| * rtol:
+ *   mode 0:  out_sumsq[s]          = sum (a / scale)^2           (a = y0 -> d0 ; misc.py:55)
+ *            out_sumsq[n_seg + s]  = sum (b / scale)^2           (b = f0 -> d1 ; misc.py:56)
+ *   mode 1:  out_sumsq[s]          = sum ((a - b) / scale)^2     (a = f1, b = f0 -> d2*h0 ; misc.py:68)
+ * out_nonfinite[s] counts non-finite elements of yscale (the state) per segment.
+ */
+int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale,
+                    const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk,
+                    int64_t n_chunks, double* out_sumsq, double* out_nonfinite, void* workspace, size_t workspace_bytes,
+                    int dtype, void* stream);
+
+/*
+ * Dense output, fused fit + evaluate (rk_common.py:363-369 + interp.py:1-48):
+ *   y_mid = y0 + sum_j fl_T(coef_j*dt) * k_j ; quartic [e,d,c,b,a] from (y0,y1,y_mid,f0,f1,dt);
+ *   out = e + x d + x^2 c + x^3 b + x^4 a, with x already rounded to T by the caller.
+ * f0 / f1 are the first / last stage slots (k[...,0], k[...,-1]).
+ */
+int tdeq_dense_eval(void* out, const void* y0, const void* y1, const void* f0, const void* f1,
+                    const void* const* k, const double* coef, int n_terms, double dt, double x,
+                    int64_t n, int dtype, void* stream);
+
+/*
+ * Dense-output fit only: writes the 5 interpolation coefficients [e,d,c,b,a] contiguously into
+ * `coeffs` (5*n elements; interp.py:17-22).  Used by odeint_dense-style consumers ("next" row).
+ */
+int tdeq_interp_fit(void* coeffs, const void* y0, const void* y1, const void* f0, const void* f1,
+                    const void* const* k, const double* coef, int n_terms, double dt, int64_t n,
+                    int dtype, void* stream);
+
+/*
+ * rk4 "3/8 rule" stages (rk_common.py:110-118, solvers.py:115), dt already in T:
+ *   stage 1: out = y0 + (dt*k1)*(1/3)
+ *   stage 2: out = y0 + dt*(k2 - k1*(1/3))
+ *   stage 3: out = y0 + dt*((k1 - k2) + k3)
+ *   stage 4: out = y0 + (((k1 + 3*(k2+k3)) + k4)*dt)*0.125
+ * Unused k pointers may be NULL.
+ */
+int tdeq_rk4_38_stage(int stage, void* out, const void* y0, const void* k1, const void* k2,
+                      const void* k3, const void* k4, double dt, int64_t n, int dtype, void* stream);
+
+/* Fixed-grid output interpolation  out = y0 + slope*(y1 - y0)  (solvers.py:175-181). */
+int tdeq_lerp(void* out, const void* y0, const void* y1, double slope, int64_t n, int dtype,
+              void* stream);
+
+/* Writes n_vals scalars (converted to T) to consecutive elements of dst (stage times for func). */
+int tdeq_fill_scalars(void* dst, const double* vals, int n_vals, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDEQ_HIP_H */

@@ -1,0 +1,148 @@
+"""ctypes binding of oracle/_build/librk_oracle.so with the same tensor-level interface as
+torchdiffeq_amd._native.HipKernels, operating on CPU torch tensors.
+
+TEST INFRASTRUCTURE ONLY (see rk_oracle.c).  Two uses:
+  * kernel parity: tests call the same method on `HipKernels` (GPU) and `OracleKernels` (CPU) with the
+    same seeded inputs and compare;
+  * host-logic tests without a GPU: tests monkeypatch `torchdiffeq_amd._native.get_kernels` to return an
+    `OracleKernels`, which lets the product's solver / adjoint / sharding control flow run on CPU
+    tensors.  The product itself never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from typing import List, Sequence, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "librk_oracle.so")
+
+_c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+class Segment(ctypes.Structure):
+    _fields_ = [("chunk_start", ctypes.c_int64), ("numel", ctypes.c_int64),
+                ("rtol", ctypes.c_double), ("atol", ctypes.c_double)]
+
+
+def build(force: bool = False) -> str:
+    """Compile rk_oracle.c with gcc (seconds)."""
+    src = os.path.join(_HERE, "rk_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "_build/librk_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    lib = ctypes.CDLL(build())
+    V, I, I64, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+    sigs = {
+        "oracle_abi_version": [],
+        "oracle_stage_combine": [V, V, _c_void_pp, _c_double_p, I, D, I64, I],
+        "oracle_error_norm": [V, V, V, _c_void_pp, _c_double_p, I, D, ctypes.POINTER(Segment), I, I64, I64,
+                              V, V, I],
+        "oracle_init_norms": [I, V, V, V, ctypes.POINTER(Segment), I, I64, I64, V, V, I],
+        "oracle_dense_eval": [V, V, V, V, V, _c_void_pp, _c_double_p, I, D, D, I64, I],
+        "oracle_interp_fit": [V, V, V, V, V, _c_void_pp, _c_double_p, I, D, I64, I],
+        "oracle_rk4_38_stage": [I, V, V, V, V, V, V, D, I64, I],
+        "oracle_lerp": [V, V, V, D, I64, I],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = argtypes
+    return lib
+
+
+def _code(dtype: torch.dtype) -> int:
+    return {torch.float32: 0, torch.float64: 1}[dtype]
+
+
+def _ok(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code}")
+
+
+class OraclePlan:
+    def __init__(self, segments: Sequence[Tuple[int, int, float, float]], total: int, chunk: int):
+        self.chunk = chunk
+        self.n_seg = len(segments)
+        self.numels = [int(s[1]) for s in segments]
+        self.n_chunks = max(1, math.ceil(total / chunk))
+        arr = (Segment * self.n_seg)()
+        for i, (off, numel, rtol, atol) in enumerate(segments):
+            assert off % chunk == 0
+            arr[i] = Segment(off // chunk, numel, float(rtol), float(atol))
+        self.segs = arr
+        self.out = torch.zeros(3 * self.n_seg, dtype=torch.float64)
+        self.out_ptr = self.out.data_ptr()
+        self.bad_ptr = self.out_ptr + 16 * self.n_seg
+
+
+class OracleKernels:
+    """CPU twin of HipKernels (same method names and argument meaning)."""
+    name = "oracle"
+
+    def __init__(self):
+        self.lib = load()
+
+    @staticmethod
+    def _terms(ks, coefs):
+        n = len(ks)
+        for k in ks:
+            assert k.device.type == "cpu" and k.is_contiguous()
+        return (ctypes.c_void_p * n)(*[k.data_ptr() for k in ks]), (ctypes.c_double * n)(*coefs), n
+
+    def make_plan(self, segments, total, chunk, device) -> OraclePlan:
+        return OraclePlan(segments, total, chunk)
+
+    def stage_combine(self, out, y0, ks, coefs, dt):
+        ptrs, cf, n = self._terms(ks, coefs)
+        _ok(self.lib.oracle_stage_combine(out.data_ptr(), y0.data_ptr(), ptrs, cf, n, dt, y0.numel(),
+                                          _code(y0.dtype)), "oracle_stage_combine")
+
+    def error_norm(self, plan, y0, y1, ks, coefs, dt, scaled_out=None):
+        ptrs, cf, n = self._terms(ks, coefs)
+        so = None if scaled_out is None else scaled_out.data_ptr()
+        _ok(self.lib.oracle_error_norm(so, y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, plan.segs, plan.n_seg,
+                                       plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr, _code(y0.dtype)),
+            "oracle_error_norm")
+
+    def error_scaled(self, plan, out, y0, y1, ks, coefs, dt):
+        self.error_norm(plan, y0, y1, ks, coefs, dt, scaled_out=out)
+
+    def init_norms(self, plan, mode, a, b, yscale):
+        _ok(self.lib.oracle_init_norms(mode, a.data_ptr(), b.data_ptr(), yscale.data_ptr(), plan.segs, plan.n_seg,
+                                       plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr, _code(yscale.dtype)),
+            "oracle_init_norms")
+
+    def read_norms(self, plan) -> Tuple[List[float], List[float], List[float]]:
+        v = plan.out.tolist()
+        n = plan.n_seg
+        return v[:n], v[n:2 * n], v[2 * n:]
+
+    def dense_eval(self, out, y0, y1, f0, f1, ks, coefs, dt, x):
+        ptrs, cf, n = self._terms(ks, coefs)
+        _ok(self.lib.oracle_dense_eval(out.data_ptr(), y0.data_ptr(), y1.data_ptr(), f0.data_ptr(), f1.data_ptr(),
+                                       ptrs, cf, n, dt, x, y0.numel(), _code(y0.dtype)), "oracle_dense_eval")
+
+    def interp_fit(self, coeffs, y0, y1, f0, f1, ks, coefs, dt):
+        ptrs, cf, n = self._terms(ks, coefs)
+        _ok(self.lib.oracle_interp_fit(coeffs.data_ptr(), y0.data_ptr(), y1.data_ptr(), f0.data_ptr(),
+                                       f1.data_ptr(), ptrs, cf, n, dt, y0.numel(), _code(y0.dtype)),
+            "oracle_interp_fit")
+
+    def rk4_stage(self, stage, out, y0, k1, k2, k3, k4, dt):
+        p = lambda t: None if t is None else t.data_ptr()
+        _ok(self.lib.oracle_rk4_38_stage(stage, out.data_ptr(), y0.data_ptr(), p(k1), p(k2), p(k3), p(k4), dt,
+                                         y0.numel(), _code(y0.dtype)), "oracle_rk4_38_stage")
+
+    def lerp(self, out, y0, y1, slope):
+        _ok(self.lib.oracle_lerp(out.data_ptr(), y0.data_ptr(), y1.data_ptr(), slope, y0.numel(),
+                                 _code(y0.dtype)), "oracle_lerp")

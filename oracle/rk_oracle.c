@@ -1,0 +1,309 @@
+/*
+ * rk_oracle.c — CPU restatement of the reference's explicit Runge–Kutta step arithmetic.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle for libtdeq_hip.so: it restates, in plain
+ * C loops on host memory, the state-sized arithmetic of rtqichen/torchdiffeq v0.2.5 that the HIP
+ * kernels replace.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it;
+ * the product (torchdiffeq_amd/) never does.
+ *
+ * Each function cites the reference lines it follows (paths relative to torchdiffeq/_impl/).  All
+ * element arithmetic is in the state dtype T with every product and sum rounded separately
+ * (-ffp-contract=off), coefficients formed as fl_T(fl_T(coef) * fl_T(dt)) like the reference's
+ * `beta_i * dt` on a tableau already cast to T (rk_common.py:79, 201-205).  Reductions accumulate in
+ * fp64 over fixed-size chunks (deterministic for any thread count); the reference accumulates in T
+ * with ATen's blocked order, which differs from the exact value by a few ulp_T — see DESIGN.md.
+ *
+ * Pinning: tests/test_oracle_golden.py checks every function here against vectors produced by the
+ * imported reference itself (tests/golden/make_golden.py -> tests/golden/ npz files).
+ *
+ * Signatures mirror include/tdeq_hip.h (minus the stream) so the same test harness drives both.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#define ORACLE_F32 0
+#define ORACLE_F64 1
+#define ORACLE_MAX_TERMS 14
+
+typedef struct oracle_segment {
+    int64_t chunk_start;
+    int64_t numel;
+    double rtol;
+    double atol;
+} oracle_segment;
+
+int oracle_abi_version(void) { return 1; }
+
+/* ---------------------------------------------------------------------------------------------------
+ * yi = y0 + sum_j (beta_ij * dt) * k_j            rk_common.py:79 (and :83-85, misc.py:65)
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_COMBINE(NAME, T)                                                                          \
+    static void NAME(T* out, const T* y0, const T* const* k, const double* coef, int nt, double dt,   \
+                     int64_t n) {                                                                     \
+        T c[ORACLE_MAX_TERMS];                                                                        \
+        const T dtT = (T)dt;                                                                          \
+        for (int j = 0; j < nt; ++j) c[j] = (T)coef[j] * dtT;                                         \
+        _Pragma("omp parallel for schedule(static)")                                                  \
+        for (int64_t i = 0; i < n; ++i) {                                                             \
+            T acc = k[0][i] * c[0];                                                                   \
+            for (int j = 1; j < nt; ++j) acc = acc + k[j][i] * c[j];                                  \
+            out[i] = y0[i] + acc;                                                                     \
+        }                                                                                             \
+    }
+DEF_COMBINE(combine_f32, float)
+DEF_COMBINE(combine_f64, double)
+
+int oracle_stage_combine(void* out, const void* y0, const void* const* k, const double* coef, int n_terms,
+                         double dt, int64_t n, int dtype) {
+    if (!out || !y0 || !k || !coef || n_terms < 1 || n_terms > ORACLE_MAX_TERMS) return -1;
+    if (dtype == ORACLE_F32) combine_f32((float*)out, (const float*)y0, (const float* const*)k, coef, n_terms, dt, n);
+    else if (dtype == ORACLE_F64) combine_f64((double*)out, (const double*)y0, (const double* const*)k, coef, n_terms, dt, n);
+    else return -1;
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * y1_error = sum_j (dt * c_error_j) * k_j                       rk_common.py:89
+ * error_tol = atol + rtol * max(|y0|, |y1|); err / error_tol     misc.py:81-82
+ * per-segment sum of squares (-> sqrt(mean) on the caller)       misc.py:22-23, 30-33
+ * non-finite census of the state                                 rk_common.py:287
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_ERROR(NAME, T, ABS, MAX)                                                                  \
+    static int NAME(T* scaled, const T* y0, const T* y1, const T* const* k, const double* coef,       \
+                    int nt, double dt, const oracle_segment* segs, int n_seg, int64_t chunk,          \
+                    int64_t n_chunks, double* out_sumsq, double* out_bad) {                           \
+        T c[ORACLE_MAX_TERMS];                                                                        \
+        const T dtT = (T)dt;                                                                          \
+        for (int j = 0; j < nt; ++j) c[j] = (T)coef[j] * dtT;                                         \
+        double* part = (double*)malloc(sizeof(double) * 2 * (size_t)n_chunks);                        \
+        if (!part) return -2;                                                                         \
+        for (int s = 0; s < n_seg; ++s) {                                                             \
+            const int64_t c0 = segs[s].chunk_start;                                                   \
+            const int64_t c1 = (s + 1 < n_seg) ? segs[s + 1].chunk_start : n_chunks;                  \
+            const T rtol = (T)segs[s].rtol, atol = (T)segs[s].atol;                                   \
+            _Pragma("omp parallel for schedule(static)")                                              \
+            for (int64_t b = c0; b < c1; ++b) {                                                       \
+                int64_t valid = segs[s].numel - (b - c0) * chunk;                                     \
+                if (valid > chunk) valid = chunk;                                                     \
+                if (valid < 0) valid = 0;                                                             \
+                const int64_t base = b * chunk;                                                       \
+                double acc = 0.0, bad = 0.0;                                                          \
+                for (int64_t t = 0; t < valid; ++t) {                                                 \
+                    const int64_t i = base + t;                                                       \
+                    T e = k[0][i] * c[0];                                                             \
+                    for (int j = 1; j < nt; ++j) e = e + k[j][i] * c[j];                              \
+                    const T a0 = ABS(y0[i]), a1 = ABS(y1[i]);                                         \
+                    const T tol = atol + rtol * MAX(a0, a1);                                          \
+                    const T r = e / tol;                                                              \
+                    if (scaled) scaled[i] = r;                                                        \
+                    acc += (double)r * (double)r;                                                     \
+                    if (!isfinite((double)y0[i]) || !isfinite((double)y1[i])) bad += 1.0;             \
+                }                                                                                     \
+                if (scaled && n_seg > 1)                                                              \
+                    for (int64_t t = valid; t < chunk; ++t) scaled[base + t] = (T)0;                  \
+                part[2 * b] = acc;                                                                    \
+                part[2 * b + 1] = bad;                                                                \
+            }                                                                                         \
+            double total = 0.0, bad_total = 0.0;                                                      \
+            for (int64_t b = c0; b < c1; ++b) {                                                       \
+                total += part[2 * b];                                                                 \
+                bad_total += part[2 * b + 1];                                                         \
+            }                                                                                         \
+            out_sumsq[s] = total;                                                                     \
+            out_bad[s] = bad_total;                                                                   \
+        }                                                                                             \
+        free(part);                                                                                   \
+        return 0;                                                                                     \
+    }
+DEF_ERROR(error_f32, float, fabsf, fmaxf)
+DEF_ERROR(error_f64, double, fabs, fmax)
+
+int oracle_error_norm(void* scaled_out, const void* y0, const void* y1, const void* const* k,
+                      const double* coef, int n_terms, double dt, const oracle_segment* segs, int n_seg,
+                      int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite, int dtype) {
+    if (!y0 || !y1 || !k || !coef || !segs || n_terms < 1 || n_terms > ORACLE_MAX_TERMS) return -1;
+    if (dtype == ORACLE_F32)
+        return error_f32((float*)scaled_out, (const float*)y0, (const float*)y1, (const float* const*)k, coef, n_terms, dt,
+                  segs, n_seg, chunk, n_chunks, out_sumsq, out_nonfinite);
+    else if (dtype == ORACLE_F64)
+        return error_f64((double*)scaled_out, (const double*)y0, (const double*)y1, (const double* const*)k, coef, n_terms,
+                  dt, segs, n_seg, chunk, n_chunks, out_sumsq, out_nonfinite);
+    else return -1;
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * Initial-step norms, scale = atol + |y0| * rtol                  misc.py:53
+ *   mode 0: sum (a/scale)^2 and sum (b/scale)^2   (d0, d1)       misc.py:55-56
+ *   mode 1: sum ((a-b)/scale)^2                   (d2 * h0)      misc.py:68
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_INIT(NAME, T, ABS)                                                                        \
+    static void NAME(int mode, const T* a, const T* b, const T* y, const oracle_segment* segs,        \
+                     int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_bad) {\
+        for (int s = 0; s < n_seg; ++s) {                                                             \
+            const int64_t c0 = segs[s].chunk_start;                                                   \
+            const int64_t c1 = (s + 1 < n_seg) ? segs[s + 1].chunk_start : n_chunks;                  \
+            const T rtol = (T)segs[s].rtol, atol = (T)segs[s].atol;                                   \
+            double t0 = 0.0, t1 = 0.0, bad = 0.0;                                                     \
+            for (int64_t blk = c0; blk < c1; ++blk) {                                                 \
+                int64_t valid = segs[s].numel - (blk - c0) * chunk;                                   \
+                if (valid > chunk) valid = chunk;                                                     \
+                double p0 = 0.0, p1 = 0.0;                                                            \
+                for (int64_t t = 0; t < valid; ++t) {                                                 \
+                    const int64_t i = blk * chunk + t;                                                \
+                    const T scale = atol + ABS(y[i]) * rtol;                                          \
+                    if (mode == 0) {                                                                  \
+                        const T r0 = a[i] / scale, r1 = b[i] / scale;                                 \
+                        p0 += (double)r0 * (double)r0;                                                \
+                        p1 += (double)r1 * (double)r1;                                                \
+                    } else {                                                                          \
+                        const T r0 = (a[i] - b[i]) / scale;                                           \
+                        p0 += (double)r0 * (double)r0;                                                \
+                    }                                                                                 \
+                    if (!isfinite((double)y[i])) bad += 1.0;                                          \
+                }                                                                                     \
+                t0 += p0;                                                                             \
+                t1 += p1;                                                                             \
+            }                                                                                         \
+            out_sumsq[s] = t0;                                                                        \
+            if (mode == 0) out_sumsq[n_seg + s] = t1;                                                 \
+            out_bad[s] = bad;                                                                         \
+        }                                                                                             \
+    }
+DEF_INIT(init_f32, float, fabsf)
+DEF_INIT(init_f64, double, fabs)
+
+int oracle_init_norms(int mode, const void* a, const void* b, const void* yscale, const oracle_segment* segs,
+                      int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite,
+                      int dtype) {
+    if ((mode != 0 && mode != 1) || !a || !b || !yscale || !segs) return -1;
+    if (dtype == ORACLE_F32)
+        init_f32(mode, (const float*)a, (const float*)b, (const float*)yscale, segs, n_seg, chunk, n_chunks,
+                 out_sumsq, out_nonfinite);
+    else if (dtype == ORACLE_F64)
+        init_f64(mode, (const double*)a, (const double*)b, (const double*)yscale, segs, n_seg, chunk, n_chunks,
+                 out_sumsq, out_nonfinite);
+    else return -1;
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * Dense output.  y_mid = y0 + sum_j (dt * mid_j) k_j               rk_common.py:365-366
+ *   a = 2 dt (f1 - f0) - 8 (y1 + y0) + 16 y_mid                     interp.py:17
+ *   b = dt (5 f0 - 3 f1) + 18 y0 + 14 y1 - 32 y_mid                 interp.py:18
+ *   c = dt (f1 - 4 f0) - 11 y0 - 5 y1 + 16 y_mid                    interp.py:19
+ *   d = dt f0 ; e = y0                                              interp.py:20-21
+ *   p(x) = e + x d + x^2 c + x^3 b + x^4 a  (x_power *= x)          interp.py:42-47
+ * fit_only != 0: out holds the five planes [e,d,c,b,a] (5*n elements).
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_DENSE(NAME, T)                                                                            \
+    static void NAME(T* out, const T* y0, const T* y1, const T* f0, const T* f1, const T* const* k,   \
+                     const double* coef, int nt, double dt_, double x_, int64_t n, int fit_only) {    \
+        T c[ORACLE_MAX_TERMS];                                                                        \
+        const T dt = (T)dt_, x = (T)x_;                                                               \
+        for (int j = 0; j < nt; ++j) c[j] = (T)coef[j] * dt;                                          \
+        const T two_dt = (T)2 * dt;                                                                   \
+        _Pragma("omp parallel for schedule(static)")                                                  \
+        for (int64_t i = 0; i < n; ++i) {                                                             \
+            T acc = k[0][i] * c[0];                                                                   \
+            for (int j = 1; j < nt; ++j) acc = acc + k[j][i] * c[j];                                  \
+            const T ymid = y0[i] + acc;                                                               \
+            const T qa = (two_dt * (f1[i] - f0[i]) - (T)8 * (y1[i] + y0[i])) + (T)16 * ymid;          \
+            const T qb = ((dt * ((T)5 * f0[i] - (T)3 * f1[i]) + (T)18 * y0[i]) + (T)14 * y1[i]) -     \
+                         (T)32 * ymid;                                                                \
+            const T qc = ((dt * (f1[i] - (T)4 * f0[i]) - (T)11 * y0[i]) - (T)5 * y1[i]) +             \
+                         (T)16 * ymid;                                                                \
+            const T qd = dt * f0[i];                                                                  \
+            const T qe = y0[i];                                                                       \
+            if (fit_only) {                                                                           \
+                out[i] = qe;                                                                          \
+                out[n + i] = qd;                                                                      \
+                out[2 * n + i] = qc;                                                                  \
+                out[3 * n + i] = qb;                                                                  \
+                out[4 * n + i] = qa;                                                                  \
+            } else {                                                                                  \
+                T total = qe + x * qd;                                                                \
+                T xp = x * x;                                                                         \
+                total = total + xp * qc;                                                              \
+                xp = xp * x;                                                                          \
+                total = total + xp * qb;                                                              \
+                xp = xp * x;                                                                          \
+                total = total + xp * qa;                                                              \
+                out[i] = total;                                                                       \
+            }                                                                                         \
+        }                                                                                             \
+    }
+DEF_DENSE(dense_f32, float)
+DEF_DENSE(dense_f64, double)
+
+static int dense_dispatch(void* out, const void* y0, const void* y1, const void* f0, const void* f1,
+                          const void* const* k, const double* coef, int n_terms, double dt, double x, int64_t n,
+                          int dtype, int fit_only) {
+    if (!out || !y0 || !y1 || !f0 || !f1 || !k || !coef || n_terms < 1 || n_terms > ORACLE_MAX_TERMS) return -1;
+    if (dtype == ORACLE_F32)
+        dense_f32((float*)out, (const float*)y0, (const float*)y1, (const float*)f0, (const float*)f1,
+                  (const float* const*)k, coef, n_terms, dt, x, n, fit_only);
+    else if (dtype == ORACLE_F64)
+        dense_f64((double*)out, (const double*)y0, (const double*)y1, (const double*)f0, (const double*)f1,
+                  (const double* const*)k, coef, n_terms, dt, x, n, fit_only);
+    else return -1;
+    return 0;
+}
+
+int oracle_dense_eval(void* out, const void* y0, const void* y1, const void* f0, const void* f1,
+                      const void* const* k, const double* coef, int n_terms, double dt, double x, int64_t n,
+                      int dtype) {
+    return dense_dispatch(out, y0, y1, f0, f1, k, coef, n_terms, dt, x, n, dtype, 0);
+}
+
+int oracle_interp_fit(void* coeffs, const void* y0, const void* y1, const void* f0, const void* f1,
+                      const void* const* k, const double* coef, int n_terms, double dt, int64_t n, int dtype) {
+    return dense_dispatch(coeffs, y0, y1, f0, f1, k, coef, n_terms, dt, 0.0, n, dtype, 1);
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * rk4, 3/8 rule                                                    rk_common.py:110-118, solvers.py:115
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_RK4(NAME, T)                                                                              \
+    static void NAME(int stage, T* out, const T* y0, const T* k1, const T* k2, const T* k3,           \
+                     const T* k4, double dt_, int64_t n) {                                            \
+        const T dt = (T)dt_, third = (T)(1.0 / 3.0);                                                  \
+        _Pragma("omp parallel for schedule(static)")                                                  \
+        for (int64_t i = 0; i < n; ++i) {                                                             \
+            if (stage == 1) out[i] = y0[i] + (dt * k1[i]) * third;                                    \
+            else if (stage == 2) out[i] = y0[i] + dt * (k2[i] - k1[i] * third);                       \
+            else if (stage == 3) out[i] = y0[i] + dt * ((k1[i] - k2[i]) + k3[i]);                     \
+            else out[i] = y0[i] + (((k1[i] + (T)3 * (k2[i] + k3[i])) + k4[i]) * dt) * (T)0.125;       \
+        }                                                                                             \
+    }
+DEF_RK4(rk4_f32, float)
+DEF_RK4(rk4_f64, double)
+
+int oracle_rk4_38_stage(int stage, void* out, const void* y0, const void* k1, const void* k2, const void* k3,
+                        const void* k4, double dt, int64_t n, int dtype) {
+    if (stage < 1 || stage > 4 || !out || !y0 || !k1) return -1;
+    if (dtype == ORACLE_F32)
+        rk4_f32(stage, (float*)out, (const float*)y0, (const float*)k1, (const float*)k2, (const float*)k3,
+                (const float*)k4, dt, n);
+    else if (dtype == ORACLE_F64)
+        rk4_f64(stage, (double*)out, (const double*)y0, (const double*)k1, (const double*)k2, (const double*)k3,
+                (const double*)k4, dt, n);
+    else return -1;
+    return 0;
+}
+
+/* y0 + slope * (y1 - y0)                                           solvers.py:175-181 */
+int oracle_lerp(void* out, const void* y0, const void* y1, double slope, int64_t n, int dtype) {
+    if (!out || !y0 || !y1) return -1;
+    if (dtype == ORACLE_F32) {
+        const float s = (float)slope;
+        for (int64_t i = 0; i < n; ++i)
+            ((float*)out)[i] = ((const float*)y0)[i] + s * (((const float*)y1)[i] - ((const float*)y0)[i]);
+    } else if (dtype == ORACLE_F64) {
+        for (int64_t i = 0; i < n; ++i)
+            ((double*)out)[i] = ((const double*)y0)[i] + slope * (((const double*)y1)[i] - ((const double*)y0)[i]);
+    } else return -1;
+    return 0;
+}

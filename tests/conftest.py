@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_kernels():
+    """CPU oracle with the HipKernels interface (test infrastructure, never used by the product)."""
+    from oracle.kernels import OracleKernels
+    return OracleKernels()
+
+
+@pytest.fixture()
+def cpu_backend(monkeypatch, oracle_kernels):
+    """Run the product's HOST logic on CPU tensors by substituting the oracle for the HIP kernels.
+
+    The product has no CPU path (get_kernels raises for non-ROCm devices); this patch exists only so
+    the solver / adjoint / sharding control flow can be tested in the GPU-less container."""
+    from torchdiffeq_amd import _native
+    monkeypatch.setattr(_native, "get_kernels", lambda device: oracle_kernels)
+    return oracle_kernels
+
+
+@pytest.fixture(scope="session")
+def hip_kernels():
+    import torch
+    from torchdiffeq_amd import _native
+    assert torch.cuda.is_available(), "gpu test on a box without a GPU"
+    return _native.get_kernels(torch.device("cuda:0"))

@@ -1,0 +1,241 @@
+"""Kernel parity on the MI355X: every C-ABI entry point vs the CPU oracle on the same seeded inputs.
+
+Tolerances: the element arithmetic of both sides is the same sequence of individually rounded T
+operations, so elementwise outputs must agree BIT-EXACTLY; reductions accumulate in fp64 with a
+different association on the two sides, so sums agree to ~1e-13 relative."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from torchdiffeq_amd.tableaus import DOPRI5, DOPRI8, SparseRow
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.float64]
+SIZES = [1, 3, 255, 1024, 4099, 65536 + 7, 1 << 20]
+
+
+def _rand(n, dtype, seed, offset=0):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(n + offset, generator=g, dtype=torch.float64).to(dtype)
+    return base[offset:] if offset else base
+
+
+def _dev(ts):
+    return [t.cuda() for t in ts]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("tab", [DOPRI5, DOPRI8], ids=["dopri5", "dopri8"])
+def test_stage_combine_all_rows(hip_kernels, oracle_kernels, dtype, n, tab):
+    S = tab.n_stages
+    y0 = _rand(n, dtype, 1)
+    ks = [_rand(n, dtype, 10 + j) for j in range(S + 1)]
+    y0d, ksd = y0.cuda(), _dev(ks)
+    for sign in (1.0, -1.0):
+        dt = 0.0371 * sign
+        for row in tab.beta_rows():
+            out_ref = torch.empty_like(y0)
+            oracle_kernels.stage_combine(out_ref, y0, [ks[j] for j in row.idx], row.coef, dt)
+            out = torch.empty_like(y0d)
+            hip_kernels.stage_combine(out, y0d, [ksd[j] for j in row.idx], row.coef, dt)
+            assert torch.equal(out.cpu(), out_ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stage_combine_unaligned(hip_kernels, oracle_kernels, dtype):
+    n = 10007
+    row = DOPRI5.beta_rows()[4]
+    y0 = _rand(n, dtype, 1, offset=1)          # views at odd element offsets -> scalar path
+    ks = [_rand(n, dtype, 10 + j, offset=1 + (j % 3)) for j in range(7)]
+    y0c, ksc = y0.contiguous(), [k.contiguous() for k in ks]
+    ref = torch.empty_like(y0c)
+    oracle_kernels.stage_combine(ref, y0c, [ksc[j] for j in row.idx], row.coef, 0.1)
+    base_y = torch.empty(n + 1, dtype=dtype).cuda()
+    y0d = base_y[1:]
+    y0d.copy_(y0c)
+    ksd = []
+    for j, k in enumerate(ksc):
+        buf = torch.empty(n + 3, dtype=dtype).cuda()
+        v = buf[1 + (j % 3):1 + (j % 3) + n]
+        v.copy_(k)
+        ksd.append(v)
+    out = torch.empty(n + 1, dtype=dtype).cuda()[1:]
+    hip_kernels.stage_combine(out, y0d, [ksd[j] for j in row.idx], row.coef, 0.1)
+    assert torch.equal(out.cpu(), ref)
+
+
+def _plan_pair(hip_kernels, oracle_kernels, segments, total, chunk):
+    return (hip_kernels.make_plan(segments, total, chunk, torch.device("cuda:0")),
+            oracle_kernels.make_plan(segments, total, chunk, None))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("chunk", [1024, 2048, 4096])
+def test_error_norm_single_segment(hip_kernels, oracle_kernels, dtype, n, chunk):
+    for tab in (DOPRI5, DOPRI8):
+        S = tab.n_stages
+        err = SparseRow.from_dense(tab.c_error)
+        y0, y1 = _rand(n, dtype, 1), _rand(n, dtype, 2)
+        ks = [_rand(n, dtype, 10 + j) for j in range(S + 1)]
+        segs = [(0, n, 1e-3, 1e-4)]
+        pg, pc = _plan_pair(hip_kernels, oracle_kernels, segs, n, chunk)
+        oracle_kernels.error_norm(pc, y0, y1, [ks[j] for j in err.idx], err.coef, 0.0371)
+        ref, _, bad_ref = oracle_kernels.read_norms(pc)
+        ksd = _dev(ks)
+        hip_kernels.error_norm(pg, y0.cuda(), y1.cuda(), [ksd[j] for j in err.idx], err.coef, 0.0371)
+        got, _, bad = hip_kernels.read_norms(pg)
+        assert bad == [0.0] and bad_ref == [0.0]
+        assert got[0] == pytest.approx(ref[0], rel=1e-12)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_error_norm_segments_and_scaled(hip_kernels, oracle_kernels, dtype):
+    chunk = 1024
+    numels = [5000, 1, 1024, 77, 3000]
+    offs, off = [], 0
+    for m in numels:
+        offs.append(off)
+        off += math.ceil(m / chunk) * chunk
+    total = off
+    segs = [(o, m, 1e-3 * (i + 1), 1e-5 * (i + 1)) for i, (o, m) in enumerate(zip(offs, numels))]
+    err = SparseRow.from_dense(DOPRI5.c_error)
+    y0, y1 = _rand(total, dtype, 1), _rand(total, dtype, 2)
+    ks = [_rand(total, dtype, 10 + j) for j in range(7)]
+    # poison the padding: it must be ignored by the norms
+    mask = torch.ones(total, dtype=torch.bool)
+    for o, m in zip(offs, numels):
+        mask[o:o + m] = False
+    for tns in [y0, y1] + ks:
+        tns[mask] = float("nan")
+    pg, pc = _plan_pair(hip_kernels, oracle_kernels, segs, total, chunk)
+    sc_ref = torch.full((total,), 7.0, dtype=dtype)
+    oracle_kernels.error_scaled(pc, sc_ref, y0, y1, [ks[j] for j in err.idx], err.coef, -0.02)
+    ref, _, bad_ref = oracle_kernels.read_norms(pc)
+    ksd = _dev(ks)
+    sc = torch.full((total,), 7.0, dtype=dtype).cuda()
+    hip_kernels.error_scaled(pg, sc, y0.cuda(), y1.cuda(), [ksd[j] for j in err.idx], err.coef, -0.02)
+    got, _, bad = hip_kernels.read_norms(pg)
+    assert bad == bad_ref == [0.0] * len(numels)
+    assert got == pytest.approx(ref, rel=1e-12)
+    assert torch.equal(sc.cpu(), sc_ref)
+    # and the plain (non-writing) kernel gives the same sums
+    hip_kernels.error_norm(pg, y0.cuda(), y1.cuda(), [ksd[j] for j in err.idx], err.coef, -0.02)
+    got2, _, _ = hip_kernels.read_norms(pg)
+    assert got2 == got
+
+
+def test_error_norm_many_segments_device_table(hip_kernels, oracle_kernels):
+    chunk, dtype = 1024, torch.float32
+    numels = [((i * 37) % 2500) + 1 for i in range(40)]     # > TDEQ_INLINE_SEGMENTS
+    offs, off = [], 0
+    for m in numels:
+        offs.append(off)
+        off += math.ceil(m / chunk) * chunk
+    total = off
+    segs = [(o, m, 1e-3, 1e-6) for o, m in zip(offs, numels)]
+    err = SparseRow.from_dense(DOPRI5.c_error)
+    y0, y1 = _rand(total, dtype, 1), _rand(total, dtype, 2)
+    ks = [_rand(total, dtype, 10 + j) for j in range(7)]
+    pg, pc = _plan_pair(hip_kernels, oracle_kernels, segs, total, chunk)
+    oracle_kernels.error_norm(pc, y0, y1, [ks[j] for j in err.idx], err.coef, 0.3)
+    ref, _, _ = oracle_kernels.read_norms(pc)
+    ksd = _dev(ks)
+    hip_kernels.error_norm(pg, y0.cuda(), y1.cuda(), [ksd[j] for j in err.idx], err.coef, 0.3)
+    got, _, bad = hip_kernels.read_norms(pg)
+    assert got == pytest.approx(ref, rel=1e-12)
+    assert sum(bad) == 0
+
+
+def test_error_norm_nonfinite_census(hip_kernels, oracle_kernels):
+    n, dtype = 5000, torch.float32
+    err = SparseRow.from_dense(DOPRI5.c_error)
+    y0, y1 = _rand(n, dtype, 1), _rand(n, dtype, 2)
+    y1[17] = float("inf")
+    y0[4000] = float("nan")
+    ks = [_rand(n, dtype, 10 + j) for j in range(7)]
+    pg, pc = _plan_pair(hip_kernels, oracle_kernels, [(0, n, 1e-3, 1e-6)], n, 1024)
+    ksd = _dev(ks)
+    hip_kernels.error_norm(pg, y0.cuda(), y1.cuda(), [ksd[j] for j in err.idx], err.coef, 0.3)
+    got, _, bad = hip_kernels.read_norms(pg)
+    assert bad == [2.0]
+    assert math.isnan(got[0])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 1000, 4099, 1 << 20])
+def test_init_norms(hip_kernels, oracle_kernels, dtype, n):
+    a, b, y = _rand(n, dtype, 1), _rand(n, dtype, 2), _rand(n, dtype, 3)
+    pg, pc = _plan_pair(hip_kernels, oracle_kernels, [(0, n, 1e-5, 1e-7)], n, 2048)
+    for mode in (0, 1):
+        oracle_kernels.init_norms(pc, mode, a, b, y)
+        r0, r1, _ = oracle_kernels.read_norms(pc)
+        hip_kernels.init_norms(pg, mode, a.cuda(), b.cuda(), y.cuda())
+        g0, g1, bad = hip_kernels.read_norms(pg)
+        assert g0 == pytest.approx(r0, rel=1e-12)
+        if mode == 0:
+            assert g1 == pytest.approx(r1, rel=1e-12)
+        assert bad == [0.0]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 1001, 4099, 1 << 20])
+@pytest.mark.parametrize("tab", [DOPRI5, DOPRI8], ids=["dopri5", "dopri8"])
+def test_dense_eval_and_fit(hip_kernels, oracle_kernels, dtype, n, tab):
+    S = tab.n_stages
+    mid = SparseRow.from_dense(tab.c_mid)
+    y0, y1 = _rand(n, dtype, 1), _rand(n, dtype, 2)
+    ks = [_rand(n, dtype, 10 + j) for j in range(S + 1)]
+    ksd = _dev(ks)
+    for dt, x in [(0.05, 0.3), (-0.05, 1.0), (0.2, 0.0)]:
+        ref = torch.empty_like(y0)
+        oracle_kernels.dense_eval(ref, y0, y1, ks[0], ks[-1], [ks[j] for j in mid.idx], mid.coef, dt, x)
+        out = torch.empty_like(y0).cuda()
+        hip_kernels.dense_eval(out, y0.cuda(), y1.cuda(), ksd[0], ksd[-1], [ksd[j] for j in mid.idx], mid.coef, dt, x)
+        assert torch.equal(out.cpu(), ref)
+    cref = torch.empty(5 * n, dtype=dtype)
+    oracle_kernels.interp_fit(cref, y0, y1, ks[0], ks[-1], [ks[j] for j in mid.idx], mid.coef, 0.05)
+    cout = torch.empty(5 * n, dtype=dtype).cuda()
+    hip_kernels.interp_fit(cout, y0.cuda(), y1.cuda(), ksd[0], ksd[-1], [ksd[j] for j in mid.idx], mid.coef, 0.05)
+    assert torch.equal(cout.cpu(), cref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [2, 1001, 4099, 1 << 20])
+def test_rk4_and_lerp(hip_kernels, oracle_kernels, dtype, n):
+    y0 = _rand(n, dtype, 1)
+    k = [_rand(n, dtype, 10 + j) for j in range(4)]
+    kd = _dev(k)
+    for dt in (0.025, -0.025):
+        for stage in (1, 2, 3, 4):
+            args = [k[j] if j < stage else None for j in range(4)]
+            argsd = [kd[j] if j < stage else None for j in range(4)]
+            ref = torch.empty_like(y0)
+            oracle_kernels.rk4_stage(stage, ref, y0, *args, dt)
+            out = torch.empty_like(y0).cuda()
+            hip_kernels.rk4_stage(stage, out, y0.cuda(), *argsd, dt)
+            assert torch.equal(out.cpu(), ref)
+    ref = torch.empty_like(y0)
+    oracle_kernels.lerp(ref, y0, k[0], 0.37)
+    out = torch.empty_like(y0).cuda()
+    hip_kernels.lerp(out, y0.cuda(), kd[0], 0.37)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_readback_modes_agree(hip_kernels, oracle_kernels, monkeypatch):
+    """Zero-copy pinned read-back and the device-buffer + memcpy read-back return the same numbers."""
+    from torchdiffeq_amd import _native
+    n, dtype = 100000, torch.float32
+    err = SparseRow.from_dense(DOPRI5.c_error)
+    y0, y1 = _rand(n, dtype, 1).cuda(), _rand(n, dtype, 2).cuda()
+    ks = _dev([_rand(n, dtype, 10 + j) for j in range(7)])
+    res = []
+    for pinned in (True, False):
+        plan = _native.NormPlan([(0, n, 1e-3, 1e-6)], n, 2048, torch.device("cuda:0"), pinned)
+        hip_kernels.error_norm(plan, y0, y1, [ks[j] for j in err.idx], err.coef, 0.1)
+        res.append(hip_kernels.read_norms(plan))
+    assert res[0] == res[1]

@@ -1,0 +1,257 @@
+"""ctypes binding of libtdeq_hip.so (include/tdeq_hip.h) and the tensor-level kernel interface.
+
+`HipKernels` is the only compute backend of the package: every state-sized arithmetic operation of
+the solvers goes through it.  There is no CPU or eager-PyTorch fallback — `get_kernels()` raises if
+the library is missing or the state does not live on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+TDEQ_ABI_VERSION = 1
+TDEQ_F32, TDEQ_F64 = 0, 1
+TDEQ_MAX_TERMS = 14
+TDEQ_INLINE_SEGMENTS = 16
+TDEQ_CHUNK_QUANTUM = 1024
+
+_LIB_NAME = "libtdeq_hip.so"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+_c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+class Segment(ctypes.Structure):
+    """`tdeq_segment` of include/tdeq_hip.h."""
+    _fields_ = [("chunk_start", ctypes.c_int64), ("numel", ctypes.c_int64),
+                ("rtol", ctypes.c_double), ("atol", ctypes.c_double)]
+
+
+# name -> (restype, argtypes); the authoritative list of exported symbols (checked by the tests).
+ABI_SIGNATURES = {
+    "tdeq_abi_version": (ctypes.c_int, []),
+    "tdeq_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
+    "tdeq_stage_combine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
+                                          ctypes.c_int, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+                                          ctypes.c_void_p]),
+    "tdeq_error_norm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
+                                       ctypes.c_int, ctypes.c_double, ctypes.POINTER(Segment),
+                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_init_norms": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_dense_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
+                                       ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+                                       ctypes.c_void_p]),
+    "tdeq_interp_fit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
+                                       ctypes.c_double, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_rk4_38_stage": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_double, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_lerp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
+                                 ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_fill_scalars": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen the C-ABI library and bind every declared symbol.  Needs no GPU."""
+    path = path or _LIB_PATH
+    if not os.path.exists(path):
+        raise NativeLibraryError(
+            f"{path} not found: build it with `python -m torchdiffeq_amd.build` "
+            "(hipcc --offload-arch=gfx950).  torchdiffeq_amd has no CPU/eager fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in ABI_SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    version = lib.tdeq_abi_version()
+    if version != TDEQ_ABI_VERSION:
+        raise NativeLibraryError(f"{path}: ABI version {version}, expected {TDEQ_ABI_VERSION}")
+    return lib
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return TDEQ_F32
+    if dtype == torch.float64:
+        return TDEQ_F64
+    raise TypeError(f"torchdiffeq_amd supports float32 / float64 states, got {dtype}")
+
+
+def _check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code} "
+                           f"({'hipError_t' if code > 0 else 'argument error'})")
+
+
+def pick_chunk(numel: int) -> int:
+    """Elements per reduction chunk (one workgroup, one fp64 partial per chunk)."""
+    env = os.environ.get("TDEQ_CHUNK")
+    if env:
+        return int(env)
+    return 2048 if numel >= (1 << 20) else 1024
+
+
+class NormPlan:
+    """Segment table + workspace + read-back buffers of the norm kernels for one state layout.
+
+    `segments` = [(element offset, numel, rtol, atol)]; offsets must be multiples of `chunk`.
+    Results of the last norm launch are read with `HipKernels.read_norms(plan)`.
+    """
+
+    def __init__(self, segments: Sequence[Tuple[int, int, float, float]], total: int, chunk: int,
+                 device: torch.device, pinned: bool):
+        assert chunk % TDEQ_CHUNK_QUANTUM == 0
+        self.chunk = chunk
+        self.n_seg = len(segments)
+        self.numels = [int(s[1]) for s in segments]
+        self.n_chunks = max(1, math.ceil(total / chunk))
+        arr = (Segment * self.n_seg)()
+        for i, (off, numel, rtol, atol) in enumerate(segments):
+            assert off % chunk == 0, "segment offsets must be chunk aligned"
+            arr[i] = Segment(off // chunk, numel, float(rtol), float(atol))
+        self.segs = arr
+        self.segs_dev = None
+        if self.n_seg > TDEQ_INLINE_SEGMENTS:
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            self.segs_dev = torch.from_numpy(raw).to(device)
+        self.workspace = torch.empty(3 * self.n_chunks, dtype=torch.float64, device=device)
+        self.workspace_bytes = self.workspace.numel() * 8
+        # [2*n_seg sums | n_seg non-finite counters]; pinned host memory is written by the finalize
+        # kernel directly (zero-copy), so a read-back is one stream sync and no memcpy.
+        self.pinned = pinned
+        if pinned:
+            self.out = torch.zeros(3 * self.n_seg, dtype=torch.float64, pin_memory=True)
+            self.out_np = self.out.numpy()
+        else:
+            self.out = torch.zeros(3 * self.n_seg, dtype=torch.float64, device=device)
+            self.out_np = None
+        self.out_ptr = self.out.data_ptr()
+        self.bad_ptr = self.out_ptr + 16 * self.n_seg
+
+
+class HipKernels:
+    """Tensor-level wrappers of the C-ABI.  All launches go to the current torch HIP stream."""
+
+    name = "hip"
+
+    def __init__(self, lib: ctypes.CDLL):
+        self.lib = lib
+        self._pinned = os.environ.get("TDEQ_READBACK", "pinned") == "pinned"
+
+    # -- helpers ---------------------------------------------------------------------------------
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    @staticmethod
+    def _terms(ks: Sequence[torch.Tensor], coefs: Sequence[float]):
+        n = len(ks)
+        ptrs = (ctypes.c_void_p * n)(*[k.data_ptr() for k in ks])
+        cf = (ctypes.c_double * n)(*coefs)
+        return ptrs, cf, n
+
+    def make_plan(self, segments, total, chunk, device) -> NormPlan:
+        return NormPlan(segments, total, chunk, device, self._pinned)
+
+    # -- kernels ---------------------------------------------------------------------------------
+    def stage_combine(self, out, y0, ks, coefs, dt: float) -> None:
+        ptrs, cf, n = self._terms(ks, coefs)
+        _check(self.lib.tdeq_stage_combine(out.data_ptr(), y0.data_ptr(), ptrs, cf, n, dt, y0.numel(),
+                                           dtype_code(y0.dtype), self._stream()), "tdeq_stage_combine")
+
+    def error_norm(self, plan: NormPlan, y0, y1, ks, coefs, dt: float, scaled_out=None) -> None:
+        ptrs, cf, n = self._terms(ks, coefs)
+        dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
+        so = None if scaled_out is None else scaled_out.data_ptr()
+        _check(self.lib.tdeq_error_norm(so, y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, plan.segs, dev,
+                                        plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
+                                        plan.workspace.data_ptr(), plan.workspace_bytes,
+                                        dtype_code(y0.dtype), self._stream()), "tdeq_error_norm")
+
+    def error_scaled(self, plan: NormPlan, out, y0, y1, ks, coefs, dt: float) -> None:
+        """err/tol materialised into `out` (for user norm callables); norms are produced as well."""
+        self.error_norm(plan, y0, y1, ks, coefs, dt, scaled_out=out)
+
+    def init_norms(self, plan: NormPlan, mode: int, a, b, yscale) -> None:
+        dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
+        _check(self.lib.tdeq_init_norms(mode, a.data_ptr(), b.data_ptr(), yscale.data_ptr(), plan.segs, dev,
+                                        plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
+                                        plan.workspace.data_ptr(), plan.workspace_bytes,
+                                        dtype_code(yscale.dtype), self._stream()), "tdeq_init_norms")
+
+    def read_norms(self, plan: NormPlan) -> Tuple[List[float], List[float], List[float]]:
+        """(sumsq[0:n_seg], sumsq[n_seg:2n_seg], nonfinite[0:n_seg]) of the last norm launch."""
+        n = plan.n_seg
+        if plan.pinned:
+            torch.cuda.current_stream().synchronize()
+            v = plan.out_np.tolist()
+        else:
+            v = plan.out.tolist()
+        return v[:n], v[n:2 * n], v[2 * n:]
+
+    def dense_eval(self, out, y0, y1, f0, f1, ks, coefs, dt: float, x: float) -> None:
+        ptrs, cf, n = self._terms(ks, coefs)
+        _check(self.lib.tdeq_dense_eval(out.data_ptr(), y0.data_ptr(), y1.data_ptr(), f0.data_ptr(),
+                                        f1.data_ptr(), ptrs, cf, n, dt, x, y0.numel(),
+                                        dtype_code(y0.dtype), self._stream()), "tdeq_dense_eval")
+
+    def interp_fit(self, coeffs, y0, y1, f0, f1, ks, coefs, dt: float) -> None:
+        ptrs, cf, n = self._terms(ks, coefs)
+        _check(self.lib.tdeq_interp_fit(coeffs.data_ptr(), y0.data_ptr(), y1.data_ptr(), f0.data_ptr(),
+                                        f1.data_ptr(), ptrs, cf, n, dt, y0.numel(),
+                                        dtype_code(y0.dtype), self._stream()), "tdeq_interp_fit")
+
+    def rk4_stage(self, stage: int, out, y0, k1, k2, k3, k4, dt: float) -> None:
+        p = lambda t: None if t is None else t.data_ptr()
+        _check(self.lib.tdeq_rk4_38_stage(stage, out.data_ptr(), y0.data_ptr(), p(k1), p(k2), p(k3), p(k4),
+                                          dt, y0.numel(), dtype_code(y0.dtype), self._stream()),
+               "tdeq_rk4_38_stage")
+
+    def lerp(self, out, y0, y1, slope: float) -> None:
+        _check(self.lib.tdeq_lerp(out.data_ptr(), y0.data_ptr(), y1.data_ptr(), slope, y0.numel(),
+                                  dtype_code(y0.dtype), self._stream()), "tdeq_lerp")
+
+    def fill_scalars(self, dst, vals: Sequence[float]) -> None:
+        n = len(vals)
+        arr = (ctypes.c_double * n)(*vals)
+        _check(self.lib.tdeq_fill_scalars(dst.data_ptr(), arr, n, dtype_code(dst.dtype), self._stream()),
+               "tdeq_fill_scalars")
+
+
+_KERNELS: Optional[HipKernels] = None
+
+
+def get_kernels(device: torch.device) -> HipKernels:
+    """The compute backend for a state on `device`.  Fails loudly: no GPU / no library => error."""
+    global _KERNELS
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise NativeLibraryError(
+            f"torchdiffeq_amd runs the RK hot path in HIP kernels on an MI355X; the state is on "
+            f"'{device}'.  Move y0 to a ROCm device (there is no CPU / eager fallback).")
+    if _KERNELS is None:
+        _KERNELS = HipKernels(load_library())
+    return _KERNELS

@@ -1,0 +1,390 @@
+// tdeq_abi.hip — extern "C" entry points of libtdeq_hip.so (declared in include/tdeq_hip.h).
+// Host-side validation + template dispatch + launch; no allocation, no synchronisation, no globals.
+#include <hip/hip_runtime.h>
+
+#include "tdeq_kernels.hpp"
+
+namespace {
+using namespace tdeq;
+
+// Launch geometry for the streaming (elementwise) kernels: enough workgroups to cover the tensor once,
+// capped at kMaxBlocksPerCU resident workgroups per CU (256 CUs); the rest is grid-strided.
+constexpr int kNumCU = 256;
+constexpr int kMaxBlocksPerCU = 8;
+
+inline unsigned stream_grid(int64_t n_items, int items_per_block) {
+    int64_t g = (n_items + items_per_block - 1) / items_per_block;
+    const int64_t cap = (int64_t)kNumCU * kMaxBlocksPerCU;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int check_launch() {
+    const hipError_t e = hipGetLastError();
+    return (int)e;
+}
+
+// ---- stage_combine --------------------------------------------------------------------------------
+template <typename T, int NT>
+int launch_combine(void* out, const void* y0, const void* const* k, const double* coef, double dt,
+                   int64_t n, hipStream_t s) {
+    CombineArgs<T, NT> a;
+    a.out = static_cast<T*>(out);
+    a.y0 = static_cast<const T*>(y0);
+    bool vec = aligned16(out) && aligned16(y0);
+    const T dtT = (T)dt;
+    for (int j = 0; j < NT; ++j) {
+        a.k[j] = static_cast<const T*>(k[j]);
+        a.c[j] = (T)coef[j] * dtT;   // fl_T(fl_T(coef)*fl_T(dt)) — rk_common.py:79,201-205
+        vec = vec && aligned16(k[j]);
+    }
+    a.n = n;
+    constexpr int L = VecOf<T>::L;
+    // Few input streams -> two 16-byte elements per lane and iteration to keep enough loads in flight.
+    constexpr int U = (NT <= 3) ? 2 : 1;
+    if (vec) {
+        const unsigned g = stream_grid(n / L, kBlock * U);
+        hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true>), dim3(g), dim3(kBlock), 0, s, a);
+    } else {
+        const unsigned g = stream_grid(n, kBlock * U);
+        hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, false>), dim3(g), dim3(kBlock), 0, s, a);
+    }
+    return check_launch();
+}
+
+template <typename T>
+int dispatch_combine(void* out, const void* y0, const void* const* k, const double* coef, int nt,
+                     double dt, int64_t n, hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_combine<T, N>(out, y0, k, coef, dt, n, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
+// ---- segment table / workspace ---------------------------------------------------------------------
+int fill_segtable(SegTable& st, const tdeq_segment* segs, const void* segs_dev, int n_seg,
+                  int64_t chunk, int64_t n_chunks) {
+    if (!segs || n_seg < 1 || n_seg > TDEQ_MAX_SEGMENTS) return TDEQ_EINVAL;
+    if (chunk < TDEQ_CHUNK_QUANTUM || chunk % TDEQ_CHUNK_QUANTUM != 0 || n_chunks < 1) return TDEQ_EINVAL;
+    if (n_chunks > 0x7fffffffLL) return TDEQ_EINVAL;
+    if (n_seg > TDEQ_INLINE_SEGMENTS && !segs_dev) return TDEQ_EINVAL;
+    for (int q = 0; q < TDEQ_INLINE_SEGMENTS; ++q) {
+        if (q < n_seg && n_seg <= TDEQ_INLINE_SEGMENTS) st.inl[q] = segs[q];
+        else st.inl[q] = tdeq_segment{0, 0, 0.0, 0.0};
+    }
+    if (n_seg > TDEQ_INLINE_SEGMENTS) st.inl[0] = segs[0];
+    st.dev = static_cast<const tdeq_segment*>(segs_dev);
+    st.n_seg = n_seg;
+    st.chunk = chunk;
+    st.n_chunks = n_chunks;
+    return 0;
+}
+
+int launch_finalize(const SegTable& st, double* ws, int n_sum, double* out_sumsq, double* out_bad,
+                    hipStream_t s) {
+    FinalizeArgs f;
+    for (int q = 0; q < 3; ++q) f.part[q] = ws + (int64_t)q * st.n_chunks;
+    // the non-finite counters always live in the third array; remap so part[n_sum] is that array
+    f.part[n_sum] = ws + 2 * st.n_chunks;
+    f.st = st;
+    f.n_sum = n_sum;
+    f.out_sumsq = out_sumsq;
+    f.out_bad = out_bad;
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(st.n_seg, n_sum + 1), dim3(kBlock), 0, s, f);
+    return check_launch();
+}
+
+// ---- error_norm ------------------------------------------------------------------------------------
+template <typename T, int NT>
+int launch_error(void* scaled, const void* y0, const void* y1, const void* const* k, const double* coef,
+                 double dt, const SegTable& st, double* out_sumsq, double* out_bad, double* ws,
+                 hipStream_t s) {
+    ErrArgs<T, NT> a;
+    a.scaled = static_cast<T*>(scaled);
+    a.y0 = static_cast<const T*>(y0);
+    a.y1 = static_cast<const T*>(y1);
+    bool vec = aligned16(y0) && aligned16(y1);
+    const T dtT = (T)dt;
+    for (int j = 0; j < NT; ++j) {
+        a.k[j] = static_cast<const T*>(k[j]);
+        a.c[j] = (T)coef[j] * dtT;   // dt * c_error — rk_common.py:89
+        vec = vec && aligned16(k[j]);
+    }
+    a.st = st;
+    a.part_sumsq = ws;
+    a.part_bad = ws + 2 * st.n_chunks;
+    const dim3 g((unsigned)st.n_chunks), b(kBlock);
+    if (scaled) {
+        vec = vec && aligned16(scaled);
+        if (vec) hipLaunchKernelGGL((error_norm_kernel<T, NT, true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((error_norm_kernel<T, NT, false, true>), g, b, 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((error_norm_kernel<T, NT, true, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((error_norm_kernel<T, NT, false, false>), g, b, 0, s, a);
+    }
+    const int e = check_launch();
+    if (e) return e;
+    return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
+}
+
+template <typename T>
+int dispatch_error(void* scaled, const void* y0, const void* y1, const void* const* k, const double* coef,
+                   int nt, double dt, const SegTable& st, double* out_sumsq, double* out_bad, double* ws,
+                   hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_error<T, N>(scaled, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
+// ---- init norms ------------------------------------------------------------------------------------
+template <typename T>
+int launch_init(int mode, const void* a_, const void* b_, const void* y_, const SegTable& st,
+                double* out_sumsq, double* out_bad, double* ws, hipStream_t s) {
+    InitArgs<T> a;
+    a.a = static_cast<const T*>(a_);
+    a.b = static_cast<const T*>(b_);
+    a.y = static_cast<const T*>(y_);
+    a.st = st;
+    a.part0 = ws;
+    a.part1 = ws + st.n_chunks;
+    a.part_bad = ws + 2 * st.n_chunks;
+    const bool vec = aligned16(a_) && aligned16(b_) && aligned16(y_);
+    const dim3 g((unsigned)st.n_chunks), b(kBlock);
+    if (mode == 0) {
+        if (vec) hipLaunchKernelGGL((init_norms_kernel<T, 0, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((init_norms_kernel<T, 0, false>), g, b, 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((init_norms_kernel<T, 1, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((init_norms_kernel<T, 1, false>), g, b, 0, s, a);
+    }
+    const int e = check_launch();
+    if (e) return e;
+    return launch_finalize(st, ws, mode == 0 ? 2 : 1, out_sumsq, out_bad, s);
+}
+
+// ---- dense output ----------------------------------------------------------------------------------
+template <typename T, int NT, bool FIT_ONLY>
+int launch_dense(void* out, const void* y0, const void* y1, const void* f0, const void* f1,
+                 const void* const* k, const double* coef, double dt, double x, int64_t n, hipStream_t s) {
+    DenseArgs<T, NT> a;
+    a.out = static_cast<T*>(out);
+    a.y0 = static_cast<const T*>(y0);
+    a.y1 = static_cast<const T*>(y1);
+    a.f0 = static_cast<const T*>(f0);
+    a.f1 = static_cast<const T*>(f1);
+    bool vec = aligned16(out) && aligned16(y0) && aligned16(y1) && aligned16(f0) && aligned16(f1);
+    const T dtT = (T)dt;
+    for (int j = 0; j < NT; ++j) {
+        a.k[j] = static_cast<const T*>(k[j]);
+        a.c[j] = (T)coef[j] * dtT;   // dt * mid — rk_common.py:365-366
+        vec = vec && aligned16(k[j]);
+    }
+    a.dt = dtT;
+    a.x = (T)x;
+    a.n = n;
+    constexpr int L = VecOf<T>::L;
+    if (FIT_ONLY) vec = vec && (n % L == 0);   // the 5 coefficient planes must stay 16-byte aligned
+    if (vec) {
+        const unsigned g = stream_grid(n / L, kBlock);
+        hipLaunchKernelGGL((dense_kernel<T, NT, FIT_ONLY, true>), dim3(g), dim3(kBlock), 0, s, a);
+    } else {
+        const unsigned g = stream_grid(n, kBlock);
+        hipLaunchKernelGGL((dense_kernel<T, NT, FIT_ONLY, false>), dim3(g), dim3(kBlock), 0, s, a);
+    }
+    return check_launch();
+}
+
+template <typename T, bool FIT_ONLY>
+int dispatch_dense(void* out, const void* y0, const void* y1, const void* f0, const void* f1,
+                   const void* const* k, const double* coef, int nt, double dt, double x, int64_t n,
+                   hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_dense<T, N, FIT_ONLY>(out, y0, y1, f0, f1, k, coef, dt, x, n, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
+// ---- rk4 / lerp ------------------------------------------------------------------------------------
+template <typename T, int STAGE>
+int launch_rk4(void* out, const void* y0, const void* k1, const void* k2, const void* k3,
+               const void* k4, double dt, int64_t n, hipStream_t s) {
+    Rk4Args<T> a;
+    a.out = static_cast<T*>(out);
+    a.y0 = static_cast<const T*>(y0);
+    a.k1 = static_cast<const T*>(k1);
+    a.k2 = static_cast<const T*>(k2);
+    a.k3 = static_cast<const T*>(k3);
+    a.k4 = static_cast<const T*>(k4);
+    a.dt = (T)dt;
+    a.third = (T)(1.0 / 3.0);   // `_one_third` rounded to T — rk_common.py:94,114-115
+    a.n = n;
+    bool vec = aligned16(out) && aligned16(y0) && aligned16(k1);
+    if (STAGE >= 2) vec = vec && aligned16(k2);
+    if (STAGE >= 3) vec = vec && aligned16(k3);
+    if (STAGE >= 4) vec = vec && aligned16(k4);
+    constexpr int L = VecOf<T>::L;
+    if (vec) {
+        hipLaunchKernelGGL((rk4_kernel<T, STAGE, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((rk4_kernel<T, STAGE, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    }
+    return check_launch();
+}
+
+template <typename T>
+int dispatch_rk4(int stage, void* out, const void* y0, const void* k1, const void* k2, const void* k3,
+                 const void* k4, double dt, int64_t n, hipStream_t s) {
+    switch (stage) {
+        case 1: return k1 ? launch_rk4<T, 1>(out, y0, k1, k2, k3, k4, dt, n, s) : TDEQ_EINVAL;
+        case 2: return (k1 && k2) ? launch_rk4<T, 2>(out, y0, k1, k2, k3, k4, dt, n, s) : TDEQ_EINVAL;
+        case 3: return (k1 && k2 && k3) ? launch_rk4<T, 3>(out, y0, k1, k2, k3, k4, dt, n, s) : TDEQ_EINVAL;
+        case 4: return (k1 && k2 && k3 && k4) ? launch_rk4<T, 4>(out, y0, k1, k2, k3, k4, dt, n, s) : TDEQ_EINVAL;
+    }
+    return TDEQ_EINVAL;
+}
+
+template <typename T>
+int launch_lerp(void* out, const void* y0, const void* y1, double slope, int64_t n, hipStream_t s) {
+    LerpArgs<T> a;
+    a.out = static_cast<T*>(out);
+    a.y0 = static_cast<const T*>(y0);
+    a.y1 = static_cast<const T*>(y1);
+    a.slope = (T)slope;
+    a.n = n;
+    constexpr int L = VecOf<T>::L;
+    if (aligned16(out) && aligned16(y0) && aligned16(y1))
+        hipLaunchKernelGGL((lerp_kernel<T, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL((lerp_kernel<T, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
+}
+
+inline bool bad_dtype(int dtype) { return dtype != TDEQ_F32 && dtype != TDEQ_F64; }
+
+}  // namespace
+
+extern "C" {
+
+int tdeq_abi_version(void) { return TDEQ_ABI_VERSION; }
+
+size_t tdeq_workspace_bytes(int64_t n_chunks) {
+    if (n_chunks < 1) n_chunks = 1;
+    return (size_t)n_chunks * 3 * sizeof(double);
+}
+
+int tdeq_stage_combine(void* out, const void* y0, const void* const* k, const double* coef, int n_terms,
+                       double dt, int64_t n, int dtype, void* stream) {
+    if (!out || !y0 || !k || !coef || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? dispatch_combine<float>(out, y0, k, coef, n_terms, dt, n, s)
+                             : dispatch_combine<double>(out, y0, k, coef, n_terms, dt, n, s);
+}
+
+int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void* const* k,
+                    const double* coef, int n_terms, double dt, const tdeq_segment* segs,
+                    const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
+                    double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
+                    void* stream) {
+    if (!y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype))
+        return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    SegTable st;
+    const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
+    if (e) return e;
+    if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    return dtype == TDEQ_F32
+               ? dispatch_error<float>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s)
+               : dispatch_error<double>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
+}
+
+int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, const tdeq_segment* segs,
+                    const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
+                    double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
+                    void* stream) {
+    if ((mode != 0 && mode != 1) || !a || !b || !yscale || !out_sumsq || !out_nonfinite || !workspace ||
+        bad_dtype(dtype))
+        return TDEQ_EINVAL;
+    SegTable st;
+    const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
+    if (e) return e;
+    if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    return dtype == TDEQ_F32 ? launch_init<float>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, s)
+                             : launch_init<double>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, s);
+}
+
+int tdeq_dense_eval(void* out, const void* y0, const void* y1, const void* f0, const void* f1,
+                    const void* const* k, const double* coef, int n_terms, double dt, double x, int64_t n,
+                    int dtype, void* stream) {
+    if (!out || !y0 || !y1 || !f0 || !f1 || !k || !coef || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32
+               ? dispatch_dense<float, false>(out, y0, y1, f0, f1, k, coef, n_terms, dt, x, n, s)
+               : dispatch_dense<double, false>(out, y0, y1, f0, f1, k, coef, n_terms, dt, x, n, s);
+}
+
+int tdeq_interp_fit(void* coeffs, const void* y0, const void* y1, const void* f0, const void* f1,
+                    const void* const* k, const double* coef, int n_terms, double dt, int64_t n, int dtype,
+                    void* stream) {
+    if (!coeffs || !y0 || !y1 || !f0 || !f1 || !k || !coef || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32
+               ? dispatch_dense<float, true>(coeffs, y0, y1, f0, f1, k, coef, n_terms, dt, 0.0, n, s)
+               : dispatch_dense<double, true>(coeffs, y0, y1, f0, f1, k, coef, n_terms, dt, 0.0, n, s);
+}
+
+int tdeq_rk4_38_stage(int stage, void* out, const void* y0, const void* k1, const void* k2, const void* k3,
+                      const void* k4, double dt, int64_t n, int dtype, void* stream) {
+    if (!out || !y0 || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n == 0) return (stage >= 1 && stage <= 4) ? 0 : TDEQ_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? dispatch_rk4<float>(stage, out, y0, k1, k2, k3, k4, dt, n, s)
+                             : dispatch_rk4<double>(stage, out, y0, k1, k2, k3, k4, dt, n, s);
+}
+
+int tdeq_lerp(void* out, const void* y0, const void* y1, double slope, int64_t n, int dtype, void* stream) {
+    if (!out || !y0 || !y1 || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? launch_lerp<float>(out, y0, y1, slope, n, s)
+                             : launch_lerp<double>(out, y0, y1, slope, n, s);
+}
+
+int tdeq_fill_scalars(void* dst, const double* vals, int n_vals, int dtype, void* stream) {
+    if (!dst || !vals || n_vals < 1 || n_vals > 16 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    FillArgs a;
+    a.dst = dst;
+    for (int i = 0; i < 16; ++i) a.v[i] = i < n_vals ? vals[i] : 0.0;
+    a.n = n_vals;
+    a.dtype = dtype;
+    hipLaunchKernelGGL(fill_scalars_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,527 @@
+// tdeq_kernels.hpp — gfx950 (MI355X, CDNA4) device code of the explicit Runge–Kutta hot path.
+//
+// Everything here is bandwidth-bound streaming work (AXPY-like combines and reductions): no MFMA, no
+// LDS tiling — the levers are 16 B/lane coalesced loads, many independent loads in flight per lane,
+// ≫256 workgroups, wave64 shuffle reductions, and zero redundant passes over the state.
+//
+// Layout: the RK stages k_j are SEPARATE contiguous tensors (structure of arrays) — not the
+// reference's stage-minor `k[*shape, S+1]` (rk_common.py:69), whose stride-(S+1) scatter/gather is
+// uncoalesced.  Their addresses and the already-rounded coefficients c_j travel in the kernel-argument
+// block, i.e. they are read with scalar loads into SGPRs once per wave (cheaper than staging the
+// tableau row through LDS: no LDS round trip, no barrier, no VGPR cost).
+//
+// Arithmetic mirrors the reference's eager op sequence in the state dtype T with every product and
+// sum rounded separately (compile with -ffp-contract=off): see the per-kernel comments.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tdeq_hip.h"
+
+namespace tdeq {
+
+constexpr int kBlock = 256;   // 4 wave64 per workgroup
+constexpr int kWave = 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { using type = f32x4; static constexpr int L = 4; };
+template <> struct VecOf<double> { using type = f64x2; static constexpr int L = 2; };
+
+template <typename V> __device__ __forceinline__ V vabs(V v);
+template <> __device__ __forceinline__ f32x4 vabs(f32x4 v) {
+    return f32x4{__builtin_fabsf(v.x), __builtin_fabsf(v.y), __builtin_fabsf(v.z), __builtin_fabsf(v.w)};
+}
+template <> __device__ __forceinline__ f64x2 vabs(f64x2 v) {
+    return f64x2{__builtin_fabs(v.x), __builtin_fabs(v.y)};
+}
+__device__ __forceinline__ float sabs(float v) { return __builtin_fabsf(v); }
+__device__ __forceinline__ double sabs(double v) { return __builtin_fabs(v); }
+__device__ __forceinline__ float smax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double smax(double a, double b) { return __builtin_fmax(a, b); }
+
+// ------------------------------------------------------------------------------------------------
+// Stage accumulate:  out = y0 + ((c0*k0 + c1*k1) + ... + c_{NT-1}*k_{NT-1})      (rk_common.py:79)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+struct CombineArgs {
+    T* out;
+    const T* y0;
+    const T* k[NT];
+    T c[NT];
+    int64_t n;
+};
+
+template <typename T, int NT, typename E>   // E = T (scalar path) or the 16-byte vector of T
+__device__ __forceinline__ E combine_one(const CombineArgs<T, NT>& a, const E& y, const E (&kk)[NT]) {
+    E acc = kk[0] * a.c[0];
+#pragma unroll
+    for (int j = 1; j < NT; ++j) acc = acc + kk[j] * a.c[j];
+    return y + acc;
+}
+
+// U independent 16-byte elements per lane and iteration => (NT+1)*U loads in flight per lane.
+template <typename T, int NT, int U, bool VEC>
+__global__ __launch_bounds__(kBlock) void stage_combine_kernel(const CombineArgs<T, NT> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const E* __restrict__ y0 = reinterpret_cast<const E*>(a.y0);
+    E* __restrict__ out = reinterpret_cast<E*>(a.out);
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + (U - 1) * stride < ne; i += U * stride) {
+        E y[U];
+        E kk[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            y[u] = y0[i + u * stride];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kk[u][j] = reinterpret_cast<const E*>(a.k[j])[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) out[i + u * stride] = combine_one<T, NT, E>(a, y[u], kk[u]);
+    }
+    for (; i < ne; i += stride) {
+        E kk[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.k[j])[i];
+        out[i] = combine_one<T, NT, E>(a, y0[i], kk);
+    }
+    if (VEC) {   // scalar tail (n % L elements)
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) {
+            T kk[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kk[j] = a.k[j][t];
+            a.out[t] = combine_one<T, NT, T>(a, a.y0[t], kk);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reductions.  One workgroup per chunk -> one fp64 partial per chunk (deterministic order), then a
+// finalize launch adds the partials of each segment in a fixed tree order.  wave64 shuffles first,
+// LDS only for the 4 per-wave values.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// Sum over the workgroup; result valid in thread 0.  `red` = kBlock/kWave doubles of LDS per value.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* red) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        v[q] = wave_sum(v[q]);
+        if (lane == 0) red[q * (kBlock / kWave) + wave] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            double s = red[q * (kBlock / kWave)];
+#pragma unroll
+            for (int w = 1; w < kBlock / kWave; ++w) s += red[q * (kBlock / kWave) + w];
+            v[q] = s;
+        }
+    }
+}
+
+struct SegTable {
+    tdeq_segment inl[TDEQ_INLINE_SEGMENTS];
+    const tdeq_segment* dev;   // used when n_seg > TDEQ_INLINE_SEGMENTS
+    int n_seg;
+    int64_t chunk;             // elements per chunk
+    int64_t n_chunks;
+};
+
+__device__ __forceinline__ tdeq_segment get_segment(const SegTable& st, int s) {
+    if (st.n_seg <= TDEQ_INLINE_SEGMENTS) return st.inl[s];
+    return st.dev[s];
+}
+
+// Segment of chunk b (uniform per workgroup): last s with chunk_start[s] <= b.
+__device__ __forceinline__ tdeq_segment find_segment(const SegTable& st, int64_t b) {
+    if (st.n_seg == 1) return st.inl[0];
+    if (st.n_seg <= TDEQ_INLINE_SEGMENTS) {
+        int s = 0;
+        for (int q = 1; q < st.n_seg; ++q) s = (st.inl[q].chunk_start <= b) ? q : s;
+        return st.inl[s];
+    }
+    int lo = 0, hi = st.n_seg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (st.dev[mid].chunk_start <= b) lo = mid; else hi = mid - 1;
+    }
+    return st.dev[lo];
+}
+
+template <typename T, int NT>
+struct ErrArgs {
+    const T* y0;
+    const T* y1;
+    const T* k[NT];
+    T c[NT];
+    SegTable st;
+    double* part_sumsq;   // [n_chunks]
+    double* part_bad;     // [n_chunks]
+    T* scaled;            // WRITE variant only: err/tol per element (padding zero-filled)
+};
+
+// err = (c0*k0 + c1*k1) + ... ; tol = atol + rtol*max(|y0|,|y1|) ; r = err/tol ; acc += r*r
+// (rk_common.py:89, misc.py:80-82,22-23).  r is formed in T exactly as the reference does; the
+// square and the accumulation are fp64 (the reference accumulates in T with an unspecified tree
+// order — see DESIGN.md "norm accumulation").
+template <typename T, int NT, typename E>
+__device__ __forceinline__ E err_elem(const ErrArgs<T, NT>& a, T rtol, T atol, const E& y0,
+                                      const E& y1, const E (&kk)[NT], double& acc, double& bad) {
+    E e = kk[0] * a.c[0];
+#pragma unroll
+    for (int j = 1; j < NT; ++j) e = e + kk[j] * a.c[j];
+    if constexpr (sizeof(E) == sizeof(T)) {
+        const T tol = atol + rtol * smax(sabs(y0), sabs(y1));
+        const T r = e / tol;
+        acc += (double)r * (double)r;
+        bad += (__builtin_isfinite(y0) && __builtin_isfinite(y1)) ? 0.0 : 1.0;
+        return r;
+    } else {
+        E rv;
+#pragma unroll
+        for (int q = 0; q < VecOf<T>::L; ++q) {
+            const T tol = atol + rtol * smax(sabs(y0[q]), sabs(y1[q]));
+            const T r = e[q] / tol;
+            acc += (double)r * (double)r;
+            bad += (__builtin_isfinite(y0[q]) && __builtin_isfinite(y1[q])) ? 0.0 : 1.0;
+            rv[q] = r;
+        }
+        return rv;
+    }
+}
+
+// WRITE = also store err/tol (for user-supplied norm callables, misc.py:80-82 with a custom norm).
+template <typename T, int NT, bool VEC, bool WRITE>
+__global__ __launch_bounds__(kBlock) void error_norm_kernel(const ErrArgs<T, NT> a) {
+    using V = typename VecOf<T>::type;
+    constexpr int L = VecOf<T>::L;
+    __shared__ double red[2 * (kBlock / kWave)];
+    const int64_t b = blockIdx.x;
+    const tdeq_segment seg = find_segment(a.st, b);
+    const int64_t base = b * a.st.chunk;
+    int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+    valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
+    const T rtol = (T)seg.rtol, atol = (T)seg.atol;
+    double acc[2] = {0.0, 0.0};
+    if (VEC) {
+        const int64_t nv = valid / L;
+        const V* y0 = reinterpret_cast<const V*>(a.y0 + base);
+        const V* y1 = reinterpret_cast<const V*>(a.y1 + base);
+#pragma unroll 2
+        for (int64_t i = threadIdx.x; i < nv; i += kBlock) {
+            V kk[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const V*>(a.k[j] + base)[i];
+            const V r = err_elem<T, NT, V>(a, rtol, atol, y0[i], y1[i], kk, acc[0], acc[1]);
+            if (WRITE) reinterpret_cast<V*>(a.scaled + base)[i] = r;
+        }
+        const int64_t t = nv * L + threadIdx.x;
+        if (t < valid) {
+            T kk[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kk[j] = a.k[j][base + t];
+            const T r = err_elem<T, NT, T>(a, rtol, atol, a.y0[base + t], a.y1[base + t], kk, acc[0], acc[1]);
+            if (WRITE) a.scaled[base + t] = r;
+        }
+    } else {
+        for (int64_t t = threadIdx.x; t < valid; t += kBlock) {
+            T kk[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kk[j] = a.k[j][base + t];
+            const T r = err_elem<T, NT, T>(a, rtol, atol, a.y0[base + t], a.y1[base + t], kk, acc[0], acc[1]);
+            if (WRITE) a.scaled[base + t] = r;
+        }
+    }
+    if (WRITE && a.st.n_seg > 1)   // zero the padding of a segmented layout
+        for (int64_t t = valid + threadIdx.x; t < a.st.chunk; t += kBlock) a.scaled[base + t] = (T)0;
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        a.part_sumsq[b] = acc[0];
+        a.part_bad[b] = acc[1];
+    }
+}
+
+// Initial-step norms (misc.py:53-56,68): scale = atol + |y|*rtol.
+//   MODE 0: acc0 += (a/scale)^2 ; acc1 += (b/scale)^2        MODE 1: acc0 += ((a-b)/scale)^2
+template <typename T>
+struct InitArgs {
+    const T* a;
+    const T* b;
+    const T* y;
+    SegTable st;
+    double* part0;   // [n_chunks]
+    double* part1;   // [n_chunks] (MODE 0 only)
+    double* part_bad;
+};
+
+template <typename T, int MODE>
+__device__ __forceinline__ void init_elem(T rtol, T atol, T av, T bv, T yv, double (&acc)[3]) {
+    const T scale = atol + sabs(yv) * rtol;
+    if (MODE == 0) {
+        const T r0 = av / scale, r1 = bv / scale;
+        acc[0] += (double)r0 * (double)r0;
+        acc[1] += (double)r1 * (double)r1;
+    } else {
+        const T r0 = (av - bv) / scale;
+        acc[0] += (double)r0 * (double)r0;
+    }
+    acc[2] += __builtin_isfinite(yv) ? 0.0 : 1.0;
+}
+
+template <typename T, int MODE, bool VEC>
+__global__ __launch_bounds__(kBlock) void init_norms_kernel(const InitArgs<T> a) {
+    using V = typename VecOf<T>::type;
+    constexpr int L = VecOf<T>::L;
+    __shared__ double red[3 * (kBlock / kWave)];
+    const int64_t b = blockIdx.x;
+    const tdeq_segment seg = find_segment(a.st, b);
+    const int64_t base = b * a.st.chunk;
+    int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+    valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
+    const T rtol = (T)seg.rtol, atol = (T)seg.atol;
+    double acc[3] = {0.0, 0.0, 0.0};
+    int64_t t0 = 0;
+    if (VEC) {
+        const int64_t nv = valid / L;
+#pragma unroll 2
+        for (int64_t i = threadIdx.x; i < nv; i += kBlock) {
+            const V av = reinterpret_cast<const V*>(a.a + base)[i];
+            const V bv = reinterpret_cast<const V*>(a.b + base)[i];
+            const V yv = reinterpret_cast<const V*>(a.y + base)[i];
+#pragma unroll
+            for (int q = 0; q < L; ++q) init_elem<T, MODE>(rtol, atol, av[q], bv[q], yv[q], acc);
+        }
+        t0 = nv * L;
+        const int64_t t = t0 + threadIdx.x;
+        if (t < valid) init_elem<T, MODE>(rtol, atol, a.a[base + t], a.b[base + t], a.y[base + t], acc);
+    } else {
+        for (int64_t t = threadIdx.x; t < valid; t += kBlock)
+            init_elem<T, MODE>(rtol, atol, a.a[base + t], a.b[base + t], a.y[base + t], acc);
+    }
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        a.part0[b] = acc[0];
+        if (MODE == 0) a.part1[b] = acc[1];
+        a.part_bad[b] = acc[2];
+    }
+}
+
+// Finalize: workgroup (s, q) adds the partials of segment s from array q in a fixed order.
+//   q < n_sum  -> out_sumsq[q*n_seg + s]      q == n_sum -> out_bad[s]
+struct FinalizeArgs {
+    const double* part[3];   // part[n_sum] is the non-finite counter array
+    SegTable st;
+    int n_sum;
+    double* out_sumsq;
+    double* out_bad;
+};
+
+__global__ __launch_bounds__(kBlock) void norm_finalize_kernel(const FinalizeArgs a) {
+    __shared__ double red[kBlock / kWave];
+    const int s = blockIdx.x, q = blockIdx.y;
+    const int64_t c0 = get_segment(a.st, s).chunk_start;
+    const int64_t c1 = (s + 1 < a.st.n_seg) ? get_segment(a.st, s + 1).chunk_start : a.st.n_chunks;
+    const double* p = a.part[q];
+    double acc[1] = {0.0};
+    for (int64_t i = c0 + threadIdx.x; i < c1; i += kBlock) acc[0] += p[i];
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) {
+        if (q < a.n_sum) a.out_sumsq[(int64_t)q * a.st.n_seg + s] = acc[0];
+        else a.out_bad[s] = acc[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense output (rk_common.py:363-369, interp.py:1-48).  Op order mirrors interp.py:17-21 / :42-47.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+struct DenseArgs {
+    T* out;          // n elements (dense_eval) or 5*n (interp_fit: e,d,c,b,a)
+    const T* y0;
+    const T* y1;
+    const T* f0;
+    const T* f1;
+    const T* k[NT];
+    T c[NT];
+    T dt;
+    T x;
+    int64_t n;
+};
+
+template <typename T, typename E>
+struct Quartic { E e, d, c, b, a; };
+
+template <typename T, int NT, typename E>
+__device__ __forceinline__ Quartic<T, E> fit_one(const DenseArgs<T, NT>& a, const E& y0, const E& y1,
+                                                 const E& f0, const E& f1, const E (&kk)[NT]) {
+    E acc = kk[0] * a.c[0];
+#pragma unroll
+    for (int j = 1; j < NT; ++j) acc = acc + kk[j] * a.c[j];
+    const E ymid = y0 + acc;
+    const T dt = a.dt;
+    const T two_dt = (T)2 * dt;
+    Quartic<T, E> q;
+    q.a = ((f1 - f0) * two_dt - (y1 + y0) * (T)8) + ymid * (T)16;
+    q.b = (((f0 * (T)5 - f1 * (T)3) * dt + y0 * (T)18) + y1 * (T)14) - ymid * (T)32;
+    q.c = (((f1 - f0 * (T)4) * dt - y0 * (T)11) - y1 * (T)5) + ymid * (T)16;
+    q.d = f0 * dt;
+    q.e = y0;
+    return q;
+}
+
+template <typename T, typename E>
+__device__ __forceinline__ E eval_one(const Quartic<T, E>& q, T x) {
+    E total = q.e + q.d * x;
+    T xp = x * x;
+    total = total + q.c * xp;
+    xp = xp * x;
+    total = total + q.b * xp;
+    xp = xp * x;
+    total = total + q.a * xp;
+    return total;
+}
+
+template <typename T, int NT, bool FIT_ONLY, bool VEC>
+__global__ __launch_bounds__(kBlock) void dense_kernel(const DenseArgs<T, NT> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
+        E kk[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.k[j])[i];
+        const Quartic<T, E> q = fit_one<T, NT, E>(
+            a, reinterpret_cast<const E*>(a.y0)[i], reinterpret_cast<const E*>(a.y1)[i],
+            reinterpret_cast<const E*>(a.f0)[i], reinterpret_cast<const E*>(a.f1)[i], kk);
+        if (FIT_ONLY) {
+            reinterpret_cast<E*>(a.out)[i] = q.e;
+            reinterpret_cast<E*>(a.out + a.n)[i] = q.d;
+            reinterpret_cast<E*>(a.out + 2 * a.n)[i] = q.c;
+            reinterpret_cast<E*>(a.out + 3 * a.n)[i] = q.b;
+            reinterpret_cast<E*>(a.out + 4 * a.n)[i] = q.a;
+        } else {
+            reinterpret_cast<E*>(a.out)[i] = eval_one<T, E>(q, a.x);
+        }
+    }
+    if (VEC) {
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) {
+            T kk[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kk[j] = a.k[j][t];
+            const Quartic<T, T> q = fit_one<T, NT, T>(a, a.y0[t], a.y1[t], a.f0[t], a.f1[t], kk);
+            if (FIT_ONLY) {
+                a.out[t] = q.e;
+                a.out[a.n + t] = q.d;
+                a.out[2 * a.n + t] = q.c;
+                a.out[3 * a.n + t] = q.b;
+                a.out[4 * a.n + t] = q.a;
+            } else {
+                a.out[t] = eval_one<T, T>(q, a.x);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rk4 3/8 rule (rk_common.py:110-118) and the fixed-grid linear interpolation (solvers.py:175-181).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct Rk4Args {
+    T* out;
+    const T* y0;
+    const T* k1;
+    const T* k2;
+    const T* k3;
+    const T* k4;
+    T dt;
+    T third;   // fl_T(1/3)
+    int64_t n;
+};
+
+template <typename T, int STAGE, typename E>
+__device__ __forceinline__ E rk4_one(const Rk4Args<T>& a, int64_t i) {
+    const E y0 = reinterpret_cast<const E*>(a.y0)[i];
+    const E k1 = reinterpret_cast<const E*>(a.k1)[i];
+    if (STAGE == 1) return y0 + (k1 * a.dt) * a.third;
+    const E k2 = reinterpret_cast<const E*>(a.k2)[i];
+    if (STAGE == 2) return y0 + (k2 - k1 * a.third) * a.dt;
+    const E k3 = reinterpret_cast<const E*>(a.k3)[i];
+    if (STAGE == 3) return y0 + ((k1 - k2) + k3) * a.dt;
+    const E k4 = reinterpret_cast<const E*>(a.k4)[i];
+    return y0 + (((k1 + (k2 + k3) * (T)3) + k4) * a.dt) * (T)0.125;
+}
+
+template <typename T, int STAGE, bool VEC>
+__global__ __launch_bounds__(kBlock) void rk4_kernel(const Rk4Args<T> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
+        reinterpret_cast<E*>(a.out)[i] = rk4_one<T, STAGE, E>(a, i);
+    if (VEC) {
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) a.out[t] = rk4_one<T, STAGE, T>(a, t);
+    }
+}
+
+template <typename T>
+struct LerpArgs {
+    T* out;
+    const T* y0;
+    const T* y1;
+    T slope;
+    int64_t n;
+};
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void lerp_kernel(const LerpArgs<T> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
+        const E y0 = reinterpret_cast<const E*>(a.y0)[i];
+        const E y1 = reinterpret_cast<const E*>(a.y1)[i];
+        reinterpret_cast<E*>(a.out)[i] = y0 + (y1 - y0) * a.slope;
+    }
+    if (VEC) {
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) a.out[t] = a.y0[t] + (a.y1[t] - a.y0[t]) * a.slope;
+    }
+}
+
+struct FillArgs {
+    void* dst;
+    double v[16];
+    int n;
+    int dtype;
+};
+
+__global__ void fill_scalars_kernel(const FillArgs a) {
+    const int i = threadIdx.x;
+    if (i < a.n) {
+        if (a.dtype == TDEQ_F32) reinterpret_cast<float*>(a.dst)[i] = (float)a.v[i];
+        else reinterpret_cast<double*>(a.dst)[i] = a.v[i];
+    }
+}
+
+}  // namespace tdeq

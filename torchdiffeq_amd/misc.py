@@ -1,0 +1,341 @@
+"""Host-side input normalisation for `odeint` / `odeint_adjoint`.
+
+Mirrors the observable behaviour of the reference's `_check_inputs` (torchdiffeq/_impl/misc.py:200-345)
+— tuple states, decreasing time, `perturb`, callbacks, default norms, the same exceptions — but is
+organised for the HIP path instead of a stack of `nn.Module` wrappers:
+
+  * a (tuple) state becomes ONE flat buffer with chunk-aligned segments (`StateLayout`), so a single
+    kernel launch covers the whole state and the norm kernels see the segment table;
+  * decreasing time is a sign carried next to `dt` (bit-identical to multiplying every func output by
+    -1, see include/tdeq_hip.h) instead of an extra full-state multiply per evaluation;
+  * time perturbation (`nextafter`) and the cast of `t` to the state dtype are host scalar arithmetic.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from enum import Enum
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native
+
+ALL_CALLBACK_NAMES = ["callback_step", "callback_accept_step", "callback_reject_step"]
+ALL_ADJOINT_CALLBACK_NAMES = [name + "_adjoint" for name in ALL_CALLBACK_NAMES]
+
+
+def _null_callback(*args, **kwargs):
+    return None
+
+
+class Perturb(Enum):
+    """Same protocol as the reference's `Perturb` (misc.py:168-171)."""
+    NONE = 0
+    PREV = 1
+    NEXT = 2
+
+
+def handle_unused_kwargs(solver, unused_kwargs) -> None:
+    if len(unused_kwargs) > 0:
+        warnings.warn("{}: Unexpected arguments {}".format(solver.__class__.__name__, unused_kwargs))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Built-in norms.  The solvers recognise these objects and evaluate them inside the fused error-norm
+# kernel; any other callable is treated as a user norm and receives a materialised tensor.
+# ---------------------------------------------------------------------------------------------------
+class BuiltinNorm:
+    """Marker base: max over the selected segments of sqrt(mean(x^2)) (misc.py:22-33)."""
+
+    def __init__(self, n_skip_tail: int = 0, name: str = "rms"):
+        self.n_skip_tail = n_skip_tail   # trailing segments left out of the max ('seminorm')
+        self.name = name
+
+    def __call__(self, x):
+        # Tensor-level definition, used only if someone calls the object directly (e.g. a user
+        # wrapping the default norm).  Runs on whatever device x lives on.
+        if isinstance(x, torch.Tensor):
+            return x.abs().pow(2).mean().sqrt()
+        vals = [xi.abs().pow(2).mean().sqrt() for xi in x if xi.numel() > 0]
+        if self.n_skip_tail:
+            vals = vals[:len(vals) - self.n_skip_tail]
+        return max(vals) if vals else 0.0
+
+    def __repr__(self):
+        return f"<torchdiffeq_amd builtin norm '{self.name}'>"
+
+
+rms_norm = BuiltinNorm(name="rms")        # default for tensor states (misc.py:265)
+mixed_norm = BuiltinNorm(name="mixed")    # default for tuple states (misc.py:245)
+
+
+# ---------------------------------------------------------------------------------------------------
+# State layout
+# ---------------------------------------------------------------------------------------------------
+class StateLayout:
+    """Flat layout of a (tuple) state: segment s occupies [offset[s], offset[s]+numel[s]) and every
+    offset is a multiple of `chunk` elements, so all segments are 16-byte aligned for the vector path
+    and no reduction chunk straddles two segments.  A single tensor is one unpadded segment."""
+
+    def __init__(self, shapes: Sequence[torch.Size], is_tuple: bool, chunk: Optional[int] = None):
+        self.shapes = [torch.Size(s) for s in shapes]
+        self.is_tuple = is_tuple
+        self.numels = [int(s.numel()) for s in self.shapes]
+        self.chunk = chunk or _native.pick_chunk(max(self.numels) if self.numels else 1)
+        self.offsets: List[int] = []
+        off = 0
+        for n in self.numels:
+            self.offsets.append(off)
+            off += max(1, math.ceil(n / self.chunk)) * self.chunk if len(self.shapes) > 1 else n
+        self.total = max(off, 1) if len(self.shapes) > 1 else (self.numels[0] if self.numels else 0)
+
+    @property
+    def n_seg(self) -> int:
+        return len(self.shapes)
+
+    def pack(self, tensors: Sequence[torch.Tensor], dtype=None, negate: Sequence[bool] = ()) -> torch.Tensor:
+        """Copy the components into a fresh flat buffer (a view if the state is a single tensor)."""
+        if len(self.shapes) == 1 and not negate:
+            t = tensors[0]
+            if dtype is not None and t.dtype != dtype:
+                t = t.to(dtype)
+            return t.reshape(-1).contiguous()
+        first = tensors[0]
+        flat = torch.empty(self.total, dtype=dtype or first.dtype, device=first.device)
+        for i, (t, off, n) in enumerate(zip(tensors, self.offsets, self.numels)):
+            dst = flat[off:off + n]
+            src = t.reshape(-1)
+            if negate and negate[i]:
+                torch.neg(src, out=dst) if src.dtype == dst.dtype else dst.copy_(-src)
+            else:
+                dst.copy_(src)
+        return flat
+
+    def unpack(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Tuple[torch.Tensor, ...]:
+        """Views of the components of `flat[..., total]` shaped (*lead, *shape)."""
+        return tuple(flat[..., off:off + n].view((*lead, *shape))
+                     for off, n, shape in zip(self.offsets, self.numels, self.shapes))
+
+    def segments(self, rtol, atol) -> List[Tuple[int, int, float, float]]:
+        """[(offset, numel, rtol, atol)] with scalar or per-component tolerances (misc.py:115-123)."""
+        rt = _per_segment(rtol, self.n_seg, "rtol")
+        at = _per_segment(atol, self.n_seg, "atol")
+        return [(off, n, r, a) for off, n, r, a in zip(self.offsets, self.numels, rt, at)]
+
+
+def _per_segment(tol, n_seg: int, name: str) -> List[float]:
+    if isinstance(tol, torch.Tensor):
+        if tol.dim() == 0:
+            return [float(tol)] * n_seg
+        tol = tol.tolist()
+    try:
+        vals = [float(torch.as_tensor(v)) for v in tol]
+    except TypeError:
+        return [float(tol)] * n_seg
+    assert len(vals) == n_seg, \
+        "If using tupled {} it must have the same length as the tuple y0".format(name)
+    return vals
+
+
+# ---------------------------------------------------------------------------------------------------
+# func wrapper
+# ---------------------------------------------------------------------------------------------------
+class OdeFunc:
+    """The user's `func(t, y)` as the solvers see it: flat state in, flat contiguous state out.
+
+    `eval(t, y_flat, perturb)` takes the (ascending, possibly negated) solver time as a host scalar,
+    applies the reference's `_PerturbFunc` / `_ReverseFunc` time semantics (misc.py:158-197) on the
+    host, and hands the user a 0-dim device tensor.  Outputs are NOT multiplied by the time sign —
+    the kernels fold it into `dt`.  Calling the object like the reference's wrapped func,
+    `f(t_tensor, y_flat, perturb=...)`, is also supported (third-party solver classes).
+    """
+
+    def __init__(self, base_func: Callable, layout: StateLayout, sign: float, dtype: torch.dtype,
+                 device: torch.device):
+        self.base_func = base_func
+        self.layout = layout
+        self.sign = float(sign)
+        self.dtype = dtype
+        self.device = device
+        self.np_dtype = np.float32 if dtype == torch.float32 else np.float64
+        self.nfe = 0
+        for name in ALL_CALLBACK_NAMES:
+            setattr(self, name, _null_callback)
+
+    # -- time handling -----------------------------------------------------------------------------
+    def user_time(self, t, perturb: Perturb = Perturb.NONE) -> float:
+        """Solver time -> the value the user's func sees (state-precision, perturbed, un-negated)."""
+        tt = self.np_dtype(t)
+        if perturb is Perturb.NEXT:
+            tt = np.nextafter(tt, tt + self.np_dtype(1))
+        elif perturb is Perturb.PREV:
+            tt = np.nextafter(tt, tt - self.np_dtype(1))
+        return float(self.sign * tt)
+
+    def time_tensor(self, value: float) -> torch.Tensor:
+        return torch.full((), value, dtype=self.dtype, device=self.device)
+
+    # -- evaluation --------------------------------------------------------------------------------
+    def eval(self, t, y_flat: torch.Tensor, perturb: Perturb = Perturb.NONE) -> torch.Tensor:
+        assert isinstance(perturb, Perturb), "perturb argument must be of type Perturb enum"
+        self.nfe += 1
+        t_user = self.time_tensor(self.user_time(t, perturb))
+        return self.call_base(t_user, y_flat)
+
+    def call_base(self, t_user: torch.Tensor, y_flat: torch.Tensor) -> torch.Tensor:
+        lay = self.layout
+        if lay.is_tuple:
+            f = self.base_func(t_user, lay.unpack(y_flat))
+            out = lay.pack(tuple(f), dtype=self.dtype)
+        else:
+            f = self.base_func(t_user, y_flat.view(lay.shapes[0]))
+            if f.dtype != self.dtype:
+                f = f.to(self.dtype)
+            out = f.reshape(-1)
+            if not out.is_contiguous():
+                out = out.contiguous()
+        if out.requires_grad:
+            raise NotImplementedError(
+                "torchdiffeq_amd.odeint runs the RK arithmetic in HIP kernels that are not recorded by "
+                "autograd; func returned a tensor that requires grad.  Use odeint_adjoint for gradients "
+                "(or wrap the call in torch.no_grad()).")
+        return out
+
+    def __call__(self, t, y_flat, *, perturb: Perturb = Perturb.NONE):
+        # Reference-style call: `t` is a 0-dim tensor in (negated) solver time.
+        return self.eval(float(t), y_flat, perturb) * self.sign if self.sign != 1.0 else \
+            self.eval(float(t), y_flat, perturb)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Input checks
+# ---------------------------------------------------------------------------------------------------
+def _assert_floating(name, t):
+    if not torch.is_floating_point(t):
+        raise TypeError("`{}` must be a floating point Tensor but is a {}".format(name, t.type()))
+
+
+def check_timelike(name, timelike, can_grad):
+    assert isinstance(timelike, torch.Tensor), "{} must be a torch.Tensor".format(name)
+    _assert_floating(name, timelike)
+    assert timelike.ndimension() == 1, "{} must be one dimensional".format(name)
+    if not can_grad:
+        assert not timelike.requires_grad, "{} cannot require gradient".format(name)
+    diff = timelike[1:] > timelike[:-1]
+    assert diff.all() or (~diff).all(), "{} must be strictly increasing or decreasing".format(name)
+
+
+def _flip_option(options, name):
+    value = options.get(name)
+    if isinstance(value, torch.Tensor):
+        options[name] = -value
+
+
+class CheckedInputs:
+    """Result of `check_inputs`: everything `odeint` needs to build and run a solver."""
+    __slots__ = ("layout", "func", "y0_flat", "t", "rtol", "atol", "method", "options", "event_fn",
+                 "t_is_reversed", "original_func")
+
+
+def check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS) -> CheckedInputs:
+    """Normalise `(func, y0, t, ...)`; same accept/reject behaviour as misc.py:200-345."""
+    if event_fn is not None:
+        raise NotImplementedError(
+            "event handling (odeint_event / event_fn) is outside the scope of the MI355X RK hot path; "
+            "see DESIGN.md 'out of scope'.")
+
+    original_func = func
+    is_tuple = not isinstance(y0, torch.Tensor)
+    if is_tuple:
+        assert isinstance(y0, tuple), "y0 must be either a torch.Tensor or a tuple"
+        for y0_ in y0:
+            assert isinstance(y0_, torch.Tensor), "y0 must be either a torch.Tensor or a tuple"
+        shapes = [y0_.shape for y0_ in y0]
+        first = y0[0]
+    else:
+        shapes = [y0.shape]
+        first = y0
+    dtype = first.dtype
+    device = first.device
+    if torch.is_complex(first):
+        raise NotImplementedError("complex states are outside the scope of the MI355X RK hot path")
+    _native.dtype_code(dtype)   # float32 / float64 only
+
+    if options is None:
+        options = {}
+    else:
+        options = options.copy()
+    if method is None:
+        method = "dopri5"
+    if method not in SOLVERS:
+        raise ValueError('Invalid method "{}". Must be one of {}'.format(
+            method, '{"' + '", "'.join(SOLVERS.keys()) + '"}.'))
+
+    layout = StateLayout(shapes, is_tuple)
+    if is_tuple:
+        y0_flat = layout.pack([y_.detach() for y_ in y0], dtype=dtype)
+        if "norm" in options:
+            user_norm = options["norm"]
+            if not isinstance(user_norm, BuiltinNorm):
+                def _norm(tensor, _user=user_norm, _lay=layout):
+                    return _user(_lay.unpack(tensor))
+                options["norm"] = _norm
+        else:
+            options["norm"] = mixed_norm
+    else:
+        y0_flat = y0.detach().reshape(-1).contiguous()
+        if "norm" not in options:
+            options["norm"] = rms_norm
+
+    check_timelike("t", t, True)
+    t_is_reversed = bool(len(t) > 1 and t[0] > t[1])
+    if t_is_reversed:
+        t = -t
+        if "grid_constructor" in options:
+            _gc = options["grid_constructor"]
+            options["grid_constructor"] = lambda func, y0, t: -_gc(func, y0, -t)
+        _flip_option(options, "step_t")
+        _flip_option(options, "jump_t")
+    assert (t[1:] > t[:-1]).all(), "t must be strictly increasing or decreasing"
+
+    if torch.is_tensor(rtol):
+        assert not rtol.requires_grad, "rtol cannot require gradient"
+    if torch.is_tensor(atol):
+        assert not atol.requires_grad, "atol cannot require gradient"
+
+    if t.device != device:
+        warnings.warn("t is not on the same device as y0. Coercing to y0.device.")
+        t = t.to(device)
+
+    wrapped = OdeFunc(func, layout, -1.0 if t_is_reversed else 1.0, dtype, device)
+
+    # Callbacks: attributes of the user's func, re-bound to the wrapped func (misc.py:313-343).
+    callback_names = set()
+    for name in ALL_CALLBACK_NAMES:
+        callback = getattr(original_func, name, None)
+        if callback is None or callback is _null_callback:
+            continue
+        callback_names.add(name)
+        if is_tuple:
+            def callback(t0, y0, dt, _callback=callback, _lay=layout):
+                return _callback(t0, _lay.unpack(y0), dt)
+        if t_is_reversed:
+            def callback(t0, y0, dt, _callback=callback):
+                return _callback(-t0, y0, dt)
+        setattr(wrapped, name, callback)
+    for name in ALL_ADJOINT_CALLBACK_NAMES:
+        callback = getattr(original_func, name, None)
+        if callback is not None:
+            setattr(wrapped, name, callback)
+
+    invalid = callback_names - SOLVERS[method].valid_callbacks()
+    if len(invalid) > 0:
+        warnings.warn("Solver '{}' does not support callbacks {}".format(method, invalid))
+
+    out = CheckedInputs()
+    out.layout, out.func, out.y0_flat, out.t = layout, wrapped, y0_flat, t
+    out.rtol, out.atol, out.method, out.options = rtol, atol, method, options
+    out.event_fn, out.t_is_reversed, out.original_func = event_fn, t_is_reversed, original_func
+    return out

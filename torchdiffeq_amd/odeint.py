@@ -1,0 +1,40 @@
+"""`odeint` and the `SOLVERS` plugin table — the drop-in surface of torchdiffeq/_impl/odeint.py:19-108
+for the explicit-RK hot path (dopri5, dopri8, rk4)."""
+from __future__ import annotations
+
+import torch
+
+from .misc import check_inputs
+from .solvers import Dopri5Solver, Dopri8Solver, RK4
+
+# method name -> solver class.  Same protocol as the reference's table (odeint.py:19-46):
+#   SOLVERS[method](func=..., y0=..., rtol=..., atol=..., **options).integrate(t)
+# The names below are the methods BASELINE.json's north_star puts on the MI355X hot path; the
+# reference's other methods (implicit / Adams / scipy ...) are out of scope.
+SOLVERS = {
+    "dopri8": Dopri8Solver,
+    "dopri5": Dopri5Solver,
+    "rk4": RK4,
+}
+
+
+def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None):
+    """Integrate dy/dt = func(t, y), y(t[0]) = y0, returning y at every time in `t`.
+
+    Same signature, defaults, return layout and error behaviour as the reference `odeint`
+    (odeint.py:49-108): `y0` is a Tensor or tuple of Tensors of any shape on a ROCm device, `t` a 1-D
+    strictly monotone float Tensor; returns a Tensor `[len(t), *y0.shape]` (tuple of such for tuple
+    states) in `y0.dtype` with `y[0] == y0`.  Raises ValueError for an unknown `method`.
+
+    The Runge–Kutta arithmetic runs in hand-written HIP kernels (libtdeq_hip.so); it is not recorded
+    by autograd — use `odeint_adjoint` for gradients, and call plain `odeint` under `torch.no_grad()`
+    when `func` has parameters that require grad (otherwise NotImplementedError is raised).
+    """
+    ci = check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS)
+    # Runs under the caller's grad mode: if `func` produces tensors that require grad, the wrapped func
+    # raises (loudly) instead of returning a silently non-differentiable solution.
+    solver = SOLVERS[ci.method](func=ci.func, y0=ci.y0_flat, rtol=ci.rtol, atol=ci.atol, **ci.options)
+    solution = solver.integrate(ci.t)
+    if ci.layout.is_tuple:
+        return ci.layout.unpack(solution, (len(ci.t),))
+    return solution.view(len(ci.t), *ci.layout.shapes[0])

@@ -1,0 +1,166 @@
+"""Butcher tableaus of the in-scope explicit Runge–Kutta methods, as host-side coefficient tables.
+
+Published constants (Dormand & Prince 1980 / Shampine 1986 for the 5(4) pair and its midpoint
+weights; Prince & Dormand 1981 for the 8(7) 13-stage pair).  The reference holds the same numbers as
+`torch.float64` tensors (torchdiffeq/_impl/dopri5.py:5-30, dopri8.py:5-70); here they are kept as
+rational text and turned into doubles the same way the reference's Python literals are evaluated
+(`num / den` in double; error weights as the double difference `b - b_hat`), so both libraries feed
+bit-identical fp64 coefficients to the kernels (checked in tests/test_tableaus.py against
+tests/golden/tableaus.npz).
+
+The kernels skip structural zeros, so every row is stored sparse: `(stage indices, coefficients)`.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+def _ratio(tok: str) -> float:
+    """'a/b' -> float(a)/float(b) (one rounding, like the Python literal `a / b`)."""
+    tok = tok.strip()
+    if "/" in tok:
+        num, den = tok.split("/")
+        return float(int(num)) / float(int(den))
+    return float(tok)
+
+
+def _row(text: str) -> List[float]:
+    return [_ratio(tok) for tok in text.split()]
+
+
+@dataclasses.dataclass(frozen=True)
+class SparseRow:
+    idx: Tuple[int, ...]      # stage slots with a non-zero weight
+    coef: Tuple[float, ...]   # fp64 weights (cast to the state dtype by the kernel)
+
+    @staticmethod
+    def from_dense(values: Sequence[float]) -> "SparseRow":
+        nz = [(i, float(v)) for i, v in enumerate(values) if v != 0.0]
+        return SparseRow(tuple(i for i, _ in nz), tuple(v for _, v in nz))
+
+
+@dataclasses.dataclass(frozen=True)
+class Tableau:
+    name: str
+    order: int
+    alpha: Tuple[float, ...]          # stage abscissae c_i, i = 1..S
+    beta: Tuple[Tuple[float, ...], ...]   # dense lower-triangular rows a_ij
+    c_sol: Tuple[float, ...]          # solution weights b_j over the S+1 stage slots
+    c_error: Tuple[float, ...]        # b_j - b_hat_j over the S+1 stage slots
+    c_mid: Tuple[float, ...]          # weights of y(t0 + dt/2) (dense output), S+1 slots
+
+    @property
+    def n_stages(self) -> int:
+        return len(self.alpha)
+
+    @property
+    def fsal_solution(self) -> bool:
+        """True when the last stage input already equals y1 (rk_common.py:83: no extra combine)."""
+        return self.c_sol[-1] == 0.0 and tuple(self.c_sol[:-1]) == tuple(self.beta[-1])
+
+    def beta_rows(self) -> List[SparseRow]:
+        return [SparseRow.from_dense(r) for r in self.beta]
+
+    def dense(self):
+        """Dense fp64 numpy views (alpha, beta rows, c_sol, c_error, c_mid) for tests."""
+        return (np.array(self.alpha), [np.array(r) for r in self.beta], np.array(self.c_sol),
+                np.array(self.c_error), np.array(self.c_mid))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Dormand–Prince 5(4), 7 stage slots (FSAL).  dopri5.py:5-30
+# ---------------------------------------------------------------------------------------------------
+_DP5_ALPHA = "1/5 3/10 4/5 8/9 1 1"
+_DP5_A = """
+1/5
+3/40 9/40
+44/45 -56/15 32/9
+19372/6561 -25360/2187 64448/6561 -212/729
+9017/3168 -355/33 46732/5247 49/176 -5103/18656
+35/384 0 500/1113 125/192 -2187/6784 11/84
+"""
+_DP5_B = "35/384 0 500/1113 125/192 -2187/6784 11/84 0"
+_DP5_BHAT = "1951/21600 0 22642/50085 451/720 -12231/42400 649/6300 1/60"
+# Shampine's midpoint weights, stored as 2*w (the table value is halved below).
+_DP5_MID2 = ("6025192743/30085553152 0 51252292925/65400821598 -2691868925/45128329728 "
+             "187940372067/1594534317056 -1776094331/19743644256 11237099/235043384")
+
+
+def _dopri5() -> Tableau:
+    b = _row(_DP5_B)
+    bhat = _row(_DP5_BHAT)
+    err = [bj - bh for bj, bh in zip(b, bhat)]
+    err[-1] = -1.0 / 60.0
+    mid = [v / 2 for v in _row(_DP5_MID2)]
+    rows = tuple(tuple(_row(line)) for line in _DP5_A.strip().splitlines())
+    return Tableau("dopri5", 5, tuple(_row(_DP5_ALPHA)), rows, tuple(b), tuple(err), tuple(mid))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Prince–Dormand 8(7), 14 stage slots (FSAL).  dopri8.py:5-70
+# ---------------------------------------------------------------------------------------------------
+_DP8_ALPHA = ("1/18 1/12 1/8 5/16 3/8 59/400 93/200 5490023248/9719169821 13/20 "
+              "1201146811/1299019798 1 1 1")
+_DP8_A = """
+1/18
+1/48 1/16
+1/32 0 3/32
+5/16 0 -75/64 75/64
+3/80 0 0 3/16 3/20
+29443841/614563906 0 0 77736538/692538347 -28693883/1125000000 23124283/1800000000
+16016141/946692911 0 0 61564180/158732637 22789713/633445777 545815736/2771057229 -180193667/1043307555
+39632708/573591083 0 0 -433636366/683701615 -421739975/2616292301 100302831/723423059 790204164/839813087 800635310/3783071287
+246121993/1340847787 0 0 -37695042795/15268766246 -309121744/1061227803 -12992083/490766935 6005943493/2108947869 393006217/1396673457 123872331/1001029789
+-1028468189/846180014 0 0 8478235783/508512852 1311729495/1432422823 -10304129995/1701304382 -48777925059/3047939560 15336726248/1032824649 -45442868181/3398467696 3065993473/597172653
+185892177/718116043 0 0 -3185094517/667107341 -477755414/1098053517 -703635378/230739211 5731566787/1027545527 5232866602/850066563 -4093664535/808688257 3962137247/1805957418 65686358/487910083
+403863854/491063109 0 0 -5068492393/434740067 -411421997/543043805 652783627/914296604 11173962825/925320556 -13158990841/6184727034 3936647629/1978049680 -160528059/685178525 248638103/1413531060 0
+14005451/335480064 0 0 0 0 -59238493/1068277825 181606767/758867731 561292985/797845732 -1041891430/1371343529 760417239/1151165299 118820643/751138087 -528747749/2220607170 1/4
+"""
+_DP8_B = ("14005451/335480064 0 0 0 0 -59238493/1068277825 181606767/758867731 561292985/797845732 "
+          "-1041891430/1371343529 760417239/1151165299 118820643/751138087 -528747749/2220607170 1/4 0")
+_DP8_BHAT = ("13451932/455176623 0 0 0 0 -808719846/976000145 1757004468/5645159321 "
+             "656045339/265891186 -3867574721/1518517206 465885868/322736535 53011238/667516719 2/45 0 0")
+# Dense-output polynomials b_j(theta) (descending powers theta^5..theta^1, then the constant term),
+# evaluated at theta = 1/2 for the midpoint weights.  slot -> coefficients.
+_DP8_DENSE = {
+    0: "-6.3448349392860401388 22.1396504998094068976 -30.0610568289666450593 19.9990069333683970610 -6.6910181737837595697 1.0",
+    5: "-39.6107919852202505218 116.4422149550342161651 -121.4999627731334642623 52.2273532792945524050 -7.6142658045872677172",
+    6: "20.3761213808791436958 -67.1451318825957197185 83.1721004639847717481 -46.8919164181093621583 10.7281392630428866124",
+    7: "7.3347098826795362023 -16.5672243527496524646 9.5724507555993664382 -0.1890893225010595467 0.5526637063753648783",
+    8: "32.8801774352459155182 -89.9916014847245016028 87.8406057677205645007 -35.7075975946222072821 4.2186562625665153803",
+    9: "-10.1588990526426760954 22.6237489648532849093 -17.4152107770762969005 6.2736448083240352160 -0.6627209125361597559",
+    10: "-12.5401268098782561200 32.2362340167355370113 -28.5903289514790976966 10.3160881272450748458 -1.2636789001135462218",
+    11: "29.5553001484516038033 -82.1020315488359848644 81.6630950584341412934 -34.7650769866611817349 5.4106037898590422230",
+    12: "-41.7923486424390588923 116.2662185791119533462 -114.9375291377009418170 47.7457971078225540396 -7.0321379067945741781",
+    13: "20.3006925822100825485 -53.9020777466385396792 50.2558364226176017553 -19.0082099341608028453 2.3537586759714983486",
+}
+
+
+def _dense_weight(coeffs: Sequence[float], theta: float) -> float:
+    """sum_p c_p theta^p (left to right, descending powers) scaled by theta — dopri8.py:31-66."""
+    total = None
+    for power, c in zip((5, 4, 3, 2, 1), coeffs[:5]):
+        term = c * (theta ** power)
+        total = term if total is None else total + term
+    if len(coeffs) > 5:
+        total = total + coeffs[5]
+    return total / (1 / theta)
+
+
+def _dopri8() -> Tableau:
+    b = _row(_DP8_B)
+    bhat = _row(_DP8_BHAT)
+    err = [bj - bh for bj, bh in zip(b, bhat)]
+    err[12], err[13] = 1.0 / 4.0, 0.0
+    mid = [0.0] * 14
+    for slot, text in _DP8_DENSE.items():
+        mid[slot] = _dense_weight([float(tok) for tok in text.split()], 0.5)
+    rows = tuple(tuple(_row(line)) for line in _DP8_A.strip().splitlines())
+    return Tableau("dopri8", 8, tuple(_row(_DP8_ALPHA)), rows, tuple(b), tuple(err), tuple(mid))
+
+
+DOPRI5 = _dopri5()
+DOPRI8 = _dopri8()
