@@ -1,0 +1,308 @@
+"""Generate the golden vectors in tests/golden/*.npz by running the REFERENCE itself.
+
+Run in the build container only (the reference is mounted read-only at /root/reference and does not
+exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Every array stored here is an output of rtqichen/torchdiffeq v0.2.5 functions on CPU (or an input fed
+to them), so the CPU oracle (oracle/) and the HIP path can be pinned to the reference without the
+reference being present.  Nothing from the reference's source is copied — only its numerical outputs.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+
+import torchdiffeq  # noqa: E402
+from torchdiffeq._impl import dopri5, dopri8, interp, misc, rk_common  # noqa: E402
+from torchdiffeq._impl.misc import Perturb  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(1)   # one thread: the reference's fp32 reductions depend on the thread count
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
+def rand(*shape, seed, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64).to(dtype)
+
+
+# ---------------------------------------------------------------------------------------------------
+def gen_tableaus():
+    arrays = {}
+    for name, tab, mid in [("dopri5", dopri5._DORMAND_PRINCE_SHAMPINE_TABLEAU, dopri5.DPS_C_MID),
+                           ("dopri8", dopri8._DOPRI8_TABLEAU, dopri8._C_mid)]:
+        arrays[f"{name}_alpha"] = tab.alpha
+        arrays[f"{name}_beta_flat"] = torch.cat(list(tab.beta))
+        arrays[f"{name}_c_sol"] = tab.c_sol
+        arrays[f"{name}_c_error"] = tab.c_error
+        arrays[f"{name}_c_mid"] = mid
+    save("tableaus.npz", **arrays)
+
+
+class Replay:
+    """A `func` that returns pre-drawn stage derivatives and records what the solver passes in."""
+
+    def __init__(self, ks):
+        self.ks, self.i, self.seen_y, self.seen_t, self.seen_p = ks, 0, [], [], []
+
+    def __call__(self, t, y, perturb=Perturb.NONE):
+        self.seen_t.append(float(t))
+        self.seen_y.append(y.clone())
+        self.seen_p.append(perturb.value)
+        out = self.ks[self.i]
+        self.i += 1
+        return out
+
+
+def gen_kernel_vectors():
+    """_runge_kutta_step / _compute_error_ratio / _interp_fit / _interp_evaluate on random stages."""
+    arrays = {}
+    n = 1031
+    for mname, solver_cls in [("dopri5", dopri5.Dopri5Solver), ("dopri8", dopri8.Dopri8Solver)]:
+        for dname, dtype in [("f32", torch.float32), ("f64", torch.float64)]:
+            key = f"{mname}_{dname}"
+            y0 = rand(n, seed=1, dtype=dtype)
+            S = len(solver_cls.tableau.alpha)
+            ks = [rand(n, seed=10 + j, dtype=dtype) for j in range(S + 1)]
+            solver = solver_cls(func=None, y0=y0, rtol=1e-3, atol=1e-4, norm=misc._rms_norm)
+            t0 = torch.tensor(0.3, dtype=torch.float64)
+            dt = torch.tensor(0.0371, dtype=torch.float64)
+            replay = Replay(ks[1:])
+            y1, f1, y1_error, k = rk_common._runge_kutta_step(replay, y0, ks[0], t0, dt, t0 + dt, solver.tableau)
+            ratio = misc._compute_error_ratio(y1_error, solver.rtol, solver.atol, y0, y1, misc._rms_norm)
+            coeffs = solver._interp_fit(y0, y1, k, dt)
+            t_eval = t0 + 0.3 * dt
+            y_eval = interp._interp_evaluate(coeffs, t0, t0 + dt, t_eval)
+            arrays[f"{key}_y0"] = y0
+            arrays[f"{key}_k"] = torch.stack(ks)
+            arrays[f"{key}_t0_dt"] = torch.stack([t0, dt])
+            arrays[f"{key}_stage_inputs"] = torch.stack(replay.seen_y)
+            arrays[f"{key}_stage_times"] = torch.tensor(replay.seen_t, dtype=torch.float64)
+            arrays[f"{key}_stage_perturb"] = torch.tensor(replay.seen_p)
+            arrays[f"{key}_y1"] = y1
+            arrays[f"{key}_y1_error"] = y1_error
+            arrays[f"{key}_error_ratio"] = ratio.to(torch.float64)
+            arrays[f"{key}_rtol_atol"] = torch.tensor([1e-3, 1e-4], dtype=torch.float64)
+            arrays[f"{key}_interp_coeffs"] = torch.stack(coeffs)
+            arrays[f"{key}_t_eval"] = t_eval
+            arrays[f"{key}_y_eval"] = y_eval
+    # rk4 3/8-rule increments
+    for dname, dtype in [("f32", torch.float32), ("f64", torch.float64)]:
+        y0 = rand(n, seed=1, dtype=dtype)
+        ks = [rand(n, seed=10 + j, dtype=dtype) for j in range(4)]
+        replay = Replay(ks[1:])
+        t0 = torch.tensor(0.3, dtype=dtype)
+        dt = torch.tensor(0.025, dtype=dtype)
+        dy = rk_common.rk4_alt_step_func(replay, t0, dt, t0 + dt, y0, f0=ks[0])
+        arrays[f"rk4_{dname}_y0"] = y0
+        arrays[f"rk4_{dname}_k"] = torch.stack(ks)
+        arrays[f"rk4_{dname}_t0_dt"] = torch.stack([t0, dt]).to(torch.float64)
+        arrays[f"rk4_{dname}_stage_inputs"] = torch.stack(replay.seen_y)
+        arrays[f"rk4_{dname}_stage_times"] = torch.tensor(replay.seen_t, dtype=torch.float64)
+        arrays[f"rk4_{dname}_y1"] = y0 + dy
+    save("kernels.npz", **arrays)
+
+
+def gen_controller_vectors():
+    """_optimal_step_size and _select_initial_step on scalar / small inputs."""
+    cases, outs = [], []
+    for last_step in [0.1, 1e-3, 2.5]:
+        for ratio in [0.0, 1e-8, 0.3, 0.999, 1.0, 1.7, 50.0, 1e6, float("nan"), float("inf")]:
+            for order in [5, 8]:
+                args = [last_step, ratio, 0.9, 10.0, 0.2, order]
+                r = misc._optimal_step_size(torch.tensor(last_step, dtype=torch.float64),
+                                            torch.tensor(ratio, dtype=torch.float32),
+                                            torch.tensor(0.9, dtype=torch.float64),
+                                            torch.tensor(10.0, dtype=torch.float64),
+                                            torch.tensor(0.2, dtype=torch.float64), order)
+                cases.append(args)
+                outs.append(float(r))
+    arrays = {"optimal_step_in": np.array(cases), "optimal_step_out": np.array(outs)}
+    # initial step for a linear field
+    for dname, dtype in [("f32", torch.float32), ("f64", torch.float64)]:
+        A = rand(16, 16, seed=3, dtype=dtype) / 4
+        y0 = rand(40, 16, seed=4, dtype=dtype)
+        func = misc._PerturbFunc(lambda t, y: y @ A.T)
+        for order in [4, 7]:
+            for scale_y in [1.0, 1e-7]:
+                yy = y0 * scale_y
+                h = misc._select_initial_step(func, torch.tensor(0.5, dtype=torch.float64), yy, order,
+                                              torch.tensor(1e-6, dtype=torch.float64),
+                                              torch.tensor(1e-8, dtype=torch.float64), misc._rms_norm)
+                arrays[f"init_{dname}_o{order}_s{scale_y}"] = h
+        arrays[f"init_{dname}_A"] = A
+        arrays[f"init_{dname}_y0"] = y0
+    save("controller.npz", **arrays)
+
+
+class Counter:
+    def __init__(self):
+        self.accept, self.reject = [], []
+
+
+def solve(func, y0, t, **kw):
+    """Reference odeint with step statistics (via the reference's own callbacks)."""
+    c = Counter()
+
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.nfe = 0
+
+        def forward(self, t, y):
+            self.nfe += 1
+            return func(t, y)
+
+        def callback_accept_step(self, t0, y0, dt):
+            c.accept.append(float(dt))
+
+        def callback_reject_step(self, t0, y0, dt):
+            c.reject.append(float(dt))
+
+    f = F()
+    with torch.no_grad():
+        y = torchdiffeq.odeint(f, y0, t, **kw)
+    return y, f.nfe, c
+
+
+def linear_problem(B, D, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    G = torch.randn(D, D, generator=g, dtype=torch.float64) / D ** 0.5
+    A = 0.5 * (G - G.T) - 0.1 * torch.eye(D, dtype=torch.float64)
+    y0 = torch.randn(B, D, generator=g, dtype=torch.float64)
+    return A.to(dtype), y0.to(dtype)
+
+
+def gen_solves():
+    arrays = {}
+    # cfg1: spiral, rk4 on the output grid (examples/ode_demo.py:29-41 with method='rk4')
+    A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]])
+    y0 = torch.tensor([[2.0, 0.0]])
+    t = torch.linspace(0.0, 25.0, 1000)
+    with torch.no_grad():
+        y = torchdiffeq.odeint(lambda t, y: (y ** 3) @ A, y0, t, method="rk4")
+    arrays.update(cfg1_A=A, cfg1_y0=y0, cfg1_t=t, cfg1_y=y)
+
+    # cfg2 (reduced batch): dopri5, dy/dt = A y, fp32; reference-default and looser tolerances
+    A, y0 = linear_problem(64, 128, torch.float32)
+    arrays.update(cfg2_A=A, cfg2_y0=y0)
+    for tag, rtol, atol, tt in [("tight", 1e-7, 1e-9, [0.0, 1.0]), ("loose", 1e-5, 1e-7, [0.0, 0.25, 0.5, 1.0]),
+                                ("rev", 1e-5, 1e-7, [1.0, 0.4, 0.0])]:
+        t = torch.tensor(tt, dtype=torch.float64)
+        y, nfe, c = solve(lambda t, y: y @ A.T, y0, t, rtol=rtol, atol=atol, method="dopri5")
+        arrays[f"cfg2_{tag}_t"] = t
+        arrays[f"cfg2_{tag}_tol"] = np.array([rtol, atol])
+        arrays[f"cfg2_{tag}_y"] = y
+        arrays[f"cfg2_{tag}_nfe"] = nfe
+        arrays[f"cfg2_{tag}_accept_dt"] = np.array(c.accept)
+        arrays[f"cfg2_{tag}_reject_dt"] = np.array(c.reject)
+
+    # cfg4 (reduced): dopri8 fp64, rtol 1e-9
+    A, y0 = linear_problem(32, 64, torch.float64, seed=1)
+    t = torch.tensor([0.0, 0.3, 1.0], dtype=torch.float64)
+    y, nfe, c = solve(lambda t, y: y @ A.T, y0, t, rtol=1e-9, atol=1e-11, method="dopri8")
+    arrays.update(cfg4_A=A, cfg4_y0=y0, cfg4_t=t, cfg4_y=y, cfg4_nfe=nfe, cfg4_accept_dt=np.array(c.accept),
+                  cfg4_reject_dt=np.array(c.reject))
+
+    # dopri5 fp64 with rejections (stiff-ish scaling) and a time-dependent field
+    A, y0 = linear_problem(16, 8, torch.float64, seed=2)
+    t = torch.tensor([0.0, 2.0, 5.0], dtype=torch.float64)
+    y, nfe, c = solve(lambda t, y: torch.sin(3 * t) * (y @ A.T) * 4 - y ** 3, y0, t, rtol=1e-8, atol=1e-10,
+                      method="dopri5")
+    arrays.update(tdep_A=A, tdep_y0=y0, tdep_t=t, tdep_y=y, tdep_nfe=nfe, tdep_accept_dt=np.array(c.accept),
+                  tdep_reject_dt=np.array(c.reject))
+
+    # tuple state (mixed norm)
+    A, y0 = linear_problem(30, 8, torch.float32, seed=3)
+    ya, yb = y0[:10].clone(), y0[10:].clone()
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64)
+    with torch.no_grad():
+        out = torchdiffeq.odeint(lambda t, y: (y[0] @ A.T, 2 * (y[1] @ A.T)), (ya, yb), t, rtol=1e-6, atol=1e-8)
+    arrays.update(tuple_A=A, tuple_ya=ya, tuple_yb=yb, tuple_t=t, tuple_out_a=out[0], tuple_out_b=out[1])
+
+    # options: first_step / step_t / jump_t / max_step (fp64, dopri5)
+    A, y0 = linear_problem(8, 8, torch.float64, seed=4)
+    t = torch.tensor([0.0, 1.0, 2.0], dtype=torch.float64)
+    for tag, opts in [("first_step", dict(first_step=0.01)),
+                      ("step_t", dict(step_t=torch.tensor([0.25, 1.5]))),
+                      ("jump_t", dict(jump_t=torch.tensor([0.7]))),
+                      ("max_step", dict(max_step=0.05)),
+                      ("min_step", dict(min_step=0.2))]:
+        y, nfe, c = solve(lambda t, y: y @ A.T, y0, t, rtol=1e-6, atol=1e-8, method="dopri5", options=opts)
+        arrays[f"opt_{tag}_y"] = y
+        arrays[f"opt_{tag}_nfe"] = nfe
+        arrays[f"opt_{tag}_accept_dt"] = np.array(c.accept)
+        arrays[f"opt_{tag}_reject_dt"] = np.array(c.reject)
+    arrays.update(opt_A=A, opt_y0=y0, opt_t=t)
+
+    # rk4 with step_size (linear interpolation of outputs) and perturb
+    A, y0 = linear_problem(4, 8, torch.float32, seed=5)
+    t = torch.tensor([0.0, 0.33, 1.0])
+    with torch.no_grad():
+        y = torchdiffeq.odeint(lambda t, y: y @ A.T, y0, t, method="rk4", options=dict(step_size=0.1))
+        yp = torchdiffeq.odeint(lambda t, y: torch.cos(t) * (y @ A.T), y0, t, method="rk4",
+                                options=dict(step_size=0.1, perturb=True))
+    arrays.update(rk4s_A=A, rk4s_y0=y0, rk4s_t=t, rk4s_y=y, rk4s_y_perturb=yp)
+    save("solves.npz", **arrays)
+
+
+def gen_adjoint():
+    """cfg3 (reduced): odeint_adjoint through a tanh MLP, loss = sum(y(T)^2) (+ intermediate outputs)."""
+    arrays = {}
+    for tag, dtype, d, h, B, rtol, atol, tt in [("f32", torch.float32, 16, 32, 96, 1e-5, 1e-7, [0.0, 1.0]),
+                                                 ("f64", torch.float64, 8, 16, 40, 1e-8, 1e-10, [0.0, 0.5, 1.0])]:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(d, h), torch.nn.Tanh(), torch.nn.Linear(h, h), torch.nn.Tanh(),
+                                  torch.nn.Linear(h, d)).to(dtype)
+
+        class F(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.net = net
+
+            def forward(self, t, y):
+                return self.net(y)
+
+        f = F()
+        y0 = rand(B, d, seed=7, dtype=dtype).requires_grad_(True)
+        t = torch.tensor(tt, dtype=torch.float64)
+        for norm_tag, aopts in [("default", None), ("seminorm", dict(norm="seminorm"))]:
+            for p in f.parameters():
+                p.grad = None
+            y0.grad = None
+            y = torchdiffeq.odeint_adjoint(f, y0, t, rtol=rtol, atol=atol, method="dopri5", adjoint_options=aopts)
+            loss = y[-1].pow(2).sum() + (y[1:].sum() if len(tt) > 2 else 0.0)
+            loss.backward()
+            arrays[f"adj_{tag}_{norm_tag}_y"] = y
+            arrays[f"adj_{tag}_{norm_tag}_grad_y0"] = y0.grad
+            for i, p in enumerate(f.parameters()):
+                arrays[f"adj_{tag}_{norm_tag}_grad_p{i}"] = p.grad
+        arrays[f"adj_{tag}_y0"] = y0
+        arrays[f"adj_{tag}_t"] = t
+        arrays[f"adj_{tag}_tol"] = np.array([rtol, atol])
+        for i, p in enumerate(f.parameters()):
+            arrays[f"adj_{tag}_p{i}"] = p
+    save("adjoint.npz", **arrays)
+
+
+if __name__ == "__main__":
+    gen_tableaus()
+    gen_kernel_vectors()
+    gen_controller_vectors()
+    gen_solves()
+    gen_adjoint()

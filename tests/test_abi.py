@@ -1,0 +1,62 @@
+"""The C-ABI library builds for gfx950, loads without a GPU and exports what include/tdeq_hip.h declares."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tdeq_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tdeq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_build_and_symbols():
+    from torchdiffeq_amd import _native, build
+    path = build.build()
+    assert os.path.exists(path)
+    lib = _native.load_library(path)          # binds every symbol of ABI_SIGNATURES, checks the version
+    declared = _declared_symbols()
+    assert declared, "header parse failed"
+    assert sorted(_native.ABI_SIGNATURES) == declared
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.tdeq_abi_version() == _native.TDEQ_ABI_VERSION
+    assert lib.tdeq_workspace_bytes(10) == 10 * 3 * 8
+
+
+def test_argument_errors_without_gpu():
+    """Validation happens before any launch, so bad arguments are reported without a GPU."""
+    import ctypes
+    from torchdiffeq_amd import _native
+    lib = _native.load_library()
+    buf = (ctypes.c_double * 4)()
+    ptrs = (ctypes.c_void_p * 1)(ctypes.addressof(buf))
+    p = ctypes.addressof(buf)
+    assert lib.tdeq_stage_combine(None, p, ptrs, buf, 1, 0.1, 4, 1, None) == -1       # null out
+    assert lib.tdeq_stage_combine(p, p, ptrs, buf, 0, 0.1, 4, 1, None) == -1          # n_terms < 1
+    assert lib.tdeq_stage_combine(p, p, ptrs, buf, 15, 0.1, 4, 1, None) == -1         # n_terms > 14
+    assert lib.tdeq_stage_combine(p, p, ptrs, buf, 1, 0.1, 4, 7, None) == -1          # bad dtype
+    assert lib.tdeq_stage_combine(p, p, ptrs, buf, 1, 0.1, 0, 1, None) == 0           # empty state: no-op
+    assert lib.tdeq_rk4_38_stage(5, p, p, p, p, p, p, 0.1, 4, 1, None) == -1
+    assert lib.tdeq_fill_scalars(p, buf, 17, 1, None) == -1
+
+
+def test_cpu_state_is_rejected_loudly():
+    import torch
+    import torchdiffeq_amd as tda
+    from torchdiffeq_amd._native import NativeLibraryError
+    with pytest.raises(NativeLibraryError):
+        tda.odeint(lambda t, y: -y, torch.ones(3), torch.tensor([0.0, 1.0]))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "torchdiffeq_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") or f.endswith(".hip") or f.endswith(".hpp"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "rk_oracle" not in text, f

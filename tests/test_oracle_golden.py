@@ -1,0 +1,237 @@
+"""Pin the CPU oracle (oracle/rk_oracle.c, oracle/reference_solver.py) to the reference's own outputs.
+
+Tolerances
+  * elementwise kernels: <= 2 ulp of the state dtype — `torch.sum` over the short stage dimension is
+    not a left-to-right sum, so bitwise agreement with the reference is not defined;
+    rk4 (no reductions anywhere) must be BIT-EXACT.
+  * error ratio: the reference reduces in T with ATen's blocked order, the oracle in fp64: 1e-6 (fp32),
+    1e-13 (fp64) relative.
+  * whole solves: fp64 1e-12; fp32 per case (noise floor, see _cases.SOLVE_CASES).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _cases import SOLVE_CASES, T, load, rel_err
+from oracle import reference_solver as orc
+from oracle.kernels import OracleKernels
+
+KERN = OracleKernels()
+ULP = {"f32": 2.0 ** -23, "f64": 2.0 ** -52}
+
+
+def _ulp_err(a, b, scale, eps):
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)) / (np.abs(scale).astype(np.float64) + 1e-300))) / eps
+
+
+@pytest.mark.parametrize("method", ["dopri5", "dopri8"])
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+@pytest.mark.parametrize("ops_cls", [orc.NumpyOps, orc.COps], ids=["numpy", "c"])
+def test_rk_step_vectors(method, dname, ops_cls):
+    """_runge_kutta_step: stage inputs, y1, y1_error; _compute_error_ratio; _interp_fit/_evaluate."""
+    z = load("kernels.npz")
+    key = f"{method}_{dname}"
+    ops = ops_cls()
+    tab = orc.tableau(method)
+    y0, k = z[f"{key}_y0"], z[f"{key}_k"]
+    t0, dt = z[f"{key}_t0_dt"]
+    Tn = y0.dtype.type
+    dt_T = Tn(dt)
+    eps = ULP[dname]
+    # stage inputs (rk_common.py:79) — magnitude scale: |y0| + sum |c_j k_j|
+    for i, beta in enumerate(tab.beta):
+        idx, coef = orc._nz(beta)
+        got = ops.combine(y0, [k[j] for j in idx], coef, dt_T)
+        ref = z[f"{key}_stage_inputs"][i]
+        scale = np.abs(y0) + sum(abs(c * dt) * np.abs(k[j]) for j, c in zip(idx, coef))
+        assert _ulp_err(got, ref, scale, eps) <= 2.0, (i,)
+    assert np.array_equal(z[f"{key}_stage_inputs"][-1], z[f"{key}_y1"])   # FSAL: y1 is the last stage input
+    # stage times and perturbation flags (rk_common.py:72-78) via a recording solver run
+    seen = []
+    solver = orc.AdaptiveRK(lambda tt, y: (seen.append(float(tt)), k[len(seen)])[1], y0, tab, 1e-3, 1e-4, ops=ops,
+                            first_step=float(dt))
+    solver.y1, solver.f1, solver.t0, solver.t1, solver.dt, solver.rec = y0, k[0], float(t0), float(t0), float(dt), None
+    solver.adaptive_step()
+    # the golden times were recorded BEFORE the reference's _PerturbFunc; apply misc.py:185-196 here
+    ref_times = []
+    for tt, p in zip(z[f"{key}_stage_times"], z[f"{key}_stage_perturb"]):
+        tt = Tn(tt)
+        ref_times.append(float(np.nextafter(tt, tt - Tn(1)) if p == 1 else tt))
+    assert seen == ref_times
+    assert list(z[f"{key}_stage_perturb"]) == [1 if a == 1.0 else 0 for a in tab.alpha]
+    # error estimate -> ratio (rk_common.py:89, misc.py:80-82)
+    idx, coef = orc._nz(tab.c_error)
+    rtol, atol = z[f"{key}_rtol_atol"]
+    mean_sq, bad = ops.error_ratio_sq(y0, z[f"{key}_y1"], [k[j] for j in idx], coef, dt_T, [rtol], [atol], [(0, y0.size)])
+    ratio = float(Tn(math.sqrt(mean_sq[0])))
+    assert not bad
+    assert ratio == pytest.approx(float(z[f"{key}_error_ratio"]), rel=1e-6 if dname == "f32" else 1e-13)
+    # dense output (rk_common.py:363-369, interp.py)
+    idx, coef = orc._nz(tab.c_mid)
+    t_eval = float(z[f"{key}_t_eval"])
+    x = Tn((t_eval - t0) / ((t0 + dt) - t0))
+    got = ops.dense_eval(y0, z[f"{key}_y1"], k[0], k[-1], [k[j] for j in idx], coef, dt_T, x)
+    ref = z[f"{key}_y_eval"]
+    coeffs = z[f"{key}_interp_coeffs"]
+    scale = sum(np.abs(c) for c in coeffs) + 64 * (np.abs(y0) + np.abs(z[f"{key}_y1"]))
+    assert _ulp_err(got, ref, scale, eps) <= 2.0
+
+
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+def test_interp_fit_planes(dname):
+    z = load("kernels.npz")
+    for method in ("dopri5", "dopri8"):
+        key = f"{method}_{dname}"
+        tab = orc.tableau(method)
+        y0, k, y1 = T(z[f"{key}_y0"]), T(z[f"{key}_k"]), T(z[f"{key}_y1"])
+        dt = float(z[f"{key}_t0_dt"][1])
+        idx, coef = orc._nz(tab.c_mid)
+        out = torch.empty(5 * y0.numel(), dtype=y0.dtype)
+        KERN.interp_fit(out, y0, y1, k[0].contiguous(), k[-1].contiguous(), [k[j].contiguous() for j in idx], coef, dt)
+        ref = z[f"{key}_interp_coeffs"]
+        got = out.view(5, -1).numpy()
+        assert np.array_equal(got[0], ref[0])                       # e = y0
+        scale = np.abs(ref).sum(0) + 64 * (np.abs(z[f"{key}_y0"]) + np.abs(z[f"{key}_y1"]))
+        for p in range(1, 5):
+            assert _ulp_err(got[p], ref[p], scale, ULP[dname]) <= 2.0, p
+
+
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+def test_rk4_is_bit_exact(dname):
+    """rk4_alt_step_func has no reductions: stage inputs and y1 are reproduced bit for bit."""
+    z = load("kernels.npz")
+    y0, k = z[f"rk4_{dname}_y0"], z[f"rk4_{dname}_k"]
+    dt = z[f"rk4_{dname}_t0_dt"][1]
+    ops = orc.NumpyOps()
+    ref_in = z[f"rk4_{dname}_stage_inputs"]
+    assert np.array_equal(ops.rk4_stage(1, y0, k[0], None, None, None, dt), ref_in[0])
+    assert np.array_equal(ops.rk4_stage(2, y0, k[0], k[1], None, None, dt), ref_in[1])
+    assert np.array_equal(ops.rk4_stage(3, y0, k[0], k[1], k[2], None, dt), ref_in[2])
+    assert np.array_equal(ops.rk4_stage(4, y0, k[0], k[1], k[2], k[3], dt), z[f"rk4_{dname}_y1"])
+    ty0, tk = T(y0), [T(k[j]).contiguous() for j in range(4)]
+    for stage, ref in [(1, ref_in[0]), (2, ref_in[1]), (3, ref_in[2]), (4, z[f"rk4_{dname}_y1"])]:
+        out = torch.empty_like(ty0)
+        KERN.rk4_stage(stage, out, ty0, *[tk[j] if j < stage else None for j in range(4)], float(dt))
+        assert np.array_equal(out.numpy(), ref), stage
+
+
+def test_c_and_numpy_ops_agree_bitwise():
+    z = load("kernels.npz")
+    a, b = orc.NumpyOps(), orc.COps()
+    for key in ("dopri5_f32", "dopri8_f64"):
+        tab = orc.tableau(key.split("_")[0])
+        y0, k, y1 = z[f"{key}_y0"], z[f"{key}_k"], z[f"{key}_y1"]
+        for beta in tab.beta:
+            idx, coef = orc._nz(beta)
+            assert np.array_equal(a.combine(y0, [k[j] for j in idx], coef, 0.05), b.combine(y0, [k[j] for j in idx], coef, 0.05))
+        idx, coef = orc._nz(tab.c_mid)
+        args = (y0, y1, k[0], k[-1], [k[j] for j in idx], coef, 0.05, 0.3)
+        assert np.array_equal(a.dense_eval(*args), b.dense_eval(*args))
+        idx, coef = orc._nz(tab.c_error)
+        ra, _ = a.error_ratio_sq(y0, y1, [k[j] for j in idx], coef, 0.05, [1e-3], [1e-4], [(0, y0.size)])
+        rb, _ = b.error_ratio_sq(y0, y1, [k[j] for j in idx], coef, 0.05, [1e-3], [1e-4], [(0, y0.size)])
+        assert ra[0] == pytest.approx(rb[0], rel=1e-13)
+
+
+def test_step_controller_matches_reference():
+    """_optimal_step_size (misc.py:85-95) incl. ratio = 0, NaN, inf."""
+    from torchdiffeq_amd.solvers import optimal_step_size
+    z = load("controller.npz")
+    for args, ref in zip(z["optimal_step_in"], z["optimal_step_out"]):
+        last, ratio, safety, ifactor, dfactor, order = args
+        ratio32 = float(np.float32(ratio))
+        got = optimal_step_size(float(last), ratio32, float(safety), float(ifactor), float(dfactor), int(order))
+        if math.isnan(ref):
+            assert math.isnan(got), args
+        else:
+            assert got == pytest.approx(float(ref), rel=1e-15), args
+
+
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+def test_initial_step_matches_reference(dname):
+    z = load("controller.npz")
+    A, y0 = z[f"init_{dname}_A"], z[f"init_{dname}_y0"]
+    for order, name in [(4, "dopri5"), (7, "dopri8")]:
+        for scale_y in (1.0, 1e-7):
+            yy = (y0 * y0.dtype.type(scale_y)).reshape(-1)
+            fn = lambda tt, y: (y.reshape(y0.shape) @ A.T).reshape(-1)
+            solver = orc.AdaptiveRK(fn, yy, orc.tableau(name), 1e-6, 1e-8)
+            h = solver.select_initial_step(0.5, fn(0.5, yy))
+            ref = float(z[f"init_{dname}_o{order}_s{scale_y}"])
+            assert h == pytest.approx(ref, rel=2e-6 if dname == "f32" else 1e-13), (order, scale_y)
+
+
+def test_solver_cfg1_spiral_rk4():
+    """cfg1: 999 rk4 steps of the spiral.  The solver arithmetic is bit-exact (test_rk4_is_bit_exact and
+    tests/test_host_logic_cpu.py::test_cfg1_bit_exact, which uses the same torch func as the reference);
+    here the FIELD is numpy (`y**3 @ A` rounds differently from torch), so compare to 1e-5."""
+    z = load("solves.npz")
+    y = orc.odeint(orc.SpiralField(z["cfg1_A"]), z["cfg1_y0"], z["cfg1_t"], method="rk4")
+    assert rel_err(y, z["cfg1_y"]) < 1e-5
+    assert z["cfg1_y"][-1, 0].tolist() == [-0.4436032772064209, 0.27951884269714355]
+
+
+@pytest.mark.parametrize("prefix,method,tol", SOLVE_CASES)
+def test_solver_cfg2_reduced(prefix, method, tol):
+    z = load("solves.npz")
+    rtol, atol = z[f"{prefix}_tol"]
+    stats = {}
+    y = orc.odeint(orc.LinearField(z["cfg2_A"]), z["cfg2_y0"], z[f"{prefix}_t"], method, rtol, atol, stats=stats)
+    assert rel_err(y, z[f"{prefix}_y"]) < tol
+    assert stats["nfe"] == int(z[f"{prefix}_nfe"])
+    assert stats["n_accept"] == len(z[f"{prefix}_accept_dt"]) and stats["n_reject"] == len(z[f"{prefix}_reject_dt"])
+    np.testing.assert_allclose(stats["dts"], z[f"{prefix}_accept_dt"], rtol=5e-2)
+    # fp32: the embedded error estimate is a cancellation of O(1) stage values down to ~1e-6, so its
+    # last bits (and through ratio**(-1/5) the step sizes, at the 1e-3..1e-2 level) depend on the
+    # summation order of the 6-term combine — torch.sum's order is not ours.
+
+
+def test_solver_cfg4_reduced_dopri8_fp64():
+    z = load("solves.npz")
+    stats = {}
+    y = orc.odeint(orc.LinearField(z["cfg4_A"]), z["cfg4_y0"], z["cfg4_t"], "dopri8", 1e-9, 1e-11, stats=stats)
+    # The first dopri8 step (dt0 = 0.034) has an embedded error estimate of ~1e-16*|y|, i.e. pure fp64
+    # rounding noise, so the second step size is summation-order dependent (1 % here) and two correct
+    # implementations agree only to the solve's own accuracy (~10*rtol), not to fp64 eps.
+    assert rel_err(y, z["cfg4_y"]) < 1e-7
+    assert stats["nfe"] == int(z["cfg4_nfe"])
+    np.testing.assert_allclose(stats["dts"], z["cfg4_accept_dt"], rtol=5e-2)
+
+
+def test_solver_time_dependent_with_rejections():
+    z = load("solves.npz")
+    A = z["tdep_A"]
+
+    class Field:
+        params = []
+
+        def f(self, t, y):
+            return np.sin(3 * t) * (y @ A.T) * 4 - y ** 3
+
+    stats = {}
+    y = orc.odeint(Field(), z["tdep_y0"], z["tdep_t"], "dopri5", 1e-8, 1e-10, stats=stats)
+    assert rel_err(y, z["tdep_y"]) < 1e-10
+    assert stats["n_accept"] == len(z["tdep_accept_dt"]) and stats["n_reject"] == len(z["tdep_reject_dt"])
+    assert stats["nfe"] == int(z["tdep_nfe"])
+
+
+@pytest.mark.parametrize("tag,tol", [("f32", 1e-5), ("f64", 1e-12)])
+@pytest.mark.parametrize("norm_tag", ["default", "seminorm"])
+def test_adjoint_cfg3_reduced(tag, tol, norm_tag):
+    z = load("adjoint.npz")
+    rtol, atol = [float(v) for v in z[f"adj_{tag}_tol"]]
+    field = orc.MLPField([z[f"adj_{tag}_p{i}"] for i in range(6)])
+    t = z[f"adj_{tag}_t"]
+    y = orc.odeint(field, z[f"adj_{tag}_y0"], t, "dopri5", rtol, atol)
+    grad_y = np.zeros_like(y)
+    grad_y[-1] = 2 * y[-1]
+    if len(t) > 2:
+        grad_y[1:] += 1
+    _, g0, gp = orc.adjoint_grads(field, z[f"adj_{tag}_y0"], t, grad_y, "dopri5", rtol, atol,
+                                  seminorm=(norm_tag == "seminorm"))
+    assert rel_err(y, z[f"adj_{tag}_{norm_tag}_y"]) < tol
+    assert rel_err(g0, z[f"adj_{tag}_{norm_tag}_grad_y0"]) < tol
+    for i, g in enumerate(gp):
+        assert rel_err(g, z[f"adj_{tag}_{norm_tag}_grad_p{i}"]) < tol, i

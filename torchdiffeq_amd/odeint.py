@@ -30,6 +30,13 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
     by autograd — use `odeint_adjoint` for gradients, and call plain `odeint` under `torch.no_grad()`
     when `func` has parameters that require grad (otherwise NotImplementedError is raised).
     """
+    if torch.is_grad_enabled():
+        y0_list = y0 if isinstance(y0, tuple) else (y0,)
+        if any(isinstance(y_, torch.Tensor) and y_.requires_grad for y_ in y0_list) or \
+                (isinstance(t, torch.Tensor) and t.requires_grad):
+            raise NotImplementedError(
+                "torchdiffeq_amd.odeint does not backpropagate through the solver (the RK arithmetic runs in "
+                "HIP kernels outside autograd): use odeint_adjoint for gradients wrt y0 / t / parameters.")
     ci = check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS)
     # Runs under the caller's grad mode: if `func` produces tensors that require grad, the wrapped func
     # raises (loudly) instead of returning a silently non-differentiable solution.

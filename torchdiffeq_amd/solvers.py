@@ -159,7 +159,10 @@ class RKAdaptiveStepsizeODESolver:
             first_step = self._select_initial_step(t0, self.y0, f0)
         else:
             first_step = self.first_step
-            self._y_nonfinite = False
+            # no initial-step heuristic -> still take the non-finite census of y0 (rk_common.py:287)
+            self.kernels.init_norms(self.plan, 1, f0, f0, self.y0)
+            _, _, bad = self.kernels.read_norms(self.plan)
+            self._y_nonfinite = any(b != 0 for b in bad)
         self.y1, self.f1 = self.y0, f0
         self.t0, self.t1, self.dt = t0, t0, first_step
         self._dense: Optional[_DenseRecord] = None
