@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's headline metric on the MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): dopri5, linear field dy/dt = A y, state
+65536 x 128 fp32 per GPU, rtol 1e-7 / atol 1e-9 (reference defaults), synthetic seeded data.
+One "step" = one dopri5 trial step of the adaptive solver = 6 RK stages: 6 `stage_combine` launches
+interleaved with 6 evaluations of the field (a 65536x128x128 GEMM run by PyTorch-ROCm), one fused
+`error_norm` launch, one read-back of the error sum and the host step controller.  The state is
+resident in HBM before the timed region.  value = RK stages per second over all ranks (weak scaling:
+every rank integrates its own 65536-row shard with its own accept/reject loop, no data-path
+collective — SURVEY.md §8e).
+
+Extra objects in the JSON line:
+  roofline      dominant kernel = stage_combine with 5 stage terms (tableau rows 5 and 6: read 5 k_j + y0,
+                write y_i = 7 words/element = 234.9 MB per launch at this size); its launches inside the
+                TIMED region are bracketed with HIP events on the launch stream.
+  cpu_baseline  the CPU oracle (oracle/reference_solver.py + rk_oracle.c, OpenMP on all host cores) on
+                a bounded sample of the same workload (rank 0, N=1 only).
+  rel_err       max rel-err of a full odeint(t=[0,1]) at this size vs the closed form y0 expm(A)^T.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH, DIM = 65536, 128
+RTOL, ATOL = 1e-7, 1e-9
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_problem(device, seed_offset=0):
+    """SURVEY.md §8(d) cfg2 synthetic inputs (per-rank seed offset for the weak-scaling shards)."""
+    g = torch.Generator().manual_seed(0)
+    G = torch.randn(DIM, DIM, generator=g, dtype=torch.float64) / DIM ** 0.5
+    A = (0.5 * (G - G.T) - 0.1 * torch.eye(DIM, dtype=torch.float64)).float()
+    # rank 0 draws y0 from the same generator right after A (exactly the survey's cfg2 inputs);
+    # other ranks draw their own 65536 rows from generator seed = rank.
+    gy = g if seed_offset == 0 else torch.Generator().manual_seed(seed_offset)
+    y0 = torch.randn(BATCH, DIM, generator=gy, dtype=torch.float64).float()
+    return A.to(device), y0.to(device)
+
+
+class EventTimedKernels:
+    """Forwards to HipKernels; while `armed`, brackets the dominant kernel's launches with HIP events."""
+
+    def __init__(self, inner, dominant_terms):
+        self._inner = inner
+        self._nt = dominant_terms
+        self.armed = False
+        self.events = []
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+    def stage_combine(self, out, y0, ks, coefs, dt):
+        if self.armed and len(ks) == self._nt:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._inner.stage_combine(out, y0, ks, coefs, dt)
+            e1.record()
+            self.events.append((e0, e1))
+        else:
+            self._inner.stage_combine(out, y0, ks, coefs, dt)
+
+
+def cpu_baseline(max_seconds=20.0):
+    """Oracle (port of the reference algorithm) timed on this host's cores on a bounded sample."""
+    import numpy as np
+    from oracle import reference_solver as orc
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    A, y0 = make_problem("cpu")
+    A, y0 = A.numpy(), y0.numpy()
+    ops = orc.COps()
+    field = orc.LinearField(A)
+    solver = orc.AdaptiveRK(lambda tt, y: field.f(tt, y.reshape(BATCH, DIM)).reshape(-1), y0.reshape(-1),
+                            orc.tableau("dopri5"), RTOL, ATOL, ops=ops)
+    solver.before_integrate(0.0)
+    solver.adaptive_step()                      # warm-up step (page faults, thread pool)
+    steps, t0 = 0, time.perf_counter()
+    while steps < 40 and time.perf_counter() - t0 < max_seconds:
+        solver.adaptive_step()
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": 6 * steps / dt, "unit": "RK-stages/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} dopri5 trial steps ({6 * steps} RK stages) of the same 65536x128 fp32 workload, "
+                      f"oracle/rk_oracle.c with OpenMP on {cores} threads + numpy GEMM, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from torchdiffeq_amd import _native, dist as tdist
+    from torchdiffeq_amd.misc import OdeFunc, StateLayout, rms_norm
+    from torchdiffeq_amd.solvers import Dopri5Solver
+    import torchdiffeq_amd as tda
+
+    rank, world, local_rank = tdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    A, y0 = make_problem(device, seed_offset=rank)
+    At = A.T.contiguous()
+    field = lambda t, y: y @ At
+
+    # ---- parity at full size: whole odeint vs the closed form (size-independent property) ----
+    with torch.no_grad():
+        t_wall = time.perf_counter()
+        y_end = tda.odeint(field, y0, torch.tensor([0.0, 1.0], device=device), rtol=RTOL, atol=ATOL, method="dopri5")[-1]
+        torch.cuda.synchronize()
+        odeint_wall = time.perf_counter() - t_wall
+        exact = y0.double() @ torch.linalg.matrix_exp(A.double()).T
+        rel_err = float((y_end.double() - exact).abs().max() / exact.abs().max())
+
+    # ---- timed region: K trial steps of the adaptive solver ----
+    layout = StateLayout([y0.shape], False)
+    func = OdeFunc(field, layout, 1.0, y0.dtype, device)
+    solver = Dopri5Solver(func=func, y0=y0.reshape(-1), rtol=RTOL, atol=ATOL, norm=rms_norm)
+    timed = EventTimedKernels(solver.kernels, dominant_terms=5)
+    solver.kernels = timed
+    with torch.no_grad():
+        solver._before_integrate([0.0])
+        for _ in range(args.warmup):
+            solver._adaptive_step()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        timed.armed = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            solver._adaptive_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
+        timed.armed = False
+    if world > 1:
+        el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    n = BATCH * DIM
+    kernel_ms = [a.elapsed_time(b) for a, b in timed.events]
+    avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+    bytes_per_launch = 7 * n * 4
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kernel_ms else None
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_stage_combine.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "dopri5 RK-stages/sec at batch=65536x dim=128 (end-to-end adaptive trial steps incl. func, "
+                      "error norm, read-back and host controller)",
+            "value": 6 * args.steps * world / elapsed,
+            "unit": "RK-stages/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: dopri5 adaptive, linear ODE dy/dt=Ay, batch=65536 x "
+                                   "dim=128 fp32 per GPU, rtol=1e-7 atol=1e-9",
+                       "global_batch": BATCH * world, "dim": DIM, "parallelism": f"batch-sharded x{world}",
+                       "accepted": solver.n_accepted, "rejected": solver.n_rejected},
+            "rel_err": rel_err,
+            "rel_err_definition": "max|y - y_exact| / max|y_exact| of odeint(t=[0,1]) at full size vs y0 @ expm(A)^T "
+                                  "(the reference's own fp32 result scores 2.2-2.6e-6 on this, SURVEY.md §7)",
+            "odeint_t01_wall_s": odeint_wall,
+            "roofline": {"bound": "hbm", "kernel": "stage_combine_kernel<float, 5, 1, true>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+                         "launches_timed": len(kernel_ms), "traffic": traffic},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,3 +81,36 @@ def linear_case(z, prefix, device="cpu"):
     t = T(z[f"{prefix}_t"], device)
     rtol, atol = [float(v) for v in z[f"{prefix}_tol"]]
     return A, y0, t, rtol, atol
+
+
+class PlanarCNF(torch.nn.Module):
+    """The continuous normalizing flow of the reference's examples/cnf.py:34-114 (cfg5), restated:
+    a hyper-network maps t to (W, B, U); dz/dt = mean_k tanh(z.w_k + b_k) u_k and
+    dlogp/dt = -tr(d(dz/dt)/dz).  The trace is written in closed form, tr = mean_k (1-h_k^2)(w_k.u_k),
+    instead of the example's per-dimension autograd loop — same function, differentiable, no nested
+    autograd.  Parameters are loaded from the golden file (the reference's seeded init)."""
+
+    def __init__(self, z, device="cpu"):
+        super().__init__()
+        self.fc1 = torch.nn.Linear(1, 32)
+        self.fc2 = torch.nn.Linear(32, 32)
+        self.fc3 = torch.nn.Linear(32, 3 * 64 * 2 + 64)
+        with torch.no_grad():
+            for i, p in enumerate(self.parameters()):
+                p.copy_(T(z[f"cnf_p{i}"]))
+        self.width, self.dim = 64, 2
+        self.to(device)
+
+    def forward(self, t, states):
+        z, _ = states
+        width, dim, block = self.width, self.dim, self.width * self.dim
+        p = torch.tanh(self.fc1(t.reshape(1, 1)))
+        p = torch.tanh(self.fc2(p))
+        p = self.fc3(p).reshape(-1)
+        W = p[:block].reshape(width, dim)
+        U = p[block:2 * block].reshape(width, dim) * torch.sigmoid(p[2 * block:3 * block].reshape(width, dim))
+        Bv = p[3 * block:]
+        h = torch.tanh(z @ W.T + Bv)                         # [batch, width]
+        dz = (h @ U) / width
+        trace = ((1 - h * h) * (W * U).sum(-1)).sum(-1, keepdim=True) / width
+        return dz, -trace

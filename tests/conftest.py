@@ -30,6 +30,22 @@ def cpu_backend(monkeypatch, oracle_kernels):
     return oracle_kernels
 
 
+@pytest.fixture(params=["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def dev(request, monkeypatch, oracle_kernels):
+    """Device of a parity test.  "cuda": the real product path (HIP kernels).  "cpu": host-logic run with
+    the oracle substituted for the kernels (see cpu_backend).  Also the default device of the test body."""
+    import torch
+    if request.param == "cpu":
+        from torchdiffeq_amd import _native
+        monkeypatch.setattr(_native, "get_kernels", lambda device: oracle_kernels)
+    else:
+        assert torch.cuda.is_available(), "gpu test on a box without a GPU"
+    prev = torch.get_default_device()
+    torch.set_default_device(request.param)
+    yield request.param
+    torch.set_default_device(prev)
+
+
 @pytest.fixture(scope="session")
 def hip_kernels():
     import torch

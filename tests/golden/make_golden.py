@@ -300,9 +300,38 @@ def gen_adjoint():
     save("adjoint.npz", **arrays)
 
 
+def gen_cnf():
+    """cfg5 (reduced): the CNF of examples/cnf.py:34-114 at random init (seed 0), tuple state (z, logp),
+    t: 10 -> 0 (decreasing), dopri5 + adjoint, rtol = atol = 1e-5; loss = mean(logp(t1)) - sum(z(t1)^2)/100."""
+    import importlib.util
+    argv, sys.argv = sys.argv, ["cnf.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("ref_cnf_example", "/root/reference/examples/cnf.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    arrays = {}
+    torch.manual_seed(0)
+    func = mod.CNF(in_out_dim=2, hidden_dim=32, width=64)
+    B = 96
+    z0 = rand(B, 2, seed=11, dtype=torch.float32).requires_grad_(True)
+    logp0 = torch.zeros(B, 1)
+    t = torch.tensor([10.0, 0.0])
+    z_t, logp_t = torchdiffeq.odeint_adjoint(func, (z0, logp0), t, atol=1e-5, rtol=1e-5, method="dopri5")
+    loss = logp_t[-1].mean() - z_t[-1].pow(2).sum() / 100
+    loss.backward()
+    arrays.update(cnf_z0=z0, cnf_t=t, cnf_z=z_t, cnf_logp=logp_t, cnf_grad_z0=z0.grad)
+    for i, (name, p) in enumerate(func.named_parameters()):
+        arrays[f"cnf_p{i}"] = p
+        arrays[f"cnf_grad_p{i}"] = p.grad
+    arrays["cnf_param_names"] = np.array([n for n, _ in func.named_parameters()])
+    save("cnf.npz", **arrays)
+
+
 if __name__ == "__main__":
-    gen_tableaus()
-    gen_kernel_vectors()
-    gen_controller_vectors()
-    gen_solves()
-    gen_adjoint()
+    only = sys.argv[1:]
+    for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
+                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf)]:
+        if not only or name in only:
+            fn()

@@ -1,0 +1,98 @@
+"""world_size-2 gloo test of the sharded adjoint: parameter gradients summed by ONE all-reduce equal the
+single-process gradients over the whole batch; y0 gradients stay sharded."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make(dtype):
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 6)).to(dtype)
+
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = net
+
+        def forward(self, t, y):
+            return self.net(y) * torch.cos(t)
+
+    g = torch.Generator().manual_seed(1)
+    y0 = torch.randn(11, 6, generator=g, dtype=torch.float64).to(dtype)     # 11 rows: uneven shards
+    return F(), y0
+
+
+def _patch_backend():
+    from oracle.kernels import OracleKernels
+    from torchdiffeq_amd import _native
+    ok = OracleKernels()
+    _native.get_kernels = lambda device: ok      # host-logic test on CPU tensors (see conftest.cpu_backend)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    _patch_backend()
+    from torchdiffeq_amd import dist as tdist
+    r, w, _ = tdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    f, y0 = _make(torch.float64)
+    t = torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64, requires_grad=True)
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), orig(*a, **k))[1]
+    shard = tdist.shard_batch(y0).clone().requires_grad_(True)
+    y = tdist.odeint_adjoint_sharded(f, shard, t, rtol=1e-9, atol=1e-11)
+    (y[-1].pow(2).sum() + y[1].sum()).backward()
+    dist.all_reduce = orig
+    torch.save(dict(gy=shard.grad, gp=[p.grad for p in f.parameters()], gt=t.grad, calls=calls,
+                    rows=tdist.shard_rows(11, rank, world)), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_adjoint_world2(tmp_path):
+    import torchdiffeq_amd as tda
+    world = 2
+    port = 29600 + (os.getpid() % 300)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(world)]
+
+    _patch_backend()
+    f, y0 = _make(torch.float64)
+    y0 = y0.clone().requires_grad_(True)
+    t = torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64, requires_grad=True)
+    y = tda.odeint_adjoint(f, y0, t, rtol=1e-9, atol=1e-11)
+    (y[-1].pow(2).sum() + y[1].sum()).backward()
+    # per-shard step controllers take slightly different steps than the whole-batch solve
+    # (SURVEY.md §8e "caveat for parity"): compare within the solve tolerance, not bitwise.
+    for r in range(world):
+        assert torch.allclose(res[r]["gy"], y0.grad[res[r]["rows"]], rtol=1e-6, atol=1e-8)
+        for g_shard, p in zip(res[r]["gp"], f.parameters()):
+            assert torch.allclose(g_shard, p.grad, rtol=1e-6, atol=1e-8)
+        assert torch.allclose(res[r]["gt"], t.grad, rtol=1e-6, atol=1e-8)
+    # identical (already reduced) parameter gradients on both ranks
+    for a, b in zip(res[0]["gp"], res[1]["gp"]):
+        assert torch.equal(a, b)
+    # exactly one all-reduce for the parameter tail (+ one for dL/dt because t.requires_grad)
+    assert len(res[0]["calls"]) == 2 and res[0]["calls"][1] == 3
+    assert res[0]["rows"] == slice(0, 6) and res[1]["rows"] == slice(6, 11)
+
+
+def test_shard_rows_cover_batch():
+    from torchdiffeq_amd.dist import shard_rows
+    for n in (1, 7, 8, 65536):
+        for world in (1, 2, 3, 8):
+            rows = [shard_rows(n, r, world) for r in range(world)]
+            assert rows[0].start == 0 and rows[-1].stop == n
+            assert all(a.stop == b.start for a, b in zip(rows, rows[1:]))
+            sizes = [s.stop - s.start for s in rows]
+            assert max(sizes) - min(sizes) <= 1

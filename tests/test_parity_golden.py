@@ -1,6 +1,9 @@
-"""The product's HOST logic (check_inputs, solver drivers, adjoint) against the reference's golden
-outputs, on CPU tensors with the oracle substituted for the HIP kernels (conftest.cpu_backend).
-The same cases run on the MI355X through libtdeq_hip.so in tests/test_golden_gpu.py."""
+"""odeint / odeint_adjoint against the reference's golden outputs (tests/golden/*.npz).
+
+Every test runs twice through the `dev` fixture (conftest.py):
+  dev = "cuda"  (-m gpu)      the product end to end on the MI355X through libtdeq_hip.so;
+  dev = "cpu"   (-m "not gpu") the product's HOST logic (check_inputs, solver drivers, adjoint) on CPU
+                               tensors with the oracle substituted for the HIP kernels — test-only."""
 import math
 import warnings
 
@@ -9,26 +12,25 @@ import pytest
 import torch
 
 import torchdiffeq_amd as tda
-from _cases import SOLVE_CASES, StatFunc, T, linear_case, load, make_mlp, rel_err
-
-pytestmark = pytest.mark.usefixtures("cpu_backend")
+from _cases import SOLVE_CASES, PlanarCNF, StatFunc, T, linear_case, load, make_mlp, rel_err
 
 
-def test_cfg1_bit_exact():
+
+def test_cfg1_bit_exact(dev):
     """cfg1 (spiral, rk4): same torch func as the reference -> bit-identical trajectory."""
     z = load("solves.npz")
-    A, y0, t = T(z["cfg1_A"]), T(z["cfg1_y0"]), T(z["cfg1_t"])
+    A, y0, t = T(z["cfg1_A"], dev), T(z["cfg1_y0"], dev), T(z["cfg1_t"], dev)
     with torch.no_grad():
         y = tda.odeint(lambda t_, y_: (y_ ** 3) @ A, y0, t, method="rk4")
     assert y.shape == (1000, 1, 2) and y.dtype == torch.float32
-    assert torch.equal(y, T(z["cfg1_y"]))
+    assert torch.equal(y, T(z["cfg1_y"], dev))
     assert y[-1, 0].tolist() == [-0.4436032772064209, 0.27951884269714355]
 
 
 @pytest.mark.parametrize("prefix,method,tol", SOLVE_CASES)
-def test_cfg2_reduced(prefix, method, tol):
+def test_cfg2_reduced(dev, prefix, method, tol):
     z = load("solves.npz")
-    A, y0, t, rtol, atol = linear_case(z, prefix)
+    A, y0, t, rtol, atol = linear_case(z, prefix, dev)
     f = StatFunc(lambda t_, y_: y_ @ A.T)
     with torch.no_grad():
         y = tda.odeint(f, y0, t, rtol=rtol, atol=atol, method=method)
@@ -40,9 +42,9 @@ def test_cfg2_reduced(prefix, method, tol):
     np.testing.assert_allclose(f.accept, z[f"{prefix}_accept_dt"], rtol=5e-2)
 
 
-def test_cfg4_reduced_dopri8():
+def test_cfg4_reduced_dopri8(dev):
     z = load("solves.npz")
-    A, y0, t = T(z["cfg4_A"]), T(z["cfg4_y0"]), T(z["cfg4_t"])
+    A, y0, t = T(z["cfg4_A"], dev), T(z["cfg4_y0"], dev), T(z["cfg4_t"], dev)
     f = StatFunc(lambda t_, y_: y_ @ A.T)
     with torch.no_grad():
         y = tda.odeint(f, y0, t, rtol=1e-9, atol=1e-11, method="dopri8")
@@ -50,10 +52,10 @@ def test_cfg4_reduced_dopri8():
     assert f.nfe == int(z["cfg4_nfe"])
 
 
-def test_time_dependent_field_with_rejections():
+def test_time_dependent_field_with_rejections(dev):
     """202 accepted + 22 rejected steps in the reference; fp64 so the step sequence must match."""
     z = load("solves.npz")
-    A, y0, t = T(z["tdep_A"]), T(z["tdep_y0"]), T(z["tdep_t"])
+    A, y0, t = T(z["tdep_A"], dev), T(z["tdep_y0"], dev), T(z["tdep_t"], dev)
     f = StatFunc(lambda t_, y_: torch.sin(3 * t_) * (y_ @ A.T) * 4 - y_ ** 3)
     with torch.no_grad():
         y = tda.odeint(f, y0, t, rtol=1e-8, atol=1e-10, method="dopri5")
@@ -63,9 +65,9 @@ def test_time_dependent_field_with_rejections():
     np.testing.assert_allclose(f.reject, z["tdep_reject_dt"], rtol=1e-6)
 
 
-def test_tuple_state():
+def test_tuple_state(dev):
     z = load("solves.npz")
-    A, ya, yb, t = T(z["tuple_A"]), T(z["tuple_ya"]), T(z["tuple_yb"]), T(z["tuple_t"])
+    A, ya, yb, t = T(z["tuple_A"], dev), T(z["tuple_ya"], dev), T(z["tuple_yb"], dev), T(z["tuple_t"], dev)
     with torch.no_grad():
         out = tda.odeint(lambda t_, y_: (y_[0] @ A.T, 2 * (y_[1] @ A.T)), (ya, yb), t, rtol=1e-6, atol=1e-8)
     assert isinstance(out, tuple) and len(out) == 2
@@ -80,10 +82,10 @@ def test_tuple_state():
     ("max_step", dict(max_step=0.05)),
     ("min_step", dict(min_step=0.2)),
 ])
-def test_adaptive_options(tag, opts):
+def test_adaptive_options(dev, tag, opts):
     """first_step / step_t / jump_t / max_step / min_step (rk_common.py:166-177, 293-308, 324-330)."""
     z = load("solves.npz")
-    A, y0, t = T(z["opt_A"]), T(z["opt_y0"]), T(z["opt_t"])
+    A, y0, t = T(z["opt_A"], dev), T(z["opt_y0"], dev), T(z["opt_t"], dev)
     f = StatFunc(lambda t_, y_: y_ @ A.T)
     with torch.no_grad():
         y = tda.odeint(f, y0, t, rtol=1e-6, atol=1e-8, method="dopri5", options=opts)
@@ -93,26 +95,26 @@ def test_adaptive_options(tag, opts):
     np.testing.assert_allclose(f.reject, z[f"opt_{tag}_reject_dt"], rtol=1e-6)
 
 
-def test_rk4_step_size_and_perturb():
+def test_rk4_step_size_and_perturb(dev):
     """Fixed grid from `step_size` with linear interpolation of the outputs, and `perturb`
     (solvers.py:86-96, 117-125; misc.py:185-196): no reductions -> bit-exact."""
     z = load("solves.npz")
-    A, y0, t = T(z["rk4s_A"]), T(z["rk4s_y0"]), T(z["rk4s_t"])
+    A, y0, t = T(z["rk4s_A"], dev), T(z["rk4s_y0"], dev), T(z["rk4s_t"], dev)
     with torch.no_grad():
         y = tda.odeint(lambda t_, y_: y_ @ A.T, y0, t, method="rk4", options=dict(step_size=0.1))
         yp = tda.odeint(lambda t_, y_: torch.cos(t_) * (y_ @ A.T), y0, t, method="rk4",
                         options=dict(step_size=0.1, perturb=True))
-    assert torch.equal(y, T(z["rk4s_y"]))
-    assert torch.equal(yp, T(z["rk4s_y_perturb"]))
+    assert torch.equal(y, T(z["rk4s_y"], dev))
+    assert torch.equal(yp, T(z["rk4s_y_perturb"], dev))
 
 
 @pytest.mark.parametrize("tag,tol", [("f32", 1e-5), ("f64", 1e-12)])
 @pytest.mark.parametrize("norm_tag,aopts", [("default", None), ("seminorm", dict(norm="seminorm"))])
-def test_adjoint_cfg3_reduced(tag, tol, norm_tag, aopts):
+def test_adjoint_cfg3_reduced(dev, tag, tol, norm_tag, aopts):
     z = load("adjoint.npz")
-    f = make_mlp(z, tag)
-    y0 = T(z[f"adj_{tag}_y0"]).requires_grad_(True)
-    t = T(z[f"adj_{tag}_t"])
+    f = make_mlp(z, tag, dev)
+    y0 = T(z[f"adj_{tag}_y0"], dev).requires_grad_(True)
+    t = T(z[f"adj_{tag}_t"], dev)
     rtol, atol = [float(v) for v in z[f"adj_{tag}_tol"]]
     y = tda.odeint_adjoint(f, y0, t, rtol=rtol, atol=atol, method="dopri5", adjoint_options=aopts)
     loss = y[-1].pow(2).sum() + (y[1:].sum() if len(t) > 2 else 0.0)
@@ -123,7 +125,25 @@ def test_adjoint_cfg3_reduced(tag, tol, norm_tag, aopts):
         assert rel_err(p.grad, z[f"adj_{tag}_{norm_tag}_grad_p{i}"]) < tol, i
 
 
-def test_adjoint_unused_parameter_gets_exact_zero():
+def test_cnf_cfg5_reduced(dev):
+    """cfg5 (reduced batch): CNF, tuple state (z, logp), decreasing time 10 -> 0, dopri5 + adjoint at
+    rtol = atol = 1e-5, vs the reference run on examples/cnf.py's own model (golden)."""
+    z = load("cnf.npz")
+    f = PlanarCNF(z, dev)
+    z0 = T(z["cnf_z0"], dev).requires_grad_(True)
+    logp0 = torch.zeros(z0.shape[0], 1)
+    t = T(z["cnf_t"], dev)
+    z_t, logp_t = tda.odeint_adjoint(f, (z0, logp0), t, atol=1e-5, rtol=1e-5, method="dopri5")
+    (logp_t[-1].mean() - z_t[-1].pow(2).sum() / 100).backward()
+    # rtol = 1e-5: two correct solvers agree to ~10*rtol on the solution and on its gradients
+    assert rel_err(z_t.detach(), z["cnf_z"]) < 1e-4
+    assert rel_err(logp_t.detach(), z["cnf_logp"]) < 1e-4
+    assert rel_err(z0.grad, z["cnf_grad_z0"]) < 1e-3
+    for i, p in enumerate(f.parameters()):
+        assert rel_err(p.grad, z[f"cnf_grad_p{i}"]) < 1e-3, i
+
+
+def test_adjoint_unused_parameter_gets_exact_zero(dev):
     """gradient_tests.py:89-135 behaviour: parameters that do not influence f get exactly 0."""
     class F(torch.nn.Module):
         def __init__(self):
@@ -144,7 +164,7 @@ def test_adjoint_unused_parameter_gets_exact_zero():
     assert torch.equal(f.unused.bias.grad, torch.zeros(4, dtype=torch.float64))
 
 
-def test_adjoint_matches_finite_differences_and_time_grad():
+def test_adjoint_matches_finite_differences_and_time_grad(dev):
     """dL/dy0, dL/dθ and dL/dt (t.requires_grad) against central finite differences, fp64."""
     torch.manual_seed(1)
     W = torch.nn.Parameter(torch.randn(3, 3, dtype=torch.float64) * 0.5)
@@ -180,7 +200,7 @@ def test_adjoint_matches_finite_differences_and_time_grad():
         assert t.grad[i].item() == pytest.approx(fd, rel=1e-4, abs=1e-6), i
 
 
-def test_adjoint_tuple_state_and_reverse_time():
+def test_adjoint_tuple_state_and_reverse_time(dev):
     torch.manual_seed(2)
     lin = torch.nn.Linear(3, 3).double()
 
@@ -217,7 +237,7 @@ def test_adjoint_tuple_state_and_reverse_time():
     assert lin.weight.grad.abs().max() > 0
 
 
-def test_adjoint_rk4_and_custom_adjoint_norm():
+def test_adjoint_rk4_and_custom_adjoint_norm(dev):
     torch.manual_seed(3)
     lin = torch.nn.Linear(3, 3).double()
     f = lambda t_, y_: torch.tanh(lin(y_))
@@ -242,7 +262,7 @@ def test_adjoint_rk4_and_custom_adjoint_norm():
     assert isinstance(y.grad_fn.adjoint_options, dict) and "norm" in y.grad_fn.adjoint_options   # norm_tests.py:128
 
 
-def test_api_errors_and_warnings():
+def test_api_errors_and_warnings(dev):
     y0 = torch.ones(3)
     t = torch.tensor([0.0, 1.0])
     f = lambda t_, y_: -y_
@@ -279,7 +299,7 @@ def test_api_errors_and_warnings():
     assert y.shape == (1, 3) and torch.equal(y[0], y0)
 
 
-def test_t_on_other_device_warns_and_default_method():
+def test_t_on_other_device_warns_and_default_method(dev):
     y0 = torch.ones(2, dtype=torch.float64)
     with torch.no_grad():
         y = tda.odeint(lambda t_, y_: -y_, y0, torch.tensor([0.0, 1.0], dtype=torch.float64), rtol=1e-9, atol=1e-12)

@@ -143,7 +143,7 @@ class NormPlan:
         # kernel directly (zero-copy), so a read-back is one stream sync and no memcpy.
         self.pinned = pinned
         if pinned:
-            self.out = torch.zeros(3 * self.n_seg, dtype=torch.float64, pin_memory=True)
+            self.out = torch.zeros(3 * self.n_seg, dtype=torch.float64, device="cpu", pin_memory=True)
             self.out_np = self.out.numpy()
         else:
             self.out = torch.zeros(3 * self.n_seg, dtype=torch.float64, device=device)

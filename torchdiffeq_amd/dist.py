@@ -1,0 +1,65 @@
+"""Batch-axis data parallelism for the RK hot path: one process per GPU, RCCL over xGMI.
+
+The solver arithmetic is elementwise over the state, so independent batch rows shard across ranks with
+NO data-path collective: each rank integrates its rows with its own accept/reject loop.
+The only cross-rank quantity is the adjoint's parameter gradient (a sum over the batch): the θ-adjoint
+segments are a contiguous tail of the flat augmented state, summed with ONE all-reduce at the end of
+`backward` (≈0.4 MB for cfg3 — latency-bound on xGMI, so a single coalesced call, not a bucketed ring).
+
+Nothing of this exists in the reference (no torch.distributed call anywhere in its tree).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .adjoint import odeint_adjoint
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (as set by
+    `python -m torch.distributed.run`).  backend: 'nccl' (= RCCL on ROCm) when a GPU is visible, else
+    'gloo'.  Returns (rank, world_size, local_rank); a no-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_rows(n_rows: int, rank: int, world: int) -> slice:
+    """Contiguous row block of `rank` (block sizes differ by at most one row)."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return slice(lo, lo + base + (1 if rank < rem else 0))
+
+
+def shard_batch(y0: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None) -> torch.Tensor:
+    """This rank's rows of a batch-first state."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    return y0[shard_rows(y0.shape[0], rank, world)]
+
+
+def odeint_adjoint_sharded(func, y0_shard, t, *, group=None, **kwargs):
+    """`odeint_adjoint` on this rank's batch shard; parameter gradients (and dL/dt, if requested) come out
+    of `backward` already summed over the ranks of `group` (default group if None) by one all-reduce.
+    Gradients wrt y0 stay sharded.  With no initialised process group this is plain `odeint_adjoint`."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        adjoint_options = dict(kwargs.pop("adjoint_options", None) or
+                               {k: v for k, v in (kwargs.get("options") or {}).items() if k != "norm"})
+        adjoint_options["dist_group"] = True if group is None else group
+        kwargs["adjoint_options"] = adjoint_options
+    return odeint_adjoint(func, y0_shard, t, **kwargs)

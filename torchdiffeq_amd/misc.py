@@ -188,7 +188,7 @@ class OdeFunc:
         lay = self.layout
         if lay.is_tuple:
             f = self.base_func(t_user, lay.unpack(y_flat))
-            out = lay.pack(tuple(f), dtype=self.dtype)
+            out = lay.pack(tuple(f_.detach() if not torch.is_grad_enabled() else f_ for f_ in f), dtype=self.dtype)
         else:
             f = self.base_func(t_user, y_flat.view(lay.shapes[0]))
             if f.dtype != self.dtype:
@@ -196,6 +196,8 @@ class OdeFunc:
             out = f.reshape(-1)
             if not out.is_contiguous():
                 out = out.contiguous()
+        if out.requires_grad and not torch.is_grad_enabled():
+            out = out.detach()      # func built its own graph internally (e.g. a Jacobian trace): drop it
         if out.requires_grad:
             raise NotImplementedError(
                 "torchdiffeq_amd.odeint runs the RK arithmetic in HIP kernels that are not recorded by "
