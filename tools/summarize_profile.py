@@ -1,0 +1,70 @@
+"""Condense rocprofv3 output (kernel stats + PMC passes) into small files under gpurun_out/prof_<tag>/summary
+that are then committed under profiles/.  Usage: summarize_profile.py <prof_dir> <tag>"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(root, pattern):
+    hits = sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+    return hits[0] if hits else None
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    out_dir = os.path.join(root, "summary")
+    os.makedirs(out_dir, exist_ok=True)
+    summary = {"tag": tag}
+    stats = find(os.path.join(root, "trace"), "*kernel_stats.csv")
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
+            f.write(open(stats).read())
+        summary["kernel_stats"] = rows[:25]
+        print("== kernel stats (top 15 by total time) ==")
+        for r in rows[:15]:
+            print({k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+    trace = find(os.path.join(root, "trace"), "*kernel_trace.csv")
+    if trace:
+        rows = list(csv.DictReader(open(trace)))
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        # timeline of the last ~40 dispatches: name, duration, gap to previous
+        tl = []
+        prev_end = None
+        for r in rows[-60:]:
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            tl.append({"kernel": r["Kernel_Name"][:70], "dur_us": (e - s) / 1e3,
+                       "gap_us": None if prev_end is None else (s - prev_end) / 1e3})
+            prev_end = e
+        summary["timeline_tail"] = tl
+        busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[-600:])
+        span = int(rows[-1]["End_Timestamp"]) - int(rows[-600]["Start_Timestamp"]) if len(rows) >= 600 else None
+        summary["gpu_busy_frac_last600"] = busy / span if span else None
+        print("gpu busy fraction over the last 600 dispatches:", summary["gpu_busy_frac_last600"])
+        for t in tl[-26:]:
+            print(t)
+    for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        cc = find(os.path.join(root, name), "*counter_collection.csv")
+        if not cc:
+            continue
+        rows = list(csv.DictReader(open(cc)))
+        agg = {}
+        for r in rows:
+            if r.get("Counter_Name") != counter:
+                continue
+            k = r["Kernel_Name"]
+            a = agg.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+        per = {k: {"dispatches": v[0], "avg_" + counter: v[1] / v[0]} for k, v in agg.items()}
+        summary[name] = per
+        print(f"== {counter} per kernel (avg per dispatch, raw counter units) ==")
+        for k, v in sorted(per.items(), key=lambda kv: -kv[1]["avg_" + counter])[:12]:
+            print(k[:80], v)
+    json.dump(summary, open(os.path.join(out_dir, f"{tag}_summary.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
