@@ -157,9 +157,20 @@ def main():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(el.item())
 
+    # cost of an empty HIP event pair on this stream (subtracted from the bracketed launches below)
+    pairs = []
+    for _ in range(50):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    overhead = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
+
     n = BATCH * DIM
     kernel_ms = [a.elapsed_time(b) for a, b in timed.events]
-    avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+    raw_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+    avg_ms = max(raw_ms - overhead, 1e-6)
     bytes_per_launch = 7 * n * 4
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kernel_ms else None
     traffic = None
@@ -197,6 +208,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+                         "avg_event_bracket_ms": raw_ms, "empty_event_pair_ms": overhead,
                          "launches_timed": len(kernel_ms), "traffic": traffic},
         }
         if world == 1 and not args.no_cpu_baseline:

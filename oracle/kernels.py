@@ -146,3 +146,8 @@ class OracleKernels:
     def lerp(self, out, y0, y1, slope):
         _ok(self.lib.oracle_lerp(out.data_ptr(), y0.data_ptr(), y1.data_ptr(), slope, y0.numel(),
                                  _code(y0.dtype)), "oracle_lerp")
+
+    def fill_scalars(self, dst, vals):
+        """Host twin of tdeq_fill_scalars: vals converted to dst's dtype."""
+        import torch as _torch
+        dst.copy_(_torch.tensor(list(vals), dtype=_torch.float64).to(dst.dtype))

@@ -177,6 +177,19 @@ class OdeFunc:
     def time_tensor(self, value: float) -> torch.Tensor:
         return torch.full((), value, dtype=self.dtype, device=self.device)
 
+    def time_tensors(self, kernels, times_and_perturbs) -> Tuple[torch.Tensor, ...]:
+        """0-dim device tensors for several evaluation times with ONE launch (instead of one fill kernel
+        per stage): the values are computed on the host and travel in the kernel arguments."""
+        vals = [self.user_time(t, p) for t, p in times_and_perturbs]
+        buf = torch.empty(len(vals), dtype=self.dtype, device=self.device)
+        kernels.fill_scalars(buf, vals)
+        return buf.unbind(0)
+
+    def eval_at(self, t_user: torch.Tensor, y_flat: torch.Tensor) -> torch.Tensor:
+        """Evaluate with a time tensor produced by `time_tensors`."""
+        self.nfe += 1
+        return self.call_base(t_user, y_flat)
+
     # -- evaluation --------------------------------------------------------------------------------
     def eval(self, t, y_flat: torch.Tensor, perturb: Perturb = Perturb.NONE) -> torch.Tensor:
         assert isinstance(perturb, Perturb), "perturb argument must be of type Perturb enum"

@@ -257,16 +257,15 @@ class RKAdaptiveStepsizeODESolver:
         # ---- Runge–Kutta stages (rk_common.py:43-90); times in the state precision T ----
         t0_T, dt_T, t1_T = T(t0), T(dt), T(t1)
         dt_signed = float(dt_T) * func.sign
+        stage_times = func.time_tensors(kern, [
+            (t1_T, Perturb.PREV) if self._alpha_is_one[i] else (t0_T + self._alpha[i] * dt_T, Perturb.NONE)
+            for i in range(len(self._beta))])
         k: List[torch.Tensor] = [f0]
         yi = y0
         for i, row in enumerate(self._beta):
-            if self._alpha_is_one[i]:
-                ti, perturb = t1_T, Perturb.PREV
-            else:
-                ti, perturb = t0_T + self._alpha[i] * dt_T, Perturb.NONE
             yi = torch.empty_like(y0)
             kern.stage_combine(yi, y0, [k[j] for j in row.idx], row.coef, dt_signed)
-            k.append(func.eval(ti, yi, perturb))
+            k.append(func.eval_at(stage_times[i], yi))
         if self.tableau.fsal_solution:
             y1 = yi
         else:
@@ -414,16 +413,20 @@ class RK4(object):
             if has_cb:
                 func.callback_step(torch.tensor(t0, device=self.device), y0, torch.tensor(dt, device=self.device))
             dts = float(dt) * func.sign
-            k1 = func.eval(t0, y0, Perturb.NEXT if self.perturb else Perturb.NONE)
+            ts = func.time_tensors(kern, [(t0, Perturb.NEXT if self.perturb else Perturb.NONE),
+                                          (scalar(t0 + scalar(dt * scalar(third))), Perturb.NONE),
+                                          (scalar(t0 + scalar(dt * scalar(two_thirds))), Perturb.NONE),
+                                          (t1, Perturb.PREV if self.perturb else Perturb.NONE)])
+            k1 = func.eval_at(ts[0], y0)
             ya = torch.empty_like(y0)
             kern.rk4_stage(1, ya, y0, k1, None, None, None, dts)
-            k2 = func.eval(scalar(t0 + scalar(dt * scalar(third))), ya)
+            k2 = func.eval_at(ts[1], ya)
             yb = torch.empty_like(y0)
             kern.rk4_stage(2, yb, y0, k1, k2, None, None, dts)
-            k3 = func.eval(scalar(t0 + scalar(dt * scalar(two_thirds))), yb)
+            k3 = func.eval_at(ts[2], yb)
             yc = torch.empty_like(y0)
             kern.rk4_stage(3, yc, y0, k1, k2, k3, None, dts)
-            k4 = func.eval(t1, yc, Perturb.PREV if self.perturb else Perturb.NONE)
+            k4 = func.eval_at(ts[3], yc)
             # y1 goes straight into the output row when the grid point is an output time
             if j < len(tt) and t1 == tt[j]:
                 y1 = solution[j]
