@@ -229,16 +229,23 @@ def test_rk4_and_lerp(hip_kernels, oracle_kernels, dtype, n):
     assert torch.equal(out.cpu(), ref)
 
 
-def test_readback_modes_agree(hip_kernels, oracle_kernels, monkeypatch):
-    """Zero-copy pinned read-back and the device-buffer + memcpy read-back return the same numbers."""
+def test_readback_modes_agree(hip_kernels, monkeypatch):
+    """poll (spin on pinned words), pinned (stream sync) and copy (device buffer + memcpy) read-backs
+    return the same numbers, repeatedly (the poll sentinel is re-armed per launch)."""
     from torchdiffeq_amd import _native
     n, dtype = 100000, torch.float32
     err = SparseRow.from_dense(DOPRI5.c_error)
     y0, y1 = _rand(n, dtype, 1).cuda(), _rand(n, dtype, 2).cuda()
     ks = _dev([_rand(n, dtype, 10 + j) for j in range(7)])
     res = []
-    for pinned in (True, False):
-        plan = _native.NormPlan([(0, n, 1e-3, 1e-6)], n, 2048, torch.device("cuda:0"), pinned)
-        hip_kernels.error_norm(plan, y0, y1, [ks[j] for j in err.idx], err.coef, 0.1)
-        res.append(hip_kernels.read_norms(plan))
-    assert res[0] == res[1]
+    for mode in ("poll", "pinned", "copy"):
+        monkeypatch.setenv("TDEQ_READBACK", mode)
+        kern = _native.HipKernels(hip_kernels.lib)
+        plan = kern.make_plan([(0, n, 1e-3, 1e-6)], n, 2048, torch.device("cuda:0"))
+        for rep in range(3):
+            kern.error_norm(plan, y0, y1, [ks[j] for j in err.idx], err.coef, 0.1 * (rep + 1))
+            out = kern.read_norms(plan)
+            kern.init_norms(plan, 0, y0, y1, y0)
+            out2 = kern.read_norms(plan)
+        res.append((out, out2))
+    assert res[0] == res[1] == res[2]
