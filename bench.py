@@ -169,8 +169,10 @@ def main():
 
     n = BATCH * DIM
     kernel_ms = [a.elapsed_time(b) for a, b in timed.events]
+    # The bracketed time (event -> kernel -> event) is used as is: it tracks rocprofv3's kernel duration
+    # within a few percent (profiles/), whereas subtracting the empty-pair cost over-corrects.
     raw_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-    avg_ms = max(raw_ms - overhead, 1e-6)
+    avg_ms = raw_ms
     bytes_per_launch = 7 * n * 4
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kernel_ms else None
     traffic = None

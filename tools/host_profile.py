@@ -1,0 +1,63 @@
+"""Where does the HOST time of one dopri5 trial step go?  (run on the GPU box)
+Wraps the kernel interface and func with perf_counter timers; prints per-step averages in microseconds."""
+import os
+import sys
+import time
+from collections import defaultdict
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from torchdiffeq_amd.misc import OdeFunc, StateLayout, rms_norm  # noqa: E402
+from torchdiffeq_amd.solvers import Dopri5Solver  # noqa: E402
+
+acc = defaultdict(float)
+
+
+def timed(name, fn):
+    def w(*a, **k):
+        t = time.perf_counter()
+        r = fn(*a, **k)
+        acc[name] += time.perf_counter() - t
+        return r
+    return w
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    dev = torch.device("cuda:0")
+    A, y0 = bench.make_problem(dev)
+    At = A.T.contiguous()
+    field = timed("func(matmul dispatch)", lambda t, y: y @ At)
+    func = OdeFunc(field, StateLayout([y0.shape], False), 1.0, y0.dtype, dev)
+    solver = Dopri5Solver(func=func, y0=y0.reshape(-1), rtol=1e-7, atol=1e-9, norm=rms_norm)
+    k = solver.kernels
+
+    class K:
+        pass
+    kk = K()
+    for name in ("stage_combine", "error_norm", "read_norms", "fill_scalars", "dense_eval", "init_norms", "make_plan"):
+        setattr(kk, name, timed(name, getattr(k, name)))
+    solver.kernels = kk
+    with torch.no_grad():
+        solver._before_integrate([0.0])
+        for _ in range(20):
+            solver._adaptive_step()
+        torch.cuda.synchronize()
+        acc.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            solver._adaptive_step()
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+    print(f"step wall: {1e6*total/steps:.1f} us")
+    s = 0.0
+    for name, v in sorted(acc.items(), key=lambda kv: -kv[1]):
+        print(f"  {name:28s} {1e6*v/steps:8.1f} us/step")
+        s += v
+    print(f"  {'other python in the step':28s} {1e6*(total-s)/steps:8.1f} us/step")
+
+
+if __name__ == "__main__":
+    main()

@@ -63,8 +63,21 @@ __device__ __forceinline__ E combine_one(const CombineArgs<T, NT>& a, const E& y
     return y + acc;
 }
 
+// Cache-policy variants for tuning: bit 0 = non-temporal loads of the k_j / y0 streams, bit 1 =
+// non-temporal store of the result.
+template <int POLICY, typename E>
+__device__ __forceinline__ E ld_stream(const E* p) {
+    if constexpr (POLICY & 1) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int POLICY, typename E>
+__device__ __forceinline__ void st_stream(E* p, const E& v) {
+    if constexpr (POLICY & 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // U independent 16-byte elements per lane and iteration => (NT+1)*U loads in flight per lane.
-template <typename T, int NT, int U, bool VEC>
+template <typename T, int NT, int U, bool VEC, int POLICY = 0>
 __global__ __launch_bounds__(kBlock) void stage_combine_kernel(const CombineArgs<T, NT> a) {
     using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
     constexpr int L = VEC ? VecOf<T>::L : 1;
@@ -78,18 +91,19 @@ __global__ __launch_bounds__(kBlock) void stage_combine_kernel(const CombineArgs
         E kk[U][NT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            y[u] = y0[i + u * stride];
+            y[u] = ld_stream<POLICY>(y0 + i + u * stride);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) kk[u][j] = reinterpret_cast<const E*>(a.k[j])[i + u * stride];
+            for (int j = 0; j < NT; ++j)
+                kk[u][j] = ld_stream<POLICY>(reinterpret_cast<const E*>(a.k[j]) + i + u * stride);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) out[i + u * stride] = combine_one<T, NT, E>(a, y[u], kk[u]);
+        for (int u = 0; u < U; ++u) st_stream<POLICY>(out + i + u * stride, combine_one<T, NT, E>(a, y[u], kk[u]));
     }
     for (; i < ne; i += stride) {
         E kk[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.k[j])[i];
-        out[i] = combine_one<T, NT, E>(a, y0[i], kk);
+        for (int j = 0; j < NT; ++j) kk[j] = ld_stream<POLICY>(reinterpret_cast<const E*>(a.k[j]) + i);
+        st_stream<POLICY>(out + i, combine_one<T, NT, E>(a, ld_stream<POLICY>(y0 + i), kk));
     }
     if (VEC) {   // scalar tail (n % L elements)
         const int64_t t = ne * L + threadIdx.x;
