@@ -2,19 +2,22 @@
 // Host-side validation + template dispatch + launch; no allocation, no synchronisation, no globals.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "tdeq_kernels.hpp"
 
 namespace {
 using namespace tdeq;
 
-// Launch geometry for the streaming (elementwise) kernels: enough workgroups to cover the tensor once,
-// capped at kMaxBlocksPerCU resident workgroups per CU (256 CUs); the rest is grid-strided.
-constexpr int kNumCU = 256;
-constexpr int kMaxBlocksPerCU = 8;
+// Launch geometry for the streaming (elementwise) kernels: one 16-byte element per lane, i.e. enough
+// workgroups to cover the tensor exactly once (tools/sweep_combine.hip on the MI355X: 8192 workgroups
+// of one float4 per lane beat a 2048-workgroup grid-stride loop by 6-8 %, cold and warm); only beyond
+// kMaxGrid workgroups does the kernel grid-stride.
+constexpr int64_t kMaxGrid = 1 << 16;
 
 inline unsigned stream_grid(int64_t n_items, int items_per_block) {
     int64_t g = (n_items + items_per_block - 1) / items_per_block;
-    const int64_t cap = (int64_t)kNumCU * kMaxBlocksPerCU;
+    const int64_t cap = kMaxGrid;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (unsigned)g;
@@ -25,6 +28,17 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
     return (int)e;
+}
+
+// Cache policy of the stage_combine streams (bit 0: non-temporal loads, bit 1: non-temporal store).
+// Read once from TDEQ_COMBINE_POLICY for tuning runs; the default is the measured best.
+inline int combine_policy() {
+    static const int policy = [] {
+        const char* e = getenv("TDEQ_COMBINE_POLICY");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 0 && v <= 3) ? v : 0;
+    }();
+    return policy;
 }
 
 // ---- stage_combine --------------------------------------------------------------------------------
@@ -43,11 +57,15 @@ int launch_combine(void* out, const void* y0, const void* const* k, const double
     }
     a.n = n;
     constexpr int L = VecOf<T>::L;
-    // Few input streams -> two 16-byte elements per lane and iteration to keep enough loads in flight.
-    constexpr int U = (NT <= 3) ? 2 : 1;
+    constexpr int U = 1;
     if (vec) {
         const unsigned g = stream_grid(n / L, kBlock * U);
-        hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true>), dim3(g), dim3(kBlock), 0, s, a);
+        switch (combine_policy()) {   // tuning knob, see combine_policy()
+            case 1: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 1>), dim3(g), dim3(kBlock), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 2>), dim3(g), dim3(kBlock), 0, s, a); break;
+            case 3: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 3>), dim3(g), dim3(kBlock), 0, s, a); break;
+            default: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 0>), dim3(g), dim3(kBlock), 0, s, a);
+        }
     } else {
         const unsigned g = stream_grid(n, kBlock * U);
         hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, false>), dim3(g), dim3(kBlock), 0, s, a);
