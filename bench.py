@@ -175,13 +175,19 @@ def main():
     avg_ms = raw_ms
     bytes_per_launch = 7 * n * 4
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kernel_ms else None
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile_gpu.sh ->
+    # profiles/<tag>_pmc_hbm.json; counters cannot be collected from inside this process).
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_stage_combine.json")
-    if os.path.exists(pmc_path):
+    import glob
+    for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            kernels = json.load(open(pmc_path))["kernels"]
+            hit = [v for k, v in kernels.items() if k.startswith("tdeq::stage_combine_kernel<float, 5,")]
+            if hit:
+                traffic = hit[0]["hbm_bytes_per_launch"]
+                break
         except Exception:
-            traffic = None
+            continue
 
     if rank == 0:
         out = {
