@@ -38,10 +38,11 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 1
+#define TDEQ_ABI_VERSION 2
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
+#define TDEQ_MAX_SUM_TERMS 8    /* tdeq_weighted_sum */
 #define TDEQ_MAX_SEGMENTS 4096
 #define TDEQ_INLINE_SEGMENTS 16  /* segment tables up to this size travel in the kernel arguments */
 #define TDEQ_CHUNK_QUANTUM 1024
@@ -136,6 +137,26 @@ int tdeq_rk4_38_stage(int stage, void* out, const void* y0, const void* k1, cons
 /* Fixed-grid output interpolation  out = y0 + slope*(y1 - y0)  (solvers.py:175-181). */
 int tdeq_lerp(void* out, const void* y0, const void* y1, double slope, int64_t n, int dtype,
               void* stream);
+
+/*
+ * Low-order fixed-grid Runge–Kutta stages with the reference's operation order (euler / midpoint use
+ * tdeq_stage_combine, which is bit-identical for their single-term forms).  w_j and dt rounded to T:
+ *   mode 0: out = y0 + dt * ((k0*w0 + k1*w1) + ...)   `y0 + dt * (k1*a31 + k2*a32)`, and y1 = y0 + dy with
+ *                                                    dy = `dt * (k1*b1 + k2*b2 [+ k3*b3])`
+ *                                                    (rk_common.py:139,140,156,157; solvers.py:115)
+ *   mode 1: out = y0 + (dt * k0) * w0                 `y0 + dt * k1 * a21` (rk_common.py:138,156); n_terms == 1
+ * 1 <= n_terms <= 4; structural zeros are skipped by the caller (heun2 / heun3, fixed_grid.py:32-60).
+ */
+int tdeq_fixed_stage(int mode, void* out, const void* y0, const void* const* k, const double* w, int n_terms,
+                     double dt, int64_t n, int dtype, void* stream);
+
+/*
+ * out = (x0*w0 + x1*w1) + ... (left to right, w_j rounded to T), 1 <= n_terms <= TDEQ_MAX_SUM_TERMS.
+ * Cubic Hermite output interpolation of the fixed-grid solvers,
+ * `h00*y0 + h10*dt*f0 + h01*y1 + h11*dt*f1` (solvers.py:166-173), with the scalar products formed by the host.
+ */
+int tdeq_weighted_sum(void* out, const void* const* x, const double* w, int n_terms, int64_t n, int dtype,
+                      void* stream);
 
 /* Writes n_vals scalars (converted to T) to consecutive elements of dst (stage times for func). */
 int tdeq_fill_scalars(void* dst, const double* vals, int n_vals, int dtype, void* stream);

@@ -52,6 +52,8 @@ def load() -> ctypes.CDLL:
         "oracle_interp_fit": [V, V, V, V, V, _c_void_pp, _c_double_p, I, D, I64, I],
         "oracle_rk4_38_stage": [I, V, V, V, V, V, V, D, I64, I],
         "oracle_lerp": [V, V, V, D, I64, I],
+        "oracle_fixed_stage": [I, V, V, _c_void_pp, _c_double_p, I, D, I64, I],
+        "oracle_weighted_sum": [V, _c_void_pp, _c_double_p, I, I64, I],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -146,6 +148,16 @@ class OracleKernels:
     def lerp(self, out, y0, y1, slope):
         _ok(self.lib.oracle_lerp(out.data_ptr(), y0.data_ptr(), y1.data_ptr(), slope, y0.numel(),
                                  _code(y0.dtype)), "oracle_lerp")
+
+    def fixed_stage(self, mode, out, y0, ks, ws, dt):
+        ptrs, cf, n = self._terms(ks, ws)
+        _ok(self.lib.oracle_fixed_stage(mode, out.data_ptr(), y0.data_ptr(), ptrs, cf, n, dt, y0.numel(),
+                                        _code(y0.dtype)), "oracle_fixed_stage")
+
+    def weighted_sum(self, out, xs, ws):
+        ptrs, cf, n = self._terms(xs, ws)
+        _ok(self.lib.oracle_weighted_sum(out.data_ptr(), ptrs, cf, n, out.numel(), _code(out.dtype)),
+            "oracle_weighted_sum")
 
     def fill_scalars(self, dst, vals):
         """Host twin of tdeq_fill_scalars: vals converted to dst's dtype."""

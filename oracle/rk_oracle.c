@@ -307,3 +307,44 @@ int oracle_lerp(void* out, const void* y0, const void* y1, double slope, int64_t
     } else return -1;
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * Low-order fixed-grid steps                                      rk_common.py:121-157, fixed_grid.py:32-60
+ *   mode 0: out = y0 + dt * ((k0*w0 + k1*w1) + ...)   `y0 + dt * (k1*a31 + k2*a32)`; y0 + `dt * (k1*b1 + ...)`
+ *   mode 1: out = y0 + (dt * k0) * w0                 `y0 + dt * k1 * a21`
+ *   mode 2: out = (x0*w0 + x1*w1) + ...               cubic Hermite interpolation, solvers.py:166-173
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_FIXED(NAME, T)                                                                            \
+    static void NAME(int mode, T* out, const T* y0, const T* const* k, const double* w, int nt,       \
+                     double dt, int64_t n) {                                                          \
+        T wT[8];                                                                                      \
+        const T dtT = (T)dt;                                                                          \
+        for (int j = 0; j < nt; ++j) wT[j] = (T)w[j];                                                 \
+        _Pragma("omp parallel for schedule(static)")                                                  \
+        for (int64_t i = 0; i < n; ++i) {                                                             \
+            if (mode == 1) { out[i] = y0[i] + (k[0][i] * dtT) * wT[0]; continue; }                    \
+            T acc = k[0][i] * wT[0];                                                                  \
+            for (int j = 1; j < nt; ++j) acc = acc + k[j][i] * wT[j];                                 \
+            out[i] = (mode == 2) ? acc : y0[i] + acc * dtT;                                           \
+        }                                                                                             \
+    }
+DEF_FIXED(fixed_f32, float)
+DEF_FIXED(fixed_f64, double)
+
+int oracle_fixed_stage(int mode, void* out, const void* y0, const void* const* k, const double* w, int n_terms,
+                       double dt, int64_t n, int dtype) {
+    if (!out || !y0 || !k || !w || (mode != 0 && mode != 1) || n_terms < 1 || n_terms > 4) return -1;
+    if (mode == 1 && n_terms != 1) return -1;
+    if (dtype == ORACLE_F32) fixed_f32(mode, (float*)out, (const float*)y0, (const float* const*)k, w, n_terms, dt, n);
+    else if (dtype == ORACLE_F64) fixed_f64(mode, (double*)out, (const double*)y0, (const double* const*)k, w, n_terms, dt, n);
+    else return -1;
+    return 0;
+}
+
+int oracle_weighted_sum(void* out, const void* const* x, const double* w, int n_terms, int64_t n, int dtype) {
+    if (!out || !x || !w || n_terms < 1 || n_terms > 8) return -1;
+    if (dtype == ORACLE_F32) fixed_f32(2, (float*)out, NULL, (const float* const*)x, w, n_terms, 0.0, n);
+    else if (dtype == ORACLE_F64) fixed_f64(2, (double*)out, NULL, (const double* const*)x, w, n_terms, 0.0, n);
+    else return -1;
+    return 0;
+}

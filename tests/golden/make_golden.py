@@ -19,7 +19,7 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 
 import torchdiffeq  # noqa: E402
-from torchdiffeq._impl import dopri5, dopri8, interp, misc, rk_common  # noqa: E402
+from torchdiffeq._impl import adaptive_heun, bosh3, dopri5, dopri8, fehlberg2, interp, misc, rk_common, tsit5  # noqa: E402
 from torchdiffeq._impl.misc import Perturb  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -45,7 +45,11 @@ def rand(*shape, seed, dtype=torch.float64):
 def gen_tableaus():
     arrays = {}
     for name, tab, mid in [("dopri5", dopri5._DORMAND_PRINCE_SHAMPINE_TABLEAU, dopri5.DPS_C_MID),
-                           ("dopri8", dopri8._DOPRI8_TABLEAU, dopri8._C_mid)]:
+                           ("dopri8", dopri8._DOPRI8_TABLEAU, dopri8._C_mid),
+                           ("tsit5", tsit5._TSITOURAS_TABLEAU, tsit5.TSIT_C_MID),
+                           ("bosh3", bosh3._BOGACKI_SHAMPINE_TABLEAU, bosh3._BS_C_MID),
+                           ("fehlberg2", fehlberg2._FEHLBERG2_TABLEAU, fehlberg2._FE_C_MID),
+                           ("adaptive_heun", adaptive_heun._ADAPTIVE_HEUN_TABLEAU, adaptive_heun._AH_C_MID)]:
         arrays[f"{name}_alpha"] = tab.alpha
         arrays[f"{name}_beta_flat"] = torch.cat(list(tab.beta))
         arrays[f"{name}_c_sol"] = tab.c_sol
@@ -329,9 +333,56 @@ def gen_cnf():
     save("cnf.npz", **arrays)
 
 
+def gen_methods():
+    """§8(f) rank 2: every other explicit RK method of the reference's SOLVERS table.
+    Adaptive pairs on a time-dependent nonlinear field (fp64: step sequences must match; fp32: solution),
+    fixed-grid methods with step_size / perturb / cubic interpolation (no reductions -> bit-exact)."""
+    arrays = {}
+    A, y0 = linear_problem(12, 8, torch.float64, seed=6)
+    field = lambda t, y: torch.sin(2 * t) * (y @ A.T) * 2 - 0.5 * y ** 3
+    t = torch.tensor([0.0, 0.6, 2.0], dtype=torch.float64)
+    arrays.update(ad_A=A, ad_y0=y0, ad_t=t)
+    for method, rtol, atol in [("tsit5", 1e-8, 1e-10), ("bosh3", 1e-6, 1e-8), ("fehlberg2", 1e-4, 1e-6),
+                               ("adaptive_heun", 1e-4, 1e-6)]:
+        y, nfe, c = solve(field, y0, t, rtol=rtol, atol=atol, method=method)
+        arrays[f"ad_{method}_tol"] = np.array([rtol, atol])
+        arrays[f"ad_{method}_y"] = y
+        arrays[f"ad_{method}_nfe"] = nfe
+        arrays[f"ad_{method}_accept_dt"] = np.array(c.accept)
+        arrays[f"ad_{method}_reject_dt"] = np.array(c.reject)
+        # fp32 state, decreasing time
+        A32, y32 = A.float(), y0.float()
+        f32 = lambda t, y: torch.sin(2 * t) * (y @ A32.T) * 2 - 0.1 * y
+        y, nfe, c = solve(f32, y32, torch.tensor([1.0, 0.3, 0.0], dtype=torch.float64), rtol=1e-4, atol=1e-6,
+                          method=method)
+        arrays[f"ad32_{method}_y"] = y
+        arrays[f"ad32_{method}_nfe"] = nfe
+    # fixed grid
+    A, y0 = linear_problem(4, 8, torch.float32, seed=5)
+    t = torch.tensor([0.0, 0.33, 0.7, 1.0])
+    arrays.update(fx_A=A, fx_y0=y0, fx_t=t)
+    with torch.no_grad():
+        for method in ["euler", "midpoint", "heun2", "heun3", "rk4"]:
+            f = lambda t, y: torch.cos(t) * (y @ A.T) - 0.1 * y
+            arrays[f"fx_{method}_grid"] = torchdiffeq.odeint(f, y0, torch.linspace(0, 1, 9), method=method)
+            arrays[f"fx_{method}_step"] = torchdiffeq.odeint(f, y0, t, method=method, options=dict(step_size=0.1))
+            arrays[f"fx_{method}_perturb"] = torchdiffeq.odeint(f, y0, t, method=method,
+                                                                options=dict(step_size=0.1, perturb=True))
+            arrays[f"fx_{method}_cubic"] = torchdiffeq.odeint(f, y0, t, method=method,
+                                                              options=dict(step_size=0.1, interp="cubic"))
+            arrays[f"fx_{method}_rev"] = torchdiffeq.odeint(f, y0, torch.tensor([1.0, 0.45, 0.0]), method=method,
+                                                            options=dict(step_size=0.125, interp="cubic"))
+            y64 = y0.double()
+            A64 = A.double()
+            f64 = lambda t, y: torch.cos(t) * (y @ A64.T) - 0.1 * y
+            arrays[f"fx_{method}_f64"] = torchdiffeq.odeint(f64, y64, t.double(), method=method,
+                                                            options=dict(step_size=0.05))
+    save("methods.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
-                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf)]:
+                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods)]:
         if not only or name in only:
             fn()

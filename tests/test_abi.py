@@ -42,6 +42,11 @@ def test_argument_errors_without_gpu():
     assert lib.tdeq_stage_combine(p, p, ptrs, buf, 1, 0.1, 0, 1, None) == 0           # empty state: no-op
     assert lib.tdeq_rk4_38_stage(5, p, p, p, p, p, p, 0.1, 4, 1, None) == -1
     assert lib.tdeq_fill_scalars(p, buf, 17, 1, None) == -1
+    assert lib.tdeq_fixed_stage(2, p, p, ptrs, buf, 1, 0.1, 4, 1, None) == -1         # bad mode
+    assert lib.tdeq_fixed_stage(1, p, p, ptrs, buf, 2, 0.1, 4, 1, None) == -1         # mode 1 takes one term
+    assert lib.tdeq_fixed_stage(0, p, p, ptrs, buf, 5, 0.1, 4, 1, None) == -1         # n_terms > 4
+    assert lib.tdeq_weighted_sum(p, ptrs, buf, 9, 4, 1, None) == -1                   # n_terms > 8
+    assert lib.tdeq_weighted_sum(p, ptrs, buf, 1, 0, 1, None) == 0
 
 
 def test_cpu_state_is_rejected_loudly():

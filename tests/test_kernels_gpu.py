@@ -249,3 +249,41 @@ def test_readback_modes_agree(hip_kernels, monkeypatch):
             out2 = kern.read_norms(plan)
         res.append((out, out2))
     assert res[0] == res[1] == res[2]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", SIZES)
+def test_fixed_stage_and_weighted_sum(hip_kernels, oracle_kernels, dtype, n):
+    """tdeq_fixed_stage (rk2/rk3 step forms) and tdeq_weighted_sum (cubic Hermite interpolation): bit-exact."""
+    y0 = _rand(n, dtype, 1)
+    ks = [_rand(n, dtype, 10 + j) for j in range(8)]
+    y0d, ksd = y0.cuda(), _dev(ks)
+    for dt in (0.0371, -0.0371):
+        for mode, idx, ws in [(1, [0], [1 / 3]), (1, [2], [1.0]), (0, [1], [2 / 3]), (0, [0, 1], [0.5, 0.5]),
+                              (0, [0, 2], [0.25, 0.75]), (0, [0, 1, 2], [0.1, 0.2, 0.7]), (0, [0, 1, 2, 3], [0.1, 0.2, 0.3, 0.4])]:
+            ref = torch.empty_like(y0)
+            oracle_kernels.fixed_stage(mode, ref, y0, [ks[j] for j in idx], ws, dt)
+            out = torch.empty_like(y0d)
+            hip_kernels.fixed_stage(mode, out, y0d, [ksd[j] for j in idx], ws, dt)
+            assert torch.equal(out.cpu(), ref), (mode, idx)
+    for nt in range(1, 9):
+        ws = [(-1) ** j * (0.3 + j / 7) for j in range(nt)]
+        ref = torch.empty_like(y0)
+        oracle_kernels.weighted_sum(ref, ks[:nt], ws)
+        out = torch.empty_like(y0d)
+        hip_kernels.weighted_sum(out, ksd[:nt], ws)
+        assert torch.equal(out.cpu(), ref), nt
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fixed_stage_unaligned(hip_kernels, oracle_kernels, dtype):
+    n = 10007
+    y0, k1, k2 = _rand(n, dtype, 1), _rand(n, dtype, 2), _rand(n, dtype, 3)
+    ref = torch.empty_like(y0)
+    oracle_kernels.fixed_stage(0, ref, y0, [k1, k2], [0.25, 0.75], 0.1)
+    bufs = [torch.empty(n + 3, dtype=dtype).cuda() for _ in range(4)]
+    views = [b[1 + i % 3:1 + i % 3 + n] for i, b in enumerate(bufs)]
+    for v, src in zip(views[1:], (y0, k1, k2)):
+        v.copy_(src)
+    hip_kernels.fixed_stage(0, views[0], views[1], [views[2], views[3]], [0.25, 0.75], 0.1)
+    assert torch.equal(views[0].cpu(), ref)

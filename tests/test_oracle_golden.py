@@ -235,3 +235,74 @@ def test_adjoint_cfg3_reduced(tag, tol, norm_tag):
     assert rel_err(g0, z[f"adj_{tag}_{norm_tag}_grad_y0"]) < tol
     for i, g in enumerate(gp):
         assert rel_err(g, z[f"adj_{tag}_{norm_tag}_grad_p{i}"]) < tol, i
+
+
+# ---------------------------------------------------------------------------------------------------
+# §8(f) rank 2: the other explicit RK methods (tests/golden/methods.npz)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("method", ["tsit5", "bosh3", "fehlberg2", "adaptive_heun"])
+def test_oracle_adaptive_low_order_pairs(method):
+    """fp64 well above the noise floor: same accept / reject sequence and step sizes as the reference."""
+    z = load("methods.npz")
+    A = z["ad_A"]
+
+    class Field:
+        params = []
+
+        def f(self, t, y):
+            return np.sin(2 * t) * (y @ A.T) * 2 - 0.5 * y ** 3
+
+    rtol, atol = z[f"ad_{method}_tol"]
+    stats = {}
+    y = orc.odeint(Field(), z["ad_y0"], z["ad_t"], method, rtol, atol, stats=stats)
+    assert rel_err(y, z[f"ad_{method}_y"]) < 1e-10
+    assert stats["nfe"] == int(z[f"ad_{method}_nfe"])
+    assert (stats["n_accept"], stats["n_reject"]) == (len(z[f"ad_{method}_accept_dt"]), len(z[f"ad_{method}_reject_dt"]))
+    np.testing.assert_allclose(stats["dts"], z[f"ad_{method}_accept_dt"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "heun2", "heun3", "rk4"])
+def test_oracle_fixed_grid_methods(method):
+    """The field is numpy here (cos / GEMM round differently from torch's), so 1e-6 (fp32) / 1e-13 (fp64);
+    bit-exactness of the solver arithmetic itself is pinned by tests/test_methods_golden.py[cpu], which runs
+    the product's host logic over the C oracle with the reference's own torch field."""
+    z = load("methods.npz")
+    A, y0, t = z["fx_A"], z["fx_y0"], z["fx_t"]
+
+    class Field:
+        params = []
+
+        def __init__(self, A):
+            self.A = A
+
+        def f(self, tt, y):
+            return (np.cos(tt) * (y @ self.A.T) - y.dtype.type(0.1) * y).astype(y.dtype)
+
+    f32 = Field(A)
+    cases = {
+        "grid": orc.odeint(f32, y0, np.linspace(0, 1, 9, dtype=np.float32), method),
+        "step": orc.odeint(f32, y0, t, method, step_size=0.1),
+        "perturb": orc.odeint(f32, y0, t, method, step_size=0.1, perturb=True),
+        "cubic": orc.odeint(f32, y0, t, method, step_size=0.1, interp="cubic"),
+        "rev": orc.odeint(f32, y0, np.array([1.0, 0.45, 0.0], dtype=np.float32), method, step_size=0.125,
+                          interp="cubic"),
+        "f64": orc.odeint(Field(A.astype(np.float64)), y0.astype(np.float64), t.astype(np.float64), method,
+                          step_size=0.05),
+    }
+    for tag, y in cases.items():
+        assert rel_err(y, z[f"fx_{method}_{tag}"]) < (1e-13 if tag == "f64" else 1e-6), tag
+
+
+def test_oracle_c_fixed_stage_matches_numpy_bitwise():
+    z = load("kernels.npz")
+    a = orc.NumpyOps()
+    for dname in ("f32", "f64"):
+        y0, k = z[f"rk4_{dname}_y0"], z[f"rk4_{dname}_k"]
+        ty0, tk = T(y0), [T(k[j]).contiguous() for j in range(4)]
+        for mode, idx, ws in [(1, [0], [1 / 3]), (0, [1], [2 / 3]), (0, [0, 2], [0.25, 0.75]), (0, [0, 1, 2, 3], [0.1, 0.2, 0.3, 0.4])]:
+            out = torch.empty_like(ty0)
+            KERN.fixed_stage(mode, out, ty0, [tk[j] for j in idx], ws, -0.037)
+            assert np.array_equal(out.numpy(), a.fixed_stage(mode, y0, [k[j] for j in idx], ws, -0.037))
+        out = torch.empty_like(ty0)
+        KERN.weighted_sum(out, [ty0] + tk, [0.5, -0.25, 0.125, 3.0, 1 / 3])
+        assert np.array_equal(out.numpy(), a.weighted_sum([y0] + [k[j] for j in range(4)], [0.5, -0.25, 0.125, 3.0, 1 / 3]))

@@ -3,10 +3,13 @@ import numpy as np
 import pytest
 
 from _cases import load
-from torchdiffeq_amd.tableaus import DOPRI5, DOPRI8, SparseRow
+from torchdiffeq_amd.tableaus import ADAPTIVE_HEUN, BOSH3, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow
 
 
-@pytest.mark.parametrize("tab", [DOPRI5, DOPRI8], ids=["dopri5", "dopri8"])
+ALL = [DOPRI5, DOPRI8, TSIT5, BOSH3, FEHLBERG2, ADAPTIVE_HEUN]
+
+
+@pytest.mark.parametrize("tab", ALL, ids=[t.name for t in ALL])
 def test_tableau_matches_reference_bits(tab):
     z = load("tableaus.npz")
     alpha, beta, c_sol, c_err, c_mid = tab.dense()
@@ -15,7 +18,9 @@ def test_tableau_matches_reference_bits(tab):
     assert np.array_equal(c_sol, z[f"{tab.name}_c_sol"])
     assert np.array_equal(c_err, z[f"{tab.name}_c_error"])
     assert np.array_equal(c_mid, z[f"{tab.name}_c_mid"])
-    assert tab.fsal_solution   # rk_common.py:83 shortcut holds for both pairs
+    # rk_common.py:83 shortcut: holds for the Dormand–Prince pairs and bosh3; tsit5 / fehlberg2 / adaptive_heun
+    # take the extra solution combine
+    assert tab.fsal_solution == (tab.name in ("dopri5", "dopri8", "bosh3"))
 
 
 def test_structural_zero_counts():

@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 1
+TDEQ_ABI_VERSION = 2
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -61,6 +61,11 @@ ABI_SIGNATURES = {
                                          ctypes.c_double, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_lerp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                  ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_fixed_stage": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
+                                        ctypes.c_int, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+                                        ctypes.c_void_p]),
+    "tdeq_weighted_sum": (ctypes.c_int, [ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int, ctypes.c_int64,
+                                         ctypes.c_int, ctypes.c_void_p]),
     "tdeq_fill_scalars": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p]),
 }
@@ -272,6 +277,18 @@ class HipKernels:
     def lerp(self, out, y0, y1, slope: float) -> None:
         _check(self.lib.tdeq_lerp(out.data_ptr(), y0.data_ptr(), y1.data_ptr(), slope, y0.numel(),
                                   dtype_code(y0.dtype), self._stream()), "tdeq_lerp")
+
+    def fixed_stage(self, mode: int, out, y0, ks, ws, dt: float) -> None:
+        """mode 0: out = y0 + dt*(sum_j k_j*w_j); mode 1: out = y0 + (dt*k_0)*w_0 (low-order fixed-grid steps)."""
+        ptrs, cf, n = self._terms(ks, ws)
+        _check(self.lib.tdeq_fixed_stage(mode, out.data_ptr(), y0.data_ptr(), ptrs, cf, n, dt, y0.numel(),
+                                         dtype_code(y0.dtype), self._stream()), "tdeq_fixed_stage")
+
+    def weighted_sum(self, out, xs, ws) -> None:
+        """out = (x_0*w_0 + x_1*w_1) + ... (left to right)."""
+        ptrs, cf, n = self._terms(xs, ws)
+        _check(self.lib.tdeq_weighted_sum(out.data_ptr(), ptrs, cf, n, out.numel(), dtype_code(out.dtype),
+                                          self._stream()), "tdeq_weighted_sum")
 
     def fill_scalars(self, dst, vals: Sequence[float]) -> None:
         n = len(vals)

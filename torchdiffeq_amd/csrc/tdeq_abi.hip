@@ -290,6 +290,42 @@ int launch_lerp(void* out, const void* y0, const void* y1, double slope, int64_t
     return check_launch();
 }
 
+// ---- low-order fixed-grid stages / weighted sums -----------------------------------------------------
+template <typename T, int NT, int MODE>
+int launch_fixed(void* out, const void* y0, const void* const* k, const double* w, double dt, int64_t n,
+                 hipStream_t s) {
+    FixedArgs<T, NT> a;
+    a.out = static_cast<T*>(out);
+    a.y0 = static_cast<const T*>(y0);
+    bool vec = aligned16(out) && (MODE == 2 || aligned16(y0));
+    for (int j = 0; j < NT; ++j) {
+        a.k[j] = static_cast<const T*>(k[j]);
+        a.w[j] = (T)w[j];   // Python-float weights meet a T tensor: rounded to T (rk_common.py:139-157)
+        vec = vec && aligned16(k[j]);
+    }
+    a.dt = (T)dt;
+    a.n = n;
+    constexpr int L = VecOf<T>::L;
+    if (vec) hipLaunchKernelGGL((fixed_stage_kernel<T, NT, MODE, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((fixed_stage_kernel<T, NT, MODE, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
+}
+
+template <typename T, int MODE>
+int dispatch_fixed(void* out, const void* y0, const void* const* k, const double* w, int nt, double dt,
+                   int64_t n, hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_fixed<T, N, MODE>(out, y0, k, w, dt, n, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4)
+        case 5: if (MODE == 2) return launch_fixed<T, 5, MODE>(out, y0, k, w, dt, n, s); break;
+        case 6: if (MODE == 2) return launch_fixed<T, 6, MODE>(out, y0, k, w, dt, n, s); break;
+        case 7: if (MODE == 2) return launch_fixed<T, 7, MODE>(out, y0, k, w, dt, n, s); break;
+        case 8: if (MODE == 2) return launch_fixed<T, 8, MODE>(out, y0, k, w, dt, n, s); break;
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
 inline bool bad_dtype(int dtype) { return dtype != TDEQ_F32 && dtype != TDEQ_F64; }
 
 }  // namespace
@@ -392,6 +428,31 @@ int tdeq_lerp(void* out, const void* y0, const void* y1, double slope, int64_t n
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == TDEQ_F32 ? launch_lerp<float>(out, y0, y1, slope, n, s)
                              : launch_lerp<double>(out, y0, y1, slope, n, s);
+}
+
+int tdeq_fixed_stage(int mode, void* out, const void* y0, const void* const* k, const double* w, int n_terms,
+                     double dt, int64_t n, int dtype, void* stream) {
+    if (!out || !y0 || !k || !w || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if ((mode != 0 && mode != 1) || n_terms < 1 || n_terms > 4 || (mode == 1 && n_terms != 1)) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_F32)
+        return mode == 0 ? dispatch_fixed<float, 0>(out, y0, k, w, n_terms, dt, n, s)
+                         : dispatch_fixed<float, 1>(out, y0, k, w, n_terms, dt, n, s);
+    return mode == 0 ? dispatch_fixed<double, 0>(out, y0, k, w, n_terms, dt, n, s)
+                     : dispatch_fixed<double, 1>(out, y0, k, w, n_terms, dt, n, s);
+}
+
+int tdeq_weighted_sum(void* out, const void* const* x, const double* w, int n_terms, int64_t n, int dtype,
+                      void* stream) {
+    if (!out || !x || !w || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_SUM_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!x[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? dispatch_fixed<float, 2>(out, nullptr, x, w, n_terms, 0.0, n, s)
+                             : dispatch_fixed<double, 2>(out, nullptr, x, w, n_terms, 0.0, n, s);
 }
 
 int tdeq_fill_scalars(void* dst, const double* vals, int n_vals, int dtype, void* stream) {

@@ -497,6 +497,49 @@ __global__ __launch_bounds__(kBlock) void rk4_kernel(const Rk4Args<T> a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Low-order fixed-grid steps (rk_common.py:121-157, fixed_grid.py:6-60) and generic weighted sums.
+//   MODE 0:  out = y0 + dt * ((k0*w0 + k1*w1) + ...)      rk2/rk3 increments and rk3's third stage input
+//   MODE 1:  out = y0 + (dt * k0) * w0                    rk2/rk3 second stage input  `y0 + dt * k1 * a21`
+//   MODE 2:  out = (x0*w0 + x1*w1) + ...                  cubic Hermite output interpolation (solvers.py:166-173)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+struct FixedArgs {
+    T* out;
+    const T* y0;        // unused in MODE 2
+    const T* k[NT];
+    T w[NT];
+    T dt;
+    int64_t n;
+};
+
+template <typename T, int NT, int MODE, typename E>
+__device__ __forceinline__ E fixed_one(const FixedArgs<T, NT>& a, int64_t i) {
+    E kk[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.k[j])[i];
+    if (MODE == 1) return reinterpret_cast<const E*>(a.y0)[i] + (kk[0] * a.dt) * a.w[0];
+    E acc = kk[0] * a.w[0];
+#pragma unroll
+    for (int j = 1; j < NT; ++j) acc = acc + kk[j] * a.w[j];
+    if (MODE == 2) return acc;
+    return reinterpret_cast<const E*>(a.y0)[i] + acc * a.dt;
+}
+
+template <typename T, int NT, int MODE, bool VEC>
+__global__ __launch_bounds__(kBlock) void fixed_stage_kernel(const FixedArgs<T, NT> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
+        reinterpret_cast<E*>(a.out)[i] = fixed_one<T, NT, MODE, E>(a, i);
+    if (VEC) {
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) a.out[t] = fixed_one<T, NT, MODE, T>(a, t);
+    }
+}
+
 template <typename T>
 struct LerpArgs {
     T* out;

@@ -1,19 +1,28 @@
 """`odeint` and the `SOLVERS` plugin table — the drop-in surface of torchdiffeq/_impl/odeint.py:19-108
-for the explicit-RK hot path (dopri5, dopri8, rk4)."""
+for the explicit-RK hot path (every explicit RK method of the reference)."""
 from __future__ import annotations
 
 import torch
 
 from .misc import check_inputs
-from .solvers import Dopri5Solver, Dopri8Solver, RK4
+from .solvers import (RK4, AdaptiveHeunSolver, Bosh3Solver, Dopri5Solver, Dopri8Solver, Euler, Fehlberg2, Heun2,
+                      Heun3, Midpoint, Tsit5Solver)
 
 # method name -> solver class.  Same protocol as the reference's table (odeint.py:19-46):
 #   SOLVERS[method](func=..., y0=..., rtol=..., atol=..., **options).integrate(t)
-# The names below are the methods BASELINE.json's north_star puts on the MI355X hot path; the
-# reference's other methods (implicit / Adams / scipy ...) are out of scope.
+# The names below are every explicit Runge–Kutta method of the reference's table, in its order; the
+# reference's other methods (implicit RK / Adams / scipy wrapper) are out of scope.
 SOLVERS = {
     "dopri8": Dopri8Solver,
     "dopri5": Dopri5Solver,
+    "tsit5": Tsit5Solver,
+    "bosh3": Bosh3Solver,
+    "fehlberg2": Fehlberg2,
+    "adaptive_heun": AdaptiveHeunSolver,
+    "euler": Euler,
+    "midpoint": Midpoint,
+    "heun2": Heun2,
+    "heun3": Heun3,
     "rk4": RK4,
 }
 

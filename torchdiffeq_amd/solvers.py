@@ -25,7 +25,7 @@ import torch
 from . import _native
 from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, handle_unused_kwargs, rms_norm)
 from .misc import _null_callback as _null
-from .tableaus import DOPRI5, DOPRI8, SparseRow, Tableau
+from .tableaus import ADAPTIVE_HEUN, BOSH3, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau
 
 
 def _nan_max(a: float, b: float) -> float:
@@ -336,14 +336,38 @@ class Dopri8Solver(RKAdaptiveStepsizeODESolver):
     tableau = DOPRI8
 
 
+class Tsit5Solver(RKAdaptiveStepsizeODESolver):
+    """Tsitouras 5(4): 6 evaluations per step + a 7-term solution combine (tsit5.py:79-82)."""
+    order = 5
+    tableau = TSIT5
+
+
+class Bosh3Solver(RKAdaptiveStepsizeODESolver):
+    """Bogacki–Shampine 3(2), FSAL (bosh3.py:19-22)."""
+    order = 3
+    tableau = BOSH3
+
+
+class Fehlberg2(RKAdaptiveStepsizeODESolver):
+    """Fehlberg 2(1) (fehlberg2.py:19-22)."""
+    order = 2
+    tableau = FEHLBERG2
+
+
+class AdaptiveHeunSolver(RKAdaptiveStepsizeODESolver):
+    """Heun–Euler 2(1) (adaptive_heun.py:22-25)."""
+    order = 2
+    tableau = ADAPTIVE_HEUN
+
+
 # ---------------------------------------------------------------------------------------------------
 # Fixed grid
 # ---------------------------------------------------------------------------------------------------
-class RK4(object):
-    """Fixed-grid 4th-order RK, 3/8 rule (fixed_grid.py:24-29 -> rk_common.py:110-118), outputs by
-    linear interpolation between grid points (solvers.py:102-128, 175-181).  Time-like scalars keep
-    `t.dtype` (no fp64 promotion in the fixed-grid path)."""
-    order = 4
+class FixedGridODESolver(object):
+    """Fixed-grid explicit RK driver (solvers.py:52-181): grid from `t`, `step_size` or `grid_constructor`;
+    outputs by linear (default) or cubic Hermite interpolation between grid points.  Time-like scalars
+    keep `t.dtype` (no fp64 promotion in the fixed-grid path).  Subclasses implement `_step`."""
+    order: int
 
     def __init__(self, func: OdeFunc, y0: torch.Tensor, step_size=None, grid_constructor=None,
                  interp="linear", perturb=False, **unused_kwargs):
@@ -389,19 +413,29 @@ class RK4(object):
             return t_infer
         return _grid_constructor
 
+    # -- one step ------------------------------------------------------------------------------------
+    def _step(self, t0, dt, t1, y0: torch.Tensor, y1: torch.Tensor):
+        """Write y(t1) into `y1`; return f0 = func(t0, y0).  t0, dt, t1 are numpy scalars of t.dtype."""
+        raise NotImplementedError
+
+    def _first_perturb(self) -> Perturb:
+        return Perturb.NEXT if self.perturb else Perturb.NONE
+
+    def _last_perturb(self) -> Perturb:
+        return Perturb.PREV if self.perturb else Perturb.NONE
+
+    # -- integrate -----------------------------------------------------------------------------------
     def integrate(self, t: torch.Tensor) -> torch.Tensor:
         func, kern = self.func, self.kernels
         time_grid = self.grid_constructor(func, self.y0, t)
         assert time_grid[0] == t[0] and time_grid[-1] == t[-1]
-        if self.interp != "linear":
-            if self.interp == "cubic":
-                raise NotImplementedError("interp='cubic' is outside the scope of the MI355X RK hot path")
+        if self.interp not in ("linear", "cubic"):
             raise ValueError(f"Unknown interpolation method {self.interp}")
         # host copies, in the grid's own dtype (dt = t1 - t0 is formed in t.dtype: solvers.py:112)
         grid = time_grid.detach().cpu().numpy()
         tt = t.detach().cpu().numpy()
         scalar = grid.dtype.type
-        third, two_thirds = 1 / 3, 2 / 3
+        linear = self.interp == "linear"
 
         solution = torch.empty(len(tt), self.layout.total, dtype=self.dtype, device=self.device)
         solution[0].copy_(self.y0)
@@ -412,40 +446,139 @@ class RK4(object):
             dt = scalar(t1 - t0)
             if has_cb:
                 func.callback_step(torch.tensor(t0, device=self.device), y0, torch.tensor(dt, device=self.device))
-            dts = float(dt) * func.sign
-            ts = func.time_tensors(kern, [(t0, Perturb.NEXT if self.perturb else Perturb.NONE),
-                                          (scalar(t0 + scalar(dt * scalar(third))), Perturb.NONE),
-                                          (scalar(t0 + scalar(dt * scalar(two_thirds))), Perturb.NONE),
-                                          (t1, Perturb.PREV if self.perturb else Perturb.NONE)])
-            k1 = func.eval_at(ts[0], y0)
-            ya = torch.empty_like(y0)
-            kern.rk4_stage(1, ya, y0, k1, None, None, None, dts)
-            k2 = func.eval_at(ts[1], ya)
-            yb = torch.empty_like(y0)
-            kern.rk4_stage(2, yb, y0, k1, k2, None, None, dts)
-            k3 = func.eval_at(ts[2], yb)
-            yc = torch.empty_like(y0)
-            kern.rk4_stage(3, yc, y0, k1, k2, k3, None, dts)
-            k4 = func.eval_at(ts[3], yc)
             # y1 goes straight into the output row when the grid point is an output time
-            if j < len(tt) and t1 == tt[j]:
+            if linear and j < len(tt) and t1 == tt[j]:
                 y1 = solution[j]
             else:
                 y1 = torch.empty_like(y0)
-            kern.rk4_stage(4, y1, y0, k1, k2, k3, k4, dts)
+            f0 = self._step(t0, dt, t1, y0, y1)
 
+            f1 = None
             while j < len(tt) and t1 >= tt[j]:
-                if tt[j] == t1:
-                    if y1.data_ptr() != solution[j].data_ptr():
-                        solution[j].copy_(y1)
-                elif tt[j] == t0:
-                    solution[j].copy_(y0)
+                if linear:
+                    if tt[j] == t1:
+                        if y1.data_ptr() != solution[j].data_ptr():
+                            solution[j].copy_(y1)
+                    elif tt[j] == t0:
+                        solution[j].copy_(y0)
+                    else:
+                        slope = scalar(scalar(tt[j] - t0) / scalar(t1 - t0))
+                        kern.lerp(solution[j], y0, y1, float(slope))
                 else:
-                    slope = scalar(scalar(tt[j] - t0) / scalar(t1 - t0))
-                    kern.lerp(solution[j], y0, y1, float(slope))
+                    if f1 is None:
+                        f1 = func.eval(t1, y1)                   # solvers.py:121, once per grid interval hit
+                    self._cubic_hermite_interp(solution[j], scalar, t0, y0, f0, t1, y1, f1, tt[j])
                 j += 1
             y0 = y1
         return solution
 
+    def _cubic_hermite_interp(self, out, scalar, t0, y0, f0, t1, y1, f1, t) -> None:
+        """solvers.py:166-173; the basis values are scalars of t.dtype formed on the host."""
+        one, two, three = scalar(1), scalar(2), scalar(3)
+        h = scalar(scalar(t - t0) / scalar(t1 - t0))
+        omh = scalar(one - h)
+        h00 = scalar(scalar(scalar(one + scalar(two * h)) * omh) * omh)
+        h10 = scalar(scalar(h * omh) * omh)
+        hh = scalar(h * h)
+        h01 = scalar(hh * scalar(three - scalar(two * h)))
+        h11 = scalar(hh * scalar(h - one))
+        dt = scalar(t1 - t0)
+        sign = scalar(self.func.sign)       # f0 / f1 are raw func outputs: fold the time sign into their weights
+        self.kernels.weighted_sum(out, [y0, f0, y1, f1],
+                                  [float(h00), float(scalar(h10 * dt) * sign), float(h01), float(scalar(h11 * dt) * sign)])
 
-SOLVER_CLASSES = {"dopri8": Dopri8Solver, "dopri5": Dopri5Solver, "rk4": RK4}
+
+class Euler(FixedGridODESolver):
+    """Forward Euler (fixed_grid.py:6-11): dy = dt * f0."""
+    order = 1
+
+    def _step(self, t0, dt, t1, y0, y1):
+        func = self.func
+        f0 = func.eval(t0, y0, self._first_perturb())
+        self.kernels.stage_combine(y1, y0, [f0], [1.0], float(dt) * func.sign)
+        return f0
+
+
+class Midpoint(FixedGridODESolver):
+    """Explicit midpoint (fixed_grid.py:14-21): y_mid = y0 + f0*(dt/2); dy = dt * f(t0 + dt/2, y_mid)."""
+    order = 2
+
+    def _step(self, t0, dt, t1, y0, y1):
+        func, kern = self.func, self.kernels
+        scalar = type(dt)
+        dts = float(dt) * func.sign
+        half_dt = scalar(scalar(0.5) * dt)
+        f0 = func.eval(t0, y0, self._first_perturb())
+        y_mid = torch.empty_like(y0)
+        kern.stage_combine(y_mid, y0, [f0], [0.5], dts)
+        k2 = func.eval(scalar(t0 + half_dt), y_mid)
+        kern.stage_combine(y1, y0, [k2], [1.0], dts)
+        return f0
+
+
+class Heun2(FixedGridODESolver):
+    """Heun's 2nd-order method through the reference's rk2 step (fixed_grid.py:49-60, rk_common.py:142-157)."""
+    order = 2
+
+    def _step(self, t0, dt, t1, y0, y1):
+        func, kern = self.func, self.kernels
+        scalar = type(dt)
+        dts = float(dt) * func.sign
+        k1 = func.eval(t0, y0, self._first_perturb())
+        ya = torch.empty_like(y0)
+        kern.fixed_stage(1, ya, y0, [k1], [1.0], dts)
+        k2 = func.eval(scalar(t0 + scalar(dt * scalar(1.0))), ya, self._last_perturb())
+        kern.fixed_stage(0, y1, y0, [k1, k2], [0.5, 0.5], dts)
+        return k1
+
+
+class Heun3(FixedGridODESolver):
+    """Heun's 3rd-order method through the reference's rk3 step (fixed_grid.py:32-46, rk_common.py:121-140)."""
+    order = 3
+
+    def _step(self, t0, dt, t1, y0, y1):
+        func, kern = self.func, self.kernels
+        scalar = type(dt)
+        dts = float(dt) * func.sign
+        third, two_thirds = 1 / 3, 2 / 3
+        k1 = func.eval(t0, y0, self._first_perturb())
+        ya = torch.empty_like(y0)
+        kern.fixed_stage(1, ya, y0, [k1], [third], dts)
+        k2 = func.eval(scalar(t0 + scalar(dt * scalar(third))), ya)
+        yb = torch.empty_like(y0)
+        kern.fixed_stage(0, yb, y0, [k2], [two_thirds], dts)            # k1's weight is a structural zero
+        k3 = func.eval(scalar(t0 + scalar(dt * scalar(two_thirds))), yb)
+        kern.fixed_stage(0, y1, y0, [k1, k3], [1 / 4, 3 / 4], dts)      # k2's weight is a structural zero
+        return k1
+
+
+class RK4(FixedGridODESolver):
+    """Fixed-grid 4th-order RK, 3/8 rule (fixed_grid.py:24-29 -> rk_common.py:110-118)."""
+    order = 4
+
+    def _step(self, t0, dt, t1, y0, y1):
+        func, kern = self.func, self.kernels
+        scalar = type(dt)
+        third, two_thirds = 1 / 3, 2 / 3
+        dts = float(dt) * func.sign
+        ts = func.time_tensors(kern, [(t0, self._first_perturb()),
+                                      (scalar(t0 + scalar(dt * scalar(third))), Perturb.NONE),
+                                      (scalar(t0 + scalar(dt * scalar(two_thirds))), Perturb.NONE),
+                                      (t1, self._last_perturb())])
+        k1 = func.eval_at(ts[0], y0)
+        ya = torch.empty_like(y0)
+        kern.rk4_stage(1, ya, y0, k1, None, None, None, dts)
+        k2 = func.eval_at(ts[1], ya)
+        yb = torch.empty_like(y0)
+        kern.rk4_stage(2, yb, y0, k1, k2, None, None, dts)
+        k3 = func.eval_at(ts[2], yb)
+        yc = torch.empty_like(y0)
+        kern.rk4_stage(3, yc, y0, k1, k2, k3, None, dts)
+        k4 = func.eval_at(ts[3], yc)
+        kern.rk4_stage(4, y1, y0, k1, k2, k3, k4, dts)
+        return k1
+
+
+SOLVER_CLASSES = {"dopri8": Dopri8Solver, "dopri5": Dopri5Solver, "tsit5": Tsit5Solver, "bosh3": Bosh3Solver,
+                  "fehlberg2": Fehlberg2, "adaptive_heun": AdaptiveHeunSolver, "euler": Euler,
+                  "midpoint": Midpoint, "heun2": Heun2, "heun3": Heun3, "rk4": RK4}

@@ -164,3 +164,85 @@ def _dopri8() -> Tableau:
 
 DOPRI5 = _dopri5()
 DOPRI8 = _dopri8()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Tsitouras 5(4) (Tsitouras 2011, "Runge–Kutta pairs of order 5(4) satisfying only the first column
+# simplifying assumption"), 7 stage slots.  tsit5.py:6-73.  Published constants, 20 significant digits
+# (they round to the same doubles as the reference's longer literals — pinned by tests/test_tableaus.py).
+# The reference's table ends `c_sol` with 1/66 in slot 6, so rk_common.py:83's FSAL shortcut does NOT
+# apply: y1 is an extra 7-term combine and f1 = k_6 is the derivative at the last stage input.
+# ---------------------------------------------------------------------------------------------------
+_TS5_ALPHA = "0.161 0.327 0.9 0.98002554090450968573 1 1"
+_TS5_A = """
+0.161
+-0.0084806554923569885444 0.33548065549235698854
+2.8971530571054934321 -6.3594484899750748431 4.3622954328695814110
+5.3258648284392566044 -11.748883564062827878 7.4955393428898362083 -0.092495066361755249257
+5.8614554429464200287 -12.920969317847109292 8.1593678985761586432 -0.071584973281400997225 -0.028269050394068382909
+0.096460766818065229518 0.01 0.47988965041449957478 1.3790085741037418932 -3.2900695154360806799 2.3247105240997739824
+"""
+_TS5_B = ("0.094680755765839458075 0.0091835655403432530968 0.48777052842476157079 1.2342975669304789857 "
+          "-2.7077123499835254549 1.8666284181705870358 1/66")
+_TS5_ERR = ("-0.0017800110522257714434 -0.00081643445965674690322 0.0078808780102619960103 "
+            "-0.14471100717326290754 0.58235716545255522502 -0.45808210592918694666 1/66")
+
+
+def _tsit5_dense(x: float) -> List[float]:
+    """Tsitouras' continuous-extension weights b_j(x) in their published factored form (tsit5.py:66-76;
+    the second factor of b_1 uses the reference's root 1.329989018975412)."""
+    return [
+        -1.0530884977290216 * x * (x - 1.329989018975412) * (x * x - 1.4364028541716351 * x + 0.7139816917074209),
+        0.1017 * x * x * (x * x - 2.1966568338249754 * x + 1.2949852507374631),
+        2.490627285651252793 * x * x * (x * x - 2.38535645472061657 * x + 1.57803468208092486),
+        -16.54810288924490272 * (x - 1.21712927295533244) * (x - 0.61620406037800089) * x * x,
+        47.37952196281928122 * (x - 1.203071208372362603) * (x - 0.658047292653547382) * x * x,
+        -34.87065786149660974 * (x - 1.2) * (x - 2 / 3) * x * x,
+        2.5 * (x - 1) * (x - 0.6) * x * x,
+    ]
+
+
+def _tsit5() -> Tableau:
+    rows = tuple(tuple(_row(line)) for line in _TS5_A.strip().splitlines())
+    return Tableau("tsit5", 5, tuple(_row(_TS5_ALPHA)), rows, tuple(_row(_TS5_B)), tuple(_row(_TS5_ERR)),
+                   tuple(_tsit5_dense(1 / 2)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Bogacki–Shampine 3(2), 4 stage slots (FSAL).  bosh3.py:5-17
+# ---------------------------------------------------------------------------------------------------
+def _bosh3() -> Tableau:
+    b = _row("2/9 1/3 4/9 0")
+    bhat = _row("7/24 1/4 1/3 1/8")
+    err = [bj - bh for bj, bh in zip(b, bhat)]
+    rows = (tuple(_row("1/2")), tuple(_row("0 3/4")), tuple(_row("2/9 1/3 4/9")))
+    return Tableau("bosh3", 3, tuple(_row("1/2 3/4 1")), rows, tuple(b), tuple(err), (0.0, 0.5, 0.0, 0.0))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Fehlberg 2(1), 3 stage slots (solution weights differ from the last row: extra combine).  fehlberg2.py:4-17
+# ---------------------------------------------------------------------------------------------------
+def _fehlberg2() -> Tableau:
+    b = _row("1/512 255/256 1/512")
+    bhat = _row("1/256 255/256 0")
+    err = [bj - bh for bj, bh in zip(b, bhat)]
+    rows = (tuple(_row("1/2")), tuple(_row("1/256 255/256")))
+    return Tableau("fehlberg2", 2, tuple(_row("1/2 1")), rows, tuple(b), tuple(err), (0.0, 0.5, 0.0))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Heun–Euler 2(1) ("adaptive_heun"), 2 stage slots.  adaptive_heun.py:5-20
+# ---------------------------------------------------------------------------------------------------
+def _adaptive_heun() -> Tableau:
+    b = (0.5, 0.5)
+    bhat = (0.0, 1.0)
+    err = tuple(bj - bh for bj, bh in zip(b, bhat))
+    return Tableau("adaptive_heun", 2, (1.0,), ((1.0,),), b, err, (0.5, 0.0))
+
+
+TSIT5 = _tsit5()
+BOSH3 = _bosh3()
+FEHLBERG2 = _fehlberg2()
+ADAPTIVE_HEUN = _adaptive_heun()
+
+ADAPTIVE_TABLEAUS = {t.name: t for t in (DOPRI8, DOPRI5, TSIT5, BOSH3, FEHLBERG2, ADAPTIVE_HEUN)}
