@@ -380,9 +380,84 @@ def gen_methods():
     save("methods.npz", **arrays)
 
 
+def gen_events():
+    """§8(f) ranks 3-4: odeint(event_fn=...), odeint_event (+ adjoint gradients through the event time) and
+    odeint_dense, on a damped rotation dy/dt = A y whose first coordinate crosses fixed levels."""
+    arrays = {}
+    A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64)
+    y0 = torch.tensor([[2.0, 0.0], [1.0, 1.0], [0.5, -1.5]], dtype=torch.float64)
+    arrays.update(ev_A=A, ev_y0=y0)
+    f = lambda t, y: y @ A.T
+    ev_scalar = lambda t, y: y[0, 0] - 0.5
+    ev_multi = lambda t, y: torch.stack([y[0, 0] + 1.0, y[1, 1] + 0.25, t - 5.0])
+    with torch.no_grad():
+        for method, opts in [("dopri5", {}), ("dopri8", {}), ("tsit5", {}), ("bosh3", {}), ("adaptive_heun", {}),
+                             ("rk4", dict(step_size=0.01)), ("rk4", dict(step_size=0.01, interp="cubic")),
+                             ("euler", dict(step_size=0.001)), ("midpoint", dict(step_size=0.01, interp="cubic")),
+                             ("heun3", dict(step_size=0.02, interp="cubic"))]:
+            tag = method + ("_cubic" if opts.get("interp") == "cubic" else "")
+            for ename, efn in [("scalar", ev_scalar), ("multi", ev_multi)]:
+                for rev in (False, True):
+                    t = torch.tensor([0.0, -1.0] if rev else [0.0, 1.0], dtype=torch.float64)
+                    te, ye = torchdiffeq.odeint(f, y0, t, event_fn=efn, method=method, options=opts, rtol=1e-8,
+                                                atol=1e-9)
+                    arrays[f"ev_{tag}_{ename}_{'rev' if rev else 'fwd'}_t"] = te
+                    arrays[f"ev_{tag}_{ename}_{'rev' if rev else 'fwd'}_y"] = ye
+        # fp32 state, fixed grid: times are kept in the state dtype (solvers.py:132)
+        te, ye = torchdiffeq.odeint(lambda t, y: y @ A.float().T, y0.float(), torch.tensor([0.0, 1.0]),
+                                    event_fn=ev_scalar, method="rk4", options=dict(step_size=0.01), atol=1e-6)
+        arrays.update(ev32_rk4_t=te, ev32_rk4_y=ye)
+        te, ye = torchdiffeq.odeint(lambda t, y: y @ A.float().T, y0.float(), torch.tensor([0.0, 1.0]),
+                                    event_fn=ev_scalar, method="dopri5", rtol=1e-5, atol=1e-6)
+        arrays.update(ev32_dopri5_t=te, ev32_dopri5_y=ye)
+        # tuple state
+        te, (ya, yb) = torchdiffeq.odeint(lambda t, y: (y[0] @ A.T, -y[1]), (y0, torch.ones(2, dtype=torch.float64)),
+                                          torch.tensor([0.0, 1.0], dtype=torch.float64),
+                                          event_fn=lambda t, y: y[0][0, 0] - y[1][0], method="dopri5", rtol=1e-8, atol=1e-9)
+        arrays.update(ev_tuple_t=te, ev_tuple_ya=ya, ev_tuple_yb=yb)
+
+    # odeint_event + adjoint: gradient of the event time and of the state at the event
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.A = torch.nn.Parameter(A.clone())
+
+        def forward(self, t, y):
+            return y @ self.A.T
+
+    for rev in (False, True):
+        func = F()
+        y0g = y0.clone().requires_grad_(True)
+        t0 = torch.tensor(0.0, dtype=torch.float64, requires_grad=True)
+        te, sol = torchdiffeq.odeint_event(func, y0g, t0, event_fn=ev_scalar, reverse_time=rev,
+                                           odeint_interface=torchdiffeq.odeint_adjoint, method="dopri5", rtol=1e-9,
+                                           atol=1e-10)
+        loss = te * 3.0 + sol[-1].pow(2).sum()
+        loss.backward()
+        tag = "rev" if rev else "fwd"
+        arrays[f"oe_{tag}_t"] = te
+        arrays[f"oe_{tag}_sol"] = sol
+        arrays[f"oe_{tag}_grad_y0"] = y0g.grad
+        arrays[f"oe_{tag}_grad_A"] = func.A.grad
+        arrays[f"oe_{tag}_grad_t0"] = t0.grad
+
+    # odeint_dense
+    with torch.no_grad():
+        fn = torchdiffeq.odeint_dense(f, y0, torch.tensor(0.0, dtype=torch.float64), torch.tensor(3.0, dtype=torch.float64),
+                                      rtol=1e-6, atol=1e-8, method="dopri5")
+        t_eval = torch.tensor([0.0, 0.01, 0.4, 1.234, 2.0, 2.999], dtype=torch.float64)
+        arrays["dense_t_eval"] = t_eval
+        arrays["dense_y_eval"] = torch.stack([fn(te_) for te_ in t_eval])
+        y32 = y0.float()
+        fn = torchdiffeq.odeint_dense(lambda t, y: y @ A.float().T, y32, torch.tensor(0.0), torch.tensor(3.0),
+                                      rtol=1e-4, atol=1e-6, method="dopri5")
+        arrays["dense32_y_eval"] = torch.stack([fn(te_) for te_ in t_eval])
+    save("events.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
-                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods)]:
+                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events)]:
         if not only or name in only:
             fn()

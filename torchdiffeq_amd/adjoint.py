@@ -95,22 +95,39 @@ class OdeintAdjointMethod(torch.autograd.Function):
         ctx.adjoint_method = cfg["adjoint_method"]
         ctx.adjoint_options = cfg["adjoint_options"]      # mutable, visible as grad_fn.adjoint_options
         ctx.t_requires_grad = cfg["t_requires_grad"]
+        event_fn = cfg.get("event_fn")
+        ctx.event_mode = event_fn is not None
         with torch.no_grad():
             solver = SOLVERS[cfg["method"]](func=cfg["func"], y0=y0_flat.detach(), rtol=cfg["rtol"],
                                             atol=cfg["atol"], **cfg["options"])
-            solution = solver.integrate(t)
-            ctx.save_for_backward(t, solution, *adjoint_params)
+            if event_fn is None:
+                solution = solver.integrate(t)
+                ctx.save_for_backward(t, solution, *adjoint_params)
+            else:
+                event_t, solution = solver.integrate_until_event(t[0], event_fn)
+                ctx.save_for_backward(t, solution, event_t, *adjoint_params)
         layout = cfg["func"].layout
         if not layout.is_tuple:
-            return solution.view(len(t), *layout.shapes[0])
-        return solution
+            solution = solution.view(len(t), *layout.shapes[0])
+        if event_fn is None:
+            return solution
+        return event_t, solution
 
     @staticmethod
-    def backward(ctx, grad_solution):
+    def backward(ctx, *grad_outputs):
         with torch.no_grad():
             fwd: OdeFunc = ctx.func
             fwd_layout = fwd.layout
-            t, y, *adjoint_params = ctx.saved_tensors
+            # Event mode: backpropagate as if integrating up to the event time; NOT through the event time
+            # itself (adjoint.py:44-52) — odeint_event links that gradient separately.
+            if ctx.event_mode:
+                t, y, event_t, *adjoint_params = ctx.saved_tensors
+                _t = t
+                t = torch.cat([t[0].reshape(-1), event_t.reshape(-1).to(t)])
+                grad_solution = grad_outputs[1]
+            else:
+                t, y, *adjoint_params = ctx.saved_tensors
+                grad_solution = grad_outputs[0]
             adjoint_params = tuple(adjoint_params)
             t_requires_grad = ctx.t_requires_grad
             n_t = len(t)
@@ -178,6 +195,9 @@ class OdeintAdjointMethod(torch.autograd.Function):
 
             if t_requires_grad:
                 time_vjps[0] = aug_views[0]
+            # only the gradient wrt the initial time exists in event mode (adjoint.py:146-148)
+            if ctx.event_mode and t_requires_grad:
+                time_vjps = torch.cat([time_vjps[0].reshape(-1), torch.zeros_like(_t[1:])])
 
             # ---- one collective for the batch-summed quantities ----
             if group is not None:
@@ -285,11 +305,20 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
     y0_flat = _pack_differentiable(layout, y0_tensors)
     cfg = dict(func=ci.func, rtol=ci.rtol, atol=ci.atol, method=ci.method, options=ci.options,
                adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol, adjoint_method=adjoint_method,
-               adjoint_options=adjoint_options, t_requires_grad=ci.t.requires_grad)
-    solution = OdeintAdjointMethod.apply(cfg, y0_flat, ci.t, *adjoint_params)
+               adjoint_options=adjoint_options, t_requires_grad=ci.t.requires_grad, event_fn=ci.event_fn)
+    ans = OdeintAdjointMethod.apply(cfg, y0_flat, ci.t, *adjoint_params)
+    if ci.event_fn is None:
+        solution = ans
+    else:
+        event_t, solution = ans
+        event_t = event_t.to(ci.t)
+        if ci.t_is_reversed:
+            event_t = -event_t
     if layout.is_tuple:
-        return layout.unpack(solution, (len(ci.t),))
-    return solution
+        solution = layout.unpack(solution, (len(ci.t),))
+    if ci.event_fn is None:
+        return solution
+    return event_t, solution
 
 
 def _pack_differentiable(layout: StateLayout, tensors: Sequence[torch.Tensor]) -> torch.Tensor:

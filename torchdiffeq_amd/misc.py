@@ -248,6 +248,44 @@ def _flip_option(options, name):
         options[name] = -value
 
 
+def combine_event_functions(event_fn, t0, y0):
+    """event_handling.py:23-35: make every component of a multivariate event function initially positive
+    and combine them with a min, so one sign change of the combined scalar marks the first event."""
+    with torch.no_grad():
+        initial_signs = torch.sign(event_fn(t0, y0))
+
+    def combined_event_fn(t, y):
+        c = event_fn(t, y)
+        return torch.min(c * initial_signs)
+
+    return combined_event_fn
+
+
+def find_event(interp_fn, sign0, t0, t1, event_fn, tol: float, time_tensor, scalar=np.float64):
+    """Bisection on the step's interpolant (event_handling.py:5-20).  Times are host scalars of type `scalar`
+    (fp64 for the adaptive solvers, the state dtype for the fixed-grid ones — solvers.py:132) and every
+    operation is rounded in that type, like the reference's 0-dim tensor arithmetic.
+    `interp_fn(t) -> y_flat` evaluates the dense output (a kernel launch); `event_fn(t_tensor, y_flat)` is the
+    user's scalar event function, whose sign is read back once per iteration (inherent to bisection)."""
+    t0, t1 = scalar(t0), scalar(t1)
+    with torch.no_grad():
+        with np.errstate(all="ignore"):
+            nitrs = np.ceil(np.log(scalar(scalar(t1 - t0) / scalar(tol))) / scalar(math.log(2.0)))
+        if np.isinf(nitrs) and nitrs > 0:
+            raise OverflowError("find_event: cannot bisect to a tolerance of 0 (atol must be positive)")
+        nitrs = 0 if np.isnan(nitrs) else int(nitrs)
+        for _ in range(nitrs):
+            t_mid = scalar(scalar(t1 + t0) / scalar(2.0))
+            y_mid = interp_fn(t_mid)
+            sign_mid = float(torch.sign(event_fn(time_tensor(t_mid), y_mid)))
+            if sign0 == sign_mid:
+                t0 = t_mid
+            else:
+                t1 = t_mid
+        event_t = scalar(scalar(t0 + t1) / scalar(2.0))
+    return event_t, interp_fn(event_t)
+
+
 class CheckedInputs:
     """Result of `check_inputs`: everything `odeint` needs to build and run a solver."""
     __slots__ = ("layout", "func", "y0_flat", "t", "rtol", "atol", "method", "options", "event_fn",
@@ -257,9 +295,10 @@ class CheckedInputs:
 def check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS) -> CheckedInputs:
     """Normalise `(func, y0, t, ...)`; same accept/reject behaviour as misc.py:200-345."""
     if event_fn is not None:
-        raise NotImplementedError(
-            "event handling (odeint_event / event_fn) is outside the scope of the MI355X RK hot path; "
-            "see DESIGN.md 'out of scope'.")
+        if len(t) != 2:
+            raise ValueError(f"We require len(t) == 2 when in event handling mode, but got len(t)={len(t)}.")
+        # multivariate event functions: all components made initially positive, combined by a min
+        event_fn = combine_event_functions(event_fn, t[0], y0)
 
     original_func = func
     is_tuple = not isinstance(y0, torch.Tensor)
@@ -325,6 +364,18 @@ def check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS) ->
         t = t.to(device)
 
     wrapped = OdeFunc(func, layout, -1.0 if t_is_reversed else 1.0, dtype, device)
+    if event_fn is not None:
+        # the solvers call event_fn(t, y_flat) with t a 0-dim tensor in (ascending) solver time
+        # (misc.py:137-165: _TupleInputOnlyFunc, _ReverseFunc)
+        _user_event = event_fn
+        if is_tuple and t_is_reversed:
+            event_fn = lambda t_, y_, _e=_user_event, _lay=layout: _e(-t_, _lay.unpack(y_))
+        elif is_tuple:
+            event_fn = lambda t_, y_, _e=_user_event, _lay=layout: _e(t_, _lay.unpack(y_))
+        elif t_is_reversed:
+            event_fn = lambda t_, y_, _e=_user_event, _shape=shapes[0]: _e(-t_, y_.view(_shape))
+        else:
+            event_fn = lambda t_, y_, _e=_user_event, _shape=shapes[0]: _e(t_, y_.view(_shape))
 
     # Callbacks: attributes of the user's func, re-bound to the wrapped func (misc.py:313-343).
     callback_names = set()

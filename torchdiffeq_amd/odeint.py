@@ -34,6 +34,8 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
     (odeint.py:49-108): `y0` is a Tensor or tuple of Tensors of any shape on a ROCm device, `t` a 1-D
     strictly monotone float Tensor; returns a Tensor `[len(t), *y0.shape]` (tuple of such for tuple
     states) in `y0.dtype` with `y[0] == y0`.  Raises ValueError for an unknown `method`.
+    With `event_fn(t, y) -> Tensor`, `t` must have two entries (start, direction); the solve stops where the
+    event function first crosses zero and `(event_t, solution)` is returned, `solution[-1]` = the state there.
 
     The Runge–Kutta arithmetic runs in hand-written HIP kernels (libtdeq_hip.so); it is not recorded
     by autograd — use `odeint_adjoint` for gradients, and call plain `odeint` under `torch.no_grad()`
@@ -50,7 +52,138 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
     # Runs under the caller's grad mode: if `func` produces tensors that require grad, the wrapped func
     # raises (loudly) instead of returning a silently non-differentiable solution.
     solver = SOLVERS[ci.method](func=ci.func, y0=ci.y0_flat, rtol=ci.rtol, atol=ci.atol, **ci.options)
-    solution = solver.integrate(ci.t)
+    if ci.event_fn is None:
+        solution = solver.integrate(ci.t)
+    else:
+        event_t, solution = solver.integrate_until_event(ci.t[0], ci.event_fn)
+        event_t = event_t.to(ci.t)
+        if ci.t_is_reversed:
+            event_t = -event_t
     if ci.layout.is_tuple:
-        return ci.layout.unpack(solution, (len(ci.t),))
-    return solution.view(len(ci.t), *ci.layout.shapes[0])
+        solution = ci.layout.unpack(solution, (len(ci.t),))
+    else:
+        solution = solution.view(len(ci.t), *ci.layout.shapes[0])
+    if ci.event_fn is None:
+        return solution
+    return event_t, solution
+
+
+def odeint_dense(func, y0, t0, t1, *, rtol=1e-7, atol=1e-9, method=None, options=None):
+    """Solve from t0 to t1 and return `dense_output_fn(t_eval) -> y(t_eval)`, the solver's piecewise quartic
+    dense output (odeint.py:111-157; dopri5 and tensor states only, like the reference).
+
+    Wire format kept by the returned function: `times[n_steps + 1]` (host) and the per-step interpolation
+    coefficients `[n_steps, 5, numel]` = [e, d, c, b, a] written by `tdeq_interp_fit`; an evaluation is one
+    `tdeq_weighted_sum` launch over the 5 planes of the step that contains `t_eval`."""
+    assert torch.is_tensor(y0)
+    t = torch.tensor([t0, t1]).to(t0)
+    with torch.no_grad():
+        ci = check_inputs(func, y0, t, rtol, atol, method, options, None, SOLVERS)
+        assert ci.method == "dopri5"
+        solver = Dopri5Solver(func=ci.func, y0=ci.y0_flat, rtol=ci.rtol, atol=ci.atol, **ci.options)
+        times, coeffs = solver.integrate_dense(ci.t)
+    shape, sign, kernels = ci.layout.shapes[0], (-1.0 if ci.t_is_reversed else 1.0), solver.kernels
+    np_dtype = solver.np_dtype
+    import bisect
+
+    def dense_output_fn(t_eval):
+        ts = sign * float(t_eval)
+        idx = bisect.bisect_right(times, ts)
+        if idx >= len(times):
+            raise IndexError("index {} is out of bounds for dimension 0 with size {}".format(idx, len(times)))
+        ta, tb = times[idx - 1], times[idx]          # idx == 0 wraps to the last entry, as the reference's `times[idx - 1]` does
+        assert ta <= ts <= tb, "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(ta, ts, tb)
+        x = np_dtype((ts - ta) / (tb - ta))
+        w, xp = [1.0, float(x)], x
+        for _ in range(3):
+            xp = np_dtype(xp * x)
+            w.append(float(xp))
+        planes = coeffs[idx - 1]
+        out = torch.empty(planes.shape[1], dtype=planes.dtype, device=planes.device)
+        kernels.weighted_sum(out, list(planes.unbind(0)), w)
+        return out.view(shape)
+
+    dense_output_fn.times = times
+    dense_output_fn.interp_coeffs = coeffs
+    return dense_output_fn
+
+
+def odeint_event(func, y0, t0, *, event_fn, reverse_time=False, odeint_interface=odeint, **kwargs):
+    """Solve until `event_fn(t, y)` crosses zero; returns `(event_t, solution)` with gradients linked through
+    the event time by the implicit function theorem (odeint.py:160-231).  Parameters of the event function
+    must be part of the state to receive gradients, as in the reference."""
+    if reverse_time:
+        t = torch.cat([t0.reshape(-1), t0.reshape(-1).detach() - 1.0])
+    else:
+        t = torch.cat([t0.reshape(-1), t0.reshape(-1).detach() + 1.0])
+
+    event_t, solution = odeint_interface(func, y0, t, event_fn=event_fn, **kwargs)
+
+    # the flat-state views of func / event_fn (dummy tolerances: nothing is solved here)
+    ci = check_inputs(func, y0, t, 0.0, 0.0, None, None, event_fn, SOLVERS)
+    layout = ci.layout
+    if layout.is_tuple:
+        state_t = _pack_rows(layout, [s[-1] for s in solution])
+    else:
+        state_t = solution[-1].reshape(-1)
+
+    # event_fn takes the negated time when the solve runs in reverse
+    if reverse_time:
+        event_t = -event_t
+    event_t, state_t = ImplicitFnGradientRerouting.apply(ci.func, ci.event_fn, event_t, state_t)
+    if reverse_time:
+        event_t = -event_t
+
+    if layout.is_tuple:
+        state_parts = layout.unpack(state_t)
+        solution = tuple(torch.cat([s[:-1], s_t[None]], dim=0) for s, s_t in zip(solution, state_parts))
+    else:
+        solution = torch.cat([solution[:-1], state_t.view(layout.shapes[0])[None]], dim=0)
+    return event_t, solution
+
+
+def _pack_rows(layout, rows):
+    """Differentiable flat (chunk-padded) state from per-component tensors."""
+    pieces = []
+    for i, r in enumerate(rows):
+        pieces.append(r.reshape(-1))
+        end = layout.offsets[i + 1] if i + 1 < layout.n_seg else layout.total
+        pad = end - (layout.offsets[i] + layout.numels[i])
+        if pad:
+            pieces.append(torch.zeros(pad, dtype=r.dtype, device=r.device))
+    return torch.cat(pieces)
+
+
+class ImplicitFnGradientRerouting(torch.autograd.Function):
+    """Identity on (event_t, state_t) whose backward routes dL/d(event_t) into dL/d(state_t):
+    with c(t, y) = 0 defining the event, dt*/dy = -(dc/dy) / (dc/dt + dc/dy . f)   (odeint.py:199-231)."""
+
+    @staticmethod
+    def forward(ctx, func, event_fn, event_t, state_t):
+        ctx.func = func
+        ctx.event_fn = event_fn
+        ctx.save_for_backward(event_t, state_t)
+        return event_t.detach(), state_t.detach()
+
+    @staticmethod
+    def backward(ctx, grad_t, grad_state):
+        func, event_fn = ctx.func, ctx.event_fn
+        event_t, state_t = ctx.saved_tensors
+        event_t = event_t.detach().clone().requires_grad_(True)
+        state_t = state_t.detach().clone().requires_grad_(True)
+
+        with torch.no_grad():
+            f_val = func(event_t.detach(), state_t.detach())      # wrapped func: solver time, sign applied
+        with torch.enable_grad():
+            c = event_fn(event_t, state_t)
+            par_dt, dstate = torch.autograd.grad(c, (event_t, state_t), torch.ones_like(c), allow_unused=True)
+        par_dt = torch.zeros_like(event_t) if par_dt is None else par_dt
+        dstate = torch.zeros_like(state_t) if dstate is None else dstate
+
+        # total derivative of the event function along the trajectory, at the event
+        dcdt = par_dt + torch.sum(dstate * f_val)
+        # the final state's gradient also moves the final time, as in a regular odeint call
+        grad_t = grad_t + torch.sum(grad_state * f_val)
+        dstate = dstate * (-grad_t / (dcdt + 1e-12)).reshape_as(c)
+        grad_state = grad_state + dstate
+        return None, None, None, grad_state

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _native
-from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, handle_unused_kwargs, rms_norm)
+from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, find_event, handle_unused_kwargs, rms_norm)
 from .misc import _null_callback as _null
 from .tableaus import ADAPTIVE_HEUN, BOSH3, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau
 
@@ -151,6 +151,65 @@ class RKAdaptiveStepsizeODESolver:
         for i in range(1, len(t_host)):
             self._advance(t_host[i], solution[i])
         return solution
+
+    def integrate_dense(self, t: torch.Tensor):
+        """Integrate over [t[0], t[-1]] keeping the dense output of EVERY accepted step (odeint.py:124-147):
+        returns (times, coeffs) with `times` the n_steps + 1 accepted step boundaries (host doubles) and
+        `coeffs[n_steps, 5, total]` the quartic coefficients [e, d, c, b, a] (`tdeq_interp_fit`)."""
+        t_host = t.detach().to(torch.float64).cpu().tolist()
+        self._before_integrate(t_host)
+        times, planes = [self.t0], []
+        mid = self._c_mid
+        for next_t in t_host[1:]:
+            n_steps = 0
+            while next_t > self.t1:
+                assert n_steps < self.max_num_steps, \
+                    "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
+                accepted_before = self.n_accepted
+                self._adaptive_step()
+                n_steps += 1
+                if self.n_accepted != accepted_before:
+                    rec = self._dense
+                    buf = torch.empty(5, self.layout.total, dtype=self.y0.dtype, device=self.y0.device)
+                    self.kernels.interp_fit(buf, rec.y0, rec.y1, rec.k[0], rec.k[-1], [rec.k[j] for j in mid.idx],
+                                            mid.coef, rec.dt_signed)
+                    times.append(rec.t1)
+                    planes.append(buf)
+        coeffs = torch.stack(planes) if planes else torch.empty(0, 5, self.layout.total, dtype=self.y0.dtype,
+                                                                 device=self.y0.device)
+        return times, coeffs
+
+    def integrate_until_event(self, t0: torch.Tensor, event_fn):
+        """(event_t, solution[2, total]): step until `event_fn(t, y)` changes sign, then bisect on the last
+        step's dense output (solvers.py:44-49, rk_common.py:252-264, event_handling.py:5-20)."""
+        self._before_integrate([float(t0.detach())])
+        event_time, y1 = self._advance_until_event(event_fn)
+        solution = torch.stack([self.y0, y1], dim=0)
+        return self._time_tensor(float(event_time)), solution
+
+    def _advance_until_event(self, event_fn):
+        ev = lambda: event_fn(self._time_tensor(self.t1), self.y1)
+        if ev() == 0:
+            return self.t1, self.y1
+        n_steps = 0
+        sign0 = float(torch.sign(ev()))
+        while sign0 == float(torch.sign(ev())):
+            assert n_steps < self.max_num_steps, \
+                "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
+            self._adaptive_step()
+            n_steps += 1
+
+        def interp_fn(t):
+            out = torch.empty_like(self.y0)
+            self._interp_evaluate(float(t), out)
+            return out
+
+        atol = self.atol
+        if isinstance(atol, torch.Tensor):
+            atol = atol.min().item()
+        elif not isinstance(atol, (int, float)):
+            atol = min(float(a) for a in atol)
+        return find_event(interp_fn, sign0, self.t0, self.t1, event_fn, float(atol), self._time_tensor)
 
     def _before_integrate(self, t_host: List[float]) -> None:
         t0 = t_host[0]
@@ -415,8 +474,18 @@ class FixedGridODESolver(object):
 
     # -- one step ------------------------------------------------------------------------------------
     def _step(self, t0, dt, t1, y0: torch.Tensor, y1: torch.Tensor):
-        """Write y(t1) into `y1`; return f0 = func(t0, y0).  t0, dt, t1 are numpy scalars of t.dtype."""
+        """Write y(t1) into `y1`; return f0 = func(t0, y0).  t0 and t1 are numpy scalars of the grid's dtype;
+        `dt` is one too in `integrate`, and the Python float `step_size` in `integrate_until_event`."""
         raise NotImplementedError
+
+    @staticmethod
+    def _tmul(scalar, dt, c: float):
+        """`dt * c` as the reference forms it: a 0-dim tensor dt times a Python float is rounded in the
+        grid dtype with c rounded first; a Python-float dt (event mode, solvers.py:134) multiplies in double
+        and is rounded when it meets the time tensor."""
+        if isinstance(dt, float):
+            return scalar(dt * c)
+        return scalar(dt * scalar(c))
 
     def _first_perturb(self) -> Perturb:
         return Perturb.NEXT if self.perturb else Perturb.NONE
@@ -472,6 +541,56 @@ class FixedGridODESolver(object):
             y0 = y1
         return solution
 
+    def integrate_until_event(self, t0: torch.Tensor, event_fn):
+        """Fixed steps of `step_size` until the event function changes sign, then bisection on the linear /
+        cubic interpolant of that step (solvers.py:129-164).  Times are kept in the state dtype (:132)."""
+        assert self.step_size is not None, \
+            "Event handling for fixed step solvers currently requires `step_size` to be provided in options."
+        func, kern = self.func, self.kernels
+        scalar = func.np_dtype
+        time_tensor = lambda v: torch.tensor(float(v), dtype=self.dtype, device=self.device)
+        t0 = scalar(float(t0.detach()))
+        y0 = self.y0
+        dt = float(self.step_size)
+        if self.interp not in ("linear", "cubic"):
+            raise ValueError(f"Unknown interpolation method {self.interp}")
+
+        sign0 = float(torch.sign(event_fn(time_tensor(t0), y0)))
+        max_itrs = 20000
+        itr = 0
+        while True:
+            itr += 1
+            t1 = scalar(t0 + scalar(dt))
+            y1 = torch.empty_like(y0)
+            f0 = self._step(t0, dt, t1, y0, y1)
+            sign1 = float(torch.sign(event_fn(time_tensor(t1), y1)))
+            if sign0 != sign1:
+                if self.interp == "linear":
+                    def interp_fn(t, t0=t0, t1=t1, y0=y0, y1=y1):
+                        if t == t0:
+                            return y0
+                        if t == t1:
+                            return y1
+                        out = torch.empty_like(y0)
+                        kern.lerp(out, y0, y1, float(scalar(scalar(t - t0) / scalar(t1 - t0))))
+                        return out
+                else:
+                    f1 = func.eval(t1, y1)
+
+                    def interp_fn(t, t0=t0, t1=t1, y0=y0, y1=y1, f0=f0, f1=f1):
+                        out = torch.empty_like(y0)
+                        self._cubic_hermite_interp(out, scalar, t0, y0, f0, t1, y1, f1, t)
+                        return out
+                event_time, y1 = find_event(interp_fn, sign0, t0, t1, event_fn, float(self.atol), time_tensor,
+                                            scalar=scalar)
+                break
+            else:
+                t0, y0 = t1, y1
+            if itr >= max_itrs:
+                raise RuntimeError(f"Reached maximum number of iterations {max_itrs}.")
+        solution = torch.stack([self.y0, y1], dim=0)
+        return time_tensor(event_time), solution
+
     def _cubic_hermite_interp(self, out, scalar, t0, y0, f0, t1, y1, f1, t) -> None:
         """solvers.py:166-173; the basis values are scalars of t.dtype formed on the host."""
         one, two, three = scalar(1), scalar(2), scalar(3)
@@ -505,9 +624,9 @@ class Midpoint(FixedGridODESolver):
 
     def _step(self, t0, dt, t1, y0, y1):
         func, kern = self.func, self.kernels
-        scalar = type(dt)
+        scalar = type(t0)
         dts = float(dt) * func.sign
-        half_dt = scalar(scalar(0.5) * dt)
+        half_dt = self._tmul(scalar, dt, 0.5)
         f0 = func.eval(t0, y0, self._first_perturb())
         y_mid = torch.empty_like(y0)
         kern.stage_combine(y_mid, y0, [f0], [0.5], dts)
@@ -522,12 +641,12 @@ class Heun2(FixedGridODESolver):
 
     def _step(self, t0, dt, t1, y0, y1):
         func, kern = self.func, self.kernels
-        scalar = type(dt)
+        scalar = type(t0)
         dts = float(dt) * func.sign
         k1 = func.eval(t0, y0, self._first_perturb())
         ya = torch.empty_like(y0)
         kern.fixed_stage(1, ya, y0, [k1], [1.0], dts)
-        k2 = func.eval(scalar(t0 + scalar(dt * scalar(1.0))), ya, self._last_perturb())
+        k2 = func.eval(scalar(t0 + self._tmul(scalar, dt, 1.0)), ya, self._last_perturb())
         kern.fixed_stage(0, y1, y0, [k1, k2], [0.5, 0.5], dts)
         return k1
 
@@ -538,16 +657,16 @@ class Heun3(FixedGridODESolver):
 
     def _step(self, t0, dt, t1, y0, y1):
         func, kern = self.func, self.kernels
-        scalar = type(dt)
+        scalar = type(t0)
         dts = float(dt) * func.sign
         third, two_thirds = 1 / 3, 2 / 3
         k1 = func.eval(t0, y0, self._first_perturb())
         ya = torch.empty_like(y0)
         kern.fixed_stage(1, ya, y0, [k1], [third], dts)
-        k2 = func.eval(scalar(t0 + scalar(dt * scalar(third))), ya)
+        k2 = func.eval(scalar(t0 + self._tmul(scalar, dt, third)), ya)
         yb = torch.empty_like(y0)
         kern.fixed_stage(0, yb, y0, [k2], [two_thirds], dts)            # k1's weight is a structural zero
-        k3 = func.eval(scalar(t0 + scalar(dt * scalar(two_thirds))), yb)
+        k3 = func.eval(scalar(t0 + self._tmul(scalar, dt, two_thirds)), yb)
         kern.fixed_stage(0, y1, y0, [k1, k3], [1 / 4, 3 / 4], dts)      # k2's weight is a structural zero
         return k1
 
@@ -558,12 +677,12 @@ class RK4(FixedGridODESolver):
 
     def _step(self, t0, dt, t1, y0, y1):
         func, kern = self.func, self.kernels
-        scalar = type(dt)
+        scalar = type(t0)
         third, two_thirds = 1 / 3, 2 / 3
         dts = float(dt) * func.sign
         ts = func.time_tensors(kern, [(t0, self._first_perturb()),
-                                      (scalar(t0 + scalar(dt * scalar(third))), Perturb.NONE),
-                                      (scalar(t0 + scalar(dt * scalar(two_thirds))), Perturb.NONE),
+                                      (scalar(t0 + self._tmul(scalar, dt, third)), Perturb.NONE),
+                                      (scalar(t0 + self._tmul(scalar, dt, two_thirds)), Perturb.NONE),
                                       (t1, self._last_perturb())])
         k1 = func.eval_at(ts[0], y0)
         ya = torch.empty_like(y0)
