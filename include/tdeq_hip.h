@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 2
+#define TDEQ_ABI_VERSION 3
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -157,6 +157,22 @@ int tdeq_fixed_stage(int mode, void* out, const void* y0, const void* const* k, 
  */
 int tdeq_weighted_sum(void* out, const void* const* x, const double* w, int n_terms, int64_t n, int dtype,
                       void* stream);
+
+/*
+ * Backward helpers of the differentiable plain `odeint`.  Every elementwise entry
+ * point above computes out = sum_m w_m(dt, x) * X_m, so the vector-Jacobian product the reference obtains
+ * from autograd over its eager ops (incl. `_UncheckedAssign.backward`, rk_common.py:31-40) is:
+ *   grad X_m = w_m * g                            tdeq_scale_many: g is read once, n_out tensors are written
+ *   grad s   = sum_m dw_m/ds * <g, X_m>           tdeq_multi_dot: out[m] = <g, x_m> in fp64 (device memory),
+ *                                                 for the time-like scalars s = dt, x when `t` requires grad
+ * 1 <= n_out, n_x <= TDEQ_MAX_TERMS.  tdeq_multi_dot needs tdeq_dots_workspace_bytes(n, n_x) bytes of device
+ * workspace; n == 0 yields zeros.
+ */
+int tdeq_scale_many(void* const* outs, const void* g, const double* w, int n_out, int64_t n, int dtype,
+                    void* stream);
+size_t tdeq_dots_workspace_bytes(int64_t n, int n_x);
+int tdeq_multi_dot(const void* g, const void* const* x, int n_x, int64_t n, double* out, void* workspace,
+                   size_t workspace_bytes, int dtype, void* stream);
 
 /* Writes n_vals scalars (converted to T) to consecutive elements of dst (stage times for func). */
 int tdeq_fill_scalars(void* dst, const double* vals, int n_vals, int dtype, void* stream);

@@ -54,6 +54,8 @@ def load() -> ctypes.CDLL:
         "oracle_lerp": [V, V, V, D, I64, I],
         "oracle_fixed_stage": [I, V, V, _c_void_pp, _c_double_p, I, D, I64, I],
         "oracle_weighted_sum": [V, _c_void_pp, _c_double_p, I, I64, I],
+        "oracle_scale_many": [_c_void_pp, V, _c_double_p, I, I64, I],
+        "oracle_multi_dot": [V, _c_void_pp, I, I64, V, I],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -158,6 +160,19 @@ class OracleKernels:
         ptrs, cf, n = self._terms(xs, ws)
         _ok(self.lib.oracle_weighted_sum(out.data_ptr(), ptrs, cf, n, out.numel(), _code(out.dtype)),
             "oracle_weighted_sum")
+
+    def scale_many(self, outs, g, ws):
+        ptrs, cf, n = self._terms(outs, ws)
+        _ok(self.lib.oracle_scale_many(ptrs, g.data_ptr(), cf, n, g.numel(), _code(g.dtype)), "oracle_scale_many")
+
+    def multi_dot(self, g, xs):
+        """fp64 tensor [len(xs)] of <g, x_m>."""
+        n = len(xs)
+        ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+        out = torch.empty(n, dtype=torch.float64)
+        _ok(self.lib.oracle_multi_dot(g.data_ptr(), ptrs, n, g.numel(), out.data_ptr(), _code(g.dtype)),
+            "oracle_multi_dot")
+        return out
 
     def fill_scalars(self, dst, vals):
         """Host twin of tdeq_fill_scalars: vals converted to dst's dtype."""

@@ -348,3 +348,53 @@ int oracle_weighted_sum(void* out, const void* const* x, const double* w, int n_
     else return -1;
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * Backward helpers (differentiable plain odeint): outs[m] = w_m * g ; out[m] = <g, x_m> (fp64).
+ * Restates what autograd does for the reference's eager `k * (beta * dt)` / `sum` ops (rk_common.py:79).
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_SCALE(NAME, T)                                                                            \
+    static void NAME(T* const* outs, const T* g, const double* w, int nt, int64_t n) {                \
+        for (int j = 0; j < nt; ++j) {                                                                \
+            const T wj = (T)w[j];                                                                     \
+            T* o = outs[j];                                                                           \
+            _Pragma("omp parallel for schedule(static)")                                              \
+            for (int64_t i = 0; i < n; ++i) o[i] = g[i] * wj;                                         \
+        }                                                                                             \
+    }
+DEF_SCALE(scale_f32, float)
+DEF_SCALE(scale_f64, double)
+
+int oracle_scale_many(void* const* outs, const void* g, const double* w, int n_out, int64_t n, int dtype) {
+    if (!outs || !g || !w || n_out < 1 || n_out > ORACLE_MAX_TERMS) return -1;
+    if (dtype == ORACLE_F32) scale_f32((float* const*)outs, (const float*)g, w, n_out, n);
+    else if (dtype == ORACLE_F64) scale_f64((double* const*)outs, (const double*)g, w, n_out, n);
+    else return -1;
+    return 0;
+}
+
+#define DEF_DOTS(NAME, T)                                                                             \
+    static void NAME(const T* g, const T* const* x, int nt, int64_t n, double* out) {                 \
+        for (int j = 0; j < nt; ++j) {                                                                \
+            const int64_t chunk = 4096;                                                               \
+            const int64_t nc = (n + chunk - 1) / chunk;                                               \
+            double total = 0.0;                                                                       \
+            for (int64_t c = 0; c < nc; ++c) {                                                        \
+                double acc = 0.0;                                                                     \
+                const int64_t hi = (c + 1) * chunk < n ? (c + 1) * chunk : n;                         \
+                for (int64_t i = c * chunk; i < hi; ++i) acc += (double)g[i] * (double)x[j][i];       \
+                total += acc;                                                                         \
+            }                                                                                         \
+            out[j] = total;                                                                           \
+        }                                                                                             \
+    }
+DEF_DOTS(dots_f32, float)
+DEF_DOTS(dots_f64, double)
+
+int oracle_multi_dot(const void* g, const void* const* x, int n_x, int64_t n, double* out, int dtype) {
+    if (!g || !x || !out || n_x < 1 || n_x > ORACLE_MAX_TERMS) return -1;
+    if (dtype == ORACLE_F32) dots_f32((const float*)g, (const float* const*)x, n_x, n, out);
+    else if (dtype == ORACLE_F64) dots_f64((const double*)g, (const double* const*)x, n_x, n, out);
+    else return -1;
+    return 0;
+}

@@ -455,9 +455,58 @@ def gen_events():
     save("events.npz", **arrays)
 
 
+def gen_backprop():
+    """§8(f) rank 1: gradients of plain `odeint` (backprop THROUGH the solver) wrt y0, parameters and t,
+    for a time-dependent tanh field; fp64 so the comparison is limited by the algorithm, not by rounding."""
+    arrays = {}
+    torch.manual_seed(5)
+    d, h, B = 4, 8, 6
+    W1, b1, W2 = torch.randn(h, d, dtype=torch.float64) * 0.6, torch.randn(h, dtype=torch.float64) * 0.1, \
+        torch.randn(d, h, dtype=torch.float64) * 0.6
+    y0 = rand(B, d, seed=21)
+    arrays.update(bp_W1=W1, bp_b1=b1, bp_W2=W2, bp_y0=y0)
+
+    def run(method, tt, options=None, tuple_state=False, rtol=1e-8, atol=1e-10):
+        p = [x.clone().requires_grad_(True) for x in (W1, b1, W2)]
+        yy = y0.clone().requires_grad_(True)
+        t = torch.tensor(tt, dtype=torch.float64, requires_grad=True)
+        field = lambda t_, y_: torch.tanh(y_ @ p[0].T + p[1]) @ p[2].T * torch.cos(t_) - 0.1 * y_
+        if tuple_state:
+            f = lambda t_, y_: (field(t_, y_[0]), -y_[1] * y_[0].sum(-1, keepdim=True))
+            ya, yb = torchdiffeq.odeint(f, (yy, torch.ones(B, 1, dtype=torch.float64)), t, method=method,
+                                        options=options, rtol=rtol, atol=atol)
+            loss = ya[-1].pow(2).sum() + ya[1].sum() + yb[-1].sum()
+            sol = ya
+        else:
+            sol = torchdiffeq.odeint(field, yy, t, method=method, options=options, rtol=rtol, atol=atol)
+            loss = sol[-1].pow(2).sum() + sol[1].sum()
+        loss.backward()
+        return dict(y=sol, g_y0=yy.grad, g_W1=p[0].grad, g_b1=p[1].grad, g_W2=p[2].grad, g_t=t.grad)
+
+    cases = [("dopri5", "dopri5", [0.0, 0.4, 1.0], None, False), ("dopri8", "dopri8", [0.0, 0.4, 1.0], None, False),
+             ("tsit5", "tsit5", [0.0, 0.4, 1.0], None, False), ("bosh3", "bosh3", [0.0, 0.4, 1.0], None, False),
+             ("fehlberg2", "fehlberg2", [0.0, 0.4, 1.0], None, False),
+             ("adaptive_heun", "adaptive_heun", [0.0, 0.4, 1.0], None, False),
+             ("dopri5_rev", "dopri5", [1.0, 0.3, 0.0], None, False),
+             ("dopri5_tuple", "dopri5", [0.0, 0.4, 1.0], None, True),
+             ("rk4_grid", "rk4", [0.0, 0.2, 0.45, 0.7, 1.0], None, False),
+             ("euler_grid", "euler", [0.0, 0.2, 0.45, 0.7, 1.0], None, False),
+             ("midpoint_step", "midpoint", [0.0, 0.33, 1.0], dict(step_size=0.1), False),
+             ("heun2_perturb", "heun2", [0.0, 0.33, 1.0], dict(step_size=0.1, perturb=True), False),
+             ("heun3_cubic", "heun3", [0.0, 0.33, 1.0], dict(step_size=0.1, interp="cubic"), False),
+             ("rk4_cubic_rev", "rk4", [1.0, 0.45, 0.0], dict(step_size=0.125, interp="cubic"), False)]
+    for tag, method, tt, opts, tup in cases:
+        tol = dict(rtol=1e-4, atol=1e-6) if method in ("fehlberg2", "adaptive_heun") else {}
+        out = run(method, tt, opts, tup, **tol)
+        for k, v in out.items():
+            arrays[f"bp_{tag}_{k}"] = v
+        arrays[f"bp_{tag}_t"] = np.array(tt)
+    save("backprop.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
-                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events)]:
+                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop)]:
         if not only or name in only:
             fn()

@@ -47,6 +47,10 @@ def test_argument_errors_without_gpu():
     assert lib.tdeq_fixed_stage(0, p, p, ptrs, buf, 5, 0.1, 4, 1, None) == -1         # n_terms > 4
     assert lib.tdeq_weighted_sum(p, ptrs, buf, 9, 4, 1, None) == -1                   # n_terms > 8
     assert lib.tdeq_weighted_sum(p, ptrs, buf, 1, 0, 1, None) == 0
+    assert lib.tdeq_scale_many(ptrs, p, buf, 15, 4, 1, None) == -1                    # n_out > 14
+    assert lib.tdeq_scale_many(ptrs, p, buf, 1, 0, 1, None) == 0
+    assert lib.tdeq_dots_workspace_bytes(4096 * 3 + 1, 5) == 4 * 5 * 8
+    assert lib.tdeq_multi_dot(p, ptrs, 1, 4, p, p, 0, 1, None) == -2                  # workspace too small
 
 
 def test_cpu_state_is_rejected_loudly():

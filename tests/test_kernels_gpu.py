@@ -287,3 +287,25 @@ def test_fixed_stage_unaligned(hip_kernels, oracle_kernels, dtype):
         v.copy_(src)
     hip_kernels.fixed_stage(0, views[0], views[1], [views[2], views[3]], [0.25, 0.75], 0.1)
     assert torch.equal(views[0].cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", SIZES)
+def test_scale_many_and_multi_dot(hip_kernels, oracle_kernels, dtype, n):
+    """Backward helpers of the differentiable odeint: outs[m] = w_m g (bit-exact), <g, x_m> in fp64 (1e-12)."""
+    g = _rand(n, dtype, 3)
+    xs = [_rand(n, dtype, 20 + j) for j in range(14)]
+    gd, xsd = g.cuda(), _dev(xs)
+    for nt in (1, 2, 5, 7, 14):
+        ws = [(-1) ** j * (0.37 + j / 11) for j in range(nt)]
+        ref = [torch.empty_like(g) for _ in range(nt)]
+        oracle_kernels.scale_many(ref, g, ws)
+        outs = [torch.empty_like(gd) for _ in range(nt)]
+        hip_kernels.scale_many(outs, gd, ws)
+        for o, r in zip(outs, ref):
+            assert torch.equal(o.cpu(), r)
+        dref = oracle_kernels.multi_dot(g, xs[:nt])
+        d = hip_kernels.multi_dot(gd, xsd[:nt])
+        assert d.dtype == torch.float64 and d.shape == (nt,)
+        scale = torch.stack([(g.double().abs() * x.double().abs()).sum() for x in xs[:nt]])
+        assert float(((d.cpu() - dref).abs() / (scale + 1e-300)).max()) < 1e-13

@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 2
+TDEQ_ABI_VERSION = 3
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -66,6 +66,11 @@ ABI_SIGNATURES = {
                                         ctypes.c_void_p]),
     "tdeq_weighted_sum": (ctypes.c_int, [ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int, ctypes.c_int64,
                                          ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_scale_many": (ctypes.c_int, [_c_void_pp, ctypes.c_void_p, _c_double_p, ctypes.c_int, ctypes.c_int64,
+                                       ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_dots_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
+    "tdeq_multi_dot": (ctypes.c_int, [ctypes.c_void_p, _c_void_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_fill_scalars": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p]),
 }
@@ -289,6 +294,23 @@ class HipKernels:
         ptrs, cf, n = self._terms(xs, ws)
         _check(self.lib.tdeq_weighted_sum(out.data_ptr(), ptrs, cf, n, out.numel(), dtype_code(out.dtype),
                                           self._stream()), "tdeq_weighted_sum")
+
+    def scale_many(self, outs, g, ws) -> None:
+        """outs[m] = ws[m] * g (backward of the linear kernels: g is read once)."""
+        ptrs, cf, n = self._terms(outs, ws)
+        _check(self.lib.tdeq_scale_many(ptrs, g.data_ptr(), cf, n, g.numel(), dtype_code(g.dtype), self._stream()),
+               "tdeq_scale_many")
+
+    def multi_dot(self, g, xs) -> torch.Tensor:
+        """fp64 device tensor [len(xs)] of <g, x_m> (no host read-back)."""
+        n = len(xs)
+        ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+        out = torch.empty(n, dtype=torch.float64, device=g.device)
+        nbytes = self.lib.tdeq_dots_workspace_bytes(g.numel(), n)
+        ws = torch.empty(max(1, nbytes // 8), dtype=torch.float64, device=g.device)
+        _check(self.lib.tdeq_multi_dot(g.data_ptr(), ptrs, n, g.numel(), out.data_ptr(), ws.data_ptr(), nbytes,
+                                       dtype_code(g.dtype), self._stream()), "tdeq_multi_dot")
+        return out
 
     def fill_scalars(self, dst, vals: Sequence[float]) -> None:
         n = len(vals)

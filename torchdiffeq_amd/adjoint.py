@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .misc import (ALL_ADJOINT_CALLBACK_NAMES, ALL_CALLBACK_NAMES, BuiltinNorm, OdeFunc, Perturb, StateLayout,
-                   check_inputs)
+                   check_inputs, pack_differentiable)
 from .odeint import SOLVERS
 
 
@@ -302,7 +302,7 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
 
     layout = ci.layout
     y0_tensors = y0 if layout.is_tuple else (y0,)
-    y0_flat = _pack_differentiable(layout, y0_tensors)
+    y0_flat = pack_differentiable(layout, y0_tensors)
     cfg = dict(func=ci.func, rtol=ci.rtol, atol=ci.atol, method=ci.method, options=ci.options,
                adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol, adjoint_method=adjoint_method,
                adjoint_options=adjoint_options, t_requires_grad=ci.t.requires_grad, event_fn=ci.event_fn)
@@ -319,17 +319,3 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
     if ci.event_fn is None:
         return solution
     return event_t, solution
-
-
-def _pack_differentiable(layout: StateLayout, tensors: Sequence[torch.Tensor]) -> torch.Tensor:
-    """Flat state built with autograd-visible ops so dL/dy0 flows back to the caller's tensors."""
-    if layout.n_seg == 1:
-        return tensors[0].reshape(-1).contiguous()
-    pieces = []
-    for i, t in enumerate(tensors):
-        pieces.append(t.reshape(-1))
-        end = layout.offsets[i + 1] if i + 1 < layout.n_seg else layout.total
-        pad = end - (layout.offsets[i] + layout.numels[i])
-        if pad:
-            pieces.append(torch.zeros(pad, dtype=t.dtype, device=t.device))
-    return torch.cat(pieces)

@@ -326,6 +326,75 @@ int dispatch_fixed(void* out, const void* y0, const void* const* k, const double
     return TDEQ_EINVAL;
 }
 
+// ---- backward helpers: scale_many / multi_dot ------------------------------------------------------------
+template <typename T, int NT>
+int launch_scale(void* const* outs, const void* g, const double* w, int64_t n, hipStream_t s) {
+    ScaleArgs<T, NT> a;
+    a.g = static_cast<const T*>(g);
+    bool vec = aligned16(g);
+    for (int j = 0; j < NT; ++j) {
+        a.out[j] = static_cast<T*>(outs[j]);
+        a.w[j] = (T)w[j];
+        vec = vec && aligned16(outs[j]);
+    }
+    a.n = n;
+    constexpr int L = VecOf<T>::L;
+    if (vec) hipLaunchKernelGGL((scale_many_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((scale_many_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
+}
+
+template <typename T>
+int dispatch_scale(void* const* outs, const void* g, const double* w, int nt, int64_t n, hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_scale<T, N>(outs, g, w, n, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
+constexpr int64_t kDotChunk = 4096;
+
+template <typename T, int NT>
+int launch_dots(const void* g, const void* const* x, int64_t n, double* out, double* ws, hipStream_t s) {
+    DotArgs<T, NT> a;
+    a.g = static_cast<const T*>(g);
+    bool vec = aligned16(g);
+    for (int j = 0; j < NT; ++j) {
+        a.x[j] = static_cast<const T*>(x[j]);
+        vec = vec && aligned16(x[j]);
+    }
+    a.n = n;
+    a.chunk = kDotChunk;
+    a.n_chunks = (n + kDotChunk - 1) / kDotChunk;
+    if (a.n_chunks < 1) a.n_chunks = 1;
+    a.part = ws;
+    const dim3 grid((unsigned)a.n_chunks), blk(kBlock);
+    if (vec) hipLaunchKernelGGL((multi_dot_kernel<T, NT, true>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((multi_dot_kernel<T, NT, false>), grid, blk, 0, s, a);
+    const int e = check_launch();
+    if (e) return e;
+    DotFinalizeArgs f;
+    f.part = ws;
+    f.n_chunks = a.n_chunks;
+    f.out = out;
+    hipLaunchKernelGGL(dot_finalize_kernel, dim3(NT), dim3(kBlock), 0, s, f);
+    return check_launch();
+}
+
+template <typename T>
+int dispatch_dots(const void* g, const void* const* x, int nt, int64_t n, double* out, double* ws, hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_dots<T, N>(g, x, n, out, ws, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
 inline bool bad_dtype(int dtype) { return dtype != TDEQ_F32 && dtype != TDEQ_F64; }
 
 }  // namespace
@@ -453,6 +522,36 @@ int tdeq_weighted_sum(void* out, const void* const* x, const double* w, int n_te
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == TDEQ_F32 ? dispatch_fixed<float, 2>(out, nullptr, x, w, n_terms, 0.0, n, s)
                              : dispatch_fixed<double, 2>(out, nullptr, x, w, n_terms, 0.0, n, s);
+}
+
+int tdeq_scale_many(void* const* outs, const void* g, const double* w, int n_out, int64_t n, int dtype,
+                    void* stream) {
+    if (!outs || !g || !w || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_out < 1 || n_out > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_out; ++j) if (!outs[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? dispatch_scale<float>(outs, g, w, n_out, n, s)
+                             : dispatch_scale<double>(outs, g, w, n_out, n, s);
+}
+
+size_t tdeq_dots_workspace_bytes(int64_t n, int n_x) {
+    int64_t n_chunks = (n + kDotChunk - 1) / kDotChunk;
+    if (n_chunks < 1) n_chunks = 1;
+    if (n_x < 1) n_x = 1;
+    return (size_t)n_chunks * (size_t)n_x * sizeof(double);
+}
+
+int tdeq_multi_dot(const void* g, const void* const* x, int n_x, int64_t n, double* out, void* workspace,
+                   size_t workspace_bytes, int dtype, void* stream) {
+    if (!g || !x || !out || !workspace || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_x < 1 || n_x > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_x; ++j) if (!x[j]) return TDEQ_EINVAL;
+    if (workspace_bytes < tdeq_dots_workspace_bytes(n, n_x)) return TDEQ_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    return dtype == TDEQ_F32 ? dispatch_dots<float>(g, x, n_x, n, out, ws, s)
+                             : dispatch_dots<double>(g, x, n_x, n, out, ws, s);
 }
 
 int tdeq_fill_scalars(void* dst, const double* vals, int n_vals, int dtype, void* stream) {

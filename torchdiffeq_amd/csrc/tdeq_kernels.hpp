@@ -540,6 +540,106 @@ __global__ __launch_bounds__(kBlock) void fixed_stage_kernel(const FixedArgs<T, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the linear kernels (differentiable plain odeint).  Every elementwise kernel above is
+// out = sum_m w_m(dt, x) * X_m, so its VJP is  grad X_m = w_m * g  (scale_many: g read once, NT stores)
+// and  grad s = sum_m dw_m/ds * <g, X_m>  for a time-like scalar s (multi_dot: fp64 dots, one pass).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+struct ScaleArgs {
+    T* out[NT];
+    const T* g;
+    T w[NT];
+    int64_t n;
+};
+
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(kBlock) void scale_many_kernel(const ScaleArgs<T, NT> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
+        const E g = reinterpret_cast<const E*>(a.g)[i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) reinterpret_cast<E*>(a.out[j])[i] = g * a.w[j];
+    }
+    if (VEC) {
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) {
+            const T g = a.g[t];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) a.out[j][t] = g * a.w[j];
+        }
+    }
+}
+
+template <typename T, int NT>
+struct DotArgs {
+    const T* g;
+    const T* x[NT];
+    int64_t n;
+    int64_t chunk;
+    double* part;   // [NT][n_chunks]
+    int64_t n_chunks;
+};
+
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(kBlock) void multi_dot_kernel(const DotArgs<T, NT> a) {
+    using V = typename VecOf<T>::type;
+    constexpr int L = VecOf<T>::L;
+    __shared__ double red[NT * (kBlock / kWave)];
+    const int64_t b = blockIdx.x;
+    const int64_t base = b * a.chunk;
+    int64_t valid = a.n - base;
+    valid = valid > a.chunk ? a.chunk : valid;
+    double acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = 0.0;
+    int64_t t0 = 0;
+    if (VEC) {
+        const int64_t nv = valid / L;
+        const V* g = reinterpret_cast<const V*>(a.g + base);
+        for (int64_t i = threadIdx.x; i < nv; i += kBlock) {
+            const V gv = g[i];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const V xv = reinterpret_cast<const V*>(a.x[j] + base)[i];
+#pragma unroll
+                for (int q = 0; q < L; ++q) acc[j] += (double)gv[q] * (double)xv[q];
+            }
+        }
+        t0 = nv * L;
+    }
+    for (int64_t t = t0 + threadIdx.x; t < valid; t += kBlock) {
+        const double gv = (double)a.g[base + t];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] += gv * (double)a.x[j][base + t];
+    }
+    block_sum<NT>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a.part[(int64_t)j * a.n_chunks + b] = acc[j];
+    }
+}
+
+// out[j] = sum over chunks of part[j][*], fixed order; one workgroup per j.
+struct DotFinalizeArgs {
+    const double* part;
+    int64_t n_chunks;
+    double* out;
+};
+
+__global__ __launch_bounds__(kBlock) void dot_finalize_kernel(const DotFinalizeArgs a) {
+    __shared__ double red[kBlock / kWave];
+    const int j = blockIdx.x;
+    const double* p = a.part + (int64_t)j * a.n_chunks;
+    double acc[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < a.n_chunks; i += kBlock) acc[0] += p[i];
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) a.out[j] = acc[0];
+}
+
 template <typename T>
 struct LerpArgs {
     T* out;

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import _native
+from .autodiff import stitch
 
 ALL_CALLBACK_NAMES = ["callback_step", "callback_accept_step", "callback_reject_step"]
 ALL_ADJOINT_CALLBACK_NAMES = [name + "_adjoint" for name in ALL_CALLBACK_NAMES]
@@ -125,6 +126,25 @@ class StateLayout:
         return [(off, n, r, a) for off, n, r, a in zip(self.offsets, self.numels, rt, at)]
 
 
+def pack_differentiable(layout: "StateLayout", tensors: Sequence[torch.Tensor], dtype=None) -> torch.Tensor:
+    """Flat (chunk-padded) state built with autograd-visible ops, so gradients flow back to the components."""
+    if layout.n_seg == 1:
+        t = tensors[0]
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        return t.reshape(-1).contiguous()
+    pieces = []
+    for i, t in enumerate(tensors):
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        pieces.append(t.reshape(-1))
+        end = layout.offsets[i + 1] if i + 1 < layout.n_seg else layout.total
+        pad = end - (layout.offsets[i] + layout.numels[i])
+        if pad:
+            pieces.append(torch.zeros(pad, dtype=t.dtype, device=t.device))
+    return torch.cat(pieces)
+
+
 def _per_segment(tol, n_seg: int, name: str) -> List[float]:
     if isinstance(tol, torch.Tensor):
         if tol.dim() == 0:
@@ -161,8 +181,15 @@ class OdeFunc:
         self.device = device
         self.np_dtype = np.float32 if dtype == torch.float32 else np.float64
         self.nfe = 0
+        self._anchor_user = None     # user-time t[0] when `t` requires grad (adaptive solvers)
         for name in ALL_CALLBACK_NAMES:
             setattr(self, name, _null_callback)
+
+    def set_time_anchor(self, anchor) -> None:
+        """`anchor` = t[0] in solver time (a 0-dim tensor in the autograd graph of `t`) or None.  Every time the
+        adaptive solvers hand to func is t[0] + constants, so its gradient flows to this anchor
+        (rk_common.py:72-78 with t0 = t[0] + sum of detached step sizes)."""
+        self._anchor_user = None if anchor is None else anchor * self.sign
 
     # -- time handling -----------------------------------------------------------------------------
     def user_time(self, t, perturb: Perturb = Perturb.NONE) -> float:
@@ -174,16 +201,23 @@ class OdeFunc:
             tt = np.nextafter(tt, tt - self.np_dtype(1))
         return float(self.sign * tt)
 
-    def time_tensor(self, value: float) -> torch.Tensor:
-        return torch.full((), value, dtype=self.dtype, device=self.device)
+    def time_tensor(self, value: float, shadow=None) -> torch.Tensor:
+        """0-dim tensor with the host value; its gradient goes to `shadow` (user time) or the anchor."""
+        v = torch.full((), value, dtype=self.dtype, device=self.device)
+        return stitch(v, shadow if shadow is not None else self._anchor_user)
 
-    def time_tensors(self, kernels, times_and_perturbs) -> Tuple[torch.Tensor, ...]:
+    def time_tensors(self, kernels, times_and_perturbs, shadows=None) -> Tuple[torch.Tensor, ...]:
         """0-dim device tensors for several evaluation times with ONE launch (instead of one fill kernel
         per stage): the values are computed on the host and travel in the kernel arguments."""
         vals = [self.user_time(t, p) for t, p in times_and_perturbs]
         buf = torch.empty(len(vals), dtype=self.dtype, device=self.device)
         kernels.fill_scalars(buf, vals)
-        return buf.unbind(0)
+        out = buf.unbind(0)
+        if shadows is None and self._anchor_user is None:
+            return out
+        if shadows is None:
+            shadows = [self._anchor_user] * len(out)
+        return tuple(stitch(v, sh) for v, sh in zip(out, shadows))
 
     def eval_at(self, t_user: torch.Tensor, y_flat: torch.Tensor) -> torch.Tensor:
         """Evaluate with a time tensor produced by `time_tensors`."""
@@ -191,17 +225,21 @@ class OdeFunc:
         return self.call_base(t_user, y_flat)
 
     # -- evaluation --------------------------------------------------------------------------------
-    def eval(self, t, y_flat: torch.Tensor, perturb: Perturb = Perturb.NONE) -> torch.Tensor:
+    def eval(self, t, y_flat: torch.Tensor, perturb: Perturb = Perturb.NONE, shadow=None) -> torch.Tensor:
         assert isinstance(perturb, Perturb), "perturb argument must be of type Perturb enum"
         self.nfe += 1
-        t_user = self.time_tensor(self.user_time(t, perturb))
+        t_user = self.time_tensor(self.user_time(t, perturb), shadow)
         return self.call_base(t_user, y_flat)
 
     def call_base(self, t_user: torch.Tensor, y_flat: torch.Tensor) -> torch.Tensor:
         lay = self.layout
+        grad = torch.is_grad_enabled()
         if lay.is_tuple:
             f = self.base_func(t_user, lay.unpack(y_flat))
-            out = lay.pack(tuple(f_.detach() if not torch.is_grad_enabled() else f_ for f_ in f), dtype=self.dtype)
+            if grad and any(f_.requires_grad for f_ in f):
+                out = pack_differentiable(lay, f, self.dtype)     # backprop through the solver
+            else:
+                out = lay.pack(tuple(f_.detach() for f_ in f), dtype=self.dtype)
         else:
             f = self.base_func(t_user, y_flat.view(lay.shapes[0]))
             if f.dtype != self.dtype:
@@ -209,13 +247,8 @@ class OdeFunc:
             out = f.reshape(-1)
             if not out.is_contiguous():
                 out = out.contiguous()
-        if out.requires_grad and not torch.is_grad_enabled():
+        if out.requires_grad and not grad:
             out = out.detach()      # func built its own graph internally (e.g. a Jacobian trace): drop it
-        if out.requires_grad:
-            raise NotImplementedError(
-                "torchdiffeq_amd.odeint runs the RK arithmetic in HIP kernels that are not recorded by "
-                "autograd; func returned a tensor that requires grad.  Use odeint_adjoint for gradients "
-                "(or wrap the call in torch.no_grad()).")
         return out
 
     def __call__(self, t, y_flat, *, perturb: Perturb = Perturb.NONE):

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import torch
 
-from .misc import check_inputs
+from .misc import check_inputs, pack_differentiable
 from .solvers import (RK4, AdaptiveHeunSolver, Bosh3Solver, Dopri5Solver, Dopri8Solver, Euler, Fehlberg2, Heun2,
                       Heun3, Midpoint, Tsit5Solver)
 
@@ -37,21 +37,18 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
     With `event_fn(t, y) -> Tensor`, `t` must have two entries (start, direction); the solve stops where the
     event function first crosses zero and `(event_t, solution)` is returned, `solution[-1]` = the state there.
 
-    The Runge–Kutta arithmetic runs in hand-written HIP kernels (libtdeq_hip.so); it is not recorded
-    by autograd — use `odeint_adjoint` for gradients, and call plain `odeint` under `torch.no_grad()`
-    when `func` has parameters that require grad (otherwise NotImplementedError is raised).
+    The Runge–Kutta arithmetic runs in hand-written HIP kernels (libtdeq_hip.so).  With grad mode on and
+    `y0`, `t` or parameters of `func` requiring grad, every kernel call is recorded as one autograd node with a
+    hand-written backward (autodiff.py), so the result can be backpropagated *through* the solver like the
+    reference's; `odeint_adjoint` gives the same gradients in O(1) memory.
     """
-    if torch.is_grad_enabled():
-        y0_list = y0 if isinstance(y0, tuple) else (y0,)
-        if any(isinstance(y_, torch.Tensor) and y_.requires_grad for y_ in y0_list) or \
-                (isinstance(t, torch.Tensor) and t.requires_grad):
-            raise NotImplementedError(
-                "torchdiffeq_amd.odeint does not backpropagate through the solver (the RK arithmetic runs in "
-                "HIP kernels outside autograd): use odeint_adjoint for gradients wrt y0 / t / parameters.")
     ci = check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS)
-    # Runs under the caller's grad mode: if `func` produces tensors that require grad, the wrapped func
-    # raises (loudly) instead of returning a silently non-differentiable solution.
-    solver = SOLVERS[ci.method](func=ci.func, y0=ci.y0_flat, rtol=ci.rtol, atol=ci.atol, **ci.options)
+    y0_flat = ci.y0_flat
+    if torch.is_grad_enabled():
+        y0_list = y0 if ci.layout.is_tuple else (y0,)
+        if any(y_.requires_grad for y_ in y0_list):
+            y0_flat = pack_differentiable(ci.layout, y0_list)        # backprop through the solver (autodiff.py)
+    solver = SOLVERS[ci.method](func=ci.func, y0=y0_flat, rtol=ci.rtol, atol=ci.atol, **ci.options)
     if ci.event_fn is None:
         solution = solver.integrate(ci.t)
     else:

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import _native
+from .autodiff import Ops, stitch
 from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, find_event, handle_unused_kwargs, rms_norm)
 from .misc import _null_callback as _null
 from .tableaus import ADAPTIVE_HEUN, BOSH3, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau
@@ -106,8 +107,10 @@ class RKAdaptiveStepsizeODESolver:
         self.jump_t = None if jump_t is None else torch.as_tensor(jump_t, dtype=torch.float64).reshape(-1).tolist()
 
         self.kernels = _native.get_kernels(y0.device)
+        self.ops = Ops(self.kernels, self.np_dtype)      # elementwise kernels, differentiable when grad is needed
         self.plan = self.kernels.make_plan(self.layout.segments(rtol, atol), self.layout.total,
                                            self.layout.chunk, y0.device)
+        self._anchor = None        # t[0] (solver time) when `t` requires grad: every step time moves with it
         tab = self.tableau
         self._beta = tab.beta_rows()
         self._c_err = SparseRow.from_dense(tab.c_error)
@@ -145,18 +148,36 @@ class RKAdaptiveStepsizeODESolver:
     def integrate(self, t: torch.Tensor) -> torch.Tensor:
         """solution[len(t), total] with solution[0] = y0 (solvers.py:28-35)."""
         t_host = t.detach().to(torch.float64).cpu().tolist()
+        self._set_time_anchor(t)
+        self._before_integrate(t_host)
+        if self._differentiable():
+            # backprop through the solver: rows are autograd nodes, assembled by a differentiable stack
+            rows = [self.y0]
+            for i in range(1, len(t_host)):
+                rows.append(self._advance(t_host[i], None, t[i] if self._anchor is not None else None))
+            return torch.stack(rows, dim=0)
         solution = torch.empty(len(t_host), self.layout.total, dtype=self.y0.dtype, device=self.y0.device)
         solution[0].copy_(self.y0)
-        self._before_integrate(t_host)
         for i in range(1, len(t_host)):
             self._advance(t_host[i], solution[i])
         return solution
+
+    def _set_time_anchor(self, t: torch.Tensor) -> None:
+        self._anchor = t[0] if (torch.is_grad_enabled() and t.requires_grad) else None
+        self.func.set_time_anchor(self._anchor)
+
+    def _differentiable(self) -> bool:
+        """True when the solution must carry an autograd graph (grad mode on and y0, `t` or func's output —
+        i.e. its parameters — require grad)."""
+        return torch.is_grad_enabled() and (self.y0.requires_grad or self._anchor is not None or
+                                            self.f1.requires_grad)
 
     def integrate_dense(self, t: torch.Tensor):
         """Integrate over [t[0], t[-1]] keeping the dense output of EVERY accepted step (odeint.py:124-147):
         returns (times, coeffs) with `times` the n_steps + 1 accepted step boundaries (host doubles) and
         `coeffs[n_steps, 5, total]` the quartic coefficients [e, d, c, b, a] (`tdeq_interp_fit`)."""
         t_host = t.detach().to(torch.float64).cpu().tolist()
+        self._set_time_anchor(t.detach())
         self._before_integrate(t_host)
         times, planes = [self.t0], []
         mid = self._c_mid
@@ -182,6 +203,7 @@ class RKAdaptiveStepsizeODESolver:
     def integrate_until_event(self, t0: torch.Tensor, event_fn):
         """(event_t, solution[2, total]): step until `event_fn(t, y)` changes sign, then bisect on the last
         step's dense output (solvers.py:44-49, rk_common.py:252-264, event_handling.py:5-20)."""
+        self._set_time_anchor(t0.reshape(-1))
         self._before_integrate([float(t0.detach())])
         event_time, y1 = self._advance_until_event(event_fn)
         solution = torch.stack([self.y0, y1], dim=0)
@@ -200,9 +222,7 @@ class RKAdaptiveStepsizeODESolver:
             n_steps += 1
 
         def interp_fn(t):
-            out = torch.empty_like(self.y0)
-            self._interp_evaluate(float(t), out)
-            return out
+            return self._interp_evaluate(float(t))
 
         atol = self.atol
         if isinstance(atol, torch.Tensor):
@@ -219,7 +239,7 @@ class RKAdaptiveStepsizeODESolver:
         else:
             first_step = self.first_step
             # no initial-step heuristic -> still take the non-finite census of y0 (rk_common.py:287)
-            self.kernels.init_norms(self.plan, 1, f0, f0, self.y0)
+            self.kernels.init_norms(self.plan, 1, f0.detach(), f0.detach(), self.y0.detach())
             _, _, bad = self.kernels.read_norms(self.plan)
             self._y_nonfinite = any(b != 0 for b in bad)
         self.y1, self.f1 = self.y0, f0
@@ -240,6 +260,7 @@ class RKAdaptiveStepsizeODESolver:
         T = self.np_dtype
         kern, plan = self.kernels, self.plan
         order = self.order - 1   # the reference passes `self.order - 1` (rk_common.py:217)
+        y0, f0 = y0.detach(), f0.detach()        # the step-size heuristic is a constant of the backward pass
         kern.init_norms(plan, 0, y0, f0, y0)
         s0, s1, bad = kern.read_norms(plan)
         self._y_nonfinite = any(b != 0 for b in bad)
@@ -252,7 +273,8 @@ class RKAdaptiveStepsizeODESolver:
         h0 = abs(h0)
         y1 = torch.empty_like(y0)
         kern.stage_combine(y1, y0, [f0], [1.0], float(h0) * self.func.sign)
-        f1 = self.func.eval(t0 + float(h0), y1)
+        with torch.no_grad():
+            f1 = self.func.eval(t0 + float(h0), y1)
         kern.init_norms(plan, 1, f1, f0, y0)
         s2, _, bad = kern.read_norms(plan)
         with np.errstate(all="ignore"):
@@ -264,25 +286,30 @@ class RKAdaptiveStepsizeODESolver:
             h1 = abs(h1)
             return float(min(T(100) * h0, h1))
 
-    def _advance(self, next_t: float, out: torch.Tensor) -> None:
-        """Step until next_t is inside the last accepted step, then write y(next_t) into `out`."""
+    def _advance(self, next_t: float, out: Optional[torch.Tensor], t_shadow=None) -> torch.Tensor:
+        """Step until next_t is inside the last accepted step, then return y(next_t) (written into `out` if
+        given).  `t_shadow` = the entry of `t` this output belongs to, when `t` requires grad."""
         n_steps = 0
         while next_t > self.t1:
             assert n_steps < self.max_num_steps, \
                 "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
             self._adaptive_step()
             n_steps += 1
-        self._interp_evaluate(next_t, out)
+        return self._interp_evaluate(next_t, out, t_shadow)
 
-    def _interp_evaluate(self, t: float, out: torch.Tensor) -> None:
+    def _interp_evaluate(self, t: float, out: Optional[torch.Tensor] = None, t_shadow=None) -> torch.Tensor:
         """Fused `_interp_fit` + `_interp_evaluate` (rk_common.py:363-369, interp.py:25-48)."""
         rec = self._dense
         assert rec is not None and rec.t0 <= t <= rec.t1, \
             "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(self.t0, t, self.t1)
         x = float(self.np_dtype((t - rec.t0) / (rec.t1 - rec.t0)))
+        x_shadow = None
+        if self._anchor is not None:
+            # x = (t - t0_step) / (t1_step - t0_step): the step boundaries move with t[0], the width is a constant
+            x_shadow = ((t_shadow if t_shadow is not None else 0.0) - self._anchor) / (rec.t1 - rec.t0)
         mid = self._c_mid
-        self.kernels.dense_eval(out, rec.y0, rec.y1, rec.k[0], rec.k[-1], [rec.k[j] for j in mid.idx],
-                                mid.coef, rec.dt_signed, x)
+        return self.ops.dense_eval(rec.y0, rec.y1, rec.k, mid.idx, mid.coef, rec.dt_signed, x,
+                                   x_shadow=x_shadow, out=out)
 
     def _adaptive_step(self) -> None:
         """One trial step (rk_common.py:266-361)."""
@@ -321,21 +348,20 @@ class RKAdaptiveStepsizeODESolver:
             for i in range(len(self._beta))])
         k: List[torch.Tensor] = [f0]
         yi = y0
+        ops = self.ops
         for i, row in enumerate(self._beta):
-            yi = torch.empty_like(y0)
-            kern.stage_combine(yi, y0, [k[j] for j in row.idx], row.coef, dt_signed)
+            yi = ops.combine(y0, [k[j] for j in row.idx], row.coef, dt_signed)
             k.append(func.eval_at(stage_times[i], yi))
         if self.tableau.fsal_solution:
             y1 = yi
         else:
-            y1 = torch.empty_like(y0)
-            kern.stage_combine(y1, y0, [k[j] for j in self._c_sol.idx], self._c_sol.coef, dt_signed)
+            y1 = ops.combine(y0, [k[j] for j in self._c_sol.idx], self._c_sol.coef, dt_signed)
         f1 = k[-1]
 
         # ---- error ratio (misc.py:80-82) ----
         err = self._c_err
         if isinstance(self.norm, BuiltinNorm):
-            kern.error_norm(self.plan, y0, y1, [k[j] for j in err.idx], err.coef, dt_signed)
+            kern.error_norm(self.plan, y0.detach(), y1.detach(), [k[j].detach() for j in err.idx], err.coef, dt_signed)
             sumsq, _, bad = kern.read_norms(self.plan)
             error_ratio = self._segment_norm(sumsq, bad)
             y1_nonfinite = any(b != 0 for b in bad)
@@ -375,10 +401,12 @@ class RKAdaptiveStepsizeODESolver:
         """User-supplied `norm` callable (misc.py:80-82 with a custom norm): the kernel materialises
         err/tol (padding zero-filled) and the user's own function reduces it."""
         err = self._c_err
+        y0, y1 = y0.detach(), y1.detach()
         scaled = torch.empty_like(y0)
-        self.kernels.error_scaled(self.plan, scaled, y0, y1, [k[j] for j in err.idx], err.coef, dt_signed)
+        self.kernels.error_scaled(self.plan, scaled, y0, y1, [k[j].detach() for j in err.idx], err.coef, dt_signed)
         _, _, bad = self.kernels.read_norms(self.plan)
-        ratio = self.norm(scaled)
+        with torch.no_grad():
+            ratio = self.norm(scaled)
         ratio = abs(float(ratio))
         return ratio, any(b != 0 for b in bad)
 
@@ -446,6 +474,7 @@ class FixedGridODESolver(object):
         self.interp = interp
         self.perturb = perturb
         self.kernels = _native.get_kernels(y0.device)
+        self.ops = Ops(self.kernels, func.np_dtype)
         if step_size is None:
             if grid_constructor is None:
                 self.grid_constructor = lambda f, y0, t: t
@@ -473,9 +502,11 @@ class FixedGridODESolver(object):
         return _grid_constructor
 
     # -- one step ------------------------------------------------------------------------------------
-    def _step(self, t0, dt, t1, y0: torch.Tensor, y1: torch.Tensor):
-        """Write y(t1) into `y1`; return f0 = func(t0, y0).  t0 and t1 are numpy scalars of the grid's dtype;
-        `dt` is one too in `integrate`, and the Python float `step_size` in `integrate_until_event`."""
+    def _step(self, t0, dt, t1, y0: torch.Tensor, y1_out: Optional[torch.Tensor], sh: "_StepShadow"):
+        """Return (y(t1), f0 = func(t0, y0)); y(t1) is written into `y1_out` when given (no-grad callers).
+        t0 and t1 are numpy scalars of the grid's dtype; `dt` is one too in `integrate`, and the Python float
+        `step_size` in `integrate_until_event`.  `sh` carries the autograd shadows of t0 / dt when the grid
+        requires grad."""
         raise NotImplementedError
 
     @staticmethod
@@ -495,7 +526,7 @@ class FixedGridODESolver(object):
 
     # -- integrate -----------------------------------------------------------------------------------
     def integrate(self, t: torch.Tensor) -> torch.Tensor:
-        func, kern = self.func, self.kernels
+        func, ops = self.func, self.ops
         time_grid = self.grid_constructor(func, self.y0, t)
         assert time_grid[0] == t[0] and time_grid[-1] == t[-1]
         if self.interp not in ("linear", "cubic"):
@@ -505,40 +536,58 @@ class FixedGridODESolver(object):
         tt = t.detach().cpu().numpy()
         scalar = grid.dtype.type
         linear = self.interp == "linear"
+        grad_mode = torch.is_grad_enabled()
+        time_grad = grad_mode and (time_grid.requires_grad or t.requires_grad)
+        sign = func.sign
 
-        solution = torch.empty(len(tt), self.layout.total, dtype=self.dtype, device=self.device)
-        solution[0].copy_(self.y0)
+        rows: List[Optional[torch.Tensor]] = [self.y0] + [None] * (len(tt) - 1)
+        solution = None
         has_cb = func.callback_step is not _null
         j = 1
         y0 = self.y0
-        for t0, t1 in zip(grid[:-1], grid[1:]):
+        for n, (t0, t1) in enumerate(zip(grid[:-1], grid[1:])):
             dt = scalar(t1 - t0)
             if has_cb:
                 func.callback_step(torch.tensor(t0, device=self.device), y0, torch.tensor(dt, device=self.device))
-            # y1 goes straight into the output row when the grid point is an output time
-            if linear and j < len(tt) and t1 == tt[j]:
-                y1 = solution[j]
-            else:
-                y1 = torch.empty_like(y0)
-            f0 = self._step(t0, dt, t1, y0, y1)
+            sh = _StepShadow(time_grid[n], time_grid[n + 1], sign) if time_grad else _NO_SHADOW
+            # Without a graph, y1 goes straight into the output row when the grid point is an output time.
+            differentiable = grad_mode and (time_grad or y0.requires_grad)
+            y1_out = None
+            if not differentiable:
+                if solution is None:
+                    solution = torch.empty(len(tt), self.layout.total, dtype=self.dtype, device=self.device)
+                if linear and j < len(tt) and t1 == tt[j]:
+                    y1_out = solution[j]
+            y1, f0 = self._step(t0, dt, t1, y0, y1_out, sh)
+            differentiable = differentiable or (grad_mode and y1.requires_grad)
 
             f1 = None
             while j < len(tt) and t1 >= tt[j]:
+                tj_shadow = t[j] if time_grad else None
                 if linear:
                     if tt[j] == t1:
-                        if y1.data_ptr() != solution[j].data_ptr():
-                            solution[j].copy_(y1)
+                        rows[j] = y1
                     elif tt[j] == t0:
-                        solution[j].copy_(y0)
+                        rows[j] = y0
                     else:
                         slope = scalar(scalar(tt[j] - t0) / scalar(t1 - t0))
-                        kern.lerp(solution[j], y0, y1, float(slope))
+                        rows[j] = ops.lerp(y0, y1, float(slope), sh.fraction(tj_shadow),
+                                           out=None if differentiable or solution is None else solution[j])
                 else:
                     if f1 is None:
-                        f1 = func.eval(t1, y1)                   # solvers.py:121, once per grid interval hit
-                    self._cubic_hermite_interp(solution[j], scalar, t0, y0, f0, t1, y1, f1, tt[j])
+                        f1 = func.eval(t1, y1, shadow=sh.time(1.0))    # solvers.py:121, once per interval hit
+                    rows[j] = self._cubic_hermite_interp(scalar, t0, y0, f0, t1, y1, f1, tt[j], sh, tj_shadow,
+                                                         out=None if differentiable or solution is None
+                                                         else solution[j])
                 j += 1
             y0 = y1
+        if any(r.requires_grad for r in rows) and grad_mode:
+            return torch.stack(rows, dim=0)
+        if solution is None:
+            solution = torch.empty(len(tt), self.layout.total, dtype=self.dtype, device=self.device)
+        for i, r in enumerate(rows):
+            if r.data_ptr() != solution[i].data_ptr():
+                solution[i].copy_(r)
         return solution
 
     def integrate_until_event(self, t0: torch.Tensor, event_fn):
@@ -546,7 +595,7 @@ class FixedGridODESolver(object):
         cubic interpolant of that step (solvers.py:129-164).  Times are kept in the state dtype (:132)."""
         assert self.step_size is not None, \
             "Event handling for fixed step solvers currently requires `step_size` to be provided in options."
-        func, kern = self.func, self.kernels
+        func, ops = self.func, self.ops
         scalar = func.np_dtype
         time_tensor = lambda v: torch.tensor(float(v), dtype=self.dtype, device=self.device)
         t0 = scalar(float(t0.detach()))
@@ -561,8 +610,7 @@ class FixedGridODESolver(object):
         while True:
             itr += 1
             t1 = scalar(t0 + scalar(dt))
-            y1 = torch.empty_like(y0)
-            f0 = self._step(t0, dt, t1, y0, y1)
+            y1, f0 = self._step(t0, dt, t1, y0, None, _NO_SHADOW)
             sign1 = float(torch.sign(event_fn(time_tensor(t1), y1)))
             if sign0 != sign1:
                 if self.interp == "linear":
@@ -571,16 +619,12 @@ class FixedGridODESolver(object):
                             return y0
                         if t == t1:
                             return y1
-                        out = torch.empty_like(y0)
-                        kern.lerp(out, y0, y1, float(scalar(scalar(t - t0) / scalar(t1 - t0))))
-                        return out
+                        return ops.lerp(y0, y1, float(scalar(scalar(t - t0) / scalar(t1 - t0))))
                 else:
                     f1 = func.eval(t1, y1)
 
                     def interp_fn(t, t0=t0, t1=t1, y0=y0, y1=y1, f0=f0, f1=f1):
-                        out = torch.empty_like(y0)
-                        self._cubic_hermite_interp(out, scalar, t0, y0, f0, t1, y1, f1, t)
-                        return out
+                        return self._cubic_hermite_interp(scalar, t0, y0, f0, t1, y1, f1, t, _NO_SHADOW, None)
                 event_time, y1 = find_event(interp_fn, sign0, t0, t1, event_fn, float(self.atol), time_tensor,
                                             scalar=scalar)
                 break
@@ -591,7 +635,7 @@ class FixedGridODESolver(object):
         solution = torch.stack([self.y0, y1], dim=0)
         return time_tensor(event_time), solution
 
-    def _cubic_hermite_interp(self, out, scalar, t0, y0, f0, t1, y1, f1, t) -> None:
+    def _cubic_hermite_interp(self, scalar, t0, y0, f0, t1, y1, f1, t, sh, t_shadow, out=None) -> torch.Tensor:
         """solvers.py:166-173; the basis values are scalars of t.dtype formed on the host."""
         one, two, three = scalar(1), scalar(2), scalar(3)
         h = scalar(scalar(t - t0) / scalar(t1 - t0))
@@ -603,99 +647,144 @@ class FixedGridODESolver(object):
         h11 = scalar(hh * scalar(h - one))
         dt = scalar(t1 - t0)
         sign = scalar(self.func.sign)       # f0 / f1 are raw func outputs: fold the time sign into their weights
-        self.kernels.weighted_sum(out, [y0, f0, y1, f1],
-                                  [float(h00), float(scalar(h10 * dt) * sign), float(h01), float(scalar(h11 * dt) * sign)])
+        ws = [float(h00), float(scalar(h10 * dt) * sign), float(h01), float(scalar(h11 * dt) * sign)]
+        scalars = ()
+        if sh is not _NO_SHADOW:
+            hf, dtf, sg = float(h), float(dt), float(sign)
+            d_h = [-6 * hf * (1 - hf), (1 - hf) * (1 - 3 * hf) * dtf * sg, 6 * hf * (1 - hf),
+                   (3 * hf * hf - 2 * hf) * dtf * sg]
+            d_dt = [0.0, float(h10) * sg, 0.0, float(h11) * sg]
+            scalars = [(sh.fraction(t_shadow), d_h), (sh.width(), d_dt)]
+        return self.ops.weighted_sum([y0, f0, y1, f1], ws, scalars, out=out)
+
+
+class _StepShadow:
+    """Autograd shadows of one fixed-grid step's time scalars (solver time): t0, t1 are entries of the
+    time grid tensor (whose graph leads back to `t`); host scalars give the values, these only the gradient."""
+    __slots__ = ("t0", "t1", "sign")
+
+    def __init__(self, t0, t1, sign):
+        self.t0, self.t1, self.sign = t0, t1, sign
+
+    def width(self):
+        """dt in solver time."""
+        return self.t1 - self.t0
+
+    def dt_signed(self):
+        """The scalar handed to the kernels as `dt` (time sign folded in)."""
+        return (self.t1 - self.t0) * self.sign
+
+    def time(self, c: float):
+        """User time of the stage at t0 + c dt."""
+        return (self.t0 + (self.t1 - self.t0) * c) * self.sign
+
+    def fraction(self, t_shadow):
+        """(t - t0) / (t1 - t0) for an output time t."""
+        num = (t_shadow - self.t0) if t_shadow is not None else -self.t0
+        return num / (self.t1 - self.t0)
+
+
+class _NoShadow:
+    def width(self):
+        return None
+
+    def dt_signed(self):
+        return None
+
+    def time(self, c):
+        return None
+
+    def fraction(self, t_shadow):
+        return None
+
+
+_NO_SHADOW = _NoShadow()
 
 
 class Euler(FixedGridODESolver):
     """Forward Euler (fixed_grid.py:6-11): dy = dt * f0."""
     order = 1
 
-    def _step(self, t0, dt, t1, y0, y1):
+    def _step(self, t0, dt, t1, y0, y1_out, sh):
         func = self.func
-        f0 = func.eval(t0, y0, self._first_perturb())
-        self.kernels.stage_combine(y1, y0, [f0], [1.0], float(dt) * func.sign)
-        return f0
+        f0 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
+        y1 = self.ops.combine(y0, [f0], [1.0], float(dt) * func.sign, sh.dt_signed(), out=y1_out)
+        return y1, f0
 
 
 class Midpoint(FixedGridODESolver):
     """Explicit midpoint (fixed_grid.py:14-21): y_mid = y0 + f0*(dt/2); dy = dt * f(t0 + dt/2, y_mid)."""
     order = 2
 
-    def _step(self, t0, dt, t1, y0, y1):
-        func, kern = self.func, self.kernels
+    def _step(self, t0, dt, t1, y0, y1_out, sh):
+        func, ops = self.func, self.ops
         scalar = type(t0)
         dts = float(dt) * func.sign
         half_dt = self._tmul(scalar, dt, 0.5)
-        f0 = func.eval(t0, y0, self._first_perturb())
-        y_mid = torch.empty_like(y0)
-        kern.stage_combine(y_mid, y0, [f0], [0.5], dts)
-        k2 = func.eval(scalar(t0 + half_dt), y_mid)
-        kern.stage_combine(y1, y0, [k2], [1.0], dts)
-        return f0
+        f0 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
+        y_mid = ops.combine(y0, [f0], [0.5], dts, sh.dt_signed())
+        k2 = func.eval(scalar(t0 + half_dt), y_mid, shadow=sh.time(0.5))
+        y1 = ops.combine(y0, [k2], [1.0], dts, sh.dt_signed(), out=y1_out)
+        return y1, f0
 
 
 class Heun2(FixedGridODESolver):
     """Heun's 2nd-order method through the reference's rk2 step (fixed_grid.py:49-60, rk_common.py:142-157)."""
     order = 2
 
-    def _step(self, t0, dt, t1, y0, y1):
-        func, kern = self.func, self.kernels
+    def _step(self, t0, dt, t1, y0, y1_out, sh):
+        func, ops = self.func, self.ops
         scalar = type(t0)
         dts = float(dt) * func.sign
-        k1 = func.eval(t0, y0, self._first_perturb())
-        ya = torch.empty_like(y0)
-        kern.fixed_stage(1, ya, y0, [k1], [1.0], dts)
-        k2 = func.eval(scalar(t0 + self._tmul(scalar, dt, 1.0)), ya, self._last_perturb())
-        kern.fixed_stage(0, y1, y0, [k1, k2], [0.5, 0.5], dts)
-        return k1
+        k1 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
+        ya = ops.fixed_stage(1, y0, [k1], [1.0], dts, sh.dt_signed())
+        k2 = func.eval(scalar(t0 + self._tmul(scalar, dt, 1.0)), ya, self._last_perturb(), shadow=sh.time(1.0))
+        y1 = ops.fixed_stage(0, y0, [k1, k2], [0.5, 0.5], dts, sh.dt_signed(), out=y1_out)
+        return y1, k1
 
 
 class Heun3(FixedGridODESolver):
     """Heun's 3rd-order method through the reference's rk3 step (fixed_grid.py:32-46, rk_common.py:121-140)."""
     order = 3
 
-    def _step(self, t0, dt, t1, y0, y1):
-        func, kern = self.func, self.kernels
+    def _step(self, t0, dt, t1, y0, y1_out, sh):
+        func, ops = self.func, self.ops
         scalar = type(t0)
         dts = float(dt) * func.sign
         third, two_thirds = 1 / 3, 2 / 3
-        k1 = func.eval(t0, y0, self._first_perturb())
-        ya = torch.empty_like(y0)
-        kern.fixed_stage(1, ya, y0, [k1], [third], dts)
-        k2 = func.eval(scalar(t0 + self._tmul(scalar, dt, third)), ya)
-        yb = torch.empty_like(y0)
-        kern.fixed_stage(0, yb, y0, [k2], [two_thirds], dts)            # k1's weight is a structural zero
-        k3 = func.eval(scalar(t0 + self._tmul(scalar, dt, two_thirds)), yb)
-        kern.fixed_stage(0, y1, y0, [k1, k3], [1 / 4, 3 / 4], dts)      # k2's weight is a structural zero
-        return k1
+        k1 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
+        ya = ops.fixed_stage(1, y0, [k1], [third], dts, sh.dt_signed())
+        k2 = func.eval(scalar(t0 + self._tmul(scalar, dt, third)), ya, shadow=sh.time(third))
+        yb = ops.fixed_stage(0, y0, [k2], [two_thirds], dts, sh.dt_signed())   # k1's weight is a structural zero
+        k3 = func.eval(scalar(t0 + self._tmul(scalar, dt, two_thirds)), yb, shadow=sh.time(two_thirds))
+        y1 = ops.fixed_stage(0, y0, [k1, k3], [1 / 4, 3 / 4], dts, sh.dt_signed(), out=y1_out)   # k2: structural zero
+        return y1, k1
 
 
 class RK4(FixedGridODESolver):
     """Fixed-grid 4th-order RK, 3/8 rule (fixed_grid.py:24-29 -> rk_common.py:110-118)."""
     order = 4
 
-    def _step(self, t0, dt, t1, y0, y1):
-        func, kern = self.func, self.kernels
+    def _step(self, t0, dt, t1, y0, y1_out, sh):
+        func, ops = self.func, self.ops
         scalar = type(t0)
         third, two_thirds = 1 / 3, 2 / 3
         dts = float(dt) * func.sign
-        ts = func.time_tensors(kern, [(t0, self._first_perturb()),
-                                      (scalar(t0 + self._tmul(scalar, dt, third)), Perturb.NONE),
-                                      (scalar(t0 + self._tmul(scalar, dt, two_thirds)), Perturb.NONE),
-                                      (t1, self._last_perturb())])
+        ts = func.time_tensors(self.kernels, [(t0, self._first_perturb()),
+                                              (scalar(t0 + self._tmul(scalar, dt, third)), Perturb.NONE),
+                                              (scalar(t0 + self._tmul(scalar, dt, two_thirds)), Perturb.NONE),
+                                              (t1, self._last_perturb())],
+                               shadows=[sh.time(0.0), sh.time(third), sh.time(two_thirds), sh.time(1.0)])
+        dsh = sh.dt_signed()
         k1 = func.eval_at(ts[0], y0)
-        ya = torch.empty_like(y0)
-        kern.rk4_stage(1, ya, y0, k1, None, None, None, dts)
+        ya = ops.rk4_stage(1, y0, k1, None, None, None, dts, dsh)
         k2 = func.eval_at(ts[1], ya)
-        yb = torch.empty_like(y0)
-        kern.rk4_stage(2, yb, y0, k1, k2, None, None, dts)
+        yb = ops.rk4_stage(2, y0, k1, k2, None, None, dts, dsh)
         k3 = func.eval_at(ts[2], yb)
-        yc = torch.empty_like(y0)
-        kern.rk4_stage(3, yc, y0, k1, k2, k3, None, dts)
+        yc = ops.rk4_stage(3, y0, k1, k2, k3, None, dts, dsh)
         k4 = func.eval_at(ts[3], yc)
-        kern.rk4_stage(4, y1, y0, k1, k2, k3, k4, dts)
-        return k1
+        y1 = ops.rk4_stage(4, y0, k1, k2, k3, k4, dts, dsh, out=y1_out)
+        return y1, k1
 
 
 SOLVER_CLASSES = {"dopri8": Dopri8Solver, "dopri5": Dopri5Solver, "tsit5": Tsit5Solver, "bosh3": Bosh3Solver,
