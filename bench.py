@@ -136,6 +136,7 @@ def main():
     solver = Dopri5Solver(func=func, y0=y0.reshape(-1), rtol=RTOL, atol=ATOL, norm=rms_norm)
     timed = EventTimedKernels(solver.kernels, dominant_terms=5)
     solver.kernels = timed
+    solver.ops.k = timed        # the elementwise kernels are issued through solver.ops
     with torch.no_grad():
         solver._before_integrate([0.0])
         for _ in range(args.warmup):
@@ -166,6 +167,42 @@ def main():
         pairs.append((e0, e1))
     torch.cuda.synchronize()
     overhead = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
+
+    # ---- solver-only rate: the 6 stage_combine launches + error_norm (+ finalize) of one
+    # dopri5 step on the k tensors of the last timed step, no func, HIP events around REPS back-to-back passes.
+    solver_only = None
+    try:
+        rec = solver._dense
+        kern = solver.kernels._inner
+        ks, y0s = rec.k, rec.y0
+        outs = [torch.empty_like(y0s) for _ in range(2)]
+        REPS = 30
+
+        def one_pass():
+            for i, row in enumerate(solver._beta):
+                kern.stage_combine(outs[i & 1], y0s, [ks[j] for j in row.idx], row.coef, rec.dt_signed)
+            kern.error_norm(solver.plan, y0s, rec.y1, [ks[j] for j in solver._c_err.idx], solver._c_err.coef,
+                            rec.dt_signed)
+        for _ in range(3):
+            one_pass()
+        kern.read_norms(solver.plan)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(REPS):
+            one_pass()
+        e1.record()
+        kern.read_norms(solver.plan)
+        torch.cuda.synchronize()
+        t_step = e0.elapsed_time(e1) * 1e-3 / REPS
+        bytes_step = 40 * BATCH * DIM * 4            # dopri5 = 32 + 8 words per element
+        solver_only = {"stages_per_s": 6 / t_step, "us_per_step": 1e6 * t_step, "GBps": bytes_step / t_step / 1e9,
+                       "frac_of_hbm_peak": bytes_step / t_step / 1e9 / HBM_PEAK_GBPS,
+                       "algorithmic_bytes_per_step": bytes_step,
+                       "note": "6 stage_combine + error_norm + finalize back to back, no func; the 7 k tensors "
+                               "(235 MB) + y0/y1 fit the 256 MiB Infinity Cache only partly"}
+    except Exception as exc:      # never let the extra figure break the contract line
+        solver_only = {"error": repr(exc)}
 
     n = BATCH * DIM
     kernel_ms = [a.elapsed_time(b) for a, b in timed.events]
@@ -218,6 +255,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
                          "avg_event_bracket_ms": raw_ms, "empty_event_pair_ms": overhead,
                          "launches_timed": len(kernel_ms), "traffic": traffic},
+            "solver_only": solver_only,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -39,7 +39,11 @@ def main():
     kk = K()
     for name in ("stage_combine", "error_norm", "read_norms", "fill_scalars", "dense_eval", "init_norms", "make_plan"):
         setattr(kk, name, timed(name, getattr(k, name)))
+    for name in dir(k):
+        if not name.startswith('__') and not hasattr(kk, name):
+            setattr(kk, name, getattr(k, name))
     solver.kernels = kk
+    solver.ops.k = kk
     with torch.no_grad():
         solver._before_integrate([0.0])
         for _ in range(20):

@@ -343,13 +343,17 @@ class RKAdaptiveStepsizeODESolver:
         # ---- Runge–Kutta stages (rk_common.py:43-90); times in the state precision T ----
         t0_T, dt_T, t1_T = T(t0), T(dt), T(t1)
         dt_signed = float(dt_T) * func.sign
+        ops = self.ops
+        # The first stage input needs only (y0, f0, dt): it is launched before any other host work of the
+        # step (stage times, buffers) so the GPU restarts as early as possible after the step-boundary read-back.
+        row0 = self._beta[0]
+        yi = ops.combine(y0, [f0], row0.coef, dt_signed)
         stage_times = func.time_tensors(kern, [
             (t1_T, Perturb.PREV) if self._alpha_is_one[i] else (t0_T + self._alpha[i] * dt_T, Perturb.NONE)
             for i in range(len(self._beta))])
-        k: List[torch.Tensor] = [f0]
-        yi = y0
-        ops = self.ops
-        for i, row in enumerate(self._beta):
+        k: List[torch.Tensor] = [f0, func.eval_at(stage_times[0], yi)]
+        for i in range(1, len(self._beta)):
+            row = self._beta[i]
             yi = ops.combine(y0, [k[j] for j in row.idx], row.coef, dt_signed)
             k.append(func.eval_at(stage_times[i], yi))
         if self.tableau.fsal_solution:
