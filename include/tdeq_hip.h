@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 3
+#define TDEQ_ABI_VERSION 5
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -75,6 +75,16 @@ int tdeq_stage_combine(void* out, const void* y0, const void* const* k, const do
                        int n_terms, double dt, int64_t n, int dtype, void* stream);
 
 /*
+ * tdeq_stage_combine for the FIRST stage of a step (n_terms 1 or 2, n >= 1) that also stores `n_fill` (<= 16)
+ * scalars, converted to T, at fill_dst[0..n_fill): the stage times `ti = t0 + alpha_i * dt` (rk_common.py:72-78)
+ * that the following func evaluations read as 0-dim tensors.  Saves the separate tdeq_fill_scalars launch at the
+ * latency-critical start of a step; results are identical to the two separate calls.
+ */
+int tdeq_stage_combine_fill(void* out, const void* y0, const void* const* k, const double* coef, int n_terms,
+                            double dt, int64_t n, int dtype, void* fill_dst, const double* fill_vals, int n_fill,
+                            void* stream);
+
+/*
  * Embedded error estimate + tolerance scaling + per-segment sum of squares, fused:
  *   err = sum_j fl_T(coef_j*dt) * k_j                       (rk_common.py:89)
  *   tol = atol + rtol * max(|y0|, |y1|)                      (misc.py:81)
@@ -92,6 +102,26 @@ int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void
                     const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
                     double* out_sumsq, double* out_nonfinite, void* workspace,
                     size_t workspace_bytes, int dtype, void* stream);
+
+/*
+ * Fused pair for the END of a trial step (same results as tdeq_stage_combine + tdeq_error_norm, fewer bytes):
+ *   tdeq_stage_combine_err   the step's last combine (last stage row, or the c_sol combine of a non-FSAL pair)
+ *                            also stores  err_out = (e_0 k_0 + e_1 k_1) + ...,  e_j = fl_T(fl_T(err_coef_j)*fl_T(dt)),
+ *                            the partial embedded error over the SAME stages, left to right (rk_common.py:89);
+ *   tdeq_error_norm_partial  err = (err_partial + c_0 k_0) + ... over the 0..2 remaining stages (for an FSAL
+ *                            pair: the last stage slot only), then tolerance scaling, per-segment sums and the
+ *                            non-finite census exactly as tdeq_error_norm.
+ * The caller uses the pair only when the fused stages are a leading run of the error row's non-zero entries, so
+ * the left-to-right sum order (and therefore every bit of err) is unchanged.  Traffic per dopri5 step:
+ * 40 -> 37 words per element (7+1 and 4 instead of 7 and 8); dopri8: 105 -> 98.
+ */
+int tdeq_stage_combine_err(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
+                           const double* err_coef, int n_terms, double dt, int64_t n, int dtype, void* stream);
+int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void* y1, const void* const* k,
+                            const double* coef, int n_terms, double dt, const tdeq_segment* segs,
+                            const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
+                            double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
+                            void* stream);
 
 /*
  * Initial-step norms (Hairer II.4 as in misc.py:36-77), scale = atol + |y0| * rtol:

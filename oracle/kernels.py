@@ -54,6 +54,9 @@ def load() -> ctypes.CDLL:
         "oracle_lerp": [V, V, V, D, I64, I],
         "oracle_fixed_stage": [I, V, V, _c_void_pp, _c_double_p, I, D, I64, I],
         "oracle_weighted_sum": [V, _c_void_pp, _c_double_p, I, I64, I],
+        "oracle_stage_combine_err": [V, V, V, _c_void_pp, _c_double_p, _c_double_p, I, D, I64, I],
+        "oracle_error_norm_partial": [V, V, V, _c_void_pp, _c_double_p, I, D, ctypes.POINTER(Segment), I, I64, I64,
+                                      V, V, I],
         "oracle_scale_many": [_c_void_pp, V, _c_double_p, I, I64, I],
         "oracle_multi_dot": [V, _c_void_pp, I, I64, V, I],
     }
@@ -111,12 +114,31 @@ class OracleKernels:
         _ok(self.lib.oracle_stage_combine(out.data_ptr(), y0.data_ptr(), ptrs, cf, n, dt, y0.numel(),
                                           _code(y0.dtype)), "oracle_stage_combine")
 
+    def stage_combine_fill(self, out, y0, ks, coefs, dt, fill_dst, fill_vals):
+        """Host twin of tdeq_stage_combine_fill = stage_combine + fill_scalars."""
+        self.stage_combine(out, y0, ks, coefs, dt)
+        self.fill_scalars(fill_dst, fill_vals)
+
     def error_norm(self, plan, y0, y1, ks, coefs, dt, scaled_out=None):
         ptrs, cf, n = self._terms(ks, coefs)
         so = None if scaled_out is None else scaled_out.data_ptr()
         _ok(self.lib.oracle_error_norm(so, y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, plan.segs, plan.n_seg,
                                        plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr, _code(y0.dtype)),
             "oracle_error_norm")
+
+    def stage_combine_err(self, out, err_out, y0, ks, coefs, err_coefs, dt):
+        ptrs, cf, n = self._terms(ks, coefs)
+        ef = (ctypes.c_double * n)(*err_coefs)
+        _ok(self.lib.oracle_stage_combine_err(out.data_ptr(), err_out.data_ptr(), y0.data_ptr(), ptrs, cf, ef, n, dt,
+                                              y0.numel(), _code(y0.dtype)), "oracle_stage_combine_err")
+
+    def error_norm_partial(self, plan, err_partial, y0, y1, ks, coefs, dt):
+        n = len(ks)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
+        cf = (ctypes.c_double * max(n, 1))(*coefs)
+        _ok(self.lib.oracle_error_norm_partial(err_partial.data_ptr(), y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt,
+                                               plan.segs, plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr,
+                                               plan.bad_ptr, _code(y0.dtype)), "oracle_error_norm_partial")
 
     def error_scaled(self, plan, out, y0, y1, ks, coefs, dt):
         self.error_norm(plan, y0, y1, ks, coefs, dt, scaled_out=out)

@@ -398,3 +398,98 @@ int oracle_multi_dot(const void* g, const void* const* x, int n_x, int64_t n, do
     else return -1;
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused end-of-step pair (same arithmetic as oracle_stage_combine + oracle_error_norm, split differently):
+ *   combine_err:        out = y0 + sum_j c_j k_j ; err_out = (e_0 k_0 + e_1 k_1) + ...     rk_common.py:79/85, :89
+ *   error_norm_partial: err = (partial + c_0 k_0) + ... ; tol, sums and census as above     misc.py:80-82
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_COMBINE_ERR(NAME, T)                                                                      \
+    static void NAME(T* out, T* err_out, const T* y0, const T* const* k, const double* coef,          \
+                     const double* ecoef, int nt, double dt, int64_t n) {                             \
+        T c[ORACLE_MAX_TERMS], e[ORACLE_MAX_TERMS];                                                   \
+        const T dtT = (T)dt;                                                                          \
+        for (int j = 0; j < nt; ++j) { c[j] = (T)coef[j] * dtT; e[j] = (T)ecoef[j] * dtT; }           \
+        _Pragma("omp parallel for schedule(static)")                                                  \
+        for (int64_t i = 0; i < n; ++i) {                                                             \
+            T acc = k[0][i] * c[0];                                                                   \
+            T err = k[0][i] * e[0];                                                                   \
+            for (int j = 1; j < nt; ++j) { acc = acc + k[j][i] * c[j]; err = err + k[j][i] * e[j]; }  \
+            out[i] = y0[i] + acc;                                                                     \
+            err_out[i] = err;                                                                         \
+        }                                                                                             \
+    }
+DEF_COMBINE_ERR(combine_err_f32, float)
+DEF_COMBINE_ERR(combine_err_f64, double)
+
+int oracle_stage_combine_err(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
+                             const double* err_coef, int n_terms, double dt, int64_t n, int dtype) {
+    if (!out || !err_out || !y0 || !k || !coef || !err_coef || n_terms < 1 || n_terms > ORACLE_MAX_TERMS) return -1;
+    if (dtype == ORACLE_F32)
+        combine_err_f32((float*)out, (float*)err_out, (const float*)y0, (const float* const*)k, coef, err_coef, n_terms, dt, n);
+    else if (dtype == ORACLE_F64)
+        combine_err_f64((double*)out, (double*)err_out, (const double*)y0, (const double* const*)k, coef, err_coef, n_terms, dt, n);
+    else return -1;
+    return 0;
+}
+
+#define DEF_ERROR_PARTIAL(NAME, T, ABS, MAX)                                                          \
+    static int NAME(const T* partial, const T* y0, const T* y1, const T* const* k, const double* coef,\
+                    int nt, double dt, const oracle_segment* segs, int n_seg, int64_t chunk,          \
+                    int64_t n_chunks, double* out_sumsq, double* out_bad) {                           \
+        T c[2] = {0, 0};                                                                              \
+        const T dtT = (T)dt;                                                                          \
+        for (int j = 0; j < nt; ++j) c[j] = (T)coef[j] * dtT;                                         \
+        double* part = (double*)malloc(sizeof(double) * 2 * (size_t)n_chunks);                        \
+        if (!part) return -2;                                                                         \
+        for (int s = 0; s < n_seg; ++s) {                                                             \
+            const int64_t c0 = segs[s].chunk_start;                                                   \
+            const int64_t c1 = (s + 1 < n_seg) ? segs[s + 1].chunk_start : n_chunks;                  \
+            const T rtol = (T)segs[s].rtol, atol = (T)segs[s].atol;                                   \
+            _Pragma("omp parallel for schedule(static)")                                              \
+            for (int64_t b = c0; b < c1; ++b) {                                                       \
+                int64_t valid = segs[s].numel - (b - c0) * chunk;                                     \
+                if (valid > chunk) valid = chunk;                                                     \
+                if (valid < 0) valid = 0;                                                             \
+                const int64_t base = b * chunk;                                                       \
+                double acc = 0.0, bad = 0.0;                                                          \
+                for (int64_t t = 0; t < valid; ++t) {                                                 \
+                    const int64_t i = base + t;                                                       \
+                    T e = partial[i];                                                                 \
+                    for (int j = 0; j < nt; ++j) e = e + k[j][i] * c[j];                              \
+                    const T a0 = ABS(y0[i]), a1 = ABS(y1[i]);                                         \
+                    const T tol = atol + rtol * MAX(a0, a1);                                          \
+                    const T r = e / tol;                                                              \
+                    acc += (double)r * (double)r;                                                     \
+                    if (!isfinite((double)y0[i]) || !isfinite((double)y1[i])) bad += 1.0;             \
+                }                                                                                     \
+                part[2 * b] = acc;                                                                    \
+                part[2 * b + 1] = bad;                                                                \
+            }                                                                                         \
+            double total = 0.0, bad_total = 0.0;                                                      \
+            for (int64_t b = c0; b < c1; ++b) {                                                       \
+                total += part[2 * b];                                                                 \
+                bad_total += part[2 * b + 1];                                                         \
+            }                                                                                         \
+            out_sumsq[s] = total;                                                                     \
+            out_bad[s] = bad_total;                                                                   \
+        }                                                                                             \
+        free(part);                                                                                   \
+        return 0;                                                                                     \
+    }
+DEF_ERROR_PARTIAL(error_partial_f32, float, fabsf, fmaxf)
+DEF_ERROR_PARTIAL(error_partial_f64, double, fabs, fmax)
+
+int oracle_error_norm_partial(const void* err_partial, const void* y0, const void* y1, const void* const* k,
+                              const double* coef, int n_terms, double dt, const oracle_segment* segs, int n_seg,
+                              int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite, int dtype) {
+    if (!err_partial || !y0 || !y1 || !segs || n_terms < 0 || n_terms > 2) return -1;
+    if (dtype == ORACLE_F32)
+        return error_partial_f32((const float*)err_partial, (const float*)y0, (const float*)y1, (const float* const*)k,
+                                 coef, n_terms, dt, segs, n_seg, chunk, n_chunks, out_sumsq, out_nonfinite);
+    else if (dtype == ORACLE_F64)
+        return error_partial_f64((const double*)err_partial, (const double*)y0, (const double*)y1,
+                                 (const double* const*)k, coef, n_terms, dt, segs, n_seg, chunk, n_chunks, out_sumsq,
+                                 out_nonfinite);
+    return -1;
+}

@@ -47,6 +47,10 @@ def test_argument_errors_without_gpu():
     assert lib.tdeq_fixed_stage(0, p, p, ptrs, buf, 5, 0.1, 4, 1, None) == -1         # n_terms > 4
     assert lib.tdeq_weighted_sum(p, ptrs, buf, 9, 4, 1, None) == -1                   # n_terms > 8
     assert lib.tdeq_weighted_sum(p, ptrs, buf, 1, 0, 1, None) == 0
+    assert lib.tdeq_stage_combine_fill(p, p, ptrs, buf, 3, 0.1, 4, 1, p, buf, 2, None) == -1   # n_terms > 2
+    assert lib.tdeq_stage_combine_fill(p, p, ptrs, buf, 1, 0.1, 4, 1, p, buf, 17, None) == -1  # n_fill > 16
+    assert lib.tdeq_stage_combine_err(p, None, p, ptrs, buf, buf, 1, 0.1, 4, 1, None) == -1    # null err_out
+    assert lib.tdeq_error_norm_partial(p, p, p, ptrs, buf, 3, 0.1, None, None, 1, 1024, 1, p, p, p, 24, 1, None) == -1
     assert lib.tdeq_scale_many(ptrs, p, buf, 15, 4, 1, None) == -1                    # n_out > 14
     assert lib.tdeq_scale_many(ptrs, p, buf, 1, 0, 1, None) == 0
     assert lib.tdeq_dots_workspace_bytes(4096 * 3 + 1, 5) == 4 * 5 * 8

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from torchdiffeq_amd.tableaus import DOPRI5, DOPRI8, SparseRow
+from torchdiffeq_amd.tableaus import ADAPTIVE_HEUN, BOSH3, DOPRI5, DOPRI8, TSIT5, SparseRow
 
 pytestmark = pytest.mark.gpu
 
@@ -309,3 +309,56 @@ def test_scale_many_and_multi_dot(hip_kernels, oracle_kernels, dtype, n):
         assert d.dtype == torch.float64 and d.shape == (nt,)
         scale = torch.stack([(g.double().abs() * x.double().abs()).sum() for x in xs[:nt]])
         assert float(((d.cpu() - dref).abs() / (scale + 1e-300)).max()) < 1e-13
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 255, 4099, 1 << 20])
+def test_stage_combine_fill(hip_kernels, oracle_kernels, dtype, n):
+    """First-stage combine fused with the stage-time fill == the two separate calls, bit for bit."""
+    y0, f0, k1 = _rand(n, dtype, 1), _rand(n, dtype, 2), _rand(n, dtype, 3)
+    vals = [0.1 * j + 1e-9 for j in range(13)]
+    for ks, coefs in (([f0], [0.2]), ([f0, k1], [3 / 40, 9 / 40])):
+        ref, tref = torch.empty_like(y0), torch.empty(13, dtype=dtype)
+        oracle_kernels.stage_combine_fill(ref, y0, ks, coefs, -0.05, tref, vals)
+        out, tb = torch.empty_like(y0).cuda(), torch.full((16,), -7.0, dtype=dtype).cuda()
+        hip_kernels.stage_combine_fill(out, y0.cuda(), _dev(ks), coefs, -0.05, tb, vals)
+        assert torch.equal(out.cpu(), ref)
+        assert torch.equal(tb[:13].cpu(), tref) and torch.all(tb[13:] == -7.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 255, 4099, 65536 + 7, 1 << 20])
+@pytest.mark.parametrize("tab", [DOPRI5, DOPRI8, BOSH3, TSIT5, ADAPTIVE_HEUN], ids=lambda t: t.name)
+def test_fused_end_of_step_pair(hip_kernels, oracle_kernels, dtype, n, tab):
+    """tdeq_stage_combine_err + tdeq_error_norm_partial == tdeq_stage_combine + tdeq_error_norm:
+    elementwise outputs bit for bit, and the SAME fp64 sums (same per-element values, same chunk order)."""
+    S = tab.n_stages
+    last = tab.beta_rows()[-1] if tab.fsal_solution else SparseRow.from_dense(tab.c_sol)
+    err = SparseRow.from_dense(tab.c_error)
+    n_lead = len(last.idx)
+    assert err.idx[:n_lead] == last.idx
+    y0, y1 = _rand(n, dtype, 1), _rand(n, dtype, 2)
+    ks = [_rand(n, dtype, 10 + j) for j in range(S + 1)]
+    y0d, y1d, ksd = y0.cuda(), y1.cuda(), _dev(ks)
+    dt = -0.0371
+    # oracle, fused
+    out_ref, ep_ref = torch.empty_like(y0), torch.empty_like(y0)
+    oracle_kernels.stage_combine_err(out_ref, ep_ref, y0, [ks[j] for j in last.idx], last.coef, err.coef[:n_lead], dt)
+    out, ep = torch.empty_like(y0d), torch.empty_like(y0d)
+    hip_kernels.stage_combine_err(out, ep, y0d, [ksd[j] for j in last.idx], last.coef, err.coef[:n_lead], dt)
+    assert torch.equal(out.cpu(), out_ref) and torch.equal(ep.cpu(), ep_ref)
+    plain = torch.empty_like(y0d)
+    hip_kernels.stage_combine(plain, y0d, [ksd[j] for j in last.idx], last.coef, dt)
+    assert torch.equal(plain, out)
+    segs = [(0, n, 1e-3, 1e-4)]
+    for chunk in (1024, 2048):
+        pg, pc = _plan_pair(hip_kernels, oracle_kernels, segs, n, chunk)
+        rest_idx, rest_coef = err.idx[n_lead:], err.coef[n_lead:]
+        hip_kernels.error_norm_partial(pg, ep, y0d, y1d, [ksd[j] for j in rest_idx], rest_coef, dt)
+        fused, _, bad_f = hip_kernels.read_norms(pg)
+        hip_kernels.error_norm(pg, y0d, y1d, [ksd[j] for j in err.idx], err.coef, dt)
+        unfused, _, bad_u = hip_kernels.read_norms(pg)
+        assert fused == unfused and bad_f == bad_u == [0.0]
+        oracle_kernels.error_norm_partial(pc, ep_ref, y0, y1, [ks[j] for j in rest_idx], rest_coef, dt)
+        ref, _, _ = oracle_kernels.read_norms(pc)
+        assert fused[0] == pytest.approx(ref[0], rel=1e-12)

@@ -306,3 +306,23 @@ def test_oracle_c_fixed_stage_matches_numpy_bitwise():
         out = torch.empty_like(ty0)
         KERN.weighted_sum(out, [ty0] + tk, [0.5, -0.25, 0.125, 3.0, 1 / 3])
         assert np.array_equal(out.numpy(), a.weighted_sum([y0] + [k[j] for j in range(4)], [0.5, -0.25, 0.125, 3.0, 1 / 3]))
+
+
+def test_oracle_fused_end_of_step_pair_is_the_same_arithmetic():
+    """oracle_stage_combine_err / oracle_error_norm_partial == oracle_stage_combine / oracle_error_norm."""
+    z = load("kernels.npz")
+    for key, method in (("dopri5_f32", "dopri5"), ("dopri8_f64", "dopri8")):
+        tab = orc.tableau(method)
+        y0, k, y1 = T(z[f"{key}_y0"]), [T(z[f"{key}_k"][j]).contiguous() for j in range(len(tab.alpha) + 1)], T(z[f"{key}_y1"])
+        idx, coef = orc._nz(tab.beta[-1])
+        eidx, ecoef = orc._nz(tab.c_error)
+        assert eidx[:len(idx)] == idx
+        out, ep, plain = torch.empty_like(y0), torch.empty_like(y0), torch.empty_like(y0)
+        KERN.stage_combine_err(out, ep, y0, [k[j] for j in idx], coef, ecoef[:len(idx)], 0.0371)
+        KERN.stage_combine(plain, y0, [k[j] for j in idx], coef, 0.0371)
+        assert torch.equal(out, plain)
+        plan = KERN.make_plan([(0, y0.numel(), 1e-3, 1e-4)], y0.numel(), 1024, None)
+        KERN.error_norm_partial(plan, ep, y0, y1, [k[j] for j in eidx[len(idx):]], ecoef[len(idx):], 0.0371)
+        a = KERN.read_norms(plan)[0][0]
+        KERN.error_norm(plan, y0, y1, [k[j] for j in eidx], ecoef, 0.0371)
+        assert a == KERN.read_norms(plan)[0][0]

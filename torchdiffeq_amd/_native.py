@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 3
+TDEQ_ABI_VERSION = 5
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -40,11 +40,22 @@ ABI_SIGNATURES = {
     "tdeq_stage_combine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
                                           ctypes.c_int, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_void_p]),
+    "tdeq_stage_combine_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
+                                               ctypes.c_int, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+                                               ctypes.c_void_p, _c_double_p, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_error_norm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
                                        ctypes.c_int, ctypes.c_double, ctypes.POINTER(Segment),
                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_stage_combine_err": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
+                                              _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_double,
+                                              ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_error_norm_partial": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
+                                               _c_double_p, ctypes.c_int, ctypes.c_double, ctypes.POINTER(Segment),
+                                               ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_init_norms": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int,
                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
@@ -213,6 +224,15 @@ class HipKernels:
         _check(self.lib.tdeq_stage_combine(out.data_ptr(), y0.data_ptr(), ptrs, cf, n, dt, y0.numel(),
                                            dtype_code(y0.dtype), self._stream()), "tdeq_stage_combine")
 
+    def stage_combine_fill(self, out, y0, ks, coefs, dt: float, fill_dst, fill_vals) -> None:
+        """stage_combine of a step's first stage that also writes `fill_vals` (stage times) into `fill_dst`."""
+        ptrs, cf, n = self._terms(ks, coefs)
+        m = len(fill_vals)
+        fv = (ctypes.c_double * m)(*fill_vals)
+        _check(self.lib.tdeq_stage_combine_fill(out.data_ptr(), y0.data_ptr(), ptrs, cf, n, dt, y0.numel(),
+                                                dtype_code(y0.dtype), fill_dst.data_ptr(), fv, m, self._stream()),
+               "tdeq_stage_combine_fill")
+
     def error_norm(self, plan: NormPlan, y0, y1, ks, coefs, dt: float, scaled_out=None) -> None:
         ptrs, cf, n = self._terms(ks, coefs)
         dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
@@ -222,6 +242,26 @@ class HipKernels:
                                         plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
                                         plan.workspace.data_ptr(), plan.workspace_bytes,
                                         dtype_code(y0.dtype), self._stream()), "tdeq_error_norm")
+
+    def stage_combine_err(self, out, err_out, y0, ks, coefs, err_coefs, dt: float) -> None:
+        """Last combine of a step + partial embedded error over the same stages (tdeq_stage_combine_err)."""
+        ptrs, cf, n = self._terms(ks, coefs)
+        ef = (ctypes.c_double * n)(*err_coefs)
+        _check(self.lib.tdeq_stage_combine_err(out.data_ptr(), err_out.data_ptr(), y0.data_ptr(), ptrs, cf, ef, n, dt,
+                                               y0.numel(), dtype_code(y0.dtype), self._stream()),
+               "tdeq_stage_combine_err")
+
+    def error_norm_partial(self, plan: NormPlan, err_partial, y0, y1, ks, coefs, dt: float) -> None:
+        """Error norm continuing `err_partial` with the remaining stages `ks` (0..2 of them)."""
+        n = len(ks)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
+        cf = (ctypes.c_double * max(n, 1))(*coefs)
+        dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
+        self._arm(plan, 1)
+        _check(self.lib.tdeq_error_norm_partial(err_partial.data_ptr(), y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt,
+                                                plan.segs, dev, plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr,
+                                                plan.bad_ptr, plan.workspace.data_ptr(), plan.workspace_bytes,
+                                                dtype_code(y0.dtype), self._stream()), "tdeq_error_norm_partial")
 
     def error_scaled(self, plan: NormPlan, out, y0, y1, ks, coefs, dt: float) -> None:
         """err/tol materialised into `out` (for user norm callables); norms are produced as well."""

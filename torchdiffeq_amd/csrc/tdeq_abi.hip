@@ -73,6 +73,64 @@ int launch_combine(void* out, const void* y0, const void* const* k, const double
     return check_launch();
 }
 
+template <typename T, int NT>
+int launch_combine_fill(void* out, const void* y0, const void* const* k, const double* coef, double dt, int64_t n,
+                        void* fill_dst, const double* fill_vals, int n_fill, hipStream_t s) {
+    CombineArgs<T, NT> a;
+    a.out = static_cast<T*>(out);
+    a.y0 = static_cast<const T*>(y0);
+    bool vec = aligned16(out) && aligned16(y0);
+    const T dtT = (T)dt;
+    for (int j = 0; j < NT; ++j) {
+        a.k[j] = static_cast<const T*>(k[j]);
+        a.c[j] = (T)coef[j] * dtT;
+        vec = vec && aligned16(k[j]);
+    }
+    a.n = n;
+    SideFill<T> f;
+    f.dst = static_cast<T*>(fill_dst);
+    for (int i = 0; i < 16; ++i) f.v[i] = i < n_fill ? (T)fill_vals[i] : (T)0;
+    f.n = n_fill;
+    constexpr int L = VecOf<T>::L;
+    if (vec) hipLaunchKernelGGL((stage_combine_fill_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a, f);
+    else hipLaunchKernelGGL((stage_combine_fill_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a, f);
+    return check_launch();
+}
+
+template <typename T, int NT>
+int launch_combine_err(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
+                       const double* err_coef, double dt, int64_t n, hipStream_t s) {
+    CombineErrArgs<T, NT> a;
+    a.c.out = static_cast<T*>(out);
+    a.c.y0 = static_cast<const T*>(y0);
+    a.err_out = static_cast<T*>(err_out);
+    bool vec = aligned16(out) && aligned16(y0) && aligned16(err_out);
+    const T dtT = (T)dt;
+    for (int j = 0; j < NT; ++j) {
+        a.c.k[j] = static_cast<const T*>(k[j]);
+        a.c.c[j] = (T)coef[j] * dtT;
+        a.e[j] = (T)err_coef[j] * dtT;      // dt * c_error_j — rk_common.py:89
+        vec = vec && aligned16(k[j]);
+    }
+    a.c.n = n;
+    constexpr int L = VecOf<T>::L;
+    if (vec) hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
+}
+
+template <typename T>
+int dispatch_combine_err(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
+                         const double* err_coef, int nt, double dt, int64_t n, hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_combine_err<T, N>(out, err_out, y0, k, coef, err_coef, dt, n, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
 template <typename T>
 int dispatch_combine(void* out, const void* y0, const void* const* k, const double* coef, int nt,
                      double dt, int64_t n, hipStream_t s) {
@@ -160,6 +218,46 @@ int dispatch_error(void* scaled, const void* y0, const void* y1, const void* con
         TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
         TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
 #undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
+template <typename T, int NT>
+int launch_error_partial(const void* partial, const void* y0, const void* y1, const void* const* k,
+                         const double* coef, double dt, const SegTable& st, double* out_sumsq, double* out_bad,
+                         double* ws, hipStream_t s) {
+    ErrPartialArgs<T, NT> a;
+    a.partial = static_cast<const T*>(partial);
+    a.y0 = static_cast<const T*>(y0);
+    a.y1 = static_cast<const T*>(y1);
+    bool vec = aligned16(partial) && aligned16(y0) && aligned16(y1);
+    const T dtT = (T)dt;
+    a.k[0] = nullptr;
+    a.c[0] = (T)0;
+    for (int j = 0; j < NT; ++j) {
+        a.k[j] = static_cast<const T*>(k[j]);
+        a.c[j] = (T)coef[j] * dtT;
+        vec = vec && aligned16(k[j]);
+    }
+    a.st = st;
+    a.part_sumsq = ws;
+    a.part_bad = ws + 2 * st.n_chunks;
+    const dim3 g((unsigned)st.n_chunks), b(kBlock);
+    if (vec) hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, false>), g, b, 0, s, a);
+    const int e = check_launch();
+    if (e) return e;
+    return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
+}
+
+template <typename T>
+int dispatch_error_partial(const void* partial, const void* y0, const void* y1, const void* const* k,
+                           const double* coef, int nt, double dt, const SegTable& st, double* out_sumsq,
+                           double* out_bad, double* ws, hipStream_t s) {
+    switch (nt) {
+        case 0: return launch_error_partial<T, 0>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, s);
+        case 1: return launch_error_partial<T, 1>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, s);
+        case 2: return launch_error_partial<T, 2>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, s);
     }
     return TDEQ_EINVAL;
 }
@@ -419,6 +517,20 @@ int tdeq_stage_combine(void* out, const void* y0, const void* const* k, const do
                              : dispatch_combine<double>(out, y0, k, coef, n_terms, dt, n, s);
 }
 
+int tdeq_stage_combine_fill(void* out, const void* y0, const void* const* k, const double* coef, int n_terms,
+                            double dt, int64_t n, int dtype, void* fill_dst, const double* fill_vals, int n_fill,
+                            void* stream) {
+    if (!out || !y0 || !k || !coef || n < 1 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > 2 || !k[0] || (n_terms == 2 && !k[1])) return TDEQ_EINVAL;
+    if (!fill_dst || !fill_vals || n_fill < 1 || n_fill > 16) return TDEQ_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_F32)
+        return n_terms == 1 ? launch_combine_fill<float, 1>(out, y0, k, coef, dt, n, fill_dst, fill_vals, n_fill, s)
+                            : launch_combine_fill<float, 2>(out, y0, k, coef, dt, n, fill_dst, fill_vals, n_fill, s);
+    return n_terms == 1 ? launch_combine_fill<double, 1>(out, y0, k, coef, dt, n, fill_dst, fill_vals, n_fill, s)
+                        : launch_combine_fill<double, 2>(out, y0, k, coef, dt, n, fill_dst, fill_vals, n_fill, s);
+}
+
 int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void* const* k,
                     const double* coef, int n_terms, double dt, const tdeq_segment* segs,
                     const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
@@ -437,6 +549,37 @@ int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void
     return dtype == TDEQ_F32
                ? dispatch_error<float>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s)
                : dispatch_error<double>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
+}
+
+int tdeq_stage_combine_err(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
+                           const double* err_coef, int n_terms, double dt, int64_t n, int dtype, void* stream) {
+    if (!out || !err_out || !y0 || !k || !coef || !err_coef || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? dispatch_combine_err<float>(out, err_out, y0, k, coef, err_coef, n_terms, dt, n, s)
+                             : dispatch_combine_err<double>(out, err_out, y0, k, coef, err_coef, n_terms, dt, n, s);
+}
+
+int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void* y1, const void* const* k,
+                            const double* coef, int n_terms, double dt, const tdeq_segment* segs,
+                            const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
+                            double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
+                            void* stream) {
+    if (!err_partial || !y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype))
+        return TDEQ_EINVAL;
+    if (n_terms < 0 || n_terms > 2 || (n_terms > 0 && (!k || !coef))) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    SegTable st;
+    const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
+    if (e) return e;
+    if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    return dtype == TDEQ_F32
+               ? dispatch_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s)
+               : dispatch_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
 }
 
 int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, const tdeq_segment* segs,

@@ -76,6 +76,85 @@ __device__ __forceinline__ void st_stream(E* p, const E& v) {
     else *p = v;
 }
 
+// Optional side payload of the first stage combine of a step: up to 16 scalars (the stage times handed to
+// func) stored by workgroup 0 — saves the separate fill launch at the latency-critical start of a step.
+template <typename T>
+struct SideFill {
+    T* dst;
+    T v[16];
+    int n;
+};
+
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(kBlock) void stage_combine_fill_kernel(const CombineArgs<T, NT> a, const SideFill<T> f) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    if (blockIdx.x == 0 && (int)threadIdx.x < f.n) f.dst[threadIdx.x] = f.v[threadIdx.x];
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const E* __restrict__ y0 = reinterpret_cast<const E*>(a.y0);
+    E* __restrict__ out = reinterpret_cast<E*>(a.out);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
+        E kk[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.k[j])[i];
+        out[i] = combine_one<T, NT, E>(a, y0[i], kk);
+    }
+    if (VEC) {   // scalar tail (n % L elements)
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) {
+            T kk[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kk[j] = a.k[j][t];
+            a.out[t] = combine_one<T, NT, T>(a, a.y0[t], kk);
+        }
+    }
+}
+
+// Last combine of a step fused with the partial embedded error over the SAME stage set:
+//   out = y0 + sum_j c_j k_j          err_out = (e_0 k_0 + e_1 k_1) + ...        (rk_common.py:79/85 and :89)
+// The k_j are in registers anyway; the extra N-word store replaces |set| N-word re-reads in the norm kernel.
+template <typename T, int NT>
+struct CombineErrArgs {
+    CombineArgs<T, NT> c;
+    T* err_out;
+    T e[NT];
+};
+
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(kBlock) void stage_combine_err_kernel(const CombineErrArgs<T, NT> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.c.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const E* __restrict__ y0 = reinterpret_cast<const E*>(a.c.y0);
+    E* __restrict__ out = reinterpret_cast<E*>(a.c.out);
+    E* __restrict__ eo = reinterpret_cast<E*>(a.err_out);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
+        E kk[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.c.k[j])[i];
+        out[i] = combine_one<T, NT, E>(a.c, y0[i], kk);
+        E err = kk[0] * a.e[0];
+#pragma unroll
+        for (int j = 1; j < NT; ++j) err = err + kk[j] * a.e[j];
+        eo[i] = err;
+    }
+    if (VEC) {   // scalar tail (n % L elements)
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.c.n) {
+            T kk[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kk[j] = a.c.k[j][t];
+            a.c.out[t] = combine_one<T, NT, T>(a.c, a.c.y0[t], kk);
+            T err = kk[0] * a.e[0];
+#pragma unroll
+            for (int j = 1; j < NT; ++j) err = err + kk[j] * a.e[j];
+            a.err_out[t] = err;
+        }
+    }
+}
+
 // U independent 16-byte elements per lane and iteration => (NT+1)*U loads in flight per lane.
 template <typename T, int NT, int U, bool VEC, int POLICY = 0>
 __global__ __launch_bounds__(kBlock) void stage_combine_kernel(const CombineArgs<T, NT> a) {
@@ -264,6 +343,70 @@ __global__ __launch_bounds__(kBlock) void error_norm_kernel(const ErrArgs<T, NT>
     }
     if (WRITE && a.st.n_seg > 1)   // zero the padding of a segmented layout
         for (int64_t t = valid + threadIdx.x; t < a.st.chunk; t += kBlock) a.scaled[base + t] = (T)0;
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        a.part_sumsq[b] = acc[0];
+        a.part_bad[b] = acc[1];
+    }
+}
+
+// Error norm continuing a partial error sum produced by stage_combine_err_kernel:
+//   err = (partial + c_0 k_0) + ... over the NT >= 0 remaining stages; everything else as error_norm_kernel.
+template <typename T, int NT>
+struct ErrPartialArgs {
+    const T* partial;
+    const T* y0;
+    const T* y1;
+    const T* k[NT > 0 ? NT : 1];
+    T c[NT > 0 ? NT : 1];
+    SegTable st;
+    double* part_sumsq;
+    double* part_bad;
+};
+
+template <typename T>
+__device__ __forceinline__ void tol_accumulate(T e, T y0, T y1, T rtol, T atol, double& acc, double& bad) {
+    const T tol = atol + rtol * smax(sabs(y0), sabs(y1));
+    const T r = e / tol;
+    acc += (double)r * (double)r;
+    bad += (__builtin_isfinite(y0) && __builtin_isfinite(y1)) ? 0.0 : 1.0;
+}
+
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(kBlock) void error_norm_partial_kernel(const ErrPartialArgs<T, NT> a) {
+    using V = typename VecOf<T>::type;
+    constexpr int L = VecOf<T>::L;
+    __shared__ double red[2 * (kBlock / kWave)];
+    const int64_t b = blockIdx.x;
+    const tdeq_segment seg = find_segment(a.st, b);
+    const int64_t base = b * a.st.chunk;
+    int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+    valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
+    const T rtol = (T)seg.rtol, atol = (T)seg.atol;
+    double acc[2] = {0.0, 0.0};
+    int64_t t0 = 0;
+    if (VEC) {
+        const int64_t nv = valid / L;
+        const V* y0 = reinterpret_cast<const V*>(a.y0 + base);
+        const V* y1 = reinterpret_cast<const V*>(a.y1 + base);
+        const V* pe = reinterpret_cast<const V*>(a.partial + base);
+#pragma unroll 2
+        for (int64_t i = threadIdx.x; i < nv; i += kBlock) {
+            V e = pe[i];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) e = e + reinterpret_cast<const V*>(a.k[j] + base)[i] * a.c[j];
+            const V v0 = y0[i], v1 = y1[i];
+#pragma unroll
+            for (int q = 0; q < L; ++q) tol_accumulate<T>(e[q], v0[q], v1[q], rtol, atol, acc[0], acc[1]);
+        }
+        t0 = nv * L;
+    }
+    for (int64_t t = t0 + threadIdx.x; t < valid; t += kBlock) {
+        T e = a.partial[base + t];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) e = e + a.k[j][base + t] * a.c[j];
+        tol_accumulate<T>(e, a.y0[base + t], a.y1[base + t], rtol, atol, acc[0], acc[1]);
+    }
     block_sum<2>(acc, red);
     if (threadIdx.x == 0) {
         a.part_sumsq[b] = acc[0];

@@ -119,6 +119,14 @@ class RKAdaptiveStepsizeODESolver:
         # stage abscissae rounded to the state dtype, as the reference's tableau cast (rk_common.py:201)
         self._alpha = [self.np_dtype(a) for a in tab.alpha]
         self._alpha_is_one = [a == 1.0 for a in tab.alpha]
+        # End-of-step fusion (tdeq_stage_combine_err + tdeq_error_norm_partial): the step's last combine — the last
+        # stage row of an FSAL pair, else the c_sol combine — also emits the partial embedded error over its own
+        # stages.  Bit-identical only if those stages are a leading run of the error row's non-zeros.
+        last = self._beta[-1] if tab.fsal_solution else self._c_sol
+        n_lead = len(last.idx)
+        self._fuse = None
+        if self._c_err.idx[:n_lead] == last.idx and len(self._c_err.idx) - n_lead <= 2:
+            self._fuse = (self._c_err.coef[:n_lead], self._c_err.idx[n_lead:], self._c_err.coef[n_lead:])
         self.n_accepted = 0
         self.n_rejected = 0
 
@@ -344,28 +352,54 @@ class RKAdaptiveStepsizeODESolver:
         t0_T, dt_T, t1_T = T(t0), T(dt), T(t1)
         dt_signed = float(dt_T) * func.sign
         ops = self.ops
-        # The first stage input needs only (y0, f0, dt): it is launched before any other host work of the
-        # step (stage times, buffers) so the GPU restarts as early as possible after the step-boundary read-back.
         row0 = self._beta[0]
-        yi = ops.combine(y0, [f0], row0.coef, dt_signed)
-        stage_times = func.time_tensors(kern, [
-            (t1_T, Perturb.PREV) if self._alpha_is_one[i] else (t0_T + self._alpha[i] * dt_T, Perturb.NONE)
-            for i in range(len(self._beta))])
+        times = [(t1_T, Perturb.PREV) if self._alpha_is_one[i] else (t0_T + self._alpha[i] * dt_T, Perturb.NONE)
+                 for i in range(len(self._beta))]
+        if len(times) <= 16 and not (torch.is_grad_enabled() and (y0.requires_grad or f0.requires_grad
+                                                                  or self._anchor is not None)):
+            # one launch: first stage input + the step's stage times (tdeq_stage_combine_fill)
+            yi = torch.empty_like(y0)
+            tbuf = torch.empty(len(times), dtype=y0.dtype, device=y0.device)
+            kern.stage_combine_fill(yi, y0, [f0], row0.coef, dt_signed, tbuf, [func.user_time(t, p) for t, p in times])
+            stage_times = tbuf.unbind(0)
+        else:
+            yi = ops.combine(y0, [f0], row0.coef, dt_signed)
+            stage_times = func.time_tensors(kern, times)
         k: List[torch.Tensor] = [f0, func.eval_at(stage_times[0], yi)]
-        for i in range(1, len(self._beta)):
+        n_rows = len(self._beta)
+        fsal = self.tableau.fsal_solution
+        builtin_norm = isinstance(self.norm, BuiltinNorm)
+        err_partial = None
+        for i in range(1, n_rows):
             row = self._beta[i]
-            yi = ops.combine(y0, [k[j] for j in row.idx], row.coef, dt_signed)
+            if i == n_rows - 1 and fsal and self._fuse is not None and builtin_norm and \
+                    not (torch.is_grad_enabled() and (y0.requires_grad or k[-1].requires_grad)):
+                yi, err_partial = torch.empty_like(y0), torch.empty_like(y0)
+                kern.stage_combine_err(yi, err_partial, y0, [k[j] for j in row.idx], row.coef, self._fuse[0], dt_signed)
+            else:
+                yi = ops.combine(y0, [k[j] for j in row.idx], row.coef, dt_signed)
             k.append(func.eval_at(stage_times[i], yi))
-        if self.tableau.fsal_solution:
+        if fsal:
             y1 = yi
+        elif self._fuse is not None and builtin_norm and \
+                not (torch.is_grad_enabled() and (y0.requires_grad or k[-1].requires_grad)):
+            sol = self._c_sol
+            y1, err_partial = torch.empty_like(y0), torch.empty_like(y0)
+            kern.stage_combine_err(y1, err_partial, y0, [k[j] for j in sol.idx], sol.coef, self._fuse[0], dt_signed)
         else:
             y1 = ops.combine(y0, [k[j] for j in self._c_sol.idx], self._c_sol.coef, dt_signed)
         f1 = k[-1]
 
         # ---- error ratio (misc.py:80-82) ----
         err = self._c_err
-        if isinstance(self.norm, BuiltinNorm):
-            kern.error_norm(self.plan, y0.detach(), y1.detach(), [k[j].detach() for j in err.idx], err.coef, dt_signed)
+        if err_partial is not None:
+            kern.error_norm_partial(self.plan, err_partial, y0, y1, [k[j] for j in self._fuse[1]], self._fuse[2],
+                                    dt_signed)
+            sumsq, _, bad = kern.read_norms(self.plan)
+            error_ratio = self._segment_norm(sumsq, bad)
+            y1_nonfinite = any(b != 0 for b in bad)
+        elif builtin_norm:
+            kern.error_norm(self.plan, y0, y1, [k[j] for j in err.idx], err.coef, dt_signed)
             sumsq, _, bad = kern.read_norms(self.plan)
             error_ratio = self._segment_norm(sumsq, bad)
             y1_nonfinite = any(b != 0 for b in bad)
