@@ -14,9 +14,11 @@ every rank integrates its own 65536-row shard with its own accept/reject loop, n
 collective — SURVEY.md §8e).
 
 Extra objects in the JSON line:
-  roofline      dominant kernel = stage_combine with 5 stage terms (tableau rows 5 and 6: read 5 k_j + y0,
-                write y_i = 7 words/element = 234.9 MB per launch at this size); its launches inside the
-                TIMED region are bracketed with HIP events on the launch stream.
+  roofline      dominant kernel = stage_combine with 5 stage terms (tableau row 5: read 5 k_j + y0, write
+                y_i = 7 words/element = 234.9 MB per launch at this size; row 6 is the same kernel plus the
+                fused partial-error store); its launches inside the TIMED region are bracketed with HIP events
+                on the launch stream.
+  solver_only   the step's solver kernels alone, back to back on the last step's stage tensors.
   cpu_baseline  the CPU oracle (oracle/reference_solver.py + rk_oracle.c, OpenMP on all host cores) on
                 a bounded sample of the same workload (rank 0, N=1 only).
   rel_err       max rel-err of a full odeint(t=[0,1]) at this size vs the closed form y0 expm(A)^T.
@@ -178,11 +180,23 @@ def main():
         outs = [torch.empty_like(y0s) for _ in range(2)]
         REPS = 30
 
+        fuse = solver._fuse
+        epart = torch.empty_like(y0s)
+        last = len(solver._beta) - 1
+
         def one_pass():
+            # exactly the solver's launch sequence for one trial step, minus func and the stage-time fill
             for i, row in enumerate(solver._beta):
-                kern.stage_combine(outs[i & 1], y0s, [ks[j] for j in row.idx], row.coef, rec.dt_signed)
-            kern.error_norm(solver.plan, y0s, rec.y1, [ks[j] for j in solver._c_err.idx], solver._c_err.coef,
-                            rec.dt_signed)
+                if i == last and fuse is not None:
+                    kern.stage_combine_err(outs[i & 1], epart, y0s, [ks[j] for j in row.idx], row.coef, fuse[0],
+                                           rec.dt_signed)
+                else:
+                    kern.stage_combine(outs[i & 1], y0s, [ks[j] for j in row.idx], row.coef, rec.dt_signed)
+            if fuse is not None:
+                kern.error_norm_partial(solver.plan, epart, y0s, rec.y1, [ks[j] for j in fuse[1]], fuse[2], rec.dt_signed)
+            else:
+                kern.error_norm(solver.plan, y0s, rec.y1, [ks[j] for j in solver._c_err.idx], solver._c_err.coef,
+                                rec.dt_signed)
         for _ in range(3):
             one_pass()
         kern.read_norms(solver.plan)
@@ -195,12 +209,17 @@ def main():
         kern.read_norms(solver.plan)
         torch.cuda.synchronize()
         t_step = e0.elapsed_time(e1) * 1e-3 / REPS
-        bytes_step = 40 * BATCH * DIM * 4            # dopri5 = 32 + 8 words per element
-        solver_only = {"stages_per_s": 6 / t_step, "us_per_step": 1e6 * t_step, "GBps": bytes_step / t_step / 1e9,
-                       "frac_of_hbm_peak": bytes_step / t_step / 1e9 / HBM_PEAK_GBPS,
-                       "algorithmic_bytes_per_step": bytes_step,
-                       "note": "6 stage_combine + error_norm + finalize back to back, no func; the 7 k tensors "
-                               "(235 MB) + y0/y1 fit the 256 MiB Infinity Cache only partly"}
+        # SURVEY.md §8(d) counts 32 + 8 = 40 words per element for a dopri5 step; the end-of-step fusion moves
+        # 37 (3+4+5+6+7+8 for the six combines, 4 for the norm) — both rates are reported.
+        moved = (37 if fuse is not None else 40) * BATCH * DIM * 4
+        survey = 40 * BATCH * DIM * 4
+        solver_only = {"stages_per_s": 6 / t_step, "us_per_step": 1e6 * t_step,
+                       "bytes_moved_per_step": moved, "GBps_moved": moved / t_step / 1e9,
+                       "frac_of_hbm_peak_moved": moved / t_step / 1e9 / HBM_PEAK_GBPS,
+                       "survey_algorithmic_bytes_per_step": survey, "GBps_survey_bytes": survey / t_step / 1e9,
+                       "note": "the solver's own launch sequence for one dopri5 trial step (5 stage_combine + "
+                               "stage_combine_err + error_norm_partial + finalize) back to back, no func; the 7 k "
+                               "tensors (235 MB) + y0/y1 fit the 256 MiB Infinity Cache only partly"}
     except Exception as exc:      # never let the extra figure break the contract line
         solver_only = {"error": repr(exc)}
 
