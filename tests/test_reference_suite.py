@@ -1,0 +1,521 @@
+"""The reference's own test-suite, restated for the in-scope methods and run against torchdiffeq_amd:
+tests/odeint_tests.py, gradient_tests.py, norm_tests.py, api_tests.py and event_tests.py of rtqichen/torchdiffeq
+(cited per test).  Same problems (tests/problems.py: analytic solutions), same assertions and tolerances.
+
+`dev` = "cuda": product on the MI355X; "cpu": the product's host logic over the oracle kernels (test-only)."""
+import math
+import warnings
+from functools import partial
+
+import numpy as np
+import pytest
+import scipy.linalg
+import torch
+
+import torchdiffeq_amd as tda
+
+ADAPTIVE_METHODS = ("adaptive_heun", "fehlberg2", "bosh3", "tsit5", "dopri5", "dopri8")
+FIXED_METHODS = ("euler", "midpoint", "heun2", "heun3", "rk4")
+METHODS = FIXED_METHODS + ADAPTIVE_METHODS
+DTYPES = (torch.float32, torch.float64)
+
+
+# ---- tests/problems.py ----------------------------------------------------------------------------------
+class ConstantODE(torch.nn.Module):
+    """dy/dt = a + (y - (a t + b))^5,  y = a t + b."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Parameter(torch.tensor(0.2))
+        self.b = torch.nn.Parameter(torch.tensor(3.0))
+
+    def forward(self, t, y):
+        return self.a + (y - (self.a * t + self.b)) ** 5
+
+    def y_exact(self, t):
+        return self.a * t + self.b
+
+
+class SineODE(torch.nn.Module):
+    def forward(self, t, y):
+        return 2 * y / t + t ** 4 * torch.sin(2 * t) - t ** 2 + 4 * t ** 3
+
+    def y_exact(self, t):
+        return (-0.5 * t ** 4 * torch.cos(2 * t) + 0.5 * t ** 3 * torch.sin(2 * t) + 0.25 * t ** 2 * torch.cos(2 * t)
+                - t ** 3 + 2 * t ** 4 + (math.pi - 0.25) * t ** 2)
+
+
+class LinearODE(torch.nn.Module):
+    def __init__(self, dim=10):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        U = torch.randn(dim, dim, generator=g) * 0.1
+        self.dim = dim
+        self.A = torch.nn.Parameter(2 * U - (U + U.T))
+        self.nfe = 0
+
+    def forward(self, t, y):
+        self.nfe += 1
+        return torch.mm(self.A, y.reshape(self.dim, 1)).reshape(-1)
+
+    def y_exact(self, t):
+        A = self.A.detach().cpu().double().numpy()
+        rows = [scipy.linalg.expm(A * float(ti)) @ np.ones((self.dim, 1)) for ti in t.detach().cpu()]
+        return torch.tensor(np.stack(rows)).reshape(len(t), self.dim).to(t)
+
+
+class ExpODE(torch.nn.Module):
+    def forward(self, t, y):
+        return -0.1 * self.y_exact(t)
+
+    def y_exact(self, t):
+        return torch.exp(-0.1 * t)
+
+
+PROBLEMS = {"constant": ConstantODE, "linear": LinearODE, "sine": SineODE, "exp": ExpODE}
+
+
+def construct_problem(device, npts=10, ode="constant", reverse=False, dtype=torch.float64):
+    f = PROBLEMS[ode]().to(dtype=dtype, device=device)
+    t_points = torch.linspace(1, 8, npts, dtype=torch.float64, device=device, requires_grad=True)
+    sol = f.y_exact(t_points).to(dtype)
+    if reverse:
+        t_points = t_points.flip(0).clone().detach()
+        sol = sol.flip(0).clone().detach()
+    return f, sol[0].detach().requires_grad_(True), t_points, sol
+
+
+def rel_error(true, estimate):
+    return ((true - estimate) / true).abs().max()
+
+
+# ---- odeint_tests.py:17-74 TestSolverError ----------------------------------------------------------------
+@pytest.mark.parametrize("reverse", [False, True], ids=["fwd", "rev"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("method", METHODS)
+def test_solver_error_odeint(dev, method, dtype, reverse):
+    kwargs = {}
+    if method == "dopri8" and dtype == torch.float64:
+        kwargs = dict(rtol=1e-12, atol=1e-14)
+    if method == "dopri8" and dtype == torch.float32:
+        kwargs = dict(rtol=1e-7, atol=1e-7)
+    problems = tuple(PROBLEMS) if method in ADAPTIVE_METHODS else ("constant",)
+    for ode in problems:
+        if method in ("adaptive_heun", "bosh3"):
+            eps = 4e-3
+        elif ode == "linear":
+            eps = 2e-3
+        elif ode == "exp":
+            eps = 5e-2
+        else:
+            eps = 3e-4
+        f, y0, t_points, sol = construct_problem(dtype=dtype, device=dev, ode=ode, reverse=reverse)
+        with torch.no_grad():
+            y = tda.odeint(f, y0.detach(), t_points.detach(), method=method, **kwargs)
+        assert y.shape == sol.shape and y.dtype == dtype
+        assert rel_error(sol, y) < eps, ode
+
+
+@pytest.mark.parametrize("reverse", [False, True], ids=["fwd", "rev"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("ode", list(PROBLEMS))
+def test_solver_error_adjoint(dev, ode, dtype, reverse):
+    eps = 2e-3 if ode == "linear" else 1e-4
+    f, y0, t_points, sol = construct_problem(dtype=dtype, device=dev, ode=ode, reverse=reverse)
+    y = tda.odeint_adjoint(f, y0, t_points)
+    assert rel_error(sol, y.detach()) < eps
+
+
+# ---- odeint_tests.py:98-111 TestNoIntegration ---------------------------------------------------------------
+@pytest.mark.parametrize("method", METHODS)
+def test_no_integration(dev, method):
+    for ode in PROBLEMS:
+        for reverse in (False, True):
+            f, y0, t_points, sol = construct_problem(device=dev, ode=ode, reverse=reverse)
+            with torch.no_grad():
+                y = tda.odeint(f, y0.detach(), t_points.detach()[0:1], method=method)
+            assert (sol[0] - y).abs().max() < 1e-12
+
+
+# ---- odeint_tests.py:114-160 TestDiscontinuities.test_odeint_jump_t -----------------------------------------
+class _JumpF:
+    def __init__(self):
+        self.nfe = 0
+
+    def __call__(self, t, x):
+        self.nfe += 1
+        if t < 0.5:
+            return -0.5 * x
+        return x ** 2
+
+
+@pytest.mark.parametrize("adjoint", [False, True], ids=["odeint", "adjoint"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("method", [m for m in ADAPTIVE_METHODS if m != "dopri8"])
+def test_jump_t(dev, method, dtype, adjoint):
+    x0 = torch.tensor([1.0, 2.0], dtype=dtype, requires_grad=True)
+    t = torch.tensor([0.0, 1.0])
+    simple_f, better_f = _JumpF(), _JumpF()
+    odeint = partial(tda.odeint_adjoint, adjoint_params=()) if adjoint else tda.odeint
+    simple_xs = odeint(simple_f, x0, t, atol=1e-6, method=method)
+    better_xs = odeint(better_f, x0, t, rtol=1e-6, atol=1e-6, method=method, options=dict(jump_t=torch.tensor([0.5])))
+    assert better_f.nfe < simple_f.nfe
+    if adjoint:
+        simple_f.nfe = better_f.nfe = 0
+        simple_xs.sum().backward()
+        better_xs.sum().backward()
+        assert better_f.nfe < simple_f.nfe
+
+
+# ---- odeint_tests.py:163-212 test_odeint_perturb ------------------------------------------------------------
+@pytest.mark.parametrize("adjoint", [False, True], ids=["odeint", "adjoint"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("method", FIXED_METHODS)
+def test_perturb(dev, method, dtype, adjoint):
+    for perturb in (True, False):
+        x0 = torch.tensor([1.0, 2.0], dtype=dtype, requires_grad=True)
+        t = torch.tensor([0.0, 1.0])
+        ts = []
+
+        def f(t_, x):
+            ts.append(t_.item())
+            return -x
+
+        odeint = partial(tda.odeint_adjoint, adjoint_params=()) if adjoint else tda.odeint
+        xs = odeint(f, x0, t, method=method, options=dict(step_size=0.5, perturb=perturb))
+        if perturb:
+            assert 0.0 not in ts and 0.5 not in ts
+        else:
+            assert 0.0 in ts and 0.5 in ts
+        if adjoint:
+            ts.clear()
+            xs.sum().backward()
+            if perturb:
+                assert 1.0 not in ts and 0.5 not in ts
+            else:
+                assert 1.0 in ts and 0.5 in ts
+
+
+# ---- odeint_tests.py:215-254 TestGridConstructor -------------------------------------------------------------
+@pytest.mark.parametrize("adjoint", [False, True], ids=["odeint", "adjoint"])
+def test_grid_constructor(dev, adjoint):
+    x0 = torch.tensor(1.0, requires_grad=True)
+    t = torch.tensor([0.0, 1.0])
+    first = [True]
+
+    def grid_constructor(f, y0, t_):
+        assert t_.shape == (2,)
+        if first[0]:
+            first[0] = False
+            assert t_[0] == 0.0 and t_[1] == 1.0
+            return torch.linspace(0, 1, 11)
+        assert t_[0] == 1.0 and t_[1] == 0.0         # adjoint pass
+        return torch.linspace(1, 0, 11)
+
+    odeint = tda.odeint_adjoint if adjoint else tda.odeint
+    kwargs = {"adjoint_params": ()} if adjoint else {}
+    xs = odeint(lambda t_, x: x, x0, t, method="euler", options=dict(grid_constructor=grid_constructor), **kwargs)
+    x1 = xs[1]
+    assert (x1 - x0 * 1.1 ** 10).abs().max() < 1e-6           # 'true' wrt the Euler scheme
+    x1.backward()
+    assert (x0.grad - 1.1 ** 10).abs().max() < 1e-6
+
+
+# ---- odeint_tests.py:257-274 TestMinMaxStep -----------------------------------------------------------------
+def test_min_max_step(dev):
+    for min_step in (0, 2):
+        for max_step in (float("inf"), 5):
+            f, y0, t_points, sol = construct_problem(device=dev, ode="linear")
+            with torch.no_grad(), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                tda.odeint(f, y0.detach(), t_points.detach(), method="dopri5", options=dict(min_step=min_step, max_step=max_step))
+            if min_step > 0:
+                assert f.nfe < 50
+            else:
+                assert f.nfe > 100
+
+
+# ---- odeint_tests.py:277-386 TestCallbacks ------------------------------------------------------------------
+class _NeuralF(torch.nn.Module):
+    def __init__(self, width, oscillate, freq=20):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.linears = torch.nn.Sequential(torch.nn.Linear(2, width), torch.nn.Tanh(), torch.nn.Linear(width, 2),
+                                           torch.nn.Tanh())
+        with torch.no_grad():
+            for p in self.linears.parameters():
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) / math.sqrt(p.shape[-1]))
+        self.nfe = 0
+        self.oscillate = oscillate
+        self.freq = freq
+
+    def forward(self, t, x):
+        self.nfe += 1
+        out = self.linears(x)
+        if self.oscillate:
+            out = out * t.mul(self.freq).sin()
+        return out
+
+
+@pytest.mark.parametrize("method", FIXED_METHODS)
+def test_wrong_callback_warns(dev, method):
+    x0, t = torch.tensor([1.0, 2.0]), torch.tensor([0.0, 1.0])
+    for name in ("callback_accept_step", "callback_reject_step"):
+        f = _NeuralF(width=10, oscillate=False)
+        setattr(f, name, lambda t0, y0, dt: None)
+        with pytest.warns(Warning):
+            with torch.no_grad():
+                tda.odeint(f, x0, t, method=method)
+
+
+@pytest.mark.parametrize("method", [m for m in METHODS if m != "dopri8"])
+@pytest.mark.parametrize("forward,adjoint", [(False, True), (True, False), (True, True)])
+def test_callback_step_counts(dev, method, forward, adjoint):
+    f = _NeuralF(width=10, oscillate=False)
+    c = dict(step=0, accept=0, reject=0, astep=0, aaccept=0, areject=0)
+
+    def bump(key):
+        def cb(t0, y0, dt):
+            c[key] += 1
+        return cb
+
+    if forward:
+        f.callback_step = bump("step")
+        if method in ADAPTIVE_METHODS:
+            f.callback_accept_step, f.callback_reject_step = bump("accept"), bump("reject")
+    if adjoint:
+        f.callback_step_adjoint = bump("astep")
+        if method in ADAPTIVE_METHODS:
+            f.callback_accept_step_adjoint, f.callback_reject_step_adjoint = bump("aaccept"), bump("areject")
+    x0, t = torch.tensor([1.0, 2.0]), torch.tensor([0.0, 1.0])
+    kwargs = dict(options=dict(step_size=0.1)) if method in FIXED_METHODS else {}
+    xs = tda.odeint_adjoint(f, x0, t, method=method, **kwargs)
+    if forward:
+        if method in FIXED_METHODS:
+            assert c["step"] == 10
+        else:
+            assert c["step"] > 0 and c["accept"] + c["reject"] == c["step"]
+    if adjoint:
+        xs.sum().backward()
+        if method in FIXED_METHODS:
+            assert c["astep"] == 10
+        else:
+            assert c["astep"] > 0 and c["aaccept"] + c["areject"] == c["astep"]
+
+
+# ---- norm_tests.py:43-97 test_norm ---------------------------------------------------------------------------
+def test_norm_receives_the_users_view_of_the_state(dev):
+    f = lambda t_, x: x
+    t = torch.tensor([0.0, 1.0])
+    seen = []
+
+    def norm(state):
+        seen.append(state)
+        assert isinstance(state, torch.Tensor) and state.shape == ()
+        return state.pow(2).mean().sqrt()
+    with torch.no_grad():
+        tda.odeint(f, torch.tensor(1.0), t, options=dict(norm=norm))
+    assert seen
+
+    seen.clear()
+
+    def norm1(state):
+        seen.append(state)
+        assert isinstance(state, tuple) and len(state) == 1 and state[0].shape == ()
+        return state[0].pow(2).mean().sqrt()
+    with torch.no_grad():
+        tda.odeint(f, (torch.tensor(1.0),), t, options=dict(norm=norm1))
+    assert seen
+
+    seen.clear()
+
+    def norm2(state):
+        seen.append(state)
+        assert isinstance(state, tuple) and len(state) == 2
+        assert state[0].shape == () and state[1].shape == (2, 2)
+        return state[0].pow(2).mean().sqrt()
+    with torch.no_grad():
+        tda.odeint(f, (torch.tensor(1.0), torch.tensor([[0.5, 0.5], [0.1, 0.1]])), t, options=dict(norm=norm2))
+    assert seen
+
+
+# ---- norm_tests.py:99-236 test_adjoint_norm (tensor state; the tuple case digs through the reference's own
+#      autograd graph shape and is covered by the user-norm cases below) ---------------------------------------
+@pytest.mark.parametrize("shape", [(), (1,), (2, 2)])
+@pytest.mark.parametrize("use_adjoint_options,seminorm", [(False, False), (True, False), (True, True)])
+def test_auto_adjoint_norm_is_a_callable_with_the_reference_semantics(dev, shape, use_adjoint_options, seminorm):
+    f = lambda t_, x: x
+    t = torch.tensor([0.0, 1.0])
+    g = torch.Generator().manual_seed(0)
+    adjoint_params = (torch.rand(7, generator=g).to(dev).requires_grad_(True),
+                      torch.rand((), generator=g).to(dev).requires_grad_(True))
+    x0 = torch.full(shape, 1.0)
+    kwargs = {}
+    if use_adjoint_options:
+        kwargs = dict(adjoint_options=dict(norm="seminorm") if seminorm else {})
+    xs = tda.odeint_adjoint(f, x0, t, adjoint_params=adjoint_params, **kwargs)
+    auto_norm = xs.grad_fn.adjoint_options["norm"]
+    calls = [0, 0]
+
+    def actual_norm(tensor_tuple):
+        calls[0] += 1
+        assert isinstance(tensor_tuple, tuple)
+        t_, y, adj_y, p1, p2 = tensor_tuple
+        assert t_.shape == () and y.shape == shape and adj_y.shape == shape and p1.shape == (7,) and p2.shape == ()
+        out = max(t_.abs(), y.pow(2).mean().sqrt(), adj_y.pow(2).mean().sqrt())
+        if not seminorm:
+            out = max(out, p1.pow(2).mean().sqrt(), p2.abs())
+        return out
+
+    def spy(tensor_tuple):
+        calls[1] += 1
+        got, want = auto_norm(tensor_tuple), actual_norm(tensor_tuple)
+        assert isinstance(got, torch.Tensor) and got.shape == want.shape
+        assert (got - want).abs().max() < 1e-6
+        return got
+
+    xs.grad_fn.adjoint_options["norm"] = spy
+    xs.sum().backward()
+    assert calls[0] and calls[1]
+
+
+def test_user_adjoint_norms(dev):
+    f = lambda t_, x: x
+    t = torch.tensor([0.0, 1.0])
+    adjoint_params = (torch.rand(7, requires_grad=True), torch.rand((), requires_grad=True))
+    called = []
+
+    def adjoint_norm(tensor_tuple):
+        called.append(1)
+        t_, y, adj_y, p1, p2 = tensor_tuple
+        assert t_.shape == () and y.shape == () and adj_y.shape == () and p1.shape == (7,) and p2.shape == ()
+        return max(t_.abs(), y.pow(2).mean().sqrt(), adj_y.pow(2).mean().sqrt(), p1.pow(2).mean().sqrt(), p2.abs())
+
+    xs = tda.odeint_adjoint(f, torch.tensor(1.0), t, adjoint_params=adjoint_params, adjoint_options=dict(norm=adjoint_norm))
+    xs.sum().backward()
+    assert called
+    called.clear()
+
+    def adjoint_norm2(tensor_tuple):
+        called.append(1)
+        t_, ya, yb, adj_ya, adj_yb, p1, p2 = tensor_tuple
+        assert t_.shape == () and ya.shape == () and yb.shape == (2, 2) and adj_ya.shape == () and adj_yb.shape == (2, 2)
+        assert p1.shape == (7,) and p2.shape == ()
+        return max(t_.abs(), ya.abs(), yb.pow(2).mean().sqrt(), adj_ya.abs(), adj_yb.pow(2).mean().sqrt(),
+                   p1.pow(2).mean().sqrt(), p2.abs())
+
+    x0 = torch.tensor(1.0), torch.tensor([[0.5, 0.5], [0.1, 0.1]])
+    xs = tda.odeint_adjoint(f, x0, t, adjoint_params=adjoint_params, adjoint_options=dict(norm=adjoint_norm2))
+    xs[0].sum().backward()
+    assert called
+
+
+# ---- norm_tests.py:238-267 test_large_norm / :269-306 test_seminorm -----------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("method", ADAPTIVE_METHODS)
+def test_large_norm_takes_no_fewer_evaluations(dev, method, dtype):
+    if dtype == torch.float32 and method == "dopri8":
+        pytest.skip("skipped in the reference as well")
+    x0 = torch.tensor([1.0, 2.0], dtype=dtype)
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64)
+    norm_f = _NeuralF(width=10, oscillate=True, freq=2).to(dev, dtype)
+    large_f = _NeuralF(width=10, oscillate=True, freq=2).to(dev, dtype)
+    with torch.no_grad():
+        tda.odeint(norm_f, x0, t, method=method, options=dict(norm=lambda x: x.abs().max()))
+        tda.odeint(large_f, x0, t, method=method, options=dict(norm=lambda x: 10 * x.abs().max()))
+    assert norm_f.nfe <= large_f.nfe
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("method", ADAPTIVE_METHODS)
+def test_seminorm_takes_no_more_evaluations(dev, method, dtype):
+    if dtype == torch.float32 and method == "tsit5":
+        pytest.skip("known failure in the reference as well")
+    tol = 1e-8 if dtype == torch.float64 else 1e-6
+    x0 = torch.tensor([1.0, 2.0], dtype=dtype)
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64)
+    ode_f = _NeuralF(width=1024, oscillate=True, freq=2).to(dev, dtype)
+    out = tda.odeint_adjoint(ode_f, x0, t, atol=tol, rtol=tol, method=method)
+    ode_f.nfe = 0
+    out.sum().backward()
+    default_nfe = ode_f.nfe
+    out = tda.odeint_adjoint(ode_f, x0, t, atol=tol, rtol=tol, method=method, adjoint_options=dict(norm="seminorm"))
+    ode_f.nfe = 0
+    out.sum().backward()
+    assert ode_f.nfe <= default_nfe
+
+
+# ---- api_tests.py:11-39 TestCollectionState -------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("method", ADAPTIVE_METHODS)
+def test_tuple_state_forward(dev, method, dtype):
+    eps = {torch.float32: 1e-4, torch.float64: 1e-12}[dtype]
+    f, y0, t_points, sol = construct_problem(dtype=dtype, device=dev)
+    with torch.no_grad():
+        ya, yb = tda.odeint(lambda t_, y: (f(t_, y[0]), f(t_, y[1])), (y0.detach(), y0.detach()), t_points.detach(),
+                            method=method)
+    assert (sol - ya).abs().max() < eps and (sol - yb).abs().max() < eps
+
+
+@pytest.mark.parametrize("method", ["dopri5", "bosh3"])
+def test_tuple_state_gradcheck(dev, method):
+    f, y0, t_points, sol = construct_problem(device=dev, npts=4)
+    tuple_f = lambda t_, y: (f(t_, y[0]), f(t_, y[1]))
+    for i in range(2):
+        func = lambda y0_, t_: tda.odeint(tuple_f, (y0_, y0_), t_, method=method)[i]
+        assert torch.autograd.gradcheck(func, (y0, t_points))
+
+
+# ---- gradient_tests.py:13-32 gradcheck, :34-87 adjoint vs odeint ------------------------------------------------
+@pytest.mark.parametrize("method", METHODS)
+def test_gradcheck_odeint_and_adjoint(dev, method):
+    f, y0, t_points, _ = construct_problem(device=dev, npts=4)
+    assert torch.autograd.gradcheck(lambda y0_, t_: tda.odeint(f, y0_, t_, method=method), (y0, t_points))
+    assert torch.autograd.gradcheck(lambda y0_, t_: tda.odeint_adjoint(f, y0_, t_, method=method), (y0, t_points))
+
+
+@pytest.mark.parametrize("ode,eps", [("constant", 1e-12), ("linear", 1e-5), ("sine", 5e-3), ("exp", 1e-2)])
+@pytest.mark.parametrize("t_grad", [True, False])
+def test_adjoint_against_odeint(dev, ode, eps, t_grad):
+    f, y0, t_points, _ = construct_problem(device=dev, ode=ode)
+    t_points = t_points.detach().requires_grad_(t_grad)
+    ys = tda.odeint(f, y0, t_points, rtol=1e-9, atol=1e-12)
+    g = torch.Generator().manual_seed(0)
+    gradys = torch.rand(ys.shape, generator=g, dtype=ys.dtype).to(dev)
+    ys.backward(gradys)
+    reg = [y0.grad.clone(), t_points.grad.clone() if t_grad else None] + [p.grad.clone() for p in f.parameters()]
+    y0.grad = None
+    t_points.grad = None
+    for p in f.parameters():
+        p.grad = None
+    ys = tda.odeint_adjoint(f, y0, t_points, rtol=1e-9, atol=1e-12)
+    ys.backward(gradys)
+    adj = [y0.grad, t_points.grad if t_grad else None] + [p.grad for p in f.parameters()]
+    for a, b in zip(reg, adj):
+        if a is not None:
+            assert (a - b).abs().max() < eps
+
+
+# ---- event_tests.py:14-48 / :50-63 -----------------------------------------------------------------------------
+@pytest.mark.parametrize("reverse", [False, True], ids=["fwd", "rev"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("method", METHODS)
+def test_event_odeint(dev, method, dtype, reverse):
+    tol = 5e-3 if method == "euler" else 1e-4
+    for ode in ("constant", "sine"):
+        f, y0, t_points, sol = construct_problem(dtype=dtype, device=dev, ode=ode, reverse=reverse)
+        options = {"step_size": 0.01, "interp": "cubic"} if method in FIXED_METHODS else {}
+        with torch.no_grad():
+            t, y = tda.odeint(f, y0.detach(), t_points.detach()[0:2], event_fn=lambda t_, y_: torch.sum(y_ - sol[2]),
+                              method=method, options=options)
+        assert rel_error(sol[2], y[-1]) < tol, ode
+        assert rel_error(t_points.detach()[2], t) < tol, ode
+
+
+def test_event_adjoint(dev):
+    f, y0, t_points, sol = construct_problem(device=dev, ode="constant")
+    t, y = tda.odeint_adjoint(f, y0, t_points[0:2], event_fn=lambda t_, y_: torch.sum(y_ - sol[-1]), method="dopri5")
+    y = y[-1]
+    assert rel_error(sol[-1], y.detach()) < 1e-4 and rel_error(t_points[-1].detach(), t.detach()) < 1e-4
+    t.backward(retain_graph=True)      # the adjoint-mode backward code must still run
+    y.sum().backward()

@@ -52,7 +52,13 @@ class _AugmentedDynamics(OdeFunc):
             f = fwd.base_func(t_, y_in if fwd.layout.is_tuple else y_in[0])
             f_list = list(f) if fwd.layout.is_tuple else [f]
             wrt = ((t_,) if self.t_requires_grad else ()) + y_in + self.params
-            grads = torch.autograd.grad(f_list, wrt, grad_outputs=list(adj_views), allow_unused=True)
+            # components of f that depend on nothing differentiable (e.g. f(t, y) = g(t)) contribute zero VJPs
+            live = [(fi, ai) for fi, ai in zip(f_list, adj_views) if fi.requires_grad]
+            if live:
+                grads = torch.autograd.grad([fi for fi, _ in live], wrt, grad_outputs=[ai for _, ai in live],
+                                            allow_unused=True)
+            else:
+                grads = (None,) * len(wrt)
         if self.t_requires_grad:
             g_t, grads = grads[0], grads[1:]
         else:

@@ -375,6 +375,11 @@ def check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS) ->
         y0_flat = y0.detach().reshape(-1).contiguous()
         if "norm" not in options:
             options["norm"] = rms_norm
+        elif not isinstance(options["norm"], BuiltinNorm):
+            # the user's norm sees the state in ITS shape (the reference never flattens a tensor state)
+            def _norm(tensor, _user=options["norm"], _shape=shapes[0]):
+                return _user(tensor.view(_shape))
+            options["norm"] = _norm
 
     check_timelike("t", t, True)
     t_is_reversed = bool(len(t) > 1 and t[0] > t[1])
