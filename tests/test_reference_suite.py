@@ -49,7 +49,7 @@ class LinearODE(torch.nn.Module):
     def __init__(self, dim=10):
         super().__init__()
         g = torch.Generator().manual_seed(0)
-        U = torch.randn(dim, dim, generator=g) * 0.1
+        U = torch.randn(dim, dim, generator=g, device="cpu") * 0.1
         self.dim = dim
         self.A = torch.nn.Parameter(2 * U - (U + U.T))
         self.nfe = 0
@@ -244,7 +244,7 @@ class _NeuralF(torch.nn.Module):
                                            torch.nn.Tanh())
         with torch.no_grad():
             for p in self.linears.parameters():
-                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) / math.sqrt(p.shape[-1]))
+                p.copy_((torch.rand(p.shape, generator=g, device="cpu").to(p.device) * 2 - 1) / math.sqrt(p.shape[-1]))
         self.nfe = 0
         self.oscillate = oscillate
         self.freq = freq
@@ -347,8 +347,8 @@ def test_auto_adjoint_norm_is_a_callable_with_the_reference_semantics(dev, shape
     f = lambda t_, x: x
     t = torch.tensor([0.0, 1.0])
     g = torch.Generator().manual_seed(0)
-    adjoint_params = (torch.rand(7, generator=g).to(dev).requires_grad_(True),
-                      torch.rand((), generator=g).to(dev).requires_grad_(True))
+    adjoint_params = (torch.rand(7, generator=g, device="cpu").to(dev).requires_grad_(True),
+                      torch.rand((), generator=g, device="cpu").to(dev).requires_grad_(True))
     x0 = torch.full(shape, 1.0)
     kwargs = {}
     if use_adjoint_options:
@@ -481,7 +481,7 @@ def test_adjoint_against_odeint(dev, ode, eps, t_grad):
     t_points = t_points.detach().requires_grad_(t_grad)
     ys = tda.odeint(f, y0, t_points, rtol=1e-9, atol=1e-12)
     g = torch.Generator().manual_seed(0)
-    gradys = torch.rand(ys.shape, generator=g, dtype=ys.dtype).to(dev)
+    gradys = torch.rand(ys.shape, generator=g, dtype=ys.dtype, device="cpu").to(dev)
     ys.backward(gradys)
     reg = [y0.grad.clone(), t_points.grad.clone() if t_grad else None] + [p.grad.clone() for p in f.parameters()]
     y0.grad = None
