@@ -141,6 +141,10 @@ def main():
     solver.ops.k = timed        # the elementwise kernels are issued through solver.ops
     with torch.no_grad():
         solver._before_integrate([0.0])
+        # the timed trial steps are steps in the middle of a long solve (no output time ahead), which is where the
+        # solver's look-ahead first stage applies (solvers.py: only the last steps before the final output time of
+        # an `integrate` call are driven without it)
+        solver._t_end = float("inf")
         for _ in range(args.warmup):
             solver._adaptive_step()
         if world > 1:
@@ -263,7 +267,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: dopri5 adaptive, linear ODE dy/dt=Ay, batch=65536 x "
                                    "dim=128 fp32 per GPU, rtol=1e-7 atol=1e-9",
                        "global_batch": BATCH * world, "dim": DIM, "parallelism": f"batch-sharded x{world}",
-                       "accepted": solver.n_accepted, "rejected": solver.n_rejected},
+                       "accepted": solver.n_accepted, "rejected": solver.n_rejected,
+                       "lookahead": bool(solver._lookahead)},
             "rel_err": rel_err,
             "rel_err_definition": "max|y - y_exact| / max|y_exact| of odeint(t=[0,1]) at full size vs y0 @ expm(A)^T "
                                   "(the reference's own fp32 result scores 2.2-2.6e-6 on this, SURVEY.md §7)",

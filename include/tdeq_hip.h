@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 5
+#define TDEQ_ABI_VERSION 6
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -57,6 +57,29 @@ typedef struct tdeq_segment {
     double rtol;           /* per-segment tolerances (misc.py:115-123 tuple tol) */
     double atol;
 } tdeq_segment;
+
+/*
+ * Step-controller parameters of ONE adaptive trial step (host memory, copied into the kernel arguments).
+ * Everything is a host double, as in the host loop (torchdiffeq_amd/solvers.py); the reference keeps the same
+ * quantities as 0-dim fp64 device tensors (rk_common.py:186-194).
+ */
+#define TDEQ_MAX_STAGE_TIMES 16
+typedef struct tdeq_step_ctrl {
+    double t0;          /* start of the trial step, solver (ascending) time                                  */
+    double dt;          /* its size, > 0, after the min_step / max_step clamp (rk_common.py:268-271)          */
+    double safety;      /* misc.py:85-95 `_optimal_step_size` parameters (rk_common.py:172-174)               */
+    double ifactor;
+    double dfactor;
+    double exponent;    /* 1 / order                                                                          */
+    double min_step;
+    double max_step;
+    double time_sign;   /* +1, or -1 for a decreasing-time solve: user time = sign * solver time (misc.py:158-165) */
+    double alpha[TDEQ_MAX_STAGE_TIMES];   /* stage abscissae of the tableau, already rounded to T (rk_common.py:201) */
+    uint32_t alpha_is_one;                /* bit i set: stage i is evaluated at t1 with Perturb.PREV (rk_common.py:72-75) */
+    int32_t n_times;    /* number of stages (func evaluations per step), 1..TDEQ_MAX_STAGE_TIMES               */
+    int32_t n_norm_seg; /* leading segments that enter the max of the mixed norm (seminorm: adjoint.py:267-270) */
+    int32_t reserved;
+} tdeq_step_ctrl;
 
 /* ABI version of the loaded library (== TDEQ_ABI_VERSION). */
 int tdeq_abi_version(void);
@@ -122,6 +145,42 @@ int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void*
                             const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
                             double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
                             void* stream);
+
+/*
+ * Device-resident step controller + look-ahead first stage.  The accept/reject LOOP stays on the host; what
+ * moves to the device is the scalar decision of one trial step, so that the next trial step's first stage
+ * (and the func evaluation behind it) can be enqueued BEFORE the host has read the decision back — the
+ * poll -> controller -> launch latency of the host leaves the critical path.
+ *
+ *   tdeq_error_norm_partial_ctrl   = tdeq_error_norm_partial (same partial kernel, same per-segment sums in the
+ *       same order) whose finalize step, one workgroup, also runs the reference's controller on the sums:
+ *         ratio  = max_s sqrt(sumsq_s / numel_s) over the first n_norm_seg segments, rounded to T
+ *                                                                                (misc.py:22-33, 80-82)
+ *         accept = ratio <= 1, overridden by dt > max_step -> reject, dt <= min_step -> accept
+ *                                                                                (rk_common.py:324-330)
+ *         dt_next = clamp(_optimal_step_size(dt, ratio, safety, ifactor, dfactor, order), min_step, max_step)
+ *                                                                                (misc.py:85-95, rk_common.py:353)
+ *         next trial step: t0' = accept ? t0 + dt : t0 ; dt' = dt_next (min_step if non-finite);
+ *         stage times t_i = t0' + alpha_i dt' in T, or nextafter(t1, t1 - 1) with t1 = T(t0' + dt') for alpha_i == 1
+ *         (Perturb.PREV), times the time sign                                    (rk_common.py:72-78, misc.py:174-197)
+ *       Outputs: out_sumsq / out_nonfinite as tdeq_error_norm_partial; out_ctrl[4] = {accept (0/1), dt_next,
+ *       ratio, t0'} (device or pinned host memory, read by the host loop); ctrl_dev[2] = {accept, sign * T(dt')}
+ *       (device memory, read by tdeq_stage_combine_sel); next_times[n_times] (device memory, element type T) =
+ *       the 0-dim time tensors the next trial step hands to func.  n_seg <= TDEQ_INLINE_SEGMENTS.
+ *
+ *   tdeq_stage_combine_sel   first stage of the next trial step, launched before the host knows `accept`:
+ *         (y, f) = accept ? (y_acc, f_acc) : (y_rej, f_rej) ;  out = y + fl_T(fl_T(coef) * T(dt')) * f
+ *       i.e. tdeq_stage_combine with one term on the pair the controller selected (accepted: the new state and
+ *       its FSAL derivative; rejected: the old pair, rk_common.py:335-361) and the controller's dt'.
+ *       Bit-identical to the host-driven tdeq_stage_combine call it replaces.
+ */
+int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const void* y1, const void* const* k,
+                                 const double* coef, int n_terms, double dt, const tdeq_segment* segs, int n_seg,
+                                 int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite,
+                                 const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev, void* next_times,
+                                 void* workspace, size_t workspace_bytes, int dtype, void* stream);
+int tdeq_stage_combine_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej,
+                           double coef, const double* ctrl_dev, int64_t n, int dtype, void* stream);
 
 /*
  * Initial-step norms (Hairer II.4 as in misc.py:36-77), scale = atol + |y0| * rtol:

@@ -57,6 +57,10 @@ def load() -> ctypes.CDLL:
         "oracle_stage_combine_err": [V, V, V, _c_void_pp, _c_double_p, _c_double_p, I, D, I64, I],
         "oracle_error_norm_partial": [V, V, V, _c_void_pp, _c_double_p, I, D, ctypes.POINTER(Segment), I, I64, I64,
                                       V, V, I],
+        "oracle_error_norm_partial_ctrl": [V, V, V, _c_void_pp, _c_double_p, I, D, ctypes.POINTER(Segment), I, I64, I64,
+                                           V, V, V, V, V, V, I],
+        "oracle_step_controller": [ctypes.POINTER(Segment), I, V, V, V, V, V, I],
+        "oracle_stage_combine_sel": [V, V, V, V, V, D, V, I64, I],
         "oracle_scale_many": [_c_void_pp, V, _c_double_p, I, I64, I],
         "oracle_multi_dot": [V, _c_void_pp, I, I64, V, I],
     }
@@ -87,9 +91,11 @@ class OraclePlan:
             assert off % chunk == 0
             arr[i] = Segment(off // chunk, numel, float(rtol), float(atol))
         self.segs = arr
-        self.out = torch.zeros(3 * self.n_seg, dtype=torch.float64)
+        self.out = torch.zeros(3 * self.n_seg + 4, dtype=torch.float64)
         self.out_ptr = self.out.data_ptr()
         self.bad_ptr = self.out_ptr + 16 * self.n_seg
+        self.ctrl_ptr = self.out_ptr + 24 * self.n_seg
+        self.ctrl_dev = torch.zeros(2, dtype=torch.float64)
 
 
 class OracleKernels:
@@ -151,7 +157,36 @@ class OracleKernels:
     def read_norms(self, plan) -> Tuple[List[float], List[float], List[float]]:
         v = plan.out.tolist()
         n = plan.n_seg
-        return v[:n], v[n:2 * n], v[2 * n:]
+        return v[:n], v[n:2 * n], v[2 * n:3 * n]
+
+    def error_norm_partial_ctrl(self, plan, err_partial, y0, y1, ks, coefs, dt, ctrl, next_times):
+        """Host twin of tdeq_error_norm_partial_ctrl; `ctrl` is a ctypes struct laid out as oracle_step_ctrl."""
+        n = len(ks)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
+        cf = (ctypes.c_double * max(n, 1))(*coefs)
+        _ok(self.lib.oracle_error_norm_partial_ctrl(err_partial.data_ptr(), y0.data_ptr(), y1.data_ptr(), ptrs, cf, n,
+                                                    dt, plan.segs, plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr,
+                                                    plan.bad_ptr, ctypes.addressof(ctrl), plan.ctrl_ptr,
+                                                    plan.ctrl_dev.data_ptr(), next_times.data_ptr(), _code(y0.dtype)),
+            "oracle_error_norm_partial_ctrl")
+
+    def step_controller(self, plan, sumsq, ctrl, next_times, dtype):
+        """The controller alone on given per-segment sums -> (out_ctrl[4], ctrl_dev[2]) as lists."""
+        ss = (ctypes.c_double * plan.n_seg)(*sumsq)
+        _ok(self.lib.oracle_step_controller(plan.segs, plan.n_seg, ctypes.addressof(ss), ctypes.addressof(ctrl),
+                                            plan.ctrl_ptr, plan.ctrl_dev.data_ptr(), next_times.data_ptr(),
+                                            _code(dtype)), "oracle_step_controller")
+        return plan.out.tolist()[3 * plan.n_seg:], plan.ctrl_dev.tolist()
+
+    def read_ctrl(self, plan):
+        v = plan.out.tolist()
+        n = plan.n_seg
+        return v[3 * n] != 0.0, v[3 * n + 1], v[3 * n + 2], v[2 * n:3 * n]
+
+    def stage_combine_sel(self, out, y_acc, f_acc, y_rej, f_rej, coef, plan):
+        _ok(self.lib.oracle_stage_combine_sel(out.data_ptr(), y_acc.data_ptr(), f_acc.data_ptr(), y_rej.data_ptr(),
+                                              f_rej.data_ptr(), coef, plan.ctrl_dev.data_ptr(), out.numel(),
+                                              _code(out.dtype)), "oracle_stage_combine_sel")
 
     def dense_eval(self, out, y0, y1, f0, f1, ks, coefs, dt, x):
         ptrs, cf, n = self._terms(ks, coefs)

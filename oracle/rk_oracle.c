@@ -493,3 +493,117 @@ int oracle_error_norm_partial(const void* err_partial, const void* y0, const voi
                                  out_nonfinite);
     return -1;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * Step controller + next trial step's stage times (CPU twin of tdeq_error_norm_partial_ctrl /
+ * tdeq_stage_combine_sel in include/tdeq_hip.h).  Restates, on host doubles:
+ *   error ratio  = max over segments of sqrt(mean((err/tol)^2)), in T         misc.py:22-33, 80-82
+ *   accept_step  = ratio <= 1; dt > max_step -> False; dt <= min_step -> True  rk_common.py:324-330
+ *   dt_next      = _optimal_step_size(...).clamp(min_step, max_step)            misc.py:85-95, rk_common.py:353-354
+ *   next state   = (t1, y1, f1) if accepted else (t0, y0, f0)                   rk_common.py:335-352
+ *   next trial   : dt := min_step if non-finite; clamp; ti = t1 (Perturb.PREV) if alpha_i == 1 else
+ *                  t0 + alpha_i * dt, all in T = y0.abs().dtype                 rk_common.py:268-271, 60-78
+ *   Perturb.PREV : nextafter(t, t - 1) in T; decreasing-time solves negate t    misc.py:158-165, 174-197
+ * ------------------------------------------------------------------------------------------------- */
+#define ORACLE_MAX_STAGE_TIMES 16
+typedef struct oracle_step_ctrl {
+    double t0, dt, safety, ifactor, dfactor, exponent, min_step, max_step, time_sign;
+    double alpha[ORACLE_MAX_STAGE_TIMES];
+    uint32_t alpha_is_one;
+    int32_t n_times;
+    int32_t n_norm_seg;
+    int32_t reserved;
+} oracle_step_ctrl;
+
+static double o_nan_max(double a, double b) { return (isnan(a) || isnan(b)) ? NAN : (a > b ? a : b); }
+static double o_nan_min(double a, double b) { return (isnan(a) || isnan(b)) ? NAN : (a < b ? a : b); }
+static double o_clamp(double x, double lo, double hi) {
+    if (isnan(x)) return x;
+    const double m = x > lo ? x : lo;
+    return m < hi ? m : hi;
+}
+
+static void controller(const oracle_step_ctrl* c, const oracle_segment* segs, int n_seg, const double* sumsq,
+                       int is_f32, double* out_ctrl, double* ctrl_dev, void* next_times) {
+    double val = 0.0;
+    for (int s = 0; s < c->n_norm_seg && s < n_seg; ++s) {
+        if (segs[s].numel == 0) continue;
+        val = o_nan_max(val, sqrt(sumsq[s] / (double)segs[s].numel));
+    }
+    const double ratio = is_f32 ? (double)(float)val : val;
+    int accept = ratio <= 1.0;
+    if (c->dt > c->max_step) accept = 0;
+    if (c->dt <= c->min_step) accept = 1;
+    double dt_next;
+    if (ratio == 0.0) {
+        dt_next = c->dt * c->ifactor;
+    } else {
+        const double dfactor = ratio < 1.0 ? 1.0 : c->dfactor;
+        const double scaled = c->safety / pow(ratio, c->exponent);
+        dt_next = c->dt * o_nan_min(c->ifactor, o_nan_max(scaled, dfactor));
+    }
+    dt_next = o_clamp(dt_next, c->min_step, c->max_step);
+    const double t0n = accept ? c->t0 + c->dt : c->t0;
+    double dtn = dt_next;
+    if (!isfinite(dtn)) dtn = c->min_step;
+    dtn = o_clamp(dtn, c->min_step, c->max_step);
+    if (is_f32) {
+        float* dst = (float*)next_times;
+        const float t0T = (float)t0n, dtT = (float)dtn, t1T = (float)(t0n + dtn), sg = (float)c->time_sign;
+        for (int i = 0; i < c->n_times; ++i) {
+            float tt;
+            if ((c->alpha_is_one >> i) & 1u) tt = nextafterf(t1T, t1T - 1.0f);
+            else { const float prod = (float)c->alpha[i] * dtT; tt = t0T + prod; }
+            dst[i] = sg * tt;
+        }
+        ctrl_dev[1] = (double)(float)dtn * c->time_sign;
+    } else {
+        double* dst = (double*)next_times;
+        const double t0T = t0n, dtT = dtn, t1T = t0n + dtn;
+        for (int i = 0; i < c->n_times; ++i) {
+            double tt;
+            if ((c->alpha_is_one >> i) & 1u) tt = nextafter(t1T, t1T - 1.0);
+            else { const double prod = c->alpha[i] * dtT; tt = t0T + prod; }
+            dst[i] = c->time_sign * tt;
+        }
+        ctrl_dev[1] = dtn * c->time_sign;
+    }
+    ctrl_dev[0] = accept ? 1.0 : 0.0;
+    out_ctrl[0] = accept ? 1.0 : 0.0;
+    out_ctrl[1] = dt_next;
+    out_ctrl[2] = ratio;
+    out_ctrl[3] = t0n;
+}
+
+int oracle_error_norm_partial_ctrl(const void* err_partial, const void* y0, const void* y1, const void* const* k,
+                                   const double* coef, int n_terms, double dt, const oracle_segment* segs, int n_seg,
+                                   int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite,
+                                   const oracle_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev, void* next_times,
+                                   int dtype) {
+    if (!ctrl || !out_ctrl || !ctrl_dev || !next_times || n_seg > 16) return -1;
+    if (ctrl->n_times < 1 || ctrl->n_times > ORACLE_MAX_STAGE_TIMES) return -1;
+    const int e = oracle_error_norm_partial(err_partial, y0, y1, k, coef, n_terms, dt, segs, n_seg, chunk, n_chunks,
+                                            out_sumsq, out_nonfinite, dtype);
+    if (e) return e;
+    controller(ctrl, segs, n_seg, out_sumsq, dtype == ORACLE_F32, out_ctrl, ctrl_dev, next_times);
+    return 0;
+}
+
+/* The controller alone on given per-segment sums (kernel-parity tests feed it the device's sums). */
+int oracle_step_controller(const oracle_segment* segs, int n_seg, const double* sumsq, const oracle_step_ctrl* ctrl,
+                           double* out_ctrl, double* ctrl_dev, void* next_times, int dtype) {
+    if (!segs || !sumsq || !ctrl || !out_ctrl || !ctrl_dev || !next_times) return -1;
+    controller(ctrl, segs, n_seg, sumsq, dtype == ORACLE_F32, out_ctrl, ctrl_dev, next_times);
+    return 0;
+}
+
+/* out = y + fl_T(fl_T(coef) * T(dt')) * f on the pair the controller selected (rk_common.py:79 with i = 0). */
+int oracle_stage_combine_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej,
+                             double coef, const double* ctrl_dev, int64_t n, int dtype) {
+    if (!out || !y_acc || !f_acc || !y_rej || !f_rej || !ctrl_dev) return -1;
+    const int accept = ctrl_dev[0] != 0.0;
+    const void* y = accept ? y_acc : y_rej;
+    const void* f = accept ? f_acc : f_rej;
+    const void* ks[1] = {f};
+    return oracle_stage_combine(out, y, ks, &coef, 1, ctrl_dev[1], n, dtype);
+}

@@ -14,11 +14,12 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 5
+TDEQ_ABI_VERSION = 6
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
 TDEQ_CHUNK_QUANTUM = 1024
+TDEQ_MAX_STAGE_TIMES = 16
 
 _LIB_NAME = "libtdeq_hip.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
@@ -31,6 +32,15 @@ class Segment(ctypes.Structure):
     """`tdeq_segment` of include/tdeq_hip.h."""
     _fields_ = [("chunk_start", ctypes.c_int64), ("numel", ctypes.c_int64),
                 ("rtol", ctypes.c_double), ("atol", ctypes.c_double)]
+
+
+class StepCtrl(ctypes.Structure):
+    """`tdeq_step_ctrl` of include/tdeq_hip.h: the scalar inputs of the device-resident step controller."""
+    _fields_ = [("t0", ctypes.c_double), ("dt", ctypes.c_double), ("safety", ctypes.c_double),
+                ("ifactor", ctypes.c_double), ("dfactor", ctypes.c_double), ("exponent", ctypes.c_double),
+                ("min_step", ctypes.c_double), ("max_step", ctypes.c_double), ("time_sign", ctypes.c_double),
+                ("alpha", ctypes.c_double * TDEQ_MAX_STAGE_TIMES), ("alpha_is_one", ctypes.c_uint32),
+                ("n_times", ctypes.c_int32), ("n_norm_seg", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); the authoritative list of exported symbols (checked by the tests).
@@ -56,6 +66,16 @@ ABI_SIGNATURES = {
                                                ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_error_norm_partial_ctrl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
+                                                    _c_double_p, ctypes.c_int, ctypes.c_double,
+                                                    ctypes.POINTER(Segment), ctypes.c_int, ctypes.c_int64,
+                                                    ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.POINTER(StepCtrl), ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                                    ctypes.c_void_p]),
+    "tdeq_stage_combine_sel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_int64,
+                                              ctypes.c_int, ctypes.c_void_p]),
     "tdeq_init_norms": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int,
                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
@@ -160,19 +180,22 @@ class NormPlan:
             self.segs_dev = torch.from_numpy(raw).to(device)
         self.workspace = torch.empty(3 * self.n_chunks, dtype=torch.float64, device=device)
         self.workspace_bytes = self.workspace.numel() * 8
-        # [2*n_seg sums | n_seg non-finite counters]; pinned host memory is written by the finalize
-        # kernel directly (zero-copy), so a read-back is one stream sync and no memcpy.
+        # [2*n_seg sums | n_seg non-finite counters | 4 controller words]; pinned host memory is written by
+        # the finalize kernel directly (zero-copy), so a read-back is one stream sync and no memcpy.
         self.pinned = pinned
-        self.expect = 0          # entries the pending norm launch will write (poll mode)
+        self.expect = ()         # index ranges the pending norm launch will write (poll mode)
         if pinned:
-            self.out = torch.zeros(3 * self.n_seg, dtype=torch.float64, device="cpu", pin_memory=True)
+            self.out = torch.zeros(3 * self.n_seg + 4, dtype=torch.float64, device="cpu", pin_memory=True)
             self.out_np = self.out.numpy()
             self.out_bits = self.out_np.view(np.uint64)
         else:
-            self.out = torch.zeros(3 * self.n_seg, dtype=torch.float64, device=device)
+            self.out = torch.zeros(3 * self.n_seg + 4, dtype=torch.float64, device=device)
             self.out_np = None
         self.out_ptr = self.out.data_ptr()
         self.bad_ptr = self.out_ptr + 16 * self.n_seg
+        self.ctrl_ptr = self.out_ptr + 24 * self.n_seg
+        # {accept, sign * T(dt')} of the device-resident controller, read by tdeq_stage_combine_sel
+        self.ctrl_dev = torch.zeros(2, dtype=torch.float64, device=device)
 
 
 class HipKernels:
@@ -195,13 +218,13 @@ class HipKernels:
         self._mode = mode
         self._pinned = mode in ("poll", "pinned")
 
-    def _arm(self, plan: "NormPlan", n_sum: int) -> None:
+    def _arm(self, plan: "NormPlan", n_sum: int, ctrl: bool = False) -> None:
         """Before a norm launch in poll mode: mark the entries the launch will overwrite."""
         if self._mode == "poll" and plan.pinned:
             n = plan.n_seg
             plan.out_bits[:n_sum * n] = self._SENTINEL
-            plan.out_bits[2 * n:3 * n] = self._SENTINEL
-            plan.expect = n_sum
+            plan.out_bits[2 * n:3 * n + (4 if ctrl else 0)] = self._SENTINEL
+            plan.expect = ((0, n_sum * n), (2 * n, 3 * n + (4 if ctrl else 0)))
 
     # -- helpers ---------------------------------------------------------------------------------
     @staticmethod
@@ -278,28 +301,57 @@ class HipKernels:
     def read_norms(self, plan: NormPlan) -> Tuple[List[float], List[float], List[float]]:
         """(sumsq[0:n_seg], sumsq[n_seg:2n_seg], nonfinite[0:n_seg]) of the last norm launch."""
         n = plan.n_seg
+        v = self._read_out(plan)
+        return v[:n], v[n:2 * n], v[2 * n:3 * n]
+
+    def _read_out(self, plan: NormPlan) -> List[float]:
+        """All words of the plan's result buffer once the pending norm launch has written its share."""
         if plan.pinned and self._mode == "poll" and plan.expect:
             bits, sent = plan.out_bits, self._SENTINEL
-            lo, hi = plan.expect * n, 2 * n
+            (a0, a1), (b0, b1) = plan.expect
             spins, t_start = 0, None
-            while (bits[:lo] == sent).any() or (bits[hi:] == sent).any():
+            while (bits[a0:a1] == sent).any() or (bits[b0:b1] == sent).any():
                 spins += 1
                 if spins & 0x3FFF == 0:       # every 16k spins: bounded wait, then fall back to a real sync
                     import time
                     t_start = t_start or time.monotonic()
                     if time.monotonic() - t_start > self._POLL_TIMEOUT_S:
                         torch.cuda.current_stream().synchronize()
-                        if (bits[:lo] == sent).any() or (bits[hi:] == sent).any():
+                        if (bits[a0:a1] == sent).any() or (bits[b0:b1] == sent).any():
                             raise RuntimeError("norm kernel did not write its results (poll timeout)")
                         break
-            plan.expect = 0
-            v = plan.out_np.tolist()
-        elif plan.pinned:
+            plan.expect = ()
+            return plan.out_np.tolist()
+        if plan.pinned:
             torch.cuda.current_stream().synchronize()
-            v = plan.out_np.tolist()
-        else:
-            v = plan.out.tolist()
-        return v[:n], v[n:2 * n], v[2 * n:]
+            return plan.out_np.tolist()
+        return plan.out.tolist()
+
+    def error_norm_partial_ctrl(self, plan: NormPlan, err_partial, y0, y1, ks, coefs, dt: float, ctrl: StepCtrl,
+                                next_times) -> None:
+        """`error_norm_partial` whose finalize step also runs the step controller on the device: accept flag,
+        next step size and the next trial step's stage times (`next_times`, T[n_times]) — read with `read_ctrl`."""
+        n = len(ks)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
+        cf = (ctypes.c_double * max(n, 1))(*coefs)
+        self._arm(plan, 1, ctrl=True)
+        _check(self.lib.tdeq_error_norm_partial_ctrl(
+            err_partial.data_ptr(), y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, plan.segs, plan.n_seg, plan.chunk,
+            plan.n_chunks, plan.out_ptr, plan.bad_ptr, ctypes.byref(ctrl), plan.ctrl_ptr, plan.ctrl_dev.data_ptr(),
+            next_times.data_ptr(), plan.workspace.data_ptr(), plan.workspace_bytes, dtype_code(y0.dtype),
+            self._stream()), "tdeq_error_norm_partial_ctrl")
+
+    def read_ctrl(self, plan: NormPlan) -> Tuple[bool, float, float, List[float]]:
+        """(accept, dt_next, error_ratio, nonfinite[0:n_seg]) of the last `error_norm_partial_ctrl` launch."""
+        n = plan.n_seg
+        v = self._read_out(plan)
+        return v[3 * n] != 0.0, v[3 * n + 1], v[3 * n + 2], v[2 * n:3 * n]
+
+    def stage_combine_sel(self, out, y_acc, f_acc, y_rej, f_rej, coef: float, plan: NormPlan) -> None:
+        """First stage of the next trial step on the pair the device controller selected (tdeq_stage_combine_sel)."""
+        _check(self.lib.tdeq_stage_combine_sel(out.data_ptr(), y_acc.data_ptr(), f_acc.data_ptr(), y_rej.data_ptr(),
+                                               f_rej.data_ptr(), coef, plan.ctrl_dev.data_ptr(), out.numel(),
+                                               dtype_code(out.dtype), self._stream()), "tdeq_stage_combine_sel")
 
     def dense_eval(self, out, y0, y1, f0, f1, ks, coefs, dt: float, x: float) -> None:
         ptrs, cf, n = self._terms(ks, coefs)

@@ -222,10 +222,35 @@ int dispatch_error(void* scaled, const void* y0, const void* y1, const void* con
     return TDEQ_EINVAL;
 }
 
+// Optional controller bundle of the *_ctrl entry point (null ctrl => plain finalize).
+struct CtrlBundle {
+    const tdeq_step_ctrl* ctrl;
+    double* out_ctrl;
+    double* ctrl_dev;
+    void* next_times;
+};
+
+int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, double* out_bad, const CtrlBundle& cb,
+                         bool is_f32, hipStream_t s) {
+    CtrlArgs a;
+    a.part_sumsq = ws;
+    a.part_bad = ws + 2 * st.n_chunks;
+    a.st = st;
+    a.c = *cb.ctrl;
+    a.is_f32 = is_f32 ? 1 : 0;
+    a.out_sumsq = out_sumsq;
+    a.out_bad = out_bad;
+    a.out_ctrl = cb.out_ctrl;
+    a.ctrl_dev = cb.ctrl_dev;
+    a.next_times = cb.next_times;
+    hipLaunchKernelGGL(norm_finalize_ctrl_kernel, dim3(1), dim3(kBlock), 0, s, a);
+    return check_launch();
+}
+
 template <typename T, int NT>
 int launch_error_partial(const void* partial, const void* y0, const void* y1, const void* const* k,
                          const double* coef, double dt, const SegTable& st, double* out_sumsq, double* out_bad,
-                         double* ws, hipStream_t s) {
+                         double* ws, const CtrlBundle* cb, hipStream_t s) {
     ErrPartialArgs<T, NT> a;
     a.partial = static_cast<const T*>(partial);
     a.y0 = static_cast<const T*>(y0);
@@ -247,19 +272,39 @@ int launch_error_partial(const void* partial, const void* y0, const void* y1, co
     else hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, false>), g, b, 0, s, a);
     const int e = check_launch();
     if (e) return e;
+    if (cb) return launch_finalize_ctrl(st, ws, out_sumsq, out_bad, *cb, sizeof(T) == 4, s);
     return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
 }
 
 template <typename T>
 int dispatch_error_partial(const void* partial, const void* y0, const void* y1, const void* const* k,
                            const double* coef, int nt, double dt, const SegTable& st, double* out_sumsq,
-                           double* out_bad, double* ws, hipStream_t s) {
+                           double* out_bad, double* ws, const CtrlBundle* cb, hipStream_t s) {
     switch (nt) {
-        case 0: return launch_error_partial<T, 0>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, s);
-        case 1: return launch_error_partial<T, 1>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, s);
-        case 2: return launch_error_partial<T, 2>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, s);
+        case 0: return launch_error_partial<T, 0>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s);
+        case 1: return launch_error_partial<T, 1>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s);
+        case 2: return launch_error_partial<T, 2>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s);
     }
     return TDEQ_EINVAL;
+}
+
+template <typename T>
+int launch_combine_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej,
+                       double coef, const double* ctrl_dev, int64_t n, hipStream_t s) {
+    SelArgs<T> a;
+    a.out = static_cast<T*>(out);
+    a.y_acc = static_cast<const T*>(y_acc);
+    a.f_acc = static_cast<const T*>(f_acc);
+    a.y_rej = static_cast<const T*>(y_rej);
+    a.f_rej = static_cast<const T*>(f_rej);
+    a.coef = (T)coef;
+    a.ctrl_dev = ctrl_dev;
+    a.n = n;
+    constexpr int L = VecOf<T>::L;
+    const bool vec = aligned16(out) && aligned16(y_acc) && aligned16(f_acc) && aligned16(y_rej) && aligned16(f_rej);
+    if (vec) hipLaunchKernelGGL((stage_combine_sel_kernel<T, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((stage_combine_sel_kernel<T, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
 }
 
 // ---- init norms ------------------------------------------------------------------------------------
@@ -578,8 +623,42 @@ int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void*
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
     return dtype == TDEQ_F32
-               ? dispatch_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s)
-               : dispatch_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
+               ? dispatch_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, nullptr, s)
+               : dispatch_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, nullptr, s);
+}
+
+int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const void* y1, const void* const* k,
+                                 const double* coef, int n_terms, double dt, const tdeq_segment* segs, int n_seg,
+                                 int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite,
+                                 const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev, void* next_times,
+                                 void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    if (!err_partial || !y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype))
+        return TDEQ_EINVAL;
+    if (!ctrl || !out_ctrl || !ctrl_dev || !next_times) return TDEQ_EINVAL;
+    if (n_terms < 0 || n_terms > 2 || (n_terms > 0 && (!k || !coef))) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (n_seg > TDEQ_INLINE_SEGMENTS) return TDEQ_EINVAL;
+    if (ctrl->n_times < 1 || ctrl->n_times > TDEQ_MAX_STAGE_TIMES || ctrl->n_norm_seg < 0 || ctrl->n_norm_seg > n_seg)
+        return TDEQ_EINVAL;
+    SegTable st;
+    const int e = fill_segtable(st, segs, nullptr, n_seg, chunk, n_chunks);
+    if (e) return e;
+    if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times};
+    return dtype == TDEQ_F32
+               ? dispatch_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s)
+               : dispatch_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s);
+}
+
+int tdeq_stage_combine_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej,
+                           double coef, const double* ctrl_dev, int64_t n, int dtype, void* stream) {
+    if (!out || !y_acc || !f_acc || !y_rej || !f_rej || !ctrl_dev || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? launch_combine_sel<float>(out, y_acc, f_acc, y_rej, f_rej, coef, ctrl_dev, n, s)
+                             : launch_combine_sel<double>(out, y_acc, f_acc, y_rej, f_rej, coef, ctrl_dev, n, s);
 }
 
 int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, const tdeq_segment* segs,

@@ -505,6 +505,169 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_kernel(const FinalizeArg
 }
 
 // ------------------------------------------------------------------------------------------------
+// Device-resident step controller (rk_common.py:324-361, misc.py:85-95) + the next trial step's stage
+// times (rk_common.py:72-78).  ONE workgroup: it first reduces the per-chunk partials exactly like
+// norm_finalize_kernel (same per-thread strides, same block_sum => the same fp64 sums), then thread 0
+// runs the scalar controller in fp64 — the arithmetic of solvers.optimal_step_size / _adaptive_step.
+// The accept/reject loop itself stays on the host; this only lets the host enqueue the next trial
+// step's first stage before it has read the decision back (stage_combine_sel_kernel below).
+// ------------------------------------------------------------------------------------------------
+struct CtrlArgs {
+    const double* part_sumsq;
+    const double* part_bad;
+    SegTable st;              // n_seg <= TDEQ_INLINE_SEGMENTS
+    tdeq_step_ctrl c;
+    int is_f32;
+    double* out_sumsq;        // [n_seg]   device or pinned host
+    double* out_bad;          // [n_seg]
+    double* out_ctrl;         // [4] = {accept, dt_next, ratio, t0_next}
+    double* ctrl_dev;         // [2] = {accept, sign * T(dt_next')}      device
+    void* next_times;         // [n_times] of T                          device
+};
+
+__device__ __forceinline__ double ctl_nan_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
+__device__ __forceinline__ double ctl_nan_min(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
+// torch.clamp on host doubles: NaN stays NaN, else min(max(x, lo), hi)
+__device__ __forceinline__ double ctl_clamp(double x, double lo, double hi) {
+    if (x != x) return x;
+    const double m = x > lo ? x : lo;
+    return m < hi ? m : hi;
+}
+
+// np.nextafter(x, x - 1) in T (misc.py:174-197, Perturb.PREV)
+__device__ __forceinline__ float ctl_prev(float x) {
+    const float y = x - 1.0f;
+    if (x != x) return x;
+    if (x == y) return y;
+    if (x == 0.0f) return -__uint_as_float(1u);
+    const uint32_t b = __float_as_uint(x);
+    return __uint_as_float(x > 0.0f ? b - 1u : b + 1u);
+}
+__device__ __forceinline__ double ctl_prev(double x) {
+    const double y = x - 1.0;
+    if (x != x) return x;
+    if (x == y) return y;
+    if (x == 0.0) return -__longlong_as_double(1LL);
+    const long long b = __double_as_longlong(x);
+    return __longlong_as_double(x > 0.0 ? b - 1 : b + 1);
+}
+
+// Stage time i of the next trial step (rk_common.py:72-78), one lane per stage.
+template <typename T>
+__device__ __forceinline__ T ctl_stage_time(const tdeq_step_ctrl& c, double t0n, double dtn, int i) {
+    const T t0T = (T)t0n, dtT = (T)dtn, t1T = (T)(t0n + dtn);
+    T tt;
+    if ((c.alpha_is_one >> i) & 1u) tt = ctl_prev(t1T);
+    else tt = t0T + (T)c.alpha[i] * dtT;
+    return (T)c.time_sign * tt;
+}
+
+__global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlArgs a) {
+    __shared__ double red[2 * (kBlock / kWave)];
+    __shared__ double seg_val[2][TDEQ_INLINE_SEGMENTS];
+    __shared__ double next_step[2];     // {t0', dt'} broadcast to the lanes that form the stage times
+    const int n_seg = a.st.n_seg;
+    for (int s = 0; s < n_seg; ++s) {
+        const int64_t c0 = a.st.inl[s].chunk_start;
+        const int64_t c1 = (s + 1 < n_seg) ? a.st.inl[s + 1].chunk_start : a.st.n_chunks;
+        double acc[2] = {0.0, 0.0};
+        for (int64_t i = c0 + threadIdx.x; i < c1; i += kBlock) {
+            acc[0] += a.part_sumsq[i];
+            acc[1] += a.part_bad[i];
+        }
+        block_sum<2>(acc, red);
+        if (threadIdx.x == 0) {
+            seg_val[0][s] = acc[0];
+            seg_val[1][s] = acc[1];
+        }
+        __syncthreads();
+    }
+    const tdeq_step_ctrl& c = a.c;
+    if (threadIdx.x == 0) {
+        // error ratio: max over segments of sqrt(mean), rounded to T (misc.py:22-33, 80-82)
+        double val = 0.0;
+        for (int s = 0; s < c.n_norm_seg && s < n_seg; ++s) {
+            const int64_t numel = a.st.inl[s].numel;
+            if (numel == 0) continue;
+            val = ctl_nan_max(val, __builtin_sqrt(seg_val[0][s] / (double)numel));
+        }
+        const double ratio = a.is_f32 ? (double)(float)val : val;
+        // accept / reject (rk_common.py:324-330)
+        bool accept = ratio <= 1.0;
+        if (c.dt > c.max_step) accept = false;
+        if (c.dt <= c.min_step) accept = true;
+        // next step size (misc.py:85-95), then the clamp of rk_common.py:353
+        double dt_next;
+        if (ratio == 0.0) {
+            dt_next = c.dt * c.ifactor;
+        } else {
+            const double dfactor = ratio < 1.0 ? 1.0 : c.dfactor;
+            const double scaled = c.safety / pow(ratio, c.exponent);
+            dt_next = c.dt * ctl_nan_min(c.ifactor, ctl_nan_max(scaled, dfactor));
+        }
+        dt_next = ctl_clamp(dt_next, c.min_step, c.max_step);
+        // the next trial step as the host will set it up (rk_common.py:268-275)
+        const double t0n = accept ? c.t0 + c.dt : c.t0;
+        double dtn = dt_next;
+        if (!__builtin_isfinite(dtn)) dtn = c.min_step;
+        dtn = ctl_clamp(dtn, c.min_step, c.max_step);
+        // device-side consumers first (the look-ahead stage is next in the stream), then the host's words
+        a.ctrl_dev[0] = accept ? 1.0 : 0.0;
+        a.ctrl_dev[1] = (a.is_f32 ? (double)(float)dtn : dtn) * c.time_sign;
+        next_step[0] = t0n;
+        next_step[1] = dtn;
+        a.out_ctrl[0] = accept ? 1.0 : 0.0;
+        a.out_ctrl[1] = dt_next;
+        a.out_ctrl[2] = ratio;
+        a.out_ctrl[3] = t0n;
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < c.n_times) {
+        if (a.is_f32) static_cast<float*>(a.next_times)[i] = ctl_stage_time<float>(c, next_step[0], next_step[1], i);
+        else static_cast<double*>(a.next_times)[i] = ctl_stage_time<double>(c, next_step[0], next_step[1], i);
+    }
+    if (i < n_seg) {
+        a.out_sumsq[i] = seg_val[0][i];
+        a.out_bad[i] = seg_val[1][i];
+    }
+}
+
+// First stage of the NEXT trial step on the pair the controller selected (see norm_finalize_ctrl_kernel):
+//   out = y + fl_T(coef * dt') * f ,  (y, f) = accept ? (y_acc, f_acc) : (y_rej, f_rej)
+template <typename T>
+struct SelArgs {
+    T* out;
+    const T* y_acc;
+    const T* f_acc;
+    const T* y_rej;
+    const T* f_rej;
+    T coef;                 // fl_T(coef)
+    const double* ctrl_dev; // {accept, sign * T(dt')}
+    int64_t n;
+};
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void stage_combine_sel_kernel(const SelArgs<T> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const bool accept = a.ctrl_dev[0] != 0.0;
+    const T c = a.coef * (T)a.ctrl_dev[1];
+    const T* ys = accept ? a.y_acc : a.y_rej;
+    const T* fs = accept ? a.f_acc : a.f_rej;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const E* __restrict__ y = reinterpret_cast<const E*>(ys);
+    const E* __restrict__ f = reinterpret_cast<const E*>(fs);
+    E* __restrict__ out = reinterpret_cast<E*>(a.out);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) out[i] = y[i] + f[i] * c;
+    if (VEC) {
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) a.out[t] = ys[t] + fs[t] * c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dense output (rk_common.py:363-369, interp.py:1-48).  Op order mirrors interp.py:17-21 / :42-47.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NT>

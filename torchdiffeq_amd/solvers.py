@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import bisect
 import math
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -129,6 +130,32 @@ class RKAdaptiveStepsizeODESolver:
             self._fuse = (self._c_err.coef[:n_lead], self._c_err.idx[n_lead:], self._c_err.coef[n_lead:])
         self.n_accepted = 0
         self.n_rejected = 0
+        # Device-resident controller + look-ahead first stage (tdeq_error_norm_partial_ctrl / tdeq_stage_combine_sel):
+        # the loop stays here, but the scalar decision of a trial step is also taken on the device so that the next
+        # trial step's first stage and func evaluation are enqueued before the decision has been read back.
+        n_norm_seg = self.layout.n_seg - (self.norm.n_skip_tail if isinstance(self.norm, BuiltinNorm) else 0)
+        self._lookahead = (self._fuse is not None and isinstance(self.norm, BuiltinNorm)
+                           and self.layout.n_seg <= _native.TDEQ_INLINE_SEGMENTS
+                           and len(self._beta) <= _native.TDEQ_MAX_STAGE_TIMES and n_norm_seg >= 0
+                           and self.step_t is None and self.jump_t is None
+                           and os.environ.get("TDEQ_LOOKAHEAD", "1") != "0")
+        if self._lookahead:
+            c = _native.StepCtrl()
+            c.safety, c.ifactor, c.dfactor = self.safety, self.ifactor, self.dfactor
+            c.exponent = 1.0 / self.order
+            c.min_step, c.max_step = self.min_step, self.max_step
+            c.time_sign = func.sign
+            mask = 0
+            for i, a in enumerate(self._alpha):
+                c.alpha[i] = float(a)
+                if self._alpha_is_one[i]:
+                    mask |= 1 << i
+            c.alpha_is_one = mask
+            c.n_times = len(self._alpha)
+            c.n_norm_seg = n_norm_seg
+            self._ctrl = c
+        self._t_end = -math.inf     # last output time of the running `integrate` (look-ahead only before it)
+        self._pre = None            # (stage input, stage times, k_1) of the trial step enqueued ahead
 
     @classmethod
     def valid_callbacks(cls):
@@ -158,6 +185,7 @@ class RKAdaptiveStepsizeODESolver:
         t_host = t.detach().to(torch.float64).cpu().tolist()
         self._set_time_anchor(t)
         self._before_integrate(t_host)
+        self._t_end = t_host[-1]
         if self._differentiable():
             # backprop through the solver: rows are autograd nodes, assembled by a differentiable stack
             rows = [self.y0]
@@ -187,6 +215,7 @@ class RKAdaptiveStepsizeODESolver:
         t_host = t.detach().to(torch.float64).cpu().tolist()
         self._set_time_anchor(t.detach())
         self._before_integrate(t_host)
+        self._t_end = t_host[-1]
         times, planes = [self.t0], []
         mid = self._c_mid
         for next_t in t_host[1:]:
@@ -253,6 +282,7 @@ class RKAdaptiveStepsizeODESolver:
         self.y1, self.f1 = self.y0, f0
         self.t0, self.t1, self.dt = t0, t0, first_step
         self._dense: Optional[_DenseRecord] = None
+        self._t_end, self._pre = -math.inf, None    # event mode / direct stepping: no look-ahead
 
         step_t = [] if self.step_t is None else sorted(v for v in self.step_t if v >= t0)
         jump_t = [] if self.jump_t is None else sorted(v for v in self.jump_t if v >= t0)
@@ -353,19 +383,29 @@ class RKAdaptiveStepsizeODESolver:
         dt_signed = float(dt_T) * func.sign
         ops = self.ops
         row0 = self._beta[0]
-        times = [(t1_T, Perturb.PREV) if self._alpha_is_one[i] else (t0_T + self._alpha[i] * dt_T, Perturb.NONE)
-                 for i in range(len(self._beta))]
-        if len(times) <= 16 and not (torch.is_grad_enabled() and (y0.requires_grad or f0.requires_grad
-                                                                  or self._anchor is not None)):
-            # one launch: first stage input + the step's stage times (tdeq_stage_combine_fill)
-            yi = torch.empty_like(y0)
-            tbuf = torch.empty(len(times), dtype=y0.dtype, device=y0.device)
-            kern.stage_combine_fill(yi, y0, [f0], row0.coef, dt_signed, tbuf, [func.user_time(t, p) for t, p in times])
-            stage_times = tbuf.unbind(0)
+        plain = not (torch.is_grad_enabled() and (y0.requires_grad or f0.requires_grad or self._anchor is not None))
+        lookahead = (self._lookahead and plain and func.callback_step is _null
+                     and func.callback_accept_step is _null and func.callback_reject_step is _null)
+        pre, self._pre = self._pre, None
+        if lookahead and pre is not None:
+            # this trial step's first stage was enqueued by the previous one (tdeq_stage_combine_sel on the pair and
+            # the step size the device controller chose) together with its func evaluation
+            yi, stage_times, k1 = pre
         else:
-            yi = ops.combine(y0, [f0], row0.coef, dt_signed)
-            stage_times = func.time_tensors(kern, times)
-        k: List[torch.Tensor] = [f0, func.eval_at(stage_times[0], yi)]
+            times = [(t1_T, Perturb.PREV) if self._alpha_is_one[i] else (t0_T + self._alpha[i] * dt_T, Perturb.NONE)
+                     for i in range(len(self._beta))]
+            if len(times) <= 16 and plain:
+                # one launch: first stage input + the step's stage times (tdeq_stage_combine_fill)
+                yi = torch.empty_like(y0)
+                tbuf = torch.empty(len(times), dtype=y0.dtype, device=y0.device)
+                kern.stage_combine_fill(yi, y0, [f0], row0.coef, dt_signed, tbuf,
+                                        [func.user_time(t, p) for t, p in times])
+                stage_times = tbuf.unbind(0)
+            else:
+                yi = ops.combine(y0, [f0], row0.coef, dt_signed)
+                stage_times = func.time_tensors(kern, times)
+            k1 = func.eval_at(stage_times[0], yi)
+        k: List[torch.Tensor] = [f0, k1]
         n_rows = len(self._beta)
         fsal = self.tableau.fsal_solution
         builtin_norm = isinstance(self.norm, BuiltinNorm)
@@ -392,7 +432,21 @@ class RKAdaptiveStepsizeODESolver:
 
         # ---- error ratio (misc.py:80-82) ----
         err = self._c_err
-        if err_partial is not None:
+        if err_partial is not None and lookahead:
+            ctrl = self._ctrl
+            ctrl.t0, ctrl.dt = t0, dt
+            tnext = torch.empty(ctrl.n_times, dtype=y0.dtype, device=y0.device)
+            kern.error_norm_partial_ctrl(self.plan, err_partial, y0, y1, [k[j] for j in self._fuse[1]], self._fuse[2],
+                                         dt_signed, ctrl, tnext)
+            if t1 < self._t_end:
+                # accepted or rejected, another trial step follows: enqueue its first stage and func evaluation now
+                yi_n = torch.empty_like(y0)
+                kern.stage_combine_sel(yi_n, y1, f1, y0, f0, row0.coef[0], self.plan)
+                tn = tnext.unbind(0)
+                self._pre = (yi_n, tn, func.eval_at(tn[0], yi_n))
+            accept_dev, dt_next_dev, error_ratio, bad = kern.read_ctrl(self.plan)
+            y1_nonfinite = any(b != 0 for b in bad)
+        elif err_partial is not None:
             kern.error_norm_partial(self.plan, err_partial, y0, y1, [k[j] for j in self._fuse[1]], self._fuse[2],
                                     dt_signed)
             sumsq, _, bad = kern.read_norms(self.plan)
@@ -405,11 +459,14 @@ class RKAdaptiveStepsizeODESolver:
             y1_nonfinite = any(b != 0 for b in bad)
         else:
             error_ratio, y1_nonfinite = self._user_norm_ratio(y0, y1, k, dt_signed)
-        accept_step = error_ratio <= 1
-        if dt > self.max_step:
-            accept_step = False
-        if dt <= self.min_step:
-            accept_step = True
+        if err_partial is not None and lookahead:
+            accept_step = accept_dev      # the device's decision is the one its look-ahead stage was built on
+        else:
+            accept_step = error_ratio <= 1
+            if dt > self.max_step:
+                accept_step = False
+            if dt <= self.min_step:
+                accept_step = True
 
         # ---- update state (rk_common.py:335-361) ----
         if accept_step:
@@ -432,8 +489,11 @@ class RKAdaptiveStepsizeODESolver:
                 func.callback_reject_step(self._time_tensor(t0), y0, self._time_tensor(dt))
             self.t0 = t0   # (y, f, t1) unchanged: the step is retried from t0 with a smaller dt
             self.n_rejected += 1
-        dt_next = optimal_step_size(dt, error_ratio, self.safety, self.ifactor, self.dfactor, self.order)
-        self.dt = _clamp(dt_next, self.min_step, self.max_step)
+        if err_partial is not None and lookahead:
+            self.dt = dt_next_dev         # already clamped (tdeq_error_norm_partial_ctrl)
+        else:
+            dt_next = optimal_step_size(dt, error_ratio, self.safety, self.ifactor, self.dfactor, self.order)
+            self.dt = _clamp(dt_next, self.min_step, self.max_step)
 
     def _user_norm_ratio(self, y0, y1, k, dt_signed):
         """User-supplied `norm` callable (misc.py:80-82 with a custom norm): the kernel materialises
