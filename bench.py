@@ -114,8 +114,11 @@ def main():
     from torchdiffeq_amd.solvers import Dopri5Solver
     import torchdiffeq_amd as tda
 
-    rank, world, local_rank = tdist.init_from_env()
+    # TDEQ_DIST_BACKEND=gloo lets the N>1 control flow be smoke-tested on a 1-GPU box (ranks share the device;
+    # RCCL itself refuses two ranks on one GPU).  Unset, the backend is nccl (= RCCL) and rank r owns GPU r.
+    rank, world, local_rank = tdist.init_from_env(backend=os.environ.get("TDEQ_DIST_BACKEND") or None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -188,30 +191,39 @@ def main():
         epart = torch.empty_like(y0s)
         last = len(solver._beta) - 1
 
+        la = bool(solver._lookahead and fuse is not None)
+        tnext = torch.empty(len(solver._beta), dtype=y0s.dtype, device=device)
+
         def one_pass():
-            # exactly the solver's launch sequence for one trial step, minus func and the stage-time fill
+            # exactly the solver's launch sequence for one trial step, minus func (and, without look-ahead, the
+            # stage-time fill)
             for i, row in enumerate(solver._beta):
-                if i == last and fuse is not None:
+                if i == 0 and la:
+                    kern.stage_combine_sel(outs[0], rec.y1, ks[-1], y0s, ks[0], row.coef[0], solver.plan)
+                elif i == last and fuse is not None:
                     kern.stage_combine_err(outs[i & 1], epart, y0s, [ks[j] for j in row.idx], row.coef, fuse[0],
                                            rec.dt_signed)
                 else:
                     kern.stage_combine(outs[i & 1], y0s, [ks[j] for j in row.idx], row.coef, rec.dt_signed)
-            if fuse is not None:
+            if la:
+                solver._ctrl.t0, solver._ctrl.dt = rec.t0, rec.t1 - rec.t0
+                kern.error_norm_partial_ctrl(solver.plan, epart, y0s, rec.y1, [ks[j] for j in fuse[1]], fuse[2],
+                                             rec.dt_signed, solver._ctrl, tnext)
+            elif fuse is not None:
                 kern.error_norm_partial(solver.plan, epart, y0s, rec.y1, [ks[j] for j in fuse[1]], fuse[2], rec.dt_signed)
             else:
                 kern.error_norm(solver.plan, y0s, rec.y1, [ks[j] for j in solver._c_err.idx], solver._c_err.coef,
                                 rec.dt_signed)
         for _ in range(3):
             one_pass()
-        kern.read_norms(solver.plan)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(REPS):
             one_pass()
         e1.record()
-        kern.read_norms(solver.plan)
         torch.cuda.synchronize()
+        solver.plan.expect = ()     # the passes' results are not read back
         t_step = e0.elapsed_time(e1) * 1e-3 / REPS
         # SURVEY.md §8(d) counts 32 + 8 = 40 words per element for a dopri5 step; the end-of-step fusion moves
         # 37 (3+4+5+6+7+8 for the six combines, 4 for the norm) — both rates are reported.
@@ -221,9 +233,10 @@ def main():
                        "bytes_moved_per_step": moved, "GBps_moved": moved / t_step / 1e9,
                        "frac_of_hbm_peak_moved": moved / t_step / 1e9 / HBM_PEAK_GBPS,
                        "survey_algorithmic_bytes_per_step": survey, "GBps_survey_bytes": survey / t_step / 1e9,
-                       "note": "the solver's own launch sequence for one dopri5 trial step (5 stage_combine + "
-                               "stage_combine_err + error_norm_partial + finalize) back to back, no func; the 7 k "
-                               "tensors (235 MB) + y0/y1 fit the 256 MiB Infinity Cache only partly"}
+                       "note": "the solver's own launch sequence for one dopri5 trial step (stage_combine_sel + 4 "
+                               "stage_combine + stage_combine_err + error_norm_partial + controller finalize) back "
+                               "to back, no func; the 7 k tensors (235 MB) + y0/y1 fit the 256 MiB Infinity Cache "
+                               "only partly"}
     except Exception as exc:      # never let the extra figure break the contract line
         solver_only = {"error": repr(exc)}
 

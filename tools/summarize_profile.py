@@ -45,6 +45,45 @@ def main():
         print("gpu busy fraction over the last 600 dispatches:", summary["gpu_busy_frac_last600"])
         for t in tl[-26:]:
             print(t)
+        # Per-trial-step timeline of the TIMED region (steps that end in the device controller kernel): period
+        # between consecutive controller kernels, GPU-busy time inside it, and where the idle gaps sit.
+        marks = [i for i, r in enumerate(rows) if "norm_finalize_ctrl_kernel" in r["Kernel_Name"]]
+        if len(marks) < 10:
+            marks = [i for i, r in enumerate(rows) if "norm_finalize_kernel" in r["Kernel_Name"]]
+        spans = []
+        for a, b in zip(marks[:-1], marks[1:]):
+            seg = rows[a:b + 1]
+            if not any(r["Kernel_Name"].startswith("Cijk") for r in seg):
+                continue      # solver-only passes at the end of bench.py (no func launches)
+            period = (int(seg[-1]["End_Timestamp"]) - int(seg[0]["End_Timestamp"])) / 1e3
+            busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg[1:]) / 1e3
+            gaps = []
+            for prev, cur in zip(seg[:-1], seg[1:]):
+                g = (int(cur["Start_Timestamp"]) - int(prev["End_Timestamp"])) / 1e3
+                key = prev["Kernel_Name"].split("(")[0].replace("void ", "")[:48] + " -> " + \
+                    cur["Kernel_Name"].split("(")[0].replace("void ", "")[:48]
+                gaps.append((key, g))
+            spans.append((period, busy, gaps))
+        if spans:
+            # drop the spans that contain non-step work (the parity solve before the timed loop, allocations)
+            mid0 = sorted(p for p, _, _ in spans)[len(spans) // 2]
+            spans = [sp for sp in spans if sp[0] <= 2.0 * mid0]
+            n = len(spans)
+            periods = [sp[0] for sp in spans]
+            busys = [sp[1] for sp in spans]
+            gap_after = {}
+            for _, _, gaps in spans:
+                for key, g in gaps:
+                    acc = gap_after.setdefault(key, [0, 0.0])
+                    acc[0] += 1
+                    acc[1] += g
+            summary["step_timeline"] = {
+                "steps": n, "median_period_us": sorted(periods)[n // 2], "mean_period_us": sum(periods) / n,
+                "mean_gpu_busy_us": sum(busys) / n, "mean_idle_us": (sum(periods) - sum(busys)) / n,
+                "mean_gap_us_by_boundary": {k: v[1] / v[0] for k, v in sorted(gap_after.items(),
+                                                                             key=lambda kv: -kv[1][1])[:16]}}
+            print("== per-step timeline (timed region) ==")
+            print(json.dumps(summary["step_timeline"], indent=1))
     for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         cc = find(os.path.join(root, name), "*counter_collection.csv")
         if not cc:
