@@ -1,5 +1,8 @@
-"""world_size-2 gloo test of the sharded adjoint: parameter gradients summed by ONE all-reduce equal the
-single-process gradients over the whole batch; y0 gradients stay sharded."""
+"""world_size-2 gloo tests of the sharded solves.
+  * default mode: parameter gradients summed by ONE all-reduce equal the single-process gradients over the whole
+    batch within the solve tolerance; y0 gradients stay sharded.
+  * lock-step mode (sync_steps=True): the shards share the whole-batch step controller, so the forward rows, the
+    number of func evaluations and the gradients equal the single-process run to rounding."""
 import os
 import sys
 
@@ -85,6 +88,77 @@ def test_sharded_adjoint_world2(tmp_path):
     # exactly one all-reduce for the parameter tail (+ one for dL/dt because t.requires_grad)
     assert len(res[0]["calls"]) == 2 and res[0]["calls"][1] == 3
     assert res[0]["rows"] == slice(0, 6) and res[1]["rows"] == slice(6, 11)
+
+
+class _CountingModule(torch.nn.Module):
+    def __init__(self, inner):
+        super().__init__()
+        self.inner, self.nfe = inner, 0
+
+    def forward(self, t, y):
+        self.nfe += 1
+        return self.inner(t, y)
+
+
+def _lockstep_run(tda_odeint_adjoint, f, y0, t, **kw):
+    y = tda_odeint_adjoint(f, y0, t, rtol=1e-8, atol=1e-10, method="dopri5", **kw)
+    nfe_fwd = f.nfe
+    (y[-1].pow(2).sum() + y[1].sum()).backward()
+    return y.detach(), nfe_fwd, f.nfe - nfe_fwd
+
+
+def _lockstep_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    _patch_backend()
+    from torchdiffeq_amd import dist as tdist
+    tdist.init_from_env(backend="gloo")
+    f, y0 = _make(torch.float64)
+    f = _CountingModule(f)
+    t = torch.tensor([0.0, 0.4, 1.0], dtype=torch.float64, requires_grad=True)
+    shard = tdist.shard_batch(y0).clone().requires_grad_(True)
+    # forward only, lock step
+    with torch.no_grad():
+        y_fwd = tdist.odeint_sharded(f, shard.detach(), t.detach(), rtol=1e-8, atol=1e-10, method="dopri5")
+    nfe_plain = f.nfe
+    f.nfe = 0
+    y, nfe_fwd, nfe_bwd = _lockstep_run(lambda *a, **k: tdist.odeint_adjoint_sharded(*a, sync_steps=True, **k),
+                                        f, shard, t)
+    torch.save(dict(y_fwd=y_fwd, y=y, nfe_plain=nfe_plain, nfe_fwd=nfe_fwd, nfe_bwd=nfe_bwd, gy=shard.grad,
+                    gp=[p.grad for p in f.parameters()], gt=t.grad, rows=tdist.shard_rows(11, rank, world)),
+               os.path.join(out_dir, f"ls{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lockstep_world2_equals_single_process(tmp_path):
+    import torchdiffeq_amd as tda
+    world = 2
+    port = 29950 + (os.getpid() % 300)
+    mp.spawn(_lockstep_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"ls{r}.pt"), weights_only=False) for r in range(world)]
+
+    _patch_backend()
+    f, y0 = _make(torch.float64)
+    f = _CountingModule(f)
+    y0 = y0.clone().requires_grad_(True)
+    t = torch.tensor([0.0, 0.4, 1.0], dtype=torch.float64, requires_grad=True)
+    y, nfe_fwd, nfe_bwd = _lockstep_run(tda.odeint_adjoint, f, y0, t)
+    for r in range(world):
+        rows = res[r]["rows"]
+        # same step sequence as the whole-batch solve: same NFE, rows equal to rounding (the cross-rank sum of the
+        # error norm is associated differently, which moves dt by ~1e-16 relative)
+        assert res[r]["nfe_plain"] == nfe_fwd and res[r]["nfe_fwd"] == nfe_fwd and res[r]["nfe_bwd"] == nfe_bwd
+        assert torch.allclose(res[r]["y_fwd"], y[:, rows], rtol=1e-13, atol=1e-14)
+        assert torch.allclose(res[r]["y"], y[:, rows], rtol=1e-13, atol=1e-14)
+        assert torch.allclose(res[r]["gy"], y0.grad[rows], rtol=1e-11, atol=1e-13)
+        for g_shard, p in zip(res[r]["gp"], f.parameters()):
+            assert torch.allclose(g_shard, p.grad, rtol=1e-11, atol=1e-13)
+        assert torch.allclose(res[r]["gt"], t.grad, rtol=1e-11, atol=1e-13)
+    for a, b in zip(res[0]["gp"], res[1]["gp"]):
+        assert torch.equal(a, b)
 
 
 def test_shard_rows_cover_batch():

@@ -10,7 +10,9 @@ handle_adjoint_norm_), re-organised for the MI355X path:
   * the reference's per-evaluation `-adj_y` negation, `_ReverseFunc` multiply and `torch.cat` become
     one copy per output (negation folded into the copy; time reversal folded into `dt`);
   * with a process group (`adjoint_options['dist_group']` or torchdiffeq_amd.dist), the parameter
-    adjoints — a contiguous tail of the flat buffer — are summed over ranks with ONE all-reduce.
+    adjoints — a contiguous tail of the flat buffer — are summed over ranks with ONE all-reduce; in lock-step
+    mode (`adjoint_options['dist_sync']`) they are all-reduced per evaluation instead, so that every shard
+    integrates exactly the whole-batch adjoint system with the whole-batch step sequence.
 """
 from __future__ import annotations
 
@@ -38,6 +40,8 @@ class _AugmentedDynamics(OdeFunc):
         self.params = tuple(params)
         self.t_requires_grad = t_requires_grad
         self.n_y = fwd.layout.n_seg
+        self.sync_group = None       # lock-step sharded solve: batch-summed outputs are all-reduced per evaluation
+        self.sync = False
 
     def call_base(self, t_user: torch.Tensor, aug: torch.Tensor) -> torch.Tensor:
         fwd, lay, n_y = self.fwd, self.layout, self.n_y
@@ -85,6 +89,18 @@ class _AugmentedDynamics(OdeFunc):
                 torch.neg(src.to(self.dtype), out=dst)
             else:
                 dst.copy_(src)
+        if self.sync:
+            # lock-step mode: the time- and parameter-VJPs are sums over the batch, i.e. over the shards — add them
+            # up now (one all-reduce of 1 + P words) so that these segments of the state are replicated, exactly
+            # the whole-batch solve's, and enter its error norm
+            import torch.distributed as dist
+            pieces = [o[0].reshape(1)] + [v.reshape(-1) for v in o[1 + 2 * n_y:]]
+            staging = torch.cat(pieces)
+            dist.all_reduce(staging, op=dist.ReduceOp.SUM, group=self.sync_group)
+            off = 0
+            for v in pieces:
+                v.copy_(staging[off:off + v.numel()])
+                off += v.numel()
         return out
 
 
@@ -167,6 +183,15 @@ class OdeintAdjointMethod(torch.autograd.Function):
             # ---- options of the nested solve (time is reversed: misc.py:273-293) ----
             options = dict(ctx.adjoint_options)
             group = options.pop("dist_group", None)
+            sync = options.pop("dist_sync", None)
+            options.pop("dist_replicated", None)
+            if sync is not None:
+                # lock-step backward solve: [vjp_t | θ-adjoints] replicated (all-reduced per evaluation), y / adj_y
+                # sharded; the norm sums are added over ranks (solvers._LockStep)
+                aug_func.sync, aug_func.sync_group = True, (None if sync is True else sync)
+                options["dist_sync"] = sync
+                options["dist_replicated"] = [0] + list(range(1 + 2 * n_y, aug_layout.n_seg))
+                group = None          # nothing left to reduce at the end
             norm = options.get("norm")
             if not isinstance(norm, BuiltinNorm):
                 def _user_norm(flat, _norm=norm, _lay=aug_layout):
@@ -189,6 +214,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
                                     zip(fwd_layout.unpack(func_eval), fwd_layout.unpack(grad_y[i])))
                     if fwd.sign != 1.0:
                         dLd_cur_t = dLd_cur_t * fwd.sign
+                    if sync is not None:
+                        torch.distributed.all_reduce(dLd_cur_t, group=aug_func.sync_group)   # a sum over the batch
                     aug_views[0].sub_(dLd_cur_t)
                     time_vjps[i] = dLd_cur_t
                 solver = SOLVERS[ctx.adjoint_method](func=aug_func, y0=aug, rtol=ctx.adjoint_rtol,

@@ -6,6 +6,10 @@ The only cross-rank quantity is the adjoint's parameter gradient (a sum over the
 segments are a contiguous tail of the flat augmented state, summed with ONE all-reduce at the end of
 `backward` (≈0.4 MB for cfg3 — latency-bound on xGMI, so a single coalesced call, not a bucketed ring).
 
+Optional lock-step mode (`sync_steps=True`): the shards share the whole-batch step controller through one tiny
+all-reduce of the error sums per trial step (and, in the adjoint, of the batch-summed VJPs per evaluation), which
+reproduces the single-device step sequence and results (SURVEY.md §8e "exact mode").
+
 Nothing of this exists in the reference (no torch.distributed call anywhere in its tree).
 """
 from __future__ import annotations
@@ -17,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from .adjoint import odeint_adjoint
+from .odeint import odeint
 
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
@@ -53,13 +58,39 @@ def shard_batch(y0: torch.Tensor, rank: Optional[int] = None, world: Optional[in
     return y0[shard_rows(y0.shape[0], rank, world)]
 
 
-def odeint_adjoint_sharded(func, y0_shard, t, *, group=None, **kwargs):
+def odeint_sharded(func, y0_shard, t, *, group=None, sync_steps=True, **kwargs):
+    """`odeint` on this rank's batch shard.  sync_steps=False: every rank runs its own accept/reject loop (no
+    communication at all; results agree with the whole-batch solve within the tolerances).  sync_steps=True
+    ("lock step"): the per-segment error sums are added over the ranks — one all-reduce of 3·n_seg doubles per
+    trial step, latency-bound on xGMI — so every shard takes exactly the step sequence of the whole-batch solve
+    and its rows come out as in a single-device run (adaptive methods; fixed grids are in lock step anyway)."""
+    if sync_steps and dist.is_initialized() and dist.get_world_size(group) > 1:
+        options = dict(kwargs.pop("options", None) or {})
+        options["dist_sync"] = True if group is None else group
+        kwargs["options"] = options
+    return odeint(func, y0_shard, t, **kwargs)
+
+
+def odeint_adjoint_sharded(func, y0_shard, t, *, group=None, sync_steps=False, **kwargs):
     """`odeint_adjoint` on this rank's batch shard; parameter gradients (and dL/dt, if requested) come out
-    of `backward` already summed over the ranks of `group` (default group if None) by one all-reduce.
-    Gradients wrt y0 stay sharded.  With no initialised process group this is plain `odeint_adjoint`."""
+    of `backward` already summed over the ranks of `group` (default group if None).  Gradients wrt y0 stay
+    sharded.  With no initialised process group this is plain `odeint_adjoint`.
+
+    sync_steps=False (default): per-shard step controllers, ONE all-reduce of the parameter adjoints at the end of
+    `backward`.  sync_steps=True: lock step — forward as `odeint_sharded`; in the backward solve the time- and
+    parameter-VJPs are all-reduced at every evaluation (1 + P words), which makes every rank integrate the
+    whole-batch adjoint system with the whole-batch step sequence: gradients equal the single-device ones to
+    rounding, at the price of one small collective per evaluation and per trial step."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        adjoint_options = dict(kwargs.pop("adjoint_options", None) or
-                               {k: v for k, v in (kwargs.get("options") or {}).items() if k != "norm"})
-        adjoint_options["dist_group"] = True if group is None else group
+        g = True if group is None else group
+        inherited = {k: v for k, v in (kwargs.get("options") or {}).items() if k != "norm"}
+        adjoint_options = dict(kwargs.pop("adjoint_options", None) or inherited)
+        if sync_steps:
+            options = dict(kwargs.pop("options", None) or {})
+            options["dist_sync"] = g
+            kwargs["options"] = options
+            adjoint_options["dist_sync"] = g
+        else:
+            adjoint_options["dist_group"] = g
         kwargs["adjoint_options"] = adjoint_options
     return odeint_adjoint(func, y0_shard, t, **kwargs)

@@ -72,6 +72,41 @@ def optimal_step_size(last_step: float, error_ratio: float, safety: float, ifact
     return last_step * factor
 
 
+class _LockStep:
+    """Cross-rank reduction of the norm sums for a batch-sharded solve whose shards must take identical steps
+    (SURVEY.md §8e "exact mode").  One all-reduce of 3·n_seg doubles per norm evaluation; segments that hold
+    replicated data (the adjoint's time / parameter adjoints once they are all-reduced per evaluation) are counted
+    from rank 0 only.  Nothing of this exists in the reference."""
+
+    def __init__(self, group, replicated=()):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = None if group is True else group
+        self.replicated = sorted(set(int(i) for i in replicated))
+        self.rank = dist.get_rank(self.group)
+        backend = dist.get_backend(self.group)
+        self.on_device = backend == "nccl"      # RCCL reduces device buffers; gloo host buffers
+
+    def _allreduce(self, values: List[float], device) -> List[float]:
+        v = torch.tensor(values, dtype=torch.float64, device=device if self.on_device else "cpu")
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM, group=self.group)
+        return v.tolist()
+
+    def global_numels(self, numels: Sequence[int], device) -> List[int]:
+        mine = [0 if (i in self.replicated and self.rank != 0) else int(n) for i, n in enumerate(numels)]
+        return [int(round(x)) for x in self._allreduce([float(m) for m in mine], device)]
+
+    def reduce(self, s0, s1, bad, device):
+        n = len(s0)
+        if self.rank != 0:
+            s0, s1, bad = list(s0), list(s1), list(bad)
+            for i in self.replicated:
+                s0[i] = s1[i] = bad[i] = 0.0
+        # entries a launch did not write (second sum of a one-sum launch) may hold stale values: harmless, unused
+        out = self._allreduce(list(s0) + list(s1) + list(bad), device)
+        return out[:n], out[n:2 * n], out[2 * n:]
+
+
 class _DenseRecord:
     """Data of the last accepted step, kept for lazy dense output (rk_common.py:363-369)."""
     __slots__ = ("y0", "y1", "k", "dt_signed", "t0", "t1")
@@ -84,13 +119,18 @@ class RKAdaptiveStepsizeODESolver:
 
     def __init__(self, func: OdeFunc, y0: torch.Tensor, rtol, atol, min_step=0, max_step=float("inf"),
                  first_step=None, step_t=None, jump_t=None, safety=0.9, ifactor=10.0, dfactor=0.2,
-                 max_num_steps=2 ** 31 - 1, dtype=torch.float64, norm=None, **unused_kwargs):
+                 max_num_steps=2 ** 31 - 1, dtype=torch.float64, norm=None, dist_sync=None, dist_replicated=(),
+                 **unused_kwargs):
         handle_unused_kwargs(self, unused_kwargs)
         del unused_kwargs
         if not isinstance(func, OdeFunc):
             raise TypeError("solver classes of torchdiffeq_amd take the wrapped func built by check_inputs")
         self.func = func
         self.y0 = y0
+        # Lock-step mode of a batch-sharded solve (torchdiffeq_amd.dist): the per-segment error sums of all ranks
+        # are added (one small all-reduce per norm evaluation), so every shard takes the steps of the whole-batch
+        # solve.  `dist_replicated` = segments whose content is identical on every rank (counted once).
+        self._sync = _LockStep(dist_sync, dist_replicated) if dist_sync is not None else None
         self.layout: StateLayout = func.layout
         self.state_dtype = y0.dtype
         self.np_dtype = np.float32 if y0.dtype == torch.float32 else np.float64
@@ -111,6 +151,12 @@ class RKAdaptiveStepsizeODESolver:
         self.ops = Ops(self.kernels, self.np_dtype)      # elementwise kernels, differentiable when grad is needed
         self.plan = self.kernels.make_plan(self.layout.segments(rtol, atol), self.layout.total,
                                            self.layout.chunk, y0.device)
+        # element counts behind the per-segment sums (global counts in lock-step mode)
+        self._numels = list(self.plan.numels) if self._sync is None else self._sync.global_numels(self.plan.numels,
+                                                                                                  y0.device)
+        if self._sync is not None and not isinstance(self.norm, BuiltinNorm):
+            raise NotImplementedError("lock-step sharded solves need a builtin norm (a user norm callable reduces "
+                                      "only this rank's rows)")
         self._anchor = None        # t[0] (solver time) when `t` requires grad: every step time moves with it
         tab = self.tableau
         self._beta = tab.beta_rows()
@@ -137,7 +183,7 @@ class RKAdaptiveStepsizeODESolver:
         self._lookahead = (self._fuse is not None and isinstance(self.norm, BuiltinNorm)
                            and self.layout.n_seg <= _native.TDEQ_INLINE_SEGMENTS
                            and len(self._beta) <= _native.TDEQ_MAX_STAGE_TIMES and n_norm_seg >= 0
-                           and self.step_t is None and self.jump_t is None
+                           and self.step_t is None and self.jump_t is None and self._sync is None
                            and os.environ.get("TDEQ_LOOKAHEAD", "1") != "0")
         if self._lookahead:
             c = _native.StepCtrl()
@@ -164,7 +210,7 @@ class RKAdaptiveStepsizeODESolver:
     # -- norms -------------------------------------------------------------------------------------
     def _segment_norm(self, sumsq: Sequence[float], bad: Sequence[float]):
         """max over the selected segments of sqrt(mean), rounded to the state dtype (misc.py:22-33)."""
-        numels = self.plan.numels
+        numels = self._numels
         n = len(numels)
         if isinstance(self.norm, BuiltinNorm) and self.norm.n_skip_tail:
             n -= self.norm.n_skip_tail
@@ -175,6 +221,13 @@ class RKAdaptiveStepsizeODESolver:
             val = _nan_max(val, math.sqrt(sumsq[s] / numels[s]))
         with np.errstate(over="ignore"):
             return float(self.np_dtype(val))
+
+    def _read_norms(self):
+        """Results of the last norm launch; in lock-step mode summed over the ranks of the process group."""
+        s0, s1, bad = self.kernels.read_norms(self.plan)
+        if self._sync is not None:
+            s0, s1, bad = self._sync.reduce(s0, s1, bad, self.y0.device)
+        return s0, s1, bad
 
     def _time_tensor(self, value: float) -> torch.Tensor:
         return torch.tensor(value, dtype=torch.float64, device=self.y0.device)
@@ -277,7 +330,7 @@ class RKAdaptiveStepsizeODESolver:
             first_step = self.first_step
             # no initial-step heuristic -> still take the non-finite census of y0 (rk_common.py:287)
             self.kernels.init_norms(self.plan, 1, f0.detach(), f0.detach(), self.y0.detach())
-            _, _, bad = self.kernels.read_norms(self.plan)
+            _, _, bad = self._read_norms()
             self._y_nonfinite = any(b != 0 for b in bad)
         self.y1, self.f1 = self.y0, f0
         self.t0, self.t1, self.dt = t0, t0, first_step
@@ -300,7 +353,7 @@ class RKAdaptiveStepsizeODESolver:
         order = self.order - 1   # the reference passes `self.order - 1` (rk_common.py:217)
         y0, f0 = y0.detach(), f0.detach()        # the step-size heuristic is a constant of the backward pass
         kern.init_norms(plan, 0, y0, f0, y0)
-        s0, s1, bad = kern.read_norms(plan)
+        s0, s1, bad = self._read_norms()
         self._y_nonfinite = any(b != 0 for b in bad)
         d0 = T(self._segment_norm(s0, bad))
         d1 = T(self._segment_norm(s1, bad))
@@ -314,7 +367,7 @@ class RKAdaptiveStepsizeODESolver:
         with torch.no_grad():
             f1 = self.func.eval(t0 + float(h0), y1)
         kern.init_norms(plan, 1, f1, f0, y0)
-        s2, _, bad = kern.read_norms(plan)
+        s2, _, bad = self._read_norms()
         with np.errstate(all="ignore"):
             d2 = abs(T(self._segment_norm(s2, bad)) / h0)
             if d1 <= 1e-15 and d2 <= 1e-15:
@@ -449,12 +502,12 @@ class RKAdaptiveStepsizeODESolver:
         elif err_partial is not None:
             kern.error_norm_partial(self.plan, err_partial, y0, y1, [k[j] for j in self._fuse[1]], self._fuse[2],
                                     dt_signed)
-            sumsq, _, bad = kern.read_norms(self.plan)
+            sumsq, _, bad = self._read_norms()
             error_ratio = self._segment_norm(sumsq, bad)
             y1_nonfinite = any(b != 0 for b in bad)
         elif builtin_norm:
             kern.error_norm(self.plan, y0, y1, [k[j] for j in err.idx], err.coef, dt_signed)
-            sumsq, _, bad = kern.read_norms(self.plan)
+            sumsq, _, bad = self._read_norms()
             error_ratio = self._segment_norm(sumsq, bad)
             y1_nonfinite = any(b != 0 for b in bad)
         else:
@@ -559,6 +612,8 @@ class FixedGridODESolver(object):
         self.atol = unused_kwargs.pop("atol")
         unused_kwargs.pop("rtol", None)
         unused_kwargs.pop("norm", None)
+        unused_kwargs.pop("dist_sync", None)          # fixed grids are in lock step by construction
+        unused_kwargs.pop("dist_replicated", None)
         handle_unused_kwargs(self, unused_kwargs)
         del unused_kwargs
         if not isinstance(func, OdeFunc):
