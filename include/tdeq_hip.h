@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 6
+#define TDEQ_ABI_VERSION 7
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -96,6 +96,16 @@ size_t tdeq_workspace_bytes(int64_t n_chunks);
  */
 int tdeq_stage_combine(void* out, const void* y0, const void* const* k, const double* coef,
                        int n_terms, double dt, int64_t n, int dtype, void* stream);
+
+/*
+ * Measurement hook: tdeq_stage_combine whose launch updates two caller-created hipEvent_t (enable-timing) with the
+ * dispatch's own begin and end timestamps (hipExtLaunchKernelGGL), so that hipEventElapsedTime(start, stop) is the
+ * kernel's duration as a profiler reports it — not the event -> launch -> event bracket, which adds ≈3 µs of
+ * marker cost.  Same kernel, same results; 16-byte aligned buffers only (others take the plain launch and leave the
+ * events untouched).  Used by bench.py for the live roofline figure of the dominant kernel.
+ */
+int tdeq_stage_combine_timed(void* out, const void* y0, const void* const* k, const double* coef, int n_terms,
+                             double dt, int64_t n, int dtype, void* stream, void* start_event, void* stop_event);
 
 /*
  * tdeq_stage_combine for the FIRST stage of a step (n_terms 1 or 2, n >= 1) that also stores `n_fill` (<= 16)

@@ -362,3 +362,31 @@ def test_fused_end_of_step_pair(hip_kernels, oracle_kernels, dtype, n, tab):
         oracle_kernels.error_norm_partial(pc, ep_ref, y0, y1, [ks[j] for j in rest_idx], rest_coef, dt)
         ref, _, _ = oracle_kernels.read_norms(pc)
         assert fused[0] == pytest.approx(ref[0], rel=1e-12)
+
+
+def test_stage_combine_timed_same_result_and_plausible_time(hip_kernels):
+    """Measurement hook: identical output to stage_combine; the dispatch-stamped events give a duration between the
+    HBM-roofline time of the launch and the event -> launch -> event bracket around the same kernel."""
+    n = 1 << 22
+    row = DOPRI5.beta_rows()[4]
+    y0 = _rand(n, torch.float32, 1).cuda()
+    ks = _dev([_rand(n, torch.float32, 10 + j) for j in range(7)])
+    sel = [ks[j] for j in row.idx]
+    ref, out = torch.empty_like(y0), torch.empty_like(y0)
+    hip_kernels.stage_combine(ref, y0, sel, row.coef, 0.1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    e1.record()
+    for _ in range(3):
+        hip_kernels.stage_combine_timed(out, y0, sel, row.coef, 0.1, e0, e1)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    ms = e0.elapsed_time(e1)
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0.record()
+    hip_kernels.stage_combine(out, y0, sel, row.coef, 0.1)
+    b1.record()
+    torch.cuda.synchronize()
+    bracket = b0.elapsed_time(b1)
+    floor_ms = (len(sel) + 2) * n * 4 / 8.0e12 * 1e3          # algorithmic bytes at the 8 TB/s peak
+    assert floor_ms < ms <= bracket * 1.05, (floor_ms, ms, bracket)

@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 6
+TDEQ_ABI_VERSION = 7
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -50,6 +50,9 @@ ABI_SIGNATURES = {
     "tdeq_stage_combine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
                                           ctypes.c_int, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_void_p]),
+    "tdeq_stage_combine_timed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
+                                                ctypes.c_int, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tdeq_stage_combine_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
                                                ctypes.c_int, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
                                                ctypes.c_void_p, _c_double_p, ctypes.c_int, ctypes.c_void_p]),
@@ -246,6 +249,15 @@ class HipKernels:
         ptrs, cf, n = self._terms(ks, coefs)
         _check(self.lib.tdeq_stage_combine(out.data_ptr(), y0.data_ptr(), ptrs, cf, n, dt, y0.numel(),
                                            dtype_code(y0.dtype), self._stream()), "tdeq_stage_combine")
+
+    def stage_combine_timed(self, out, y0, ks, coefs, dt: float, start_event, stop_event) -> None:
+        """`stage_combine` whose dispatch stamps two torch.cuda.Event(enable_timing=True) objects with its own begin /
+        end times (measurement hook, see include/tdeq_hip.h).  The events must have been recorded once before (torch
+        creates the underlying hipEvent_t lazily)."""
+        ptrs, cf, n = self._terms(ks, coefs)
+        _check(self.lib.tdeq_stage_combine_timed(out.data_ptr(), y0.data_ptr(), ptrs, cf, n, dt, y0.numel(),
+                                                 dtype_code(y0.dtype), self._stream(), start_event.cuda_event,
+                                                 stop_event.cuda_event), "tdeq_stage_combine_timed")
 
     def stage_combine_fill(self, out, y0, ks, coefs, dt: float, fill_dst, fill_vals) -> None:
         """stage_combine of a step's first stage that also writes `fill_vals` (stage times) into `fill_dst`."""

@@ -1,6 +1,7 @@
 // tdeq_abi.hip — extern "C" entry points of libtdeq_hip.so (declared in include/tdeq_hip.h).
 // Host-side validation + template dispatch + launch; no allocation, no synchronisation, no globals.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 
@@ -44,7 +45,7 @@ inline int combine_policy() {
 // ---- stage_combine --------------------------------------------------------------------------------
 template <typename T, int NT>
 int launch_combine(void* out, const void* y0, const void* const* k, const double* coef, double dt,
-                   int64_t n, hipStream_t s) {
+                   int64_t n, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     CombineArgs<T, NT> a;
     a.out = static_cast<T*>(out);
     a.y0 = static_cast<const T*>(y0);
@@ -58,7 +59,11 @@ int launch_combine(void* out, const void* y0, const void* const* k, const double
     a.n = n;
     constexpr int L = VecOf<T>::L;
     constexpr int U = 1;
-    if (vec) {
+    if (vec && ev_start && ev_stop) {
+        // measurement hook (tdeq_stage_combine_timed): the events carry the dispatch's own begin / end timestamps
+        const unsigned g = stream_grid(n / L, kBlock * U);
+        hipExtLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 0>), dim3(g), dim3(kBlock), 0, s, ev_start, ev_stop, 0, a);
+    } else if (vec) {
         const unsigned g = stream_grid(n / L, kBlock * U);
         switch (combine_policy()) {   // tuning knob, see combine_policy()
             case 1: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 1>), dim3(g), dim3(kBlock), 0, s, a); break;
@@ -133,9 +138,9 @@ int dispatch_combine_err(void* out, void* err_out, const void* y0, const void* c
 
 template <typename T>
 int dispatch_combine(void* out, const void* y0, const void* const* k, const double* coef, int nt,
-                     double dt, int64_t n, hipStream_t s) {
+                     double dt, int64_t n, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     switch (nt) {
-#define TDEQ_CASE(N) case N: return launch_combine<T, N>(out, y0, k, coef, dt, n, s);
+#define TDEQ_CASE(N) case N: return launch_combine<T, N>(out, y0, k, coef, dt, n, s, e0, e1);
         TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
         TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
 #undef TDEQ_CASE
@@ -560,6 +565,17 @@ int tdeq_stage_combine(void* out, const void* y0, const void* const* k, const do
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == TDEQ_F32 ? dispatch_combine<float>(out, y0, k, coef, n_terms, dt, n, s)
                              : dispatch_combine<double>(out, y0, k, coef, n_terms, dt, n, s);
+}
+
+int tdeq_stage_combine_timed(void* out, const void* y0, const void* const* k, const double* coef, int n_terms,
+                             double dt, int64_t n, int dtype, void* stream, void* start_event, void* stop_event) {
+    if (!out || !y0 || !k || !coef || n < 1 || bad_dtype(dtype) || !start_event || !stop_event) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t e0 = static_cast<hipEvent_t>(start_event), e1 = static_cast<hipEvent_t>(stop_event);
+    return dtype == TDEQ_F32 ? dispatch_combine<float>(out, y0, k, coef, n_terms, dt, n, s, e0, e1)
+                             : dispatch_combine<double>(out, y0, k, coef, n_terms, dt, n, s, e0, e1);
 }
 
 int tdeq_stage_combine_fill(void* out, const void* y0, const void* const* k, const double* coef, int n_terms,
