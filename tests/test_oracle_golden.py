@@ -149,6 +149,50 @@ def test_step_controller_matches_reference():
             assert got == pytest.approx(float(ref), rel=1e-15), args
 
 
+def test_oracle_device_controller_matches_reference(oracle_kernels):
+    """oracle_step_controller (the CPU twin of tdeq_error_norm_partial_ctrl's controller) against the reference's
+    `_optimal_step_size` vectors: one segment of one element whose sum of squares is ratio^2, so the controller's
+    sqrt(mean) is the golden error ratio (an fp32 tensor in the reference -> T = fp32 here).  Also the accept rule
+    (rk_common.py:324-330) and the next trial's times (rk_common.py:268-275, 72-78)."""
+    import ctypes
+    from torchdiffeq_amd import _native
+    from torchdiffeq_amd.tableaus import DOPRI5
+    z = load("controller.npz")
+    plan = oracle_kernels.make_plan([(0, 1, 1e-6, 1e-8)], 1, 1024, None)
+    for args, ref in zip(z["optimal_step_in"], z["optimal_step_out"]):
+        last, ratio, safety, ifactor, dfactor, order = args
+        ratio32 = float(np.float32(ratio))
+        c = _native.StepCtrl()
+        c.t0, c.dt, c.safety, c.ifactor, c.dfactor, c.exponent = 0.25, float(last), safety, ifactor, dfactor, 1.0 / order
+        c.min_step, c.max_step, c.time_sign = 0.0, math.inf, 1.0
+        mask = 0
+        for i, a in enumerate(DOPRI5.alpha):
+            c.alpha[i] = float(np.float32(a))
+            mask |= (1 << i) if a == 1.0 else 0
+        c.alpha_is_one, c.n_times, c.n_norm_seg = mask, len(DOPRI5.alpha), 1
+        tn = torch.empty(6, dtype=torch.float32)
+        sumsq = ratio32 * ratio32 if math.isfinite(ratio32) else ratio32
+        out_ctrl, ctrl_dev = oracle_kernels.step_controller(plan, [sumsq], c, tn, torch.float32)
+        accept, dt_next, got_ratio, t0n = out_ctrl
+        if math.isnan(ref):
+            assert math.isnan(dt_next), args
+        else:
+            assert dt_next == pytest.approx(float(ref), rel=1e-15), args
+        if math.isfinite(ratio32):
+            assert got_ratio == ratio32
+        assert bool(accept) == (ratio32 <= 1.0)
+        assert t0n == (0.25 + float(last) if accept else 0.25)
+        assert ctrl_dev[0] == accept
+        if math.isfinite(dt_next):
+            # next trial: T(t0') + alpha_i * T(dt') in fp32; alpha == 1 -> nextafter(T(t0' + dt'), below)
+            t0T, dtT = np.float32(t0n), np.float32(dt_next)
+            t1T = np.float32(t0n + dt_next)
+            want = [np.nextafter(t1T, t1T - np.float32(1)) if a == 1.0 else t0T + np.float32(a) * dtT
+                    for a in DOPRI5.alpha]
+            assert tn.numpy().tolist() == [float(w) for w in want], args
+            assert ctrl_dev[1] == float(dtT)
+
+
 @pytest.mark.parametrize("dname", ["f32", "f64"])
 def test_initial_step_matches_reference(dname):
     z = load("controller.npz")
