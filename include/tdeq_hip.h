@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 7
+#define TDEQ_ABI_VERSION 8
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -272,6 +272,18 @@ int tdeq_scale_many(void* const* outs, const void* g, const double* w, int n_out
 size_t tdeq_dots_workspace_bytes(int64_t n, int n_x);
 int tdeq_multi_dot(const void* g, const void* const* x, int n_x, int64_t n, double* out, void* workspace,
                    size_t workspace_bytes, int dtype, void* stream);
+
+/*
+ * Pack the pieces of a tuple-valued func output into ONE flat segmented state with one launch:
+ *   out[chunk_start[s]*chunk + i] = scale[s] * src[s][i]   for i < numel[s];   padding and src[s] == NULL -> 0
+ * over n_chunks*chunk elements of `out`.  Replaces `torch.cat([f_.reshape(-1) for f_ in f])` of _TupleFunc
+ * (misc.py:137-145) and, for the adjoint's augmented dynamics (adjoint.py:72-105), also the `-adj_y` negation (:95),
+ * the zeros_like of absent gradients (:99-103) and _ReverseFunc's multiply (misc.py:158-165): scale[s] is +1 or -1,
+ * so every product is exact.  src[s]: contiguous, element type T, numel[s] elements.  1 <= n_seg <=
+ * TDEQ_INLINE_SEGMENTS, chunk_start[0] == 0 and strictly increasing, numel[s] <= room of segment s.
+ */
+int tdeq_pack_segments(void* out, const void* const* src, const int64_t* chunk_start, const int64_t* numel,
+                       const double* scale, int n_seg, int64_t chunk, int64_t n_chunks, int dtype, void* stream);
 
 /* Writes n_vals scalars (converted to T) to consecutive elements of dst (stage times for func). */
 int tdeq_fill_scalars(void* dst, const double* vals, int n_vals, int dtype, void* stream);

@@ -61,6 +61,8 @@ def load() -> ctypes.CDLL:
                                            V, V, V, V, V, V, I],
         "oracle_step_controller": [ctypes.POINTER(Segment), I, V, V, V, V, V, I],
         "oracle_stage_combine_sel": [V, V, V, V, V, D, V, I64, I],
+        "oracle_pack_segments": [V, _c_void_pp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                 _c_double_p, I, I64, I64, I],
         "oracle_scale_many": [_c_void_pp, V, _c_double_p, I, I64, I],
         "oracle_multi_dot": [V, _c_void_pp, I, I64, V, I],
     }
@@ -230,6 +232,15 @@ class OracleKernels:
         _ok(self.lib.oracle_multi_dot(g.data_ptr(), ptrs, n, g.numel(), out.data_ptr(), _code(g.dtype)),
             "oracle_multi_dot")
         return out
+
+    def pack_segments(self, out, srcs, chunk_starts, numels, scales, chunk):
+        n = len(srcs)
+        ptrs = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in srcs])
+        cs = (ctypes.c_int64 * n)(*chunk_starts)
+        nm = (ctypes.c_int64 * n)(*numels)
+        sc = (ctypes.c_double * n)(*scales)
+        _ok(self.lib.oracle_pack_segments(out.data_ptr(), ptrs, cs, nm, sc, n, chunk, out.numel() // chunk,
+                                          _code(out.dtype)), "oracle_pack_segments")
 
     def fill_scalars(self, dst, vals):
         """Host twin of tdeq_fill_scalars: vals converted to dst's dtype."""

@@ -607,3 +607,24 @@ int oracle_stage_combine_sel(void* out, const void* y_acc, const void* f_acc, co
     const void* ks[1] = {f};
     return oracle_stage_combine(out, y, ks, &coef, 1, ctrl_dev[1], n, dtype);
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * Flat segmented state from the pieces of a tuple-valued func output (CPU twin of tdeq_pack_segments):
+ * torch.cat of the pieces (misc.py:137-145); for the adjoint's augmented dynamics also `-adj_y`
+ * (adjoint.py:95), zeros for absent gradients (adjoint.py:99-103) and _ReverseFunc's sign (misc.py:158-165).
+ * ------------------------------------------------------------------------------------------------- */
+int oracle_pack_segments(void* out, const void* const* src, const int64_t* chunk_start, const int64_t* numel,
+                         const double* scale, int n_seg, int64_t chunk, int64_t n_chunks, int dtype) {
+    if (!out || !src || !chunk_start || !numel || !scale || n_seg < 1 || n_seg > 16) return -1;
+    for (int s = 0; s < n_seg; ++s) {
+        const int64_t begin = chunk_start[s] * chunk;
+        const int64_t end = ((s + 1 < n_seg) ? chunk_start[s + 1] : n_chunks) * chunk;
+        for (int64_t i = begin; i < end; ++i) {
+            const int64_t t = i - begin;
+            const int live = src[s] && t < numel[s];
+            if (dtype == ORACLE_F32) ((float*)out)[i] = live ? ((const float*)src[s])[t] * (float)scale[s] : 0.0f;
+            else ((double*)out)[i] = live ? ((const double*)src[s])[t] * scale[s] : 0.0;
+        }
+    }
+    return 0;
+}

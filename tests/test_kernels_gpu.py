@@ -390,3 +390,46 @@ def test_stage_combine_timed_same_result_and_plausible_time(hip_kernels):
     bracket = b0.elapsed_time(b1)
     floor_ms = (len(sel) + 2) * n * 4 / 8.0e12 * 1e3          # algorithmic bytes at the 8 TB/s peak
     assert floor_ms < ms <= bracket * 1.05, (floor_ms, ms, bracket)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("chunk", [1024, 2048])
+def test_pack_segments_bit_exact(hip_kernels, oracle_kernels, dtype, chunk):
+    """tdeq_pack_segments vs the oracle and vs the torch ops it replaces (cat / neg / zeros): segments of ragged
+    sizes (1 element, sub-chunk, multi-chunk, empty, missing), +-1 scales, unaligned source views, zeroed padding."""
+    numels = [1, 5, chunk, 3 * chunk + 17, 0, 700, 2 * chunk]
+    scales = [-1.0, 1.0, -1.0, 1.0, 1.0, -1.0, 1.0]
+    g = torch.Generator().manual_seed(5)
+    srcs = []
+    for i, m in enumerate(numels):
+        if i == 5:
+            srcs.append(None)                                   # absent gradient -> zeros
+        elif i == 3:
+            srcs.append(torch.randn(m + 1, generator=g, dtype=torch.float64).to(dtype)[1:])   # odd offset: scalar path
+        else:
+            srcs.append(torch.randn(m, generator=g, dtype=torch.float64).to(dtype))
+    starts, off = [], 0
+    for m in numels:
+        starts.append(off // chunk)
+        off += max(1, math.ceil(m / chunk)) * chunk
+    ref = torch.full((off,), float("nan"), dtype=dtype)
+    oracle_kernels.pack_segments(ref, [None if t is None else t.contiguous() for t in srcs], starts, numels, scales, chunk)
+    # the torch ops being replaced
+    want = torch.zeros(off, dtype=dtype)
+    for t, st, m, sc in zip(srcs, starts, numels, scales):
+        if t is not None and m:
+            want[st * chunk:st * chunk + m] = t * sc
+    assert torch.equal(ref, want)
+    dev_srcs = []
+    for t in srcs:
+        if t is None:
+            dev_srcs.append(None)
+        elif t.storage_offset():
+            buf = torch.empty(t.numel() + 1, dtype=dtype, device="cuda")
+            buf[1:].copy_(t)
+            dev_srcs.append(buf[1:])
+        else:
+            dev_srcs.append(t.cuda())
+    out = torch.full((off,), float("nan"), dtype=dtype, device="cuda")
+    hip_kernels.pack_segments(out, dev_srcs, starts, numels, scales, chunk)
+    assert torch.equal(out.cpu(), ref)

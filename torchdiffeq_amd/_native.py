@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 7
+TDEQ_ABI_VERSION = 8
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -105,6 +105,9 @@ ABI_SIGNATURES = {
     "tdeq_dots_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
     "tdeq_multi_dot": (ctypes.c_int, [ctypes.c_void_p, _c_void_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_pack_segments": (ctypes.c_int, [ctypes.c_void_p, _c_void_pp, ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(ctypes.c_int64), _c_double_p, ctypes.c_int, ctypes.c_int64,
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_fill_scalars": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p]),
 }
@@ -415,6 +418,18 @@ class HipKernels:
         _check(self.lib.tdeq_multi_dot(g.data_ptr(), ptrs, n, g.numel(), out.data_ptr(), ws.data_ptr(), nbytes,
                                        dtype_code(g.dtype), self._stream()), "tdeq_multi_dot")
         return out
+
+    def pack_segments(self, out, srcs, chunk_starts: Sequence[int], numels: Sequence[int], scales: Sequence[float],
+                      chunk: int) -> None:
+        """out (a whole number of chunks) <- the pieces `srcs` (contiguous tensors of out's dtype, or None = zeros) at
+        their chunk-aligned segment starts, times +-1; padding zero-filled.  One launch (tdeq_pack_segments)."""
+        n = len(srcs)
+        ptrs = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in srcs])
+        cs = (ctypes.c_int64 * n)(*chunk_starts)
+        nm = (ctypes.c_int64 * n)(*numels)
+        sc = (ctypes.c_double * n)(*scales)
+        _check(self.lib.tdeq_pack_segments(out.data_ptr(), ptrs, cs, nm, sc, n, chunk, out.numel() // chunk,
+                                           dtype_code(out.dtype), self._stream()), "tdeq_pack_segments")
 
     def fill_scalars(self, dst, vals: Sequence[float]) -> None:
         n = len(vals)

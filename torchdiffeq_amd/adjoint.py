@@ -69,26 +69,15 @@ class _AugmentedDynamics(OdeFunc):
             g_t = None
         g_y, g_p = grads[:n_y], grads[n_y:]
 
-        out = torch.empty(lay.total, dtype=self.dtype, device=self.device)
-        o = lay.unpack(out)
+        # one launch assembles [ -vjp_t | f | -vjp_y | -vjp_θ ] (signs for an ascending forward solve; absent
+        # gradients are zeros) in the flat segmented buffer: tdeq_pack_segments
         neg_adj = sign_f == 1.0      # -(J^T a) for an ascending forward solve, +(J^T a) otherwise
-        if g_t is None:
-            o[0].zero_()
-        else:
-            torch.neg(g_t.detach().to(self.dtype), out=o[0])
-        for dst, src in zip(o[1:1 + n_y], f_list):
-            src = src.detach()
-            if sign_f == 1.0:
-                dst.copy_(src)
-            else:
-                torch.neg(src.to(self.dtype), out=dst)
-        for dst, src in zip(o[1 + n_y:], tuple(g_y) + tuple(g_p)):
-            if src is None:
-                dst.zero_()
-            elif neg_adj:
-                torch.neg(src.to(self.dtype), out=dst)
-            else:
-                dst.copy_(src)
+        s_f = 1.0 if sign_f == 1.0 else -1.0
+        s_a = -1.0 if neg_adj else 1.0
+        pieces = [g_t] + f_list + list(g_y) + list(g_p)
+        scales = [-1.0] + [s_f] * n_y + [s_a] * (len(g_y) + len(g_p))
+        out = lay.pack_fused(self.kernels(), pieces, self.dtype, self.device, scales)
+        o = lay.unpack(out)
         if self.sync:
             # lock-step mode: the time- and parameter-VJPs are sums over the batch, i.e. over the shards — add them
             # up now (one all-reduce of 1 + P words) so that these segments of the state are replicated, exactly

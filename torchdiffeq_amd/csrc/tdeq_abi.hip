@@ -543,6 +543,21 @@ int dispatch_dots(const void* g, const void* const* x, int nt, int64_t n, double
     return TDEQ_EINVAL;
 }
 
+template <typename T>
+int launch_pack(void* out, const void* const* src, const int64_t* chunk_start, const int64_t* numel,
+                const double* scale, int n_seg, int64_t chunk, int64_t n_chunks, hipStream_t s) {
+    PackArgs<T> a;
+    a.out = static_cast<T*>(out);
+    for (int q = 0; q < TDEQ_INLINE_SEGMENTS; ++q) {
+        if (q < n_seg) a.seg[q] = PackSeg{src[q], chunk_start[q], numel[q], scale[q], aligned16(src[q]) ? 1 : 0};
+        else a.seg[q] = PackSeg{nullptr, 0, 0, 0.0, 0};
+    }
+    a.n_seg = n_seg;
+    a.chunk = chunk;
+    hipLaunchKernelGGL((pack_segments_kernel<T>), dim3((unsigned)n_chunks), dim3(kBlock), 0, s, a);
+    return check_launch();
+}
+
 inline bool bad_dtype(int dtype) { return dtype != TDEQ_F32 && dtype != TDEQ_F64; }
 
 }  // namespace
@@ -790,6 +805,24 @@ int tdeq_multi_dot(const void* g, const void* const* x, int n_x, int64_t n, doub
     double* ws = static_cast<double*>(workspace);
     return dtype == TDEQ_F32 ? dispatch_dots<float>(g, x, n_x, n, out, ws, s)
                              : dispatch_dots<double>(g, x, n_x, n, out, ws, s);
+}
+
+int tdeq_pack_segments(void* out, const void* const* src, const int64_t* chunk_start, const int64_t* numel,
+                       const double* scale, int n_seg, int64_t chunk, int64_t n_chunks, int dtype, void* stream) {
+    if (!out || !src || !chunk_start || !numel || !scale || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_seg < 1 || n_seg > TDEQ_INLINE_SEGMENTS) return TDEQ_EINVAL;
+    if (chunk < TDEQ_CHUNK_QUANTUM || chunk % TDEQ_CHUNK_QUANTUM != 0 || n_chunks < 1 || n_chunks > 0x7fffffffLL)
+        return TDEQ_EINVAL;
+    if (chunk_start[0] != 0) return TDEQ_EINVAL;
+    for (int q = 0; q < n_seg; ++q) {
+        if (numel[q] < 0 || (q > 0 && chunk_start[q] <= chunk_start[q - 1]) || chunk_start[q] >= n_chunks) return TDEQ_EINVAL;
+        const int64_t end = (q + 1 < n_seg) ? chunk_start[q + 1] : n_chunks;
+        if (q + 1 < n_seg && chunk_start[q + 1] <= chunk_start[q]) return TDEQ_EINVAL;
+        if (numel[q] > (end - chunk_start[q]) * chunk) return TDEQ_EINVAL;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? launch_pack<float>(out, src, chunk_start, numel, scale, n_seg, chunk, n_chunks, s)
+                             : launch_pack<double>(out, src, chunk_start, numel, scale, n_seg, chunk, n_chunks, s);
 }
 
 int tdeq_fill_scalars(void* dst, const double* vals, int n_vals, int dtype, void* stream) {

@@ -972,6 +972,56 @@ __global__ __launch_bounds__(kBlock) void lerp_kernel(const LerpArgs<T> a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Segment packing: the outputs of a tuple-valued func — and of the adjoint's augmented dynamics
+// (vjp_t, f, vjp_y, vjp_θ...) — go into ONE flat chunk-aligned buffer with ONE launch:
+//   out[chunk_start_s*chunk + i] = scale_s * src_s[i]   (i < numel_s) ;  padding and missing sources -> 0
+// replacing the reference's torch.cat of the pieces (misc.py:145), the `-adj_y` negation (adjoint.py:95),
+// the zeros_like for absent gradients (adjoint.py:99-103) and _ReverseFunc's multiply (misc.py:165);
+// scale_s is +1 or -1, so the products are exact.  One workgroup per chunk.
+// ------------------------------------------------------------------------------------------------
+struct PackSeg {
+    const void* src;       // may be null: the segment is zero-filled
+    int64_t chunk_start;
+    int64_t numel;
+    double scale;
+    int vec_ok;            // src is 16-byte aligned
+};
+
+template <typename T>
+struct PackArgs {
+    T* out;
+    PackSeg seg[TDEQ_INLINE_SEGMENTS];
+    int n_seg;
+    int64_t chunk;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pack_segments_kernel(const PackArgs<T> a) {
+    using V = typename VecOf<T>::type;
+    constexpr int L = VecOf<T>::L;
+    const int64_t b = blockIdx.x;
+    int s = 0;
+    for (int q = 1; q < a.n_seg; ++q) s = (a.seg[q].chunk_start <= b) ? q : s;
+    const PackSeg seg = a.seg[s];
+    const int64_t local0 = (b - seg.chunk_start) * a.chunk;
+    int64_t valid = seg.numel - local0;
+    valid = valid < 0 ? 0 : (valid > a.chunk ? a.chunk : valid);
+    if (!seg.src) valid = 0;
+    T* __restrict__ out = a.out + b * a.chunk;
+    const T* __restrict__ src = static_cast<const T*>(seg.src) + local0;
+    const T sc = (T)seg.scale;
+    int64_t done = 0;
+    if (seg.vec_ok) {          // local0 is a multiple of the chunk (>= 1024 elements): src + local0 stays aligned
+        const int64_t nv = valid / L;
+        for (int64_t i = threadIdx.x; i < nv; i += kBlock)
+            reinterpret_cast<V*>(out)[i] = reinterpret_cast<const V*>(src)[i] * sc;
+        done = nv * L;
+    }
+    for (int64_t t = done + threadIdx.x; t < valid; t += kBlock) out[t] = src[t] * sc;
+    for (int64_t t = valid + threadIdx.x; t < a.chunk; t += kBlock) out[t] = (T)0;
+}
+
 struct FillArgs {
     void* dst;
     double v[16];

@@ -13,6 +13,7 @@ organised for the HIP path instead of a stack of `nn.Module` wrappers:
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from enum import Enum
 from typing import Callable, List, Optional, Sequence, Tuple
@@ -114,6 +115,34 @@ class StateLayout:
                 dst.copy_(src)
         return flat
 
+    def pack_fused(self, kernels, pieces: Sequence[Optional[torch.Tensor]], dtype, device,
+                   scales: Optional[Sequence[float]] = None) -> torch.Tensor:
+        """`pack` as ONE kernel launch (tdeq_pack_segments): piece s (None = zeros) times scales[s] (+-1) into
+        segment s of a fresh flat buffer, padding zero-filled.  Falls back to `pack` for layouts the kernel does not
+        take (a single unpadded segment, more than TDEQ_INLINE_SEGMENTS segments)."""
+        n = self.n_seg
+        if n == 1 or n > _native.TDEQ_INLINE_SEGMENTS or os.environ.get("TDEQ_PACK_FUSED", "1") == "0":
+            neg = [sc < 0 for sc in scales] if scales is not None else ()
+            filled = [torch.zeros(m, dtype=dtype, device=device) if t is None else t
+                      for t, m in zip(pieces, self.numels)]
+            return self.pack(filled, dtype=dtype, negate=neg if any(neg) else ())
+        srcs = []
+        for t, m in zip(pieces, self.numels):
+            if t is None or m == 0:
+                srcs.append(None)
+                continue
+            t = t.detach()
+            if t.dtype != dtype:
+                t = t.to(dtype)
+            t = t.reshape(-1)
+            if t.numel() != m:
+                raise RuntimeError(f"func returned a component with {t.numel()} elements where the state has {m}")
+            srcs.append(t if t.is_contiguous() else t.contiguous())
+        out = torch.empty(self.total, dtype=dtype, device=device)
+        kernels.pack_segments(out, srcs, [off // self.chunk for off in self.offsets], self.numels,
+                              [1.0] * n if scales is None else list(scales), self.chunk)
+        return out
+
     def unpack(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Tuple[torch.Tensor, ...]:
         """Views of the components of `flat[..., total]` shaped (*lead, *shape)."""
         return tuple(flat[..., off:off + n].view((*lead, *shape))
@@ -181,9 +210,16 @@ class OdeFunc:
         self.device = device
         self.np_dtype = np.float32 if dtype == torch.float32 else np.float64
         self.nfe = 0
+        self._kernels = None
         self._anchor_user = None     # user-time t[0] when `t` requires grad (adaptive solvers)
         for name in ALL_CALLBACK_NAMES:
             setattr(self, name, _null_callback)
+
+    def kernels(self):
+        """The HIP kernel interface of the state's device (created on first use)."""
+        if self._kernels is None:
+            self._kernels = _native.get_kernels(self.device)
+        return self._kernels
 
     def set_time_anchor(self, anchor) -> None:
         """`anchor` = t[0] in solver time (a 0-dim tensor in the autograd graph of `t`) or None.  Every time the
@@ -239,7 +275,7 @@ class OdeFunc:
             if grad and any(f_.requires_grad for f_ in f):
                 out = pack_differentiable(lay, f, self.dtype)     # backprop through the solver
             else:
-                out = lay.pack(tuple(f_.detach() for f_ in f), dtype=self.dtype)
+                out = lay.pack_fused(self.kernels(), f, self.dtype, self.device)
         else:
             f = self.base_func(t_user, y_flat.view(lay.shapes[0]))
             if f.dtype != self.dtype:
