@@ -126,3 +126,57 @@ def test_cfg3_shape_adjoint_matches_backprop_through_unrolled_rk4():
     assert rel_err(g_adj_y, y0.grad) < 1e-6
     for a, p in zip(g_adj_p, f.parameters()):
         assert rel_err(a, p.grad) < 1e-6
+
+
+def test_kernels_beyond_2_31_elements(hip_kernels):
+    """One state tensor of 2^31 + 2^20 + 3 fp32 elements (8.6 GB; the MI355X holds 288 GB): 64-bit indexing of the
+    streaming kernels (grid-stride beyond 65,536 workgroups) and of the norm kernels (> 2^20 reduction chunks).
+    Checked on windows at the start, across the 2^31 boundary and at the unaligned tail against the same rounding
+    sequence in torch; the error sums against an fp64 torch reduction; a planted inf is counted once."""
+    import numpy as np
+    from torchdiffeq_amd import _native
+    free, _ = torch.cuda.mem_get_info()
+    n = (1 << 31) + (1 << 20) + 3
+    if free < 7 * n * 4:
+        pytest.skip("not enough free HBM for the 2^31-element case")
+    dev = torch.device("cuda:0")
+
+    def ramp(scale, shift):          # cheap deterministic data, different at every index window
+        x = torch.arange(n, device=dev, dtype=torch.int64)
+        return (((x * 2654435761 + shift) % 1000003).to(torch.float32) / 1000003.0 - 0.5) * scale
+
+    y0, k0, k1 = ramp(2.0, 1), ramp(1.0, 7), ramp(3.0, 13)
+    out = torch.empty(n, device=dev)
+    dt, coefs = 0.0371, [0.3, -1.7]
+    hip_kernels.stage_combine(out, y0, [k0, k1], coefs, dt)
+    c = [np.float32(np.float32(cf) * np.float32(dt)) for cf in coefs]
+    windows = [slice(0, 4096), slice((1 << 31) - 2048, (1 << 31) + 2048), slice(n - 4099, n)]
+    for w in windows:
+        ref = y0[w] + (k0[w] * float(c[0]) + k1[w] * float(c[1]))
+        assert torch.equal(out[w], ref), w
+    # fused end-of-step pair + norm over > 2^20 chunks
+    y1, epart = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    hip_kernels.stage_combine_err(y1, epart, y0, [k0, k1], coefs, [1e-3, -2e-3], dt)
+    for w in windows:
+        assert torch.equal(y1[w], out[w])
+    del out
+    chunk = _native.pick_chunk(n)
+    plan = hip_kernels.make_plan([(0, n, 1e-5, 1e-7)], n, chunk, dev)
+    assert plan.n_chunks > (1 << 20)
+    hip_kernels.error_norm_partial(plan, epart, y0, y1, [k0], [5e-4], dt)
+    sumsq, _, bad = hip_kernels.read_norms(plan)
+    assert bad == [0.0]
+    ce = np.float32(np.float32(5e-4) * np.float32(dt))
+    total = 0.0
+    step = 1 << 27
+    for lo in range(0, n, step):
+        w = slice(lo, min(lo + step, n))
+        e = epart[w] + k0[w] * float(ce)
+        tol = 1e-7 + 1e-5 * torch.maximum(y0[w].abs(), y1[w].abs())
+        r = e / tol.to(torch.float32)
+        total += float((r.double() ** 2).sum())
+    assert sumsq[0] == pytest.approx(total, rel=1e-6)
+    y1[(1 << 31) + 5] = float("inf")
+    hip_kernels.error_norm_partial(plan, epart, y0, y1, [k0], [5e-4], dt)
+    _, _, bad = hip_kernels.read_norms(plan)
+    assert bad == [1.0]
