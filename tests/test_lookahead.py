@@ -251,3 +251,23 @@ def test_stage_combine_sel_bit_exact(hip_kernels, oracle_kernels, dtype, n):
             ysel, fsel = (td[0], td[1]) if accept else (td[2], td[3])
             hip_kernels.stage_combine(ref, ysel, [fsel], [0.2], dtT)
             assert torch.equal(out_d, ref)
+
+
+@pytest.mark.gpu
+def test_lookahead_under_every_readback_mode(hip_kernels, monkeypatch):
+    """The controller's words travel with the norm results in all three read-back modes (poll on pinned words,
+    pinned + stream sync, device buffer + copy): same decisions, same solution."""
+    fn, y0 = _problem("vdp", torch.float64, "cuda")
+    t = torch.tensor([0.0, 2.0, 5.0], dtype=torch.float64, device="cuda")
+    monkeypatch.setenv("TDEQ_LOOKAHEAD", "1")
+    outs = []
+    for mode in ("poll", "pinned", "copy"):
+        monkeypatch.setenv("TDEQ_READBACK", mode)
+        kern = _native.HipKernels(hip_kernels.lib)
+        monkeypatch.setattr(_native, "get_kernels", lambda device, _k=kern: _k)
+        f = _Counting(fn)
+        with torch.no_grad():
+            y = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(first_step=0.7))
+        outs.append((y.cpu(), f.nfe))
+    assert outs[0][1] == outs[1][1] == outs[2][1]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])
