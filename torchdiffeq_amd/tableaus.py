@@ -13,6 +13,7 @@ The kernels skip structural zeros, so every row is stored sparse: `(stage indice
 from __future__ import annotations
 
 import dataclasses
+import functools
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -38,8 +39,15 @@ class SparseRow:
 
     @staticmethod
     def from_dense(values: Sequence[float]) -> "SparseRow":
-        nz = [(i, float(v)) for i, v in enumerate(values) if v != 0.0]
-        return SparseRow(tuple(i for i, _ in nz), tuple(v for _, v in nz))
+        return _sparse_row(tuple(float(v) for v in values))
+
+
+@functools.lru_cache(maxsize=None)
+def _sparse_row(values: Tuple[float, ...]) -> SparseRow:
+    """Memoised: the rows of the (few, immutable) tableaus are rebuilt by every solver construction otherwise — the
+    adjoint constructs one solver per output interval."""
+    nz = [(i, v) for i, v in enumerate(values) if v != 0.0]
+    return SparseRow(tuple(i for i, _ in nz), tuple(v for _, v in nz))
 
 
 @dataclasses.dataclass(frozen=True)
