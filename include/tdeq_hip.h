@@ -38,11 +38,12 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 8
+#define TDEQ_ABI_VERSION 9
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
 #define TDEQ_MAX_SUM_TERMS 8    /* tdeq_weighted_sum */
+#define TDEQ_MAX_DENSE_OUTPUTS 16 /* tdeq_dense_eval_multi */
 #define TDEQ_MAX_SEGMENTS 4096
 #define TDEQ_INLINE_SEGMENTS 16  /* segment tables up to this size travel in the kernel arguments */
 #define TDEQ_CHUNK_QUANTUM 1024
@@ -213,6 +214,17 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale,
 int tdeq_dense_eval(void* out, const void* y0, const void* y1, const void* f0, const void* f1,
                     const void* const* k, const double* coef, int n_terms, double dt, double x,
                     int64_t n, int dtype, void* stream);
+
+/*
+ * tdeq_dense_eval for n_x (1..TDEQ_MAX_DENSE_OUTPUTS) output times that fall inside the SAME accepted step — the
+ * reference calls _interp_evaluate once per output time (solvers.py:28-35 -> rk_common.py:243-250): the quartic is
+ * fitted once per element and evaluated at x[0..n_x); row q is written at out + q*out_stride elements (the rows of
+ * the solution tensor).  (8 + n_x) words per element instead of 9*n_x, one launch instead of n_x; each row is
+ * bit-identical to the single-output call.
+ */
+int tdeq_dense_eval_multi(void* out, int64_t out_stride, const void* y0, const void* y1, const void* f0,
+                          const void* f1, const void* const* k, const double* coef, int n_terms, double dt,
+                          const double* x, int n_x, int64_t n, int dtype, void* stream);
 
 /*
  * Dense-output fit only: writes the 5 interpolation coefficients [e,d,c,b,a] contiguously into

@@ -195,6 +195,11 @@ class OracleKernels:
         _ok(self.lib.oracle_dense_eval(out.data_ptr(), y0.data_ptr(), y1.data_ptr(), f0.data_ptr(), f1.data_ptr(),
                                        ptrs, cf, n, dt, x, y0.numel(), _code(y0.dtype)), "oracle_dense_eval")
 
+    def dense_eval_multi(self, out_rows, y0, y1, f0, f1, ks, coefs, dt, xs):
+        """Host twin of tdeq_dense_eval_multi: the reference evaluates one output time at a time."""
+        for q, x in enumerate(xs):
+            self.dense_eval(out_rows[q], y0, y1, f0, f1, ks, coefs, dt, x)
+
     def interp_fit(self, coeffs, y0, y1, f0, f1, ks, coefs, dt):
         ptrs, cf, n = self._terms(ks, coefs)
         _ok(self.lib.oracle_interp_fit(coeffs.data_ptr(), y0.data_ptr(), y1.data_ptr(), f0.data_ptr(),

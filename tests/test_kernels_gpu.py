@@ -433,3 +433,27 @@ def test_pack_segments_bit_exact(hip_kernels, oracle_kernels, dtype, chunk):
     out = torch.full((off,), float("nan"), dtype=dtype, device="cuda")
     hip_kernels.pack_segments(out, dev_srcs, starts, numels, scales, chunk)
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 3, 1023, 4099, 65536 + 7])
+@pytest.mark.parametrize("tab", [DOPRI5, DOPRI8], ids=["dopri5", "dopri8"])
+def test_dense_eval_multi_rows_equal_single_calls(hip_kernels, oracle_kernels, dtype, n, tab):
+    """tdeq_dense_eval_multi: every output row bit-identical to tdeq_dense_eval at the same x and to the oracle;
+    row strides that keep / break 16-byte alignment; 1..16 outputs."""
+    S = tab.n_stages
+    y0, y1 = _rand(n, dtype, 1), _rand(n, dtype, 2)
+    ks = [_rand(n, dtype, 10 + j) for j in range(S + 1)]
+    mid = SparseRow.from_dense(tab.c_mid)
+    y0d, y1d, ksd = y0.cuda(), y1.cuda(), _dev(ks)
+    for m in (1, 2, 5, 16):
+        xs = [float(torch.tensor((q + 0.5) / m, dtype=dtype)) for q in range(m)]
+        rows = torch.full((m, n), float("nan"), dtype=dtype, device="cuda")
+        hip_kernels.dense_eval_multi(rows, y0d, y1d, ksd[0], ksd[-1], [ksd[j] for j in mid.idx], mid.coef, -0.07, xs)
+        ref = torch.empty(m, n, dtype=dtype)
+        oracle_kernels.dense_eval_multi(ref, y0, y1, ks[0], ks[-1], [ks[j] for j in mid.idx], mid.coef, -0.07, xs)
+        assert torch.equal(rows.cpu(), ref)
+        single = torch.empty(n, dtype=dtype, device="cuda")
+        for q, x in enumerate(xs):
+            hip_kernels.dense_eval(single, y0d, y1d, ksd[0], ksd[-1], [ksd[j] for j in mid.idx], mid.coef, -0.07, x)
+            assert torch.equal(rows[q], single)

@@ -14,12 +14,13 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 8
+TDEQ_ABI_VERSION = 9
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
 TDEQ_CHUNK_QUANTUM = 1024
 TDEQ_MAX_STAGE_TIMES = 16
+TDEQ_MAX_DENSE_OUTPUTS = 16
 
 _LIB_NAME = "libtdeq_hip.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
@@ -87,6 +88,10 @@ ABI_SIGNATURES = {
                                        ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
                                        ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
                                        ctypes.c_void_p]),
+    "tdeq_dense_eval_multi": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
+                                             ctypes.c_double, _c_double_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                             ctypes.c_void_p]),
     "tdeq_interp_fit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
                                        ctypes.c_double, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
@@ -373,6 +378,17 @@ class HipKernels:
         _check(self.lib.tdeq_dense_eval(out.data_ptr(), y0.data_ptr(), y1.data_ptr(), f0.data_ptr(),
                                         f1.data_ptr(), ptrs, cf, n, dt, x, y0.numel(),
                                         dtype_code(y0.dtype), self._stream()), "tdeq_dense_eval")
+
+    def dense_eval_multi(self, out_rows, y0, y1, f0, f1, ks, coefs, dt: float, xs: Sequence[float]) -> None:
+        """Dense output at several points of ONE step: out_rows[q] = y(x_q) for the rows of a contiguous
+        [len(xs), n] tensor (a slice of the solution)."""
+        ptrs, cf, n = self._terms(ks, coefs)
+        m = len(xs)
+        xa = (ctypes.c_double * m)(*xs)
+        _check(self.lib.tdeq_dense_eval_multi(out_rows.data_ptr(), out_rows.stride(0) if m > 1 else y0.numel(),
+                                              y0.data_ptr(), y1.data_ptr(), f0.data_ptr(), f1.data_ptr(), ptrs, cf, n,
+                                              dt, xa, m, y0.numel(), dtype_code(y0.dtype), self._stream()),
+               "tdeq_dense_eval_multi")
 
     def interp_fit(self, coeffs, y0, y1, f0, f1, ks, coefs, dt: float) -> None:
         ptrs, cf, n = self._terms(ks, coefs)

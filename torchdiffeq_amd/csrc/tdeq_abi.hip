@@ -383,6 +383,49 @@ int dispatch_dense(void* out, const void* y0, const void* y1, const void* f0, co
     return TDEQ_EINVAL;
 }
 
+template <typename T, int NT>
+int launch_dense_multi(void* out, int64_t out_stride, const void* y0, const void* y1, const void* f0, const void* f1,
+                       const void* const* k, const double* coef, double dt, const double* x, int n_x, int64_t n,
+                       hipStream_t s) {
+    DenseMultiArgs<T, NT> a;
+    a.d.out = static_cast<T*>(out);
+    a.d.y0 = static_cast<const T*>(y0);
+    a.d.y1 = static_cast<const T*>(y1);
+    a.d.f0 = static_cast<const T*>(f0);
+    a.d.f1 = static_cast<const T*>(f1);
+    bool vec = aligned16(out) && aligned16(y0) && aligned16(y1) && aligned16(f0) && aligned16(f1);
+    const T dtT = (T)dt;
+    for (int j = 0; j < NT; ++j) {
+        a.d.k[j] = static_cast<const T*>(k[j]);
+        a.d.c[j] = (T)coef[j] * dtT;
+        vec = vec && aligned16(k[j]);
+    }
+    a.d.dt = dtT;
+    a.d.x = (T)0;
+    a.d.n = n;
+    for (int r = 0; r < kMaxDenseOutputs; ++r) a.xs[r] = r < n_x ? (T)x[r] : (T)0;
+    a.m = n_x;
+    a.out_stride = out_stride;
+    vec = vec && (n_x == 1 || (out_stride * (int64_t)sizeof(T)) % 16 == 0);   // every output row 16-byte aligned
+    constexpr int L = VecOf<T>::L;
+    if (vec) hipLaunchKernelGGL((dense_multi_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((dense_multi_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
+}
+
+template <typename T>
+int dispatch_dense_multi(void* out, int64_t out_stride, const void* y0, const void* y1, const void* f0,
+                         const void* f1, const void* const* k, const double* coef, int nt, double dt,
+                         const double* x, int n_x, int64_t n, hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_dense_multi<T, N>(out, out_stride, y0, y1, f0, f1, k, coef, dt, x, n_x, n, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
 // ---- rk4 / lerp ------------------------------------------------------------------------------------
 template <typename T, int STAGE>
 int launch_rk4(void* out, const void* y0, const void* k1, const void* k2, const void* k3,
@@ -720,6 +763,20 @@ int tdeq_dense_eval(void* out, const void* y0, const void* y1, const void* f0, c
     return dtype == TDEQ_F32
                ? dispatch_dense<float, false>(out, y0, y1, f0, f1, k, coef, n_terms, dt, x, n, s)
                : dispatch_dense<double, false>(out, y0, y1, f0, f1, k, coef, n_terms, dt, x, n, s);
+}
+
+int tdeq_dense_eval_multi(void* out, int64_t out_stride, const void* y0, const void* y1, const void* f0,
+                          const void* f1, const void* const* k, const double* coef, int n_terms, double dt,
+                          const double* x, int n_x, int64_t n, int dtype, void* stream) {
+    if (!out || !y0 || !y1 || !f0 || !f1 || !k || !coef || !x || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS || n_x < 1 || n_x > TDEQ_MAX_DENSE_OUTPUTS) return TDEQ_EINVAL;
+    if (n_x > 1 && out_stride < n) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32
+               ? dispatch_dense_multi<float>(out, out_stride, y0, y1, f0, f1, k, coef, n_terms, dt, x, n_x, n, s)
+               : dispatch_dense_multi<double>(out, out_stride, y0, y1, f0, f1, k, coef, n_terms, dt, x, n_x, n, s);
 }
 
 int tdeq_interp_fit(void* coeffs, const void* y0, const void* y1, const void* f0, const void* f1,

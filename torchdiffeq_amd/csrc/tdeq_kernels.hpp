@@ -760,6 +760,49 @@ __global__ __launch_bounds__(kBlock) void dense_kernel(const DenseArgs<T, NT> a)
     }
 }
 
+// Several output times inside ONE accepted step (solvers.py:28-35 calls _interp_evaluate once per output time,
+// rk_common.py:243-250): the quartic is fitted once per element and evaluated at x_0..x_{m-1}; row q of the
+// output goes to out + q*out_stride.  (8 + m) words per element instead of 9 m; same operations per output as
+// dense_kernel, so every row is bit-identical to a single-output launch.
+constexpr int kMaxDenseOutputs = 16;
+
+template <typename T, int NT>
+struct DenseMultiArgs {
+    DenseArgs<T, NT> d;      // d.out = first output row, d.x unused
+    T xs[kMaxDenseOutputs];
+    int m;
+    int64_t out_stride;      // elements between consecutive output rows
+};
+
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(kBlock) void dense_multi_kernel(const DenseMultiArgs<T, NT> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const DenseArgs<T, NT>& d = a.d;
+    const int64_t ne = d.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
+        E kk[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(d.k[j])[i];
+        const Quartic<T, E> q = fit_one<T, NT, E>(
+            d, reinterpret_cast<const E*>(d.y0)[i], reinterpret_cast<const E*>(d.y1)[i],
+            reinterpret_cast<const E*>(d.f0)[i], reinterpret_cast<const E*>(d.f1)[i], kk);
+        for (int r = 0; r < a.m; ++r)
+            reinterpret_cast<E*>(d.out + (int64_t)r * a.out_stride)[i] = eval_one<T, E>(q, a.xs[r]);
+    }
+    if (VEC) {
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < d.n) {
+            T kk[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kk[j] = d.k[j][t];
+            const Quartic<T, T> q = fit_one<T, NT, T>(d, d.y0[t], d.y1[t], d.f0[t], d.f1[t], kk);
+            for (int r = 0; r < a.m; ++r) d.out[(int64_t)r * a.out_stride + t] = eval_one<T, T>(q, a.xs[r]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // rk4 3/8 rule (rk_common.py:110-118) and the fixed-grid linear interpolation (solvers.py:175-181).
 // ------------------------------------------------------------------------------------------------

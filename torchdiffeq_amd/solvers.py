@@ -200,6 +200,7 @@ class RKAdaptiveStepsizeODESolver:
             c.n_times = len(self._alpha)
             c.n_norm_seg = n_norm_seg
             self._ctrl = c
+        self._max_rows = _native.TDEQ_MAX_DENSE_OUTPUTS if os.environ.get("TDEQ_DENSE_MULTI", "1") != "0" else 1
         self._t_end = -math.inf     # last output time of the running `integrate` (look-ahead only before it)
         self._pre = None            # (stage input, stage times, k_1) of the trial step enqueued ahead
 
@@ -247,8 +248,16 @@ class RKAdaptiveStepsizeODESolver:
             return torch.stack(rows, dim=0)
         solution = torch.empty(len(t_host), self.layout.total, dtype=self.y0.dtype, device=self.y0.device)
         solution[0].copy_(self.y0)
-        for i in range(1, len(t_host)):
-            self._advance(t_host[i], solution[i])
+        i, n_t = 1, len(t_host)
+        while i < n_t:
+            self._step_until(t_host[i])
+            # every output time inside the step just accepted is an interpolation of that step (rk_common.py:243-250):
+            # one launch per <= 16 of them (tdeq_dense_eval_multi) instead of one per output time
+            j = i + 1
+            while j < n_t and t_host[j] <= self.t1 and j - i < self._max_rows:
+                j += 1
+            self._interp_evaluate_rows(t_host[i:j], solution[i:j])
+            i = j
         return solution
 
     def _set_time_anchor(self, t: torch.Tensor) -> None:
@@ -377,16 +386,36 @@ class RKAdaptiveStepsizeODESolver:
             h1 = abs(h1)
             return float(min(T(100) * h0, h1))
 
-    def _advance(self, next_t: float, out: Optional[torch.Tensor], t_shadow=None) -> torch.Tensor:
-        """Step until next_t is inside the last accepted step, then return y(next_t) (written into `out` if
-        given).  `t_shadow` = the entry of `t` this output belongs to, when `t` requires grad."""
+    def _step_until(self, next_t: float) -> None:
+        """Trial steps until next_t is inside the last accepted step (rk_common.py:243-249)."""
         n_steps = 0
         while next_t > self.t1:
             assert n_steps < self.max_num_steps, \
                 "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
             self._adaptive_step()
             n_steps += 1
+
+    def _advance(self, next_t: float, out: Optional[torch.Tensor], t_shadow=None) -> torch.Tensor:
+        """Step until next_t is inside the last accepted step, then return y(next_t) (written into `out` if
+        given).  `t_shadow` = the entry of `t` this output belongs to, when `t` requires grad."""
+        self._step_until(next_t)
         return self._interp_evaluate(next_t, out, t_shadow)
+
+    def _interp_evaluate_rows(self, times: Sequence[float], rows: torch.Tensor) -> None:
+        """y(t) for several output times inside the last accepted step, written to the rows of `rows` (a slice of
+        the solution tensor) by one launch; no autograd graph (the differentiable path evaluates row by row)."""
+        rec = self._dense
+        if len(times) == 1:
+            self._interp_evaluate(times[0], rows[0])
+            return
+        xs = []
+        for t in times:
+            assert rec is not None and rec.t0 <= t <= rec.t1, \
+                "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(self.t0, t, self.t1)
+            xs.append(float(self.np_dtype((t - rec.t0) / (rec.t1 - rec.t0))))
+        mid = self._c_mid
+        self.kernels.dense_eval_multi(rows, rec.y0, rec.y1, rec.k[0], rec.k[-1], [rec.k[j] for j in mid.idx],
+                                      mid.coef, rec.dt_signed, xs)
 
     def _interp_evaluate(self, t: float, out: Optional[torch.Tensor] = None, t_shadow=None) -> torch.Tensor:
         """Fused `_interp_fit` + `_interp_evaluate` (rk_common.py:363-369, interp.py:25-48)."""
