@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 9
+#define TDEQ_ABI_VERSION 10
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -244,6 +244,27 @@ int tdeq_interp_fit(void* coeffs, const void* y0, const void* y1, const void* f0
  */
 int tdeq_rk4_38_stage(int stage, void* out, const void* y0, const void* k1, const void* k2,
                       const void* k3, const void* k4, double dt, int64_t n, int dtype, void* stream);
+
+/*
+ * hipGraph mode of the fixed-grid rk4 solver (small states, where a step is launch-latency-bound): ONE captured
+ * graph — four func evaluations, four tdeq_rk4_38_stage_dev launches, tdeq_grid_commit, tdeq_grid_advance — is
+ * replayed once per grid interval; everything that changes between steps lives in device memory.
+ *   tdeq_rk4_38_stage_dev  tdeq_rk4_38_stage with dt read from *dt_dev (device double holding sign*dt).
+ *   tdeq_grid_advance      *counter += 1 (=: c); t0 = grid[c], t1 = grid[c+1], dt = t1 - t0 in the grid's dtype
+ *                          (solvers.py:110-112); times_out[0..4) = the stage times t0, t0 + dt/3, t0 + 2dt/3, t1 of
+ *                          the 3/8 rule (rk_common.py:110-118) cast to the state dtype, perturbed at both ends if
+ *                          `perturb` (fixed-grid option, misc.py:174-197), times `sign`; *dt_out = sign * dt.
+ *                          Nothing is written when c + 1 >= n_grid.  Start with *counter = -1.
+ *   tdeq_grid_commit       solution[(*counter + 1) * row_stride + i] = y_new[i] and y_cur[i] = y_new[i], i < n: the
+ *                          step's result becomes output row c + 1 and the next step's state (solvers.py:113-127
+ *                          with the grid equal to the output times).
+ */
+int tdeq_rk4_38_stage_dev(int stage, void* out, const void* y0, const void* k1, const void* k2, const void* k3,
+                          const void* k4, const double* dt_dev, int64_t n, int dtype, void* stream);
+int tdeq_grid_advance(const void* grid, int grid_dtype, int64_t n_grid, int64_t* counter, int perturb, double sign,
+                      void* times_out, double* dt_out, int state_dtype, void* stream);
+int tdeq_grid_commit(void* solution, int64_t row_stride, void* y_cur, const void* y_new, const int64_t* counter,
+                     int64_t n, int dtype, void* stream);
 
 /* Fixed-grid output interpolation  out = y0 + slope*(y1 - y0)  (solvers.py:175-181). */
 int tdeq_lerp(void* out, const void* y0, const void* y1, double slope, int64_t n, int dtype,

@@ -58,6 +58,10 @@ t1 = torch.linspace(0.0, 25.0, 1000, device=dev)
 with torch.no_grad():
     w, y = timed(lambda: tda.odeint(lambda t, y: (y ** 3) @ A1, y01, t1, method="rk4"))
 res["cfg1_rk4_spiral"] = {"wall_s": w, "steps": 999, "stages_per_s": 4 * 999 / w, "y_end": y[-1, 0].tolist()}
+with torch.no_grad():
+    wg, yg = timed(lambda: tda.odeint(lambda t, y: (y ** 3) @ A1, y01, t1, method="rk4", options=dict(hip_graph=True)))
+res["cfg1_rk4_spiral_hip_graph"] = {"wall_s": wg, "steps": 999, "stages_per_s": 4 * 999 / wg,
+                                    "bit_identical_to_eager": bool(torch.equal(y, yg))}
 
 # cfg2
 A, y0 = linear(65536, 128, torch.float32)

@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 9
+TDEQ_ABI_VERSION = 10
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -98,6 +98,14 @@ ABI_SIGNATURES = {
     "tdeq_rk4_38_stage": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_double, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_rk4_38_stage_dev": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_grid_advance": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_void_p]),
+    "tdeq_grid_commit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_lerp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                  ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_fixed_stage": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
@@ -401,6 +409,23 @@ class HipKernels:
         _check(self.lib.tdeq_rk4_38_stage(stage, out.data_ptr(), y0.data_ptr(), p(k1), p(k2), p(k3), p(k4),
                                           dt, y0.numel(), dtype_code(y0.dtype), self._stream()),
                "tdeq_rk4_38_stage")
+
+    # -- hipGraph mode of the fixed-grid rk4 solver (device-resident step state) -----------------------
+    def rk4_stage_dev(self, stage: int, out, y0, k1, k2, k3, k4, dt_dev) -> None:
+        p = lambda t: None if t is None else t.data_ptr()
+        _check(self.lib.tdeq_rk4_38_stage_dev(stage, out.data_ptr(), y0.data_ptr(), p(k1), p(k2), p(k3), p(k4),
+                                              dt_dev.data_ptr(), y0.numel(), dtype_code(y0.dtype), self._stream()),
+               "tdeq_rk4_38_stage_dev")
+
+    def grid_advance(self, grid, counter, perturb: bool, sign: float, times_out, dt_out) -> None:
+        _check(self.lib.tdeq_grid_advance(grid.data_ptr(), dtype_code(grid.dtype), grid.numel(), counter.data_ptr(),
+                                          1 if perturb else 0, sign, times_out.data_ptr(), dt_out.data_ptr(),
+                                          dtype_code(times_out.dtype), self._stream()), "tdeq_grid_advance")
+
+    def grid_commit(self, solution, y_cur, y_new, counter) -> None:
+        _check(self.lib.tdeq_grid_commit(solution.data_ptr(), solution.stride(0), y_cur.data_ptr(), y_new.data_ptr(),
+                                         counter.data_ptr(), y_cur.numel(), dtype_code(y_cur.dtype), self._stream()),
+               "tdeq_grid_commit")
 
     def lerp(self, out, y0, y1, slope: float) -> None:
         _check(self.lib.tdeq_lerp(out.data_ptr(), y0.data_ptr(), y1.data_ptr(), slope, y0.numel(),

@@ -429,8 +429,9 @@ int dispatch_dense_multi(void* out, int64_t out_stride, const void* y0, const vo
 // ---- rk4 / lerp ------------------------------------------------------------------------------------
 template <typename T, int STAGE>
 int launch_rk4(void* out, const void* y0, const void* k1, const void* k2, const void* k3,
-               const void* k4, double dt, int64_t n, hipStream_t s) {
+               const void* k4, double dt, int64_t n, hipStream_t s, const double* dt_dev = nullptr) {
     Rk4Args<T> a;
+    a.dt_dev = dt_dev;
     a.out = static_cast<T*>(out);
     a.y0 = static_cast<const T*>(y0);
     a.k1 = static_cast<const T*>(k1);
@@ -455,14 +456,28 @@ int launch_rk4(void* out, const void* y0, const void* k1, const void* k2, const 
 
 template <typename T>
 int dispatch_rk4(int stage, void* out, const void* y0, const void* k1, const void* k2, const void* k3,
-                 const void* k4, double dt, int64_t n, hipStream_t s) {
+                 const void* k4, double dt, int64_t n, hipStream_t s, const double* dt_dev = nullptr) {
     switch (stage) {
-        case 1: return k1 ? launch_rk4<T, 1>(out, y0, k1, k2, k3, k4, dt, n, s) : TDEQ_EINVAL;
-        case 2: return (k1 && k2) ? launch_rk4<T, 2>(out, y0, k1, k2, k3, k4, dt, n, s) : TDEQ_EINVAL;
-        case 3: return (k1 && k2 && k3) ? launch_rk4<T, 3>(out, y0, k1, k2, k3, k4, dt, n, s) : TDEQ_EINVAL;
-        case 4: return (k1 && k2 && k3 && k4) ? launch_rk4<T, 4>(out, y0, k1, k2, k3, k4, dt, n, s) : TDEQ_EINVAL;
+        case 1: return k1 ? launch_rk4<T, 1>(out, y0, k1, k2, k3, k4, dt, n, s, dt_dev) : TDEQ_EINVAL;
+        case 2: return (k1 && k2) ? launch_rk4<T, 2>(out, y0, k1, k2, k3, k4, dt, n, s, dt_dev) : TDEQ_EINVAL;
+        case 3: return (k1 && k2 && k3) ? launch_rk4<T, 3>(out, y0, k1, k2, k3, k4, dt, n, s, dt_dev) : TDEQ_EINVAL;
+        case 4: return (k1 && k2 && k3 && k4) ? launch_rk4<T, 4>(out, y0, k1, k2, k3, k4, dt, n, s, dt_dev) : TDEQ_EINVAL;
     }
     return TDEQ_EINVAL;
+}
+
+template <typename T>
+int launch_grid_commit(void* solution, int64_t row_stride, void* y_cur, const void* y_new, const int64_t* counter,
+                       int64_t n, hipStream_t s) {
+    GridCommitArgs<T> a;
+    a.solution = static_cast<T*>(solution);
+    a.row_stride = row_stride;
+    a.y_cur = static_cast<T*>(y_cur);
+    a.y_new = static_cast<const T*>(y_new);
+    a.counter = counter;
+    a.n = n;
+    hipLaunchKernelGGL((grid_commit_kernel<T>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
 }
 
 template <typename T>
@@ -799,6 +814,42 @@ int tdeq_rk4_38_stage(int stage, void* out, const void* y0, const void* k1, cons
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == TDEQ_F32 ? dispatch_rk4<float>(stage, out, y0, k1, k2, k3, k4, dt, n, s)
                              : dispatch_rk4<double>(stage, out, y0, k1, k2, k3, k4, dt, n, s);
+}
+
+int tdeq_rk4_38_stage_dev(int stage, void* out, const void* y0, const void* k1, const void* k2, const void* k3,
+                          const void* k4, const double* dt_dev, int64_t n, int dtype, void* stream) {
+    if (!out || !y0 || !dt_dev || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n == 0) return (stage >= 1 && stage <= 4) ? 0 : TDEQ_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? dispatch_rk4<float>(stage, out, y0, k1, k2, k3, k4, 0.0, n, s, dt_dev)
+                             : dispatch_rk4<double>(stage, out, y0, k1, k2, k3, k4, 0.0, n, s, dt_dev);
+}
+
+int tdeq_grid_advance(const void* grid, int grid_dtype, int64_t n_grid, int64_t* counter, int perturb, double sign,
+                      void* times_out, double* dt_out, int state_dtype, void* stream) {
+    if (!grid || !counter || !times_out || !dt_out || n_grid < 2 || bad_dtype(grid_dtype) || bad_dtype(state_dtype))
+        return TDEQ_EINVAL;
+    GridAdvanceArgs a;
+    a.grid = grid;
+    a.grid_is_f32 = grid_dtype == TDEQ_F32;
+    a.n_grid = n_grid;
+    a.counter = counter;
+    a.perturb = perturb ? 1 : 0;
+    a.sign = sign;
+    a.times_out = times_out;
+    a.state_is_f32 = state_dtype == TDEQ_F32;
+    a.dt_out = dt_out;
+    hipLaunchKernelGGL(grid_advance_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch();
+}
+
+int tdeq_grid_commit(void* solution, int64_t row_stride, void* y_cur, const void* y_new, const int64_t* counter,
+                     int64_t n, int dtype, void* stream) {
+    if (!solution || !y_cur || !y_new || !counter || n < 0 || row_stride < n || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? launch_grid_commit<float>(solution, row_stride, y_cur, y_new, counter, n, s)
+                             : launch_grid_commit<double>(solution, row_stride, y_cur, y_new, counter, n, s);
 }
 
 int tdeq_lerp(void* out, const void* y0, const void* y1, double slope, int64_t n, int dtype, void* stream) {

@@ -817,19 +817,20 @@ struct Rk4Args {
     T dt;
     T third;   // fl_T(1/3)
     int64_t n;
+    const double* dt_dev;   // non-null (hipGraph mode): the step size is read from device memory (grid_advance_kernel)
 };
 
 template <typename T, int STAGE, typename E>
-__device__ __forceinline__ E rk4_one(const Rk4Args<T>& a, int64_t i) {
+__device__ __forceinline__ E rk4_one(const Rk4Args<T>& a, T dt, int64_t i) {
     const E y0 = reinterpret_cast<const E*>(a.y0)[i];
     const E k1 = reinterpret_cast<const E*>(a.k1)[i];
-    if (STAGE == 1) return y0 + (k1 * a.dt) * a.third;
+    if (STAGE == 1) return y0 + (k1 * dt) * a.third;
     const E k2 = reinterpret_cast<const E*>(a.k2)[i];
-    if (STAGE == 2) return y0 + (k2 - k1 * a.third) * a.dt;
+    if (STAGE == 2) return y0 + (k2 - k1 * a.third) * dt;
     const E k3 = reinterpret_cast<const E*>(a.k3)[i];
-    if (STAGE == 3) return y0 + ((k1 - k2) + k3) * a.dt;
+    if (STAGE == 3) return y0 + ((k1 - k2) + k3) * dt;
     const E k4 = reinterpret_cast<const E*>(a.k4)[i];
-    return y0 + (((k1 + (k2 + k3) * (T)3) + k4) * a.dt) * (T)0.125;
+    return y0 + (((k1 + (k2 + k3) * (T)3) + k4) * dt) * (T)0.125;
 }
 
 template <typename T, int STAGE, bool VEC>
@@ -838,11 +839,101 @@ __global__ __launch_bounds__(kBlock) void rk4_kernel(const Rk4Args<T> a) {
     constexpr int L = VEC ? VecOf<T>::L : 1;
     const int64_t ne = a.n / L;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const T dt = a.dt_dev ? (T)*a.dt_dev : a.dt;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
-        reinterpret_cast<E*>(a.out)[i] = rk4_one<T, STAGE, E>(a, i);
+        reinterpret_cast<E*>(a.out)[i] = rk4_one<T, STAGE, E>(a, dt, i);
     if (VEC) {
         const int64_t t = ne * L + threadIdx.x;
-        if (blockIdx.x == 0 && t < a.n) a.out[t] = rk4_one<T, STAGE, T>(a, t);
+        if (blockIdx.x == 0 && t < a.n) a.out[t] = rk4_one<T, STAGE, T>(a, dt, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hipGraph mode of the fixed-grid rk4 solver: one captured graph = one step (4 func evaluations + 4 stage
+// kernels + the two kernels below), replayed once per grid interval — the launch-latency-bound regime of small
+// states (cfg1).  Everything that changes from step to step lives in device memory:
+//   grid_advance_kernel   counter += 1; t0 = grid[c], t1 = grid[c+1]; dt = t1 - t0 in the grid's dtype
+//                         (solvers.py:110-112); the four stage times t0, t0 + dt/3, t0 + 2dt/3, t1
+//                         (rk_common.py:110-118, perturbed at the ends if `perturb`, misc.py:174-197), cast to
+//                         the state dtype and multiplied by the time sign; dt_out = sign * dt (double)
+//   grid_commit_kernel    solution[c + 1] = y_new ; y_cur = y_new       (solvers.py:113-127 with grid == t)
+// ------------------------------------------------------------------------------------------------
+struct GridAdvanceArgs {
+    const void* grid;      // [n_grid] of float or double
+    int grid_is_f32;
+    int64_t n_grid;
+    int64_t* counter;
+    int perturb;           // fixed-grid `perturb` option: NEXT at t0, PREV at t1
+    double sign;
+    void* times_out;       // [4] of T
+    int state_is_f32;
+    double* dt_out;
+};
+
+__device__ __forceinline__ float ctl_next(float x) {      // np.nextafter(x, x + 1)
+    const float y = x + 1.0f;
+    if (x != x) return x;
+    if (x == y) return y;
+    if (x == 0.0f) return __uint_as_float(1u);
+    const uint32_t b = __float_as_uint(x);
+    return __uint_as_float(x > 0.0f ? b + 1u : b - 1u);
+}
+__device__ __forceinline__ double ctl_next(double x) {
+    const double y = x + 1.0;
+    if (x != x) return x;
+    if (x == y) return y;
+    if (x == 0.0) return __longlong_as_double(1LL);
+    const long long b = __double_as_longlong(x);
+    return __longlong_as_double(x > 0.0 ? b + 1 : b - 1);
+}
+
+template <typename G, typename T>
+__device__ __forceinline__ void grid_times(const GridAdvanceArgs& a, int64_t c) {
+    const G* grid = static_cast<const G*>(a.grid);
+    const G t0 = grid[c], t1 = grid[c + 1];
+    const G dt = t1 - t0;
+    const G third = (G)(1.0 / 3.0), two_thirds = (G)(2.0 / 3.0);
+    const G ts[4] = {t0, t0 + dt * third, t0 + dt * two_thirds, t1};
+    T* out = static_cast<T*>(a.times_out);
+    for (int i = 0; i < 4; ++i) {
+        T tt = (T)ts[i];
+        if (a.perturb && i == 0) tt = ctl_next(tt);
+        if (a.perturb && i == 3) tt = ctl_prev(tt);
+        out[i] = (T)a.sign * tt;
+    }
+    *a.dt_out = (double)dt * a.sign;
+}
+
+__global__ void grid_advance_kernel(const GridAdvanceArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t c = *a.counter + 1;
+    *a.counter = c;
+    if (c + 1 >= a.n_grid) return;       // past the last interval: nothing to prepare
+    if (a.grid_is_f32) {
+        if (a.state_is_f32) grid_times<float, float>(a, c); else grid_times<float, double>(a, c);
+    } else {
+        if (a.state_is_f32) grid_times<double, float>(a, c); else grid_times<double, double>(a, c);
+    }
+}
+
+template <typename T>
+struct GridCommitArgs {
+    T* solution;           // [n_grid, row_stride]
+    int64_t row_stride;
+    T* y_cur;
+    const T* y_new;
+    const int64_t* counter;
+    int64_t n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grid_commit_kernel(const GridCommitArgs<T> a) {
+    T* row = a.solution + (*a.counter + 1) * a.row_stride;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        const T v = a.y_new[i];
+        row[i] = v;
+        a.y_cur[i] = v;
     }
 }
 

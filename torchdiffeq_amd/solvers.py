@@ -18,6 +18,7 @@ from __future__ import annotations
 import bisect
 import math
 import os
+import warnings
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -637,8 +638,11 @@ class FixedGridODESolver(object):
     order: int
 
     def __init__(self, func: OdeFunc, y0: torch.Tensor, step_size=None, grid_constructor=None,
-                 interp="linear", perturb=False, **unused_kwargs):
+                 interp="linear", perturb=False, hip_graph=False, **unused_kwargs):
         self.atol = unused_kwargs.pop("atol")
+        # `hip_graph=True` (an extension, not a reference option): replay one captured hipGraph per grid interval
+        # instead of launching a step's kernels one by one — see RK4._integrate_graph
+        self.hip_graph = bool(hip_graph)
         unused_kwargs.pop("rtol", None)
         unused_kwargs.pop("norm", None)
         unused_kwargs.pop("dist_sync", None)          # fixed grids are in lock step by construction
@@ -713,6 +717,12 @@ class FixedGridODESolver(object):
         assert time_grid[0] == t[0] and time_grid[-1] == t[-1]
         if self.interp not in ("linear", "cubic"):
             raise ValueError(f"Unknown interpolation method {self.interp}")
+        if self.hip_graph:
+            if self._graph_capable(t, time_grid):
+                return self._integrate_graph(t)
+            warnings.warn("{}: hip_graph=True needs the rk4 method, the output times as the grid, linear "
+                          "interpolation, no callback, no autograd graph and a ROCm device; running the eager "
+                          "path".format(self.__class__.__name__))
         # host copies, in the grid's own dtype (dt = t1 - t0 is formed in t.dtype: solvers.py:112)
         grid = time_grid.detach().cpu().numpy()
         tt = t.detach().cpu().numpy()
@@ -771,6 +781,9 @@ class FixedGridODESolver(object):
             if r.data_ptr() != solution[i].data_ptr():
                 solution[i].copy_(r)
         return solution
+
+    def _graph_capable(self, t: torch.Tensor, time_grid: torch.Tensor) -> bool:
+        return False
 
     def integrate_until_event(self, t0: torch.Tensor, event_fn):
         """Fixed steps of `step_size` until the event function changes sign, then bisection on the linear /
@@ -967,6 +980,71 @@ class RK4(FixedGridODESolver):
         k4 = func.eval_at(ts[3], yc)
         y1 = ops.rk4_stage(4, y0, k1, k2, k3, k4, dts, dsh, out=y1_out)
         return y1, k1
+
+
+    # -- hipGraph mode --------------------------------------------------------------------------------
+    def _graph_capable(self, t: torch.Tensor, time_grid: torch.Tensor) -> bool:
+        return (time_grid is t and self.interp == "linear" and self.func.callback_step is _null
+                and self.device.type == "cuda" and hasattr(self.kernels, "grid_advance")
+                and not (torch.is_grad_enabled() and (t.requires_grad or self.y0.requires_grad)))
+
+    def _integrate_graph(self, t: torch.Tensor) -> torch.Tensor:
+        """`integrate` for small states, where a step costs launch latency, not bandwidth: ONE hipGraph — the four
+        evaluations of `func`, the four 3/8-rule stage kernels, tdeq_grid_commit (y1 -> output row and next state) and
+        tdeq_grid_advance (next step's dt and stage times, on the device) — is captured once and replayed per grid
+        interval.  Same kernels and operation order as the eager path, so the solution is bit-identical.  `func`
+        must be capturable (static shapes, no host synchronisation, no Python side effects it relies on: it runs
+        only for the first step and once more during capture)."""
+        func, kern = self.func, self.kernels
+        n_t = len(t)
+        solution = torch.empty(n_t, self.layout.total, dtype=self.dtype, device=self.device)
+        solution[0].copy_(self.y0)
+        if n_t == 1:
+            return solution
+        grid = t.detach().contiguous()
+        y_cur = self.y0.clone()
+        counter = torch.full((), -1, dtype=torch.int64, device=self.device)
+        times = torch.empty(4, dtype=self.dtype, device=self.device)
+        dt_dev = torch.empty((), dtype=torch.float64, device=self.device)
+        kern.grid_advance(grid, counter, self.perturb, func.sign, times, dt_dev)      # step 0
+        ts = times.unbind(0)
+
+        def step():
+            k1 = func.eval_at(ts[0], y_cur)
+            ya = torch.empty_like(y_cur)
+            kern.rk4_stage_dev(1, ya, y_cur, k1, None, None, None, dt_dev)
+            k2 = func.eval_at(ts[1], ya)
+            yb = torch.empty_like(y_cur)
+            kern.rk4_stage_dev(2, yb, y_cur, k1, k2, None, None, dt_dev)
+            k3 = func.eval_at(ts[2], yb)
+            yc = torch.empty_like(y_cur)
+            kern.rk4_stage_dev(3, yc, y_cur, k1, k2, k3, None, dt_dev)
+            k4 = func.eval_at(ts[3], yc)
+            y1 = torch.empty_like(y_cur)
+            kern.rk4_stage_dev(4, y1, y_cur, k1, k2, k3, k4, dt_dev)
+            kern.grid_commit(solution, y_cur, y1, counter)
+            kern.grid_advance(grid, counter, self.perturb, func.sign, times, dt_dev)
+
+        # the first step runs eagerly on a side stream (library / allocator warm-up before capture) ...
+        current = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(current)
+        with torch.cuda.stream(side):
+            step()
+        current.wait_stream(side)
+        if n_t > 2:
+            # ... the others are replays of one captured step
+            graph = torch.cuda.CUDAGraph()
+            nfe_before = func.nfe
+            with torch.cuda.graph(graph):
+                step()
+            func.nfe = nfe_before
+            for _ in range(n_t - 2):
+                graph.replay()
+            func.nfe += 4 * (n_t - 2)
+            # the graph and its private memory pool go away with this frame: let the replays finish first
+            current.synchronize()
+        return solution
 
 
 SOLVER_CLASSES = {"dopri8": Dopri8Solver, "dopri5": Dopri5Solver, "tsit5": Tsit5Solver, "bosh3": Bosh3Solver,
