@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 10
+#define TDEQ_ABI_VERSION 11
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -175,9 +175,12 @@ int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void*
  *         stage times t_i = t0' + alpha_i dt' in T, or nextafter(t1, t1 - 1) with t1 = T(t0' + dt') for alpha_i == 1
  *         (Perturb.PREV), times the time sign                                    (rk_common.py:72-78, misc.py:174-197)
  *       Outputs: out_sumsq / out_nonfinite as tdeq_error_norm_partial; out_ctrl[4] = {accept (0/1), dt_next,
- *       ratio, t0'} (device or pinned host memory, read by the host loop); ctrl_dev[2] = {accept, sign * T(dt')}
- *       (device memory, read by tdeq_stage_combine_sel); next_times[n_times] (device memory, element type T) =
- *       the 0-dim time tensors the next trial step hands to func.  n_seg <= TDEQ_INLINE_SEGMENTS.
+ *       ratio, t0'} (device or pinned host memory, read by the host loop); ctrl_dev[4] = {accept, sign * T(dt'),
+ *       t0', dt'} (device memory, read by tdeq_stage_combine_sel and by the hipGraph-mode kernels);
+ *       next_times[n_times] (device memory, element type T) = the 0-dim time tensors the next trial step hands to
+ *       func.  n_seg <= TDEQ_INLINE_SEGMENTS.  state_in_dev != 0 (hipGraph mode, below): ctrl->t0 / ctrl->dt and
+ *       the `dt` argument are ignored — the trial step's (t0, dt) are ctrl_dev[2..3] and the error coefficients are
+ *       scaled by ctrl_dev[1], all left there by the previous call (or by the host before the first one).
  *
  *   tdeq_stage_combine_sel   first stage of the next trial step, launched before the host knows `accept`:
  *         (y, f) = accept ? (y_acc, f_acc) : (y_rej, f_rej) ;  out = y + fl_T(fl_T(coef) * T(dt')) * f
@@ -189,9 +192,27 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
                                  const double* coef, int n_terms, double dt, const tdeq_segment* segs, int n_seg,
                                  int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite,
                                  const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev, void* next_times,
-                                 void* workspace, size_t workspace_bytes, int dtype, void* stream);
+                                 int state_in_dev, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 int tdeq_stage_combine_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej,
                            double coef, const double* ctrl_dev, int64_t n, int dtype, void* stream);
+
+/*
+ * hipGraph mode of the adaptive solvers (small states, where a trial step is launch-latency-bound): ONE captured
+ * graph = one trial step (S func evaluations, S + 4 launches) is replayed until the solve ends; the step size
+ * lives in device memory (ctrl_dev, maintained by tdeq_error_norm_partial_ctrl with state_in_dev = 1) and the
+ * state in static buffers.
+ *   tdeq_stage_combine_dev  tdeq_stage_combine (err_out == NULL) or tdeq_stage_combine_err with
+ *                           c_j = fl_T(fl_T(coef_j) * T(dt)), dt = ctrl_dev[1] read on the device; same operation
+ *                           order, same results as the host-dt entry points.
+ *   tdeq_step_commit        if ctrl_dev[0] (accept): (y_prev, f_prev) <- (y_cur, f_cur); (y_cur, f_cur) <- (y1, f1)
+ *                           — the accepted state becomes the next trial's base (rk_common.py:335-352) and the
+ *                           previous pair stays available for the dense output of the step just taken.
+ */
+int tdeq_stage_combine_dev(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
+                           const double* err_coef, int n_terms, const double* ctrl_dev, int64_t n, int dtype,
+                           void* stream);
+int tdeq_step_commit(void* y_prev, void* f_prev, void* y_cur, void* f_cur, const void* y1, const void* f1,
+                     const double* ctrl_dev, int64_t n, int dtype, void* stream);
 
 /*
  * Initial-step norms (Hairer II.4 as in misc.py:36-77), scale = atol + |y0| * rtol:

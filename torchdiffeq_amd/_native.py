@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 10
+TDEQ_ABI_VERSION = 11
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -75,8 +75,14 @@ ABI_SIGNATURES = {
                                                     ctypes.POINTER(Segment), ctypes.c_int, ctypes.c_int64,
                                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                                     ctypes.POINTER(StepCtrl), ctypes.c_void_p, ctypes.c_void_p,
-                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
-                                                    ctypes.c_void_p]),
+                                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                                    ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_stage_combine_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
+                                              _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                              ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_step_commit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.c_int, ctypes.c_void_p]),
     "tdeq_stage_combine_sel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                               ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_void_p]),
@@ -213,8 +219,8 @@ class NormPlan:
         self.out_ptr = self.out.data_ptr()
         self.bad_ptr = self.out_ptr + 16 * self.n_seg
         self.ctrl_ptr = self.out_ptr + 24 * self.n_seg
-        # {accept, sign * T(dt')} of the device-resident controller, read by tdeq_stage_combine_sel
-        self.ctrl_dev = torch.zeros(2, dtype=torch.float64, device=device)
+        # {accept, sign * T(dt'), t0', dt'} of the device-resident controller (tdeq_stage_combine_sel, hipGraph mode)
+        self.ctrl_dev = torch.zeros(4, dtype=torch.float64, device=device)
 
 
 class HipKernels:
@@ -356,7 +362,7 @@ class HipKernels:
         return plan.out.tolist()
 
     def error_norm_partial_ctrl(self, plan: NormPlan, err_partial, y0, y1, ks, coefs, dt: float, ctrl: StepCtrl,
-                                next_times) -> None:
+                                next_times, state_in_dev: bool = False) -> None:
         """`error_norm_partial` whose finalize step also runs the step controller on the device: accept flag,
         next step size and the next trial step's stage times (`next_times`, T[n_times]) — read with `read_ctrl`."""
         n = len(ks)
@@ -366,14 +372,32 @@ class HipKernels:
         _check(self.lib.tdeq_error_norm_partial_ctrl(
             err_partial.data_ptr(), y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, plan.segs, plan.n_seg, plan.chunk,
             plan.n_chunks, plan.out_ptr, plan.bad_ptr, ctypes.byref(ctrl), plan.ctrl_ptr, plan.ctrl_dev.data_ptr(),
-            next_times.data_ptr(), plan.workspace.data_ptr(), plan.workspace_bytes, dtype_code(y0.dtype),
-            self._stream()), "tdeq_error_norm_partial_ctrl")
+            next_times.data_ptr(), 1 if state_in_dev else 0, plan.workspace.data_ptr(), plan.workspace_bytes,
+            dtype_code(y0.dtype), self._stream()), "tdeq_error_norm_partial_ctrl")
 
     def read_ctrl(self, plan: NormPlan) -> Tuple[bool, float, float, List[float]]:
         """(accept, dt_next, error_ratio, nonfinite[0:n_seg]) of the last `error_norm_partial_ctrl` launch."""
         n = plan.n_seg
         v = self._read_out(plan)
         return v[3 * n] != 0.0, v[3 * n + 1], v[3 * n + 2], v[2 * n:3 * n]
+
+    def stage_combine_dev(self, out, err_out, y0, ks, coefs, err_coefs, plan: NormPlan) -> None:
+        """stage_combine / stage_combine_err (err_out given) with the step size read on the device from the plan's
+        controller words (hipGraph mode)."""
+        ptrs, cf, n = self._terms(ks, coefs)
+        ef = None if err_coefs is None else (ctypes.c_double * n)(*err_coefs)
+        _check(self.lib.tdeq_stage_combine_dev(out.data_ptr(), None if err_out is None else err_out.data_ptr(),
+                                               y0.data_ptr(), ptrs, cf, ef, n, plan.ctrl_dev.data_ptr(), y0.numel(),
+                                               dtype_code(y0.dtype), self._stream()), "tdeq_stage_combine_dev")
+
+    def step_commit(self, y_prev, f_prev, y_cur, f_cur, y1, f1, plan: NormPlan) -> None:
+        _check(self.lib.tdeq_step_commit(y_prev.data_ptr(), f_prev.data_ptr(), y_cur.data_ptr(), f_cur.data_ptr(),
+                                         y1.data_ptr(), f1.data_ptr(), plan.ctrl_dev.data_ptr(), y_cur.numel(),
+                                         dtype_code(y_cur.dtype), self._stream()), "tdeq_step_commit")
+
+    def arm_readback(self, plan: NormPlan, n_sum: int = 1, ctrl: bool = True) -> None:
+        """Mark the words a norm launch inside a replayed hipGraph is about to write (poll mode)."""
+        self._arm(plan, n_sum, ctrl=ctrl)
 
     def stage_combine_sel(self, out, y_acc, f_acc, y_rej, f_rej, coef: float, plan: NormPlan) -> None:
         """First stage of the next trial step on the pair the device controller selected (tdeq_stage_combine_sel)."""

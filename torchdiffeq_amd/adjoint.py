@@ -296,7 +296,9 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
         raise ValueError("If `adjoint_method != method` then we cannot infer `adjoint_options` from `options`. So as "
                          "`options` has been passed then `adjoint_options` must be passed as well.")
     if adjoint_options is None:
-        adjoint_options = {k: v for k, v in options.items() if k != "norm"} if options is not None else {}
+        # `hip_graph` (an extension) is not inherited: the backward dynamics run autograd inside `func`
+        adjoint_options = {k: v for k, v in options.items() if k not in ("norm", "hip_graph")} \
+            if options is not None else {}
     else:
         adjoint_options = adjoint_options.copy()
 

@@ -233,6 +233,7 @@ struct CtrlBundle {
     double* out_ctrl;
     double* ctrl_dev;
     void* next_times;
+    int state_in_dev;     // hipGraph mode: (t0, dt) of the trial step and the kernels' dt live in ctrl_dev
 };
 
 int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, double* out_bad, const CtrlBundle& cb,
@@ -248,6 +249,7 @@ int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, doub
     a.out_ctrl = cb.out_ctrl;
     a.ctrl_dev = cb.ctrl_dev;
     a.next_times = cb.next_times;
+    a.state_in_dev = cb.state_in_dev;
     hipLaunchKernelGGL(norm_finalize_ctrl_kernel, dim3(1), dim3(kBlock), 0, s, a);
     return check_launch();
 }
@@ -261,14 +263,16 @@ int launch_error_partial(const void* partial, const void* y0, const void* y1, co
     a.y0 = static_cast<const T*>(y0);
     a.y1 = static_cast<const T*>(y1);
     bool vec = aligned16(partial) && aligned16(y0) && aligned16(y1);
+    const bool dev_dt = cb && cb->state_in_dev;      // hipGraph mode: dt = ctrl_dev[1] on the device
     const T dtT = (T)dt;
     a.k[0] = nullptr;
     a.c[0] = (T)0;
     for (int j = 0; j < NT; ++j) {
         a.k[j] = static_cast<const T*>(k[j]);
-        a.c[j] = (T)coef[j] * dtT;
+        a.c[j] = dev_dt ? (T)coef[j] : (T)coef[j] * dtT;
         vec = vec && aligned16(k[j]);
     }
+    a.dt_dev = dev_dt ? cb->ctrl_dev + 1 : nullptr;
     a.st = st;
     a.part_sumsq = ws;
     a.part_bad = ws + 2 * st.n_chunks;
@@ -291,6 +295,41 @@ int dispatch_error_partial(const void* partial, const void* y0, const void* y1, 
         case 2: return launch_error_partial<T, 2>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s);
     }
     return TDEQ_EINVAL;
+}
+
+template <typename T>
+int launch_combine_dev(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
+                       const double* err_coef, int nt, const double* dt_dev, int64_t n, hipStream_t s) {
+    CombineDevArgs<T> a;
+    a.out = static_cast<T*>(out);
+    a.err_out = static_cast<T*>(err_out);
+    a.y0 = static_cast<const T*>(y0);
+    for (int j = 0; j < TDEQ_MAX_TERMS; ++j) {
+        a.k[j] = j < nt ? static_cast<const T*>(k[j]) : nullptr;
+        a.c[j] = j < nt ? (T)coef[j] : (T)0;
+        a.e[j] = (j < nt && err_coef) ? (T)err_coef[j] : (T)0;
+    }
+    a.nt = nt;
+    a.dt_dev = dt_dev;
+    a.n = n;
+    hipLaunchKernelGGL((combine_dev_kernel<T>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
+}
+
+template <typename T>
+int launch_commit(void* y_prev, void* f_prev, void* y_cur, void* f_cur, const void* y1, const void* f1,
+                  const double* ctrl_dev, int64_t n, hipStream_t s) {
+    CommitArgs<T> a;
+    a.y_prev = static_cast<T*>(y_prev);
+    a.f_prev = static_cast<T*>(f_prev);
+    a.y_cur = static_cast<T*>(y_cur);
+    a.f_cur = static_cast<T*>(f_cur);
+    a.y1 = static_cast<const T*>(y1);
+    a.f1 = static_cast<const T*>(f1);
+    a.ctrl_dev = ctrl_dev;
+    a.n = n;
+    hipLaunchKernelGGL((step_commit_kernel<T>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
 }
 
 template <typename T>
@@ -720,7 +759,7 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
                                  const double* coef, int n_terms, double dt, const tdeq_segment* segs, int n_seg,
                                  int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite,
                                  const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev, void* next_times,
-                                 void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+                                 int state_in_dev, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
     if (!err_partial || !y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype))
         return TDEQ_EINVAL;
     if (!ctrl || !out_ctrl || !ctrl_dev || !next_times) return TDEQ_EINVAL;
@@ -735,10 +774,33 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
     if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
-    const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times};
+    const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times, state_in_dev ? 1 : 0};
     return dtype == TDEQ_F32
                ? dispatch_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s)
                : dispatch_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s);
+}
+
+int tdeq_stage_combine_dev(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
+                           const double* err_coef, int n_terms, const double* ctrl_dev, int64_t n, int dtype,
+                           void* stream) {
+    if (!out || !y0 || !k || !coef || !ctrl_dev || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS || (err_out && !err_coef)) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32
+               ? launch_combine_dev<float>(out, err_out, y0, k, coef, err_coef, n_terms, ctrl_dev + 1, n, s)
+               : launch_combine_dev<double>(out, err_out, y0, k, coef, err_coef, n_terms, ctrl_dev + 1, n, s);
+}
+
+int tdeq_step_commit(void* y_prev, void* f_prev, void* y_cur, void* f_cur, const void* y1, const void* f1,
+                     const double* ctrl_dev, int64_t n, int dtype, void* stream) {
+    if (!y_prev || !f_prev || !y_cur || !f_cur || !y1 || !f1 || !ctrl_dev || n < 0 || bad_dtype(dtype))
+        return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? launch_commit<float>(y_prev, f_prev, y_cur, f_cur, y1, f1, ctrl_dev, n, s)
+                             : launch_commit<double>(y_prev, f_prev, y_cur, f_cur, y1, f1, ctrl_dev, n, s);
 }
 
 int tdeq_stage_combine_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej,

@@ -362,6 +362,7 @@ struct ErrPartialArgs {
     SegTable st;
     double* part_sumsq;
     double* part_bad;
+    const double* dt_dev;   // non-null (hipGraph mode): c[] holds fl_T(coef) and is multiplied by T(*dt_dev) here
 };
 
 template <typename T>
@@ -383,6 +384,12 @@ __global__ __launch_bounds__(kBlock) void error_norm_partial_kernel(const ErrPar
     int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
     valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
     const T rtol = (T)seg.rtol, atol = (T)seg.atol;
+    T cc[NT > 0 ? NT : 1];
+    {
+        const T dtT = a.dt_dev ? (T)*a.dt_dev : (T)1;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) cc[j] = a.dt_dev ? a.c[j] * dtT : a.c[j];
+    }
     double acc[2] = {0.0, 0.0};
     int64_t t0 = 0;
     if (VEC) {
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void error_norm_partial_kernel(const ErrPar
         for (int64_t i = threadIdx.x; i < nv; i += kBlock) {
             V e = pe[i];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) e = e + reinterpret_cast<const V*>(a.k[j] + base)[i] * a.c[j];
+            for (int j = 0; j < NT; ++j) e = e + reinterpret_cast<const V*>(a.k[j] + base)[i] * cc[j];
             const V v0 = y0[i], v1 = y1[i];
 #pragma unroll
             for (int q = 0; q < L; ++q) tol_accumulate<T>(e[q], v0[q], v1[q], rtol, atol, acc[0], acc[1]);
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void error_norm_partial_kernel(const ErrPar
     for (int64_t t = t0 + threadIdx.x; t < valid; t += kBlock) {
         T e = a.partial[base + t];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) e = e + a.k[j][base + t] * a.c[j];
+        for (int j = 0; j < NT; ++j) e = e + a.k[j][base + t] * cc[j];
         tol_accumulate<T>(e, a.y0[base + t], a.y1[base + t], rtol, atol, acc[0], acc[1]);
     }
     block_sum<2>(acc, red);
@@ -521,8 +528,9 @@ struct CtrlArgs {
     double* out_sumsq;        // [n_seg]   device or pinned host
     double* out_bad;          // [n_seg]
     double* out_ctrl;         // [4] = {accept, dt_next, ratio, t0_next}
-    double* ctrl_dev;         // [2] = {accept, sign * T(dt_next')}      device
+    double* ctrl_dev;         // [4] = {accept, sign * T(dt'), t0', dt'}  device
     void* next_times;         // [n_times] of T                          device
+    int state_in_dev;         // hipGraph mode: the trial step's (t0, dt) are ctrl_dev[2..3], not c.t0 / c.dt
 };
 
 __device__ __forceinline__ double ctl_nan_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
@@ -584,6 +592,8 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
     }
     const tdeq_step_ctrl& c = a.c;
     if (threadIdx.x == 0) {
+        const double step_t0 = a.state_in_dev ? a.ctrl_dev[2] : c.t0;
+        const double step_dt = a.state_in_dev ? a.ctrl_dev[3] : c.dt;
         // error ratio: max over segments of sqrt(mean), rounded to T (misc.py:22-33, 80-82)
         double val = 0.0;
         for (int s = 0; s < c.n_norm_seg && s < n_seg; ++s) {
@@ -594,26 +604,28 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         const double ratio = a.is_f32 ? (double)(float)val : val;
         // accept / reject (rk_common.py:324-330)
         bool accept = ratio <= 1.0;
-        if (c.dt > c.max_step) accept = false;
-        if (c.dt <= c.min_step) accept = true;
+        if (step_dt > c.max_step) accept = false;
+        if (step_dt <= c.min_step) accept = true;
         // next step size (misc.py:85-95), then the clamp of rk_common.py:353
         double dt_next;
         if (ratio == 0.0) {
-            dt_next = c.dt * c.ifactor;
+            dt_next = step_dt * c.ifactor;
         } else {
             const double dfactor = ratio < 1.0 ? 1.0 : c.dfactor;
             const double scaled = c.safety / pow(ratio, c.exponent);
-            dt_next = c.dt * ctl_nan_min(c.ifactor, ctl_nan_max(scaled, dfactor));
+            dt_next = step_dt * ctl_nan_min(c.ifactor, ctl_nan_max(scaled, dfactor));
         }
         dt_next = ctl_clamp(dt_next, c.min_step, c.max_step);
         // the next trial step as the host will set it up (rk_common.py:268-275)
-        const double t0n = accept ? c.t0 + c.dt : c.t0;
+        const double t0n = accept ? step_t0 + step_dt : step_t0;
         double dtn = dt_next;
         if (!__builtin_isfinite(dtn)) dtn = c.min_step;
         dtn = ctl_clamp(dtn, c.min_step, c.max_step);
         // device-side consumers first (the look-ahead stage is next in the stream), then the host's words
         a.ctrl_dev[0] = accept ? 1.0 : 0.0;
         a.ctrl_dev[1] = (a.is_f32 ? (double)(float)dtn : dtn) * c.time_sign;
+        a.ctrl_dev[2] = t0n;
+        a.ctrl_dev[3] = dtn;
         next_step[0] = t0n;
         next_step[1] = dtn;
         a.out_ctrl[0] = accept ? 1.0 : 0.0;
@@ -630,6 +642,71 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
     if (i < n_seg) {
         a.out_sumsq[i] = seg_val[0][i];
         a.out_bad[i] = seg_val[1][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hipGraph mode of the adaptive solvers (small states: a trial step is launch-latency-bound).  One captured graph
+// = one trial step; its kernels take the step size from device memory (ctrl_dev[1] = sign * T(dt), written by
+// norm_finalize_ctrl_kernel of the previous trial) and work on static buffers:
+//   combine_dev_kernel   out = y + sum_j fl_T(coef_j * dt) k_j  [, err_out = sum_j fl_T(ecoef_j * dt) k_j]
+//                        — stage_combine / stage_combine_err with a run-time term count (this regime does not
+//                        need the unrolled, register-resident streams of the large-state kernels)
+//   step_commit_kernel   on accept: (y_prev, f_prev) <- (y_cur, f_cur) ; (y_cur, f_cur) <- (y1, f1)
+//                        (rk_common.py:335-352; the previous pair stays available for the dense output)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct CombineDevArgs {
+    T* out;
+    T* err_out;              // may be null
+    const T* y0;
+    const T* k[TDEQ_MAX_TERMS];
+    T c[TDEQ_MAX_TERMS];     // fl_T(coef_j)
+    T e[TDEQ_MAX_TERMS];     // fl_T(err_coef_j)
+    int nt;
+    const double* dt_dev;    // sign * T(dt)
+    int64_t n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void combine_dev_kernel(const CombineDevArgs<T> a) {
+    const T dtT = (T)*a.dt_dev;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        T k0 = a.k[0][i];
+        T acc = k0 * (a.c[0] * dtT);
+        T err = k0 * (a.e[0] * dtT);
+        for (int j = 1; j < a.nt; ++j) {
+            const T kj = a.k[j][i];
+            acc = acc + kj * (a.c[j] * dtT);
+            err = err + kj * (a.e[j] * dtT);
+        }
+        a.out[i] = a.y0[i] + acc;
+        if (a.err_out) a.err_out[i] = err;
+    }
+}
+
+template <typename T>
+struct CommitArgs {
+    T* y_prev;
+    T* f_prev;
+    T* y_cur;
+    T* f_cur;
+    const T* y1;
+    const T* f1;
+    const double* ctrl_dev;
+    int64_t n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void step_commit_kernel(const CommitArgs<T> a) {
+    if (a.ctrl_dev[0] == 0.0) return;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        a.y_prev[i] = a.y_cur[i];
+        a.f_prev[i] = a.f_cur[i];
+        a.y_cur[i] = a.y1[i];
+        a.f_cur[i] = a.f1[i];
     }
 }
 

@@ -83,7 +83,7 @@ def odeint_adjoint_sharded(func, y0_shard, t, *, group=None, sync_steps=False, *
     rounding, at the price of one small collective per evaluation and per trial step."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         g = True if group is None else group
-        inherited = {k: v for k, v in (kwargs.get("options") or {}).items() if k != "norm"}
+        inherited = {k: v for k, v in (kwargs.get("options") or {}).items() if k not in ("norm", "hip_graph")}
         adjoint_options = dict(kwargs.pop("adjoint_options", None) or inherited)
         if sync_steps:
             options = dict(kwargs.pop("options", None) or {})

@@ -16,6 +16,8 @@ with time-like scalars (t0, t1, dt, rtol, ...) as host doubles instead of 0-dim 
 from __future__ import annotations
 
 import bisect
+import contextlib
+import gc
 import math
 import os
 import warnings
@@ -108,6 +110,105 @@ class _LockStep:
         return out[:n], out[n:2 * n], out[2 * n:]
 
 
+@contextlib.contextmanager
+def _capture(graph):
+    """Stream capture of a step body into `graph`.  Unlike the `torch.cuda.graph` context this neither synchronises
+    the device nor empties the caching allocator (both cost milliseconds — more than a short solve), and it pauses
+    the cyclic garbage collector: a collection in the middle of a capture may finalize unrelated objects that own HIP
+    resources (pinned buffers, events, other graphs), whose release calls are illegal while a stream is capturing."""
+    current = torch.cuda.current_stream()
+    side = torch.cuda.Stream(current.device)
+    side.wait_stream(current)
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.stream(side):
+            graph.capture_begin()
+            try:
+                yield
+            finally:
+                graph.capture_end()
+    finally:
+        if was_enabled:
+            gc.enable()
+    current.wait_stream(side)
+
+
+class _GraphStep:
+    """Static buffers + the captured hipGraph of one adaptive trial step (RKAdaptiveStepsizeODESolver._graph_trial_step).
+    The first trial step runs the body eagerly on a side stream (library / allocator warm-up), the second call
+    captures it, every later call is a replay.  Holds no reference to the solver (no reference cycle: the graph and
+    its memory pool are released by reference counting, deterministically, when the solver goes away)."""
+
+    def __init__(self, s, t0: float, dt: float):
+        func, kern, T = s.func, s.kernels, s.np_dtype
+        dev = s.y0.device
+        self.y_cur, self.f_cur = s.y1.detach().clone(), s.f1.detach().clone()
+        self.y_prev, self.f_prev = torch.empty_like(self.y_cur), torch.empty_like(self.y_cur)
+        self.y1 = torch.empty_like(self.y_cur)
+        self.epart = torch.empty_like(self.y_cur)
+        n_times = len(s._beta)
+        self.tbuf = torch.empty(n_times, dtype=s.y0.dtype, device=dev)
+        self.ts = self.tbuf.unbind(0)
+        self.k: List[torch.Tensor] = []
+        self.graph = None
+        self.calls = 0
+        # device-resident step state {accept, sign*T(dt), t0, dt} and the first trial's stage times
+        t0_T, dt_T, t1_T = T(t0), T(dt), T(t0 + dt)
+        s.plan.ctrl_dev.copy_(torch.tensor([0.0, float(dt_T) * func.sign, t0, dt], dtype=torch.float64))
+        times = [(t1_T, Perturb.PREV) if s._alpha_is_one[i] else (t0_T + s._alpha[i] * dt_T, Perturb.NONE)
+                 for i in range(n_times)]
+        kern.fill_scalars(self.tbuf, [func.user_time(t, p) for t, p in times])
+
+    def body(self, s) -> None:
+        func, kern, plan = s.func, s.kernels, s.plan
+        beta, fuse, fsal = s._beta, s._fuse, s.tableau.fsal_solution
+        k = [self.f_cur]
+        yi = torch.empty_like(self.y_cur)
+        kern.stage_combine_dev(yi, None, self.y_cur, [self.f_cur], beta[0].coef, None, plan)
+        k.append(func.eval_at(self.ts[0], yi))
+        n_rows = len(beta)
+        for i in range(1, n_rows):
+            row = beta[i]
+            ks = [k[j] for j in row.idx]
+            if i == n_rows - 1 and fsal:
+                yi = self.y1
+                kern.stage_combine_dev(yi, self.epart, self.y_cur, ks, row.coef, fuse[0], plan)
+            else:
+                yi = torch.empty_like(self.y_cur)
+                kern.stage_combine_dev(yi, None, self.y_cur, ks, row.coef, None, plan)
+            k.append(func.eval_at(self.ts[i], yi))
+        if not fsal:
+            sol = s._c_sol
+            kern.stage_combine_dev(self.y1, self.epart, self.y_cur, [k[j] for j in sol.idx], sol.coef, fuse[0], plan)
+        kern.error_norm_partial_ctrl(plan, self.epart, self.y_cur, self.y1, [k[j] for j in fuse[1]], fuse[2], 0.0,
+                                     s._ctrl, self.tbuf, state_in_dev=True)
+        kern.step_commit(self.y_prev, self.f_prev, self.y_cur, self.f_cur, self.y1, k[-1], plan)
+        self.k = k
+
+    def run(self, s) -> None:
+        kern, func = s.kernels, s.func
+        self.calls += 1
+        if self.calls == 1:
+            current = torch.cuda.current_stream(s.y0.device)
+            side = torch.cuda.Stream(s.y0.device)
+            side.wait_stream(current)
+            with torch.cuda.stream(side):
+                self.body(s)
+            current.wait_stream(side)
+            return
+        if self.graph is None:
+            graph = torch.cuda.CUDAGraph()
+            nfe = func.nfe
+            with _capture(graph):
+                self.body(s)
+            func.nfe = nfe
+            self.graph = graph
+        kern.arm_readback(s.plan)
+        self.graph.replay()
+        func.nfe += len(s._beta)
+
+
 class _DenseRecord:
     """Data of the last accepted step, kept for lazy dense output (rk_common.py:363-369)."""
     __slots__ = ("y0", "y1", "k", "dt_signed", "t0", "t1")
@@ -121,7 +222,7 @@ class RKAdaptiveStepsizeODESolver:
     def __init__(self, func: OdeFunc, y0: torch.Tensor, rtol, atol, min_step=0, max_step=float("inf"),
                  first_step=None, step_t=None, jump_t=None, safety=0.9, ifactor=10.0, dfactor=0.2,
                  max_num_steps=2 ** 31 - 1, dtype=torch.float64, norm=None, dist_sync=None, dist_replicated=(),
-                 **unused_kwargs):
+                 hip_graph=False, **unused_kwargs):
         handle_unused_kwargs(self, unused_kwargs)
         del unused_kwargs
         if not isinstance(func, OdeFunc):
@@ -181,12 +282,20 @@ class RKAdaptiveStepsizeODESolver:
         # the loop stays here, but the scalar decision of a trial step is also taken on the device so that the next
         # trial step's first stage and func evaluation are enqueued before the decision has been read back.
         n_norm_seg = self.layout.n_seg - (self.norm.n_skip_tail if isinstance(self.norm, BuiltinNorm) else 0)
-        self._lookahead = (self._fuse is not None and isinstance(self.norm, BuiltinNorm)
-                           and self.layout.n_seg <= _native.TDEQ_INLINE_SEGMENTS
-                           and len(self._beta) <= _native.TDEQ_MAX_STAGE_TIMES and n_norm_seg >= 0
-                           and self.step_t is None and self.jump_t is None and self._sync is None
-                           and os.environ.get("TDEQ_LOOKAHEAD", "1") != "0")
-        if self._lookahead:
+        device_ctrl = (self._fuse is not None and isinstance(self.norm, BuiltinNorm)
+                       and self.layout.n_seg <= _native.TDEQ_INLINE_SEGMENTS
+                       and len(self._beta) <= _native.TDEQ_MAX_STAGE_TIMES and n_norm_seg >= 0
+                       and self.step_t is None and self.jump_t is None and self._sync is None)
+        self._lookahead = device_ctrl and os.environ.get("TDEQ_LOOKAHEAD", "1") != "0"
+        # `hip_graph=True` (an extension, not a reference option): one captured hipGraph per trial step, see _GraphStep
+        self.hip_graph = bool(hip_graph) and device_ctrl and y0.device.type == "cuda" \
+            and hasattr(self.kernels, "stage_combine_dev")
+        if bool(hip_graph) and not self.hip_graph:
+            warnings.warn("{}: hip_graph=True needs a builtin norm, at most {} state segments, no step_t / jump_t, a "
+                          "tableau with a fused error combine and a ROCm device; running the eager path".format(
+                              self.__class__.__name__, _native.TDEQ_INLINE_SEGMENTS))
+        self._g = None
+        if device_ctrl:
             c = _native.StepCtrl()
             c.safety, c.ifactor, c.dfactor = self.safety, self.ifactor, self.dfactor
             c.exponent = 1.0 / self.order
@@ -259,6 +368,9 @@ class RKAdaptiveStepsizeODESolver:
                 j += 1
             self._interp_evaluate_rows(t_host[i:j], solution[i:j])
             i = j
+        if self._g is not None:
+            # hipGraph mode: the graph's private pool backs the last step's buffers — let its kernels finish
+            torch.cuda.current_stream(self.y0.device).synchronize()
         return solution
 
     def _set_time_anchor(self, t: torch.Tensor) -> None:
@@ -346,6 +458,7 @@ class RKAdaptiveStepsizeODESolver:
         self.t0, self.t1, self.dt = t0, t0, first_step
         self._dense: Optional[_DenseRecord] = None
         self._t_end, self._pre = -math.inf, None    # event mode / direct stepping: no look-ahead
+        self._g = None
 
         step_t = [] if self.step_t is None else sorted(v for v in self.step_t if v >= t0)
         jump_t = [] if self.jump_t is None else sorted(v for v in self.jump_t if v >= t0)
@@ -393,7 +506,10 @@ class RKAdaptiveStepsizeODESolver:
         while next_t > self.t1:
             assert n_steps < self.max_num_steps, \
                 "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
-            self._adaptive_step()
+            if self.hip_graph and self._graph_step_ok():
+                self._graph_trial_step()
+            else:
+                self._adaptive_step()
             n_steps += 1
 
     def _advance(self, next_t: float, out: Optional[torch.Tensor], t_shadow=None) -> torch.Tensor:
@@ -577,6 +693,46 @@ class RKAdaptiveStepsizeODESolver:
         else:
             dt_next = optimal_step_size(dt, error_ratio, self.safety, self.ifactor, self.dfactor, self.order)
             self.dt = _clamp(dt_next, self.min_step, self.max_step)
+
+    # -- hipGraph mode -----------------------------------------------------------------------------------
+    def _graph_step_ok(self) -> bool:
+        func = self.func
+        return (func.callback_step is _null and func.callback_accept_step is _null
+                and func.callback_reject_step is _null
+                and not (torch.is_grad_enabled() and (self.y1.requires_grad or self.f1.requires_grad
+                                                      or self._anchor is not None)))
+
+    def _graph_trial_step(self) -> None:
+        """One trial step as ONE hipGraph replay (`options={'hip_graph': True}`; small states, where a step costs
+        launch latency).  The graph holds the S evaluations of `func`, the stage combines reading the step size
+        from device memory (tdeq_stage_combine_dev), the error norm + device controller (state_in_dev) and
+        tdeq_step_commit; the host replays it, reads the controller's words and keeps its own mirror of (t0, dt) —
+        identical doubles — for the output loop.  Same kernels' arithmetic and decisions as the eager path."""
+        func, kern, T = self.func, self.kernels, self.np_dtype
+        t0, dt = self.t1, self.dt
+        if not math.isfinite(dt):
+            dt = self.min_step
+        dt = _clamp(dt, self.min_step, self.max_step)
+        t1 = t0 + dt
+        assert t0 + dt > t0, "underflow in dt {}".format(dt)
+        assert not self._y_nonfinite, "non-finite values in state `y`: {}".format(self.y1)
+        g = self._g
+        if g is None:
+            g = self._g = _GraphStep(self, t0, dt)
+        g.run(self)
+        accept_step, dt_next, _ratio, bad = kern.read_ctrl(self.plan)
+        dt_signed = float(T(dt)) * func.sign
+        if accept_step:
+            rec = _DenseRecord()
+            rec.y0, rec.y1, rec.k, rec.dt_signed, rec.t0, rec.t1 = g.y_prev, g.y1, [g.f_prev] + g.k[1:], dt_signed, t0, t1
+            self._dense = rec
+            self.y1, self.f1, self.t0, self.t1 = g.y_cur, g.f_cur, t0, t1
+            self._y_nonfinite = any(b != 0 for b in bad)
+            self.n_accepted += 1
+        else:
+            self.t0 = t0
+            self.n_rejected += 1
+        self.dt = dt_next
 
     def _user_norm_ratio(self, y0, y1, k, dt_signed):
         """User-supplied `norm` callable (misc.py:80-82 with a custom norm): the kernel materialises
@@ -1036,7 +1192,7 @@ class RK4(FixedGridODESolver):
             # ... the others are replays of one captured step
             graph = torch.cuda.CUDAGraph()
             nfe_before = func.nfe
-            with torch.cuda.graph(graph):
+            with _capture(graph):
                 step()
             func.nfe = nfe_before
             for _ in range(n_t - 2):
