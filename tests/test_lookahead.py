@@ -240,7 +240,7 @@ def test_stage_combine_sel_bit_exact(hip_kernels, oracle_kernels, dtype, n):
     for accept in (0.0, 1.0):
         for dt in (0.0371, -0.25):
             dtT = float(np_dtype(dt))
-            plan_d.ctrl_dev.copy_(torch.tensor([accept, dtT], dtype=torch.float64))
+            plan_d.ctrl_dev[:2].copy_(torch.tensor([accept, dtT], dtype=torch.float64))
             plan_o.ctrl_dev.copy_(torch.tensor([accept, dtT], dtype=torch.float64))
             out_d, out_o = torch.empty_like(td[0]), torch.empty_like(ts[0])
             hip_kernels.stage_combine_sel(out_d, td[0], td[1], td[2], td[3], 0.2, plan_d)
