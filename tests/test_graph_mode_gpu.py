@@ -142,3 +142,35 @@ def test_adaptive_graph_mode_many_outputs_and_tuple_state():
         ya, yb = tda.odeint(f, y0, t, rtol=1e-7, atol=1e-9, method="dopri5")
         ga, gb = tda.odeint(f, y0, t, rtol=1e-7, atol=1e-9, method="dopri5", options=dict(hip_graph=True))
     assert torch.equal(ga, ya) and torch.equal(gb, yb)
+
+
+def test_adjoint_backward_never_captures():
+    """hip_graph on the forward pass of odeint_adjoint is fine; for the backward solve it is refused with a warning
+    (autograd inside the augmented dynamics cannot be captured) and the gradients equal the eager ones."""
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 8).double().cuda()
+
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = lin
+
+        def forward(self, t, y):
+            return torch.tanh(self.lin(y))
+
+    y0 = torch.randn(16, 8, dtype=torch.float64, device="cuda")
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64, device="cuda")
+    grads = []
+    for opts, aopts in ((None, None), (dict(hip_graph=True), dict(hip_graph=True))):
+        f = F()
+        f.zero_grad()
+        x = y0.clone().requires_grad_(True)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            y = tda.odeint_adjoint(f, x, t, rtol=1e-7, atol=1e-9, method="dopri5", options=opts, adjoint_options=aopts)
+            y[-1].pow(2).sum().backward()
+        if aopts:
+            assert any("hip_graph" in str(w.message) for w in rec)
+        grads.append((y.detach().clone(), x.grad.clone(), lin.weight.grad.clone()))
+    for a, b in zip(grads[1], grads[0]):
+        assert torch.equal(a, b)

@@ -174,6 +174,11 @@ class OdeintAdjointMethod(torch.autograd.Function):
             group = options.pop("dist_group", None)
             sync = options.pop("dist_sync", None)
             options.pop("dist_replicated", None)
+            if options.pop("hip_graph", False):
+                # the augmented dynamics call torch.autograd.grad from inside the autograd engine's own thread;
+                # capturing that into a hipGraph crashes the capture (measured) — never attempted
+                warnings.warn("adjoint_options['hip_graph'] is ignored: the backward solve evaluates autograd inside "
+                              "func and cannot be captured into a hipGraph")
             if sync is not None:
                 # lock-step backward solve: [vjp_t | θ-adjoints] replicated (all-reduced per evaluation), y / adj_y
                 # sharded; the norm sums are added over ranks (solvers._LockStep)
