@@ -174,3 +174,31 @@ def test_adjoint_backward_never_captures():
         grads.append((y.detach().clone(), x.grad.clone(), lin.weight.grad.clone()))
     for a, b in zip(grads[1], grads[0]):
         assert torch.equal(a, b)
+
+
+def test_uncapturable_func_falls_back_to_eager():
+    """A func that synchronises with the host cannot be captured: the solver warns and finishes the solve eagerly,
+    with the same result."""
+    def f(t, y):
+        scale = float(t)              # device -> host read: illegal while a stream is capturing
+        return -y * (1.0 + 0.1 * scale)
+
+    y0 = torch.tensor([[1.0, 2.0, 3.0]], dtype=torch.float64, device="cuda")
+    t = torch.tensor([0.0, 1.0, 2.0], dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        ref = tda.odeint(f, y0, t, method="dopri5", rtol=1e-7, atol=1e-9)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            y = tda.odeint(f, y0, t, method="dopri5", rtol=1e-7, atol=1e-9, options=dict(hip_graph=True))
+    assert any("could not be captured" in str(w.message) for w in rec)
+    assert torch.equal(y, ref)
+    tg = torch.linspace(0.0, 1.0, 9, dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        ref4 = tda.odeint(f, y0, tg, method="rk4")
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            y4 = tda.odeint(f, y0, tg, method="rk4", options=dict(hip_graph=True))
+    assert any("could not be captured" in str(w.message) for w in rec)
+    assert torch.equal(y4, ref4)
+    # the device is still usable
+    assert float((y0 * 2).sum()) == 12.0

@@ -110,6 +110,10 @@ class _LockStep:
         return out[:n], out[n:2 * n], out[2 * n:]
 
 
+class _CaptureFailed(RuntimeError):
+    """The step body could not be captured into a hipGraph; no kernel of it has run."""
+
+
 @contextlib.contextmanager
 def _capture(graph):
     """Stream capture of a step body into `graph`.  Unlike the `torch.cuda.graph` context this neither synchronises
@@ -200,8 +204,12 @@ class _GraphStep:
         if self.graph is None:
             graph = torch.cuda.CUDAGraph()
             nfe = func.nfe
-            with _capture(graph):
-                self.body(s)
+            try:
+                with _capture(graph):
+                    self.body(s)
+            except Exception as exc:       # func is not capturable (host sync, unsupported op ...): nothing has run
+                func.nfe = nfe
+                raise _CaptureFailed(repr(exc)) from exc
             func.nfe = nfe
             self.graph = graph
         kern.arm_readback(s.plan)
@@ -507,7 +515,15 @@ class RKAdaptiveStepsizeODESolver:
             assert n_steps < self.max_num_steps, \
                 "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
             if self.hip_graph and self._graph_step_ok():
-                self._graph_trial_step()
+                try:
+                    self._graph_trial_step()
+                except _CaptureFailed as exc:
+                    # a failed capture executes nothing: the static buffers still hold the current state, continue
+                    # with the eager path from it
+                    warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({}); continuing with "
+                                  "the eager path".format(exc))
+                    self.hip_graph = False
+                    self._adaptive_step()
             else:
                 self._adaptive_step()
             n_steps += 1
@@ -1192,8 +1208,16 @@ class RK4(FixedGridODESolver):
             # ... the others are replays of one captured step
             graph = torch.cuda.CUDAGraph()
             nfe_before = func.nfe
-            with _capture(graph):
-                step()
+            try:
+                with _capture(graph):
+                    step()
+            except Exception as exc:      # func is not capturable: nothing has run, the same body works eagerly
+                func.nfe = nfe_before
+                warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({!r}); continuing with "
+                              "the eager path".format(exc))
+                for _ in range(n_t - 2):
+                    step()
+                return solution
             func.nfe = nfe_before
             for _ in range(n_t - 2):
                 graph.replay()
