@@ -202,3 +202,48 @@ def test_uncapturable_func_falls_back_to_eager():
     assert torch.equal(y4, ref4)
     # the device is still usable
     assert float((y0 * 2).sum()) == 12.0
+
+
+def test_graph_is_reused_across_solves_of_the_same_func():
+    """Second and later solves with the same func object and state layout replay the graph captured by the first
+    (no capture, no eager warm-up step) with the new initial state — and see in-place parameter updates."""
+    from torchdiffeq_amd.solvers import _GraphStep
+    tda.clear_graph_cache()
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 6)).double().cuda()
+
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = net
+
+        def forward(self, t, y):
+            return self.net(y) * torch.cos(t)
+
+    f = F()
+    t = torch.tensor([0.0, 0.6, 1.5], dtype=torch.float64, device="cuda")
+    kw = dict(method="dopri5", rtol=1e-7, atol=1e-9)
+    graphs = []
+    for rep in range(4):
+        y0 = torch.randn(32, 6, dtype=torch.float64, device="cuda")
+        if rep == 2:
+            with torch.no_grad():
+                net[0].weight.mul_(1.1)          # an optimizer step between solves
+        with torch.no_grad():
+            ref = tda.odeint(f, y0, t, **kw)
+            y = tda.odeint(f, y0, t, options=dict(hip_graph=True), **kw)
+        assert torch.equal(y, ref), rep
+        per_func = _GraphStep._cache.get(f)
+        assert per_func is not None and len(per_func) == 1
+        g = next(iter(per_func.values()))
+        graphs.append((g, g.graph, g.calls))
+        assert not g.in_use
+    assert all(a[0] is graphs[0][0] and a[1] is graphs[0][1] for a in graphs)      # one capture, reused
+    assert graphs[-1][2] > graphs[0][2]
+    # a different state layout gets its own graph
+    with torch.no_grad():
+        y0 = torch.randn(7, 6, dtype=torch.float64, device="cuda")
+        assert torch.equal(tda.odeint(f, y0, t, options=dict(hip_graph=True), **kw), tda.odeint(f, y0, t, **kw))
+    assert len(_GraphStep._cache.get(f)) == 2
+    tda.clear_graph_cache()
+    assert _GraphStep._cache.get(f) is None

@@ -7,6 +7,7 @@ arithmetic runs in hand-written gfx950 HIP kernels (libtdeq_hip.so, C-ABI in inc
 """
 from .odeint import SOLVERS, odeint, odeint_dense, odeint_event
 from .adjoint import odeint_adjoint
+from .solvers import clear_graph_cache
 
 __version__ = "0.1.0"
-__all__ = ["odeint", "odeint_adjoint", "odeint_event", "odeint_dense", "SOLVERS"]
+__all__ = ["odeint", "odeint_adjoint", "odeint_event", "odeint_dense", "SOLVERS", "clear_graph_cache"]

@@ -19,6 +19,7 @@ import bisect
 import contextlib
 import gc
 import math
+import weakref
 import os
 import warnings
 from typing import List, Optional, Sequence
@@ -145,24 +146,72 @@ class _GraphStep:
     its memory pool are released by reference counting, deterministically, when the solver goes away)."""
 
     def __init__(self, s, t0: float, dt: float):
-        func, kern, T = s.func, s.kernels, s.np_dtype
         dev = s.y0.device
-        self.y_cur, self.f_cur = s.y1.detach().clone(), s.f1.detach().clone()
+        self.y_cur, self.f_cur = torch.empty_like(s.y1), torch.empty_like(s.y1)
         self.y_prev, self.f_prev = torch.empty_like(self.y_cur), torch.empty_like(self.y_cur)
         self.y1 = torch.empty_like(self.y_cur)
         self.epart = torch.empty_like(self.y_cur)
-        n_times = len(s._beta)
-        self.tbuf = torch.empty(n_times, dtype=s.y0.dtype, device=dev)
+        self.tbuf = torch.empty(len(s._beta), dtype=s.y0.dtype, device=dev)
         self.ts = self.tbuf.unbind(0)
         self.k: List[torch.Tensor] = []
         self.graph = None
         self.calls = 0
-        # device-resident step state {accept, sign*T(dt), t0, dt} and the first trial's stage times
+        self.plan = s.plan          # the graph's norm kernels write into THIS plan's buffers
+        self.in_use = True
+        self.reset(s, t0, dt)
+
+    def reset(self, s, t0: float, dt: float) -> None:
+        """Load a solve's current state into the static buffers: y, f(t0, y), the device-resident step state
+        {accept, sign*T(dt), t0, dt} and the first trial's stage times."""
+        func, kern, T = s.func, s.kernels, s.np_dtype
+        self.y_cur.copy_(s.y1.detach())
+        self.f_cur.copy_(s.f1.detach())
         t0_T, dt_T, t1_T = T(t0), T(dt), T(t0 + dt)
-        s.plan.ctrl_dev.copy_(torch.tensor([0.0, float(dt_T) * func.sign, t0, dt], dtype=torch.float64))
+        self.plan.ctrl_dev.copy_(torch.tensor([0.0, float(dt_T) * func.sign, t0, dt], dtype=torch.float64))
         times = [(t1_T, Perturb.PREV) if s._alpha_is_one[i] else (t0_T + s._alpha[i] * dt_T, Perturb.NONE)
-                 for i in range(n_times)]
+                 for i in range(len(s._beta))]
         kern.fill_scalars(self.tbuf, [func.user_time(t, p) for t, p in times])
+
+    # -- reuse across solves ---------------------------------------------------------------------------------
+    # A training loop calls odeint with the same func and state layout over and over; capturing (≈1 ms) and the eager
+    # warm-up step would be paid per call.  Captured steps are therefore kept per `func` object (weakly: they go
+    # away with it) and re-armed with the next solve's state.  Valid as long as func computes the same kernels on the
+    # same parameter storages — what a captured graph requires anyway; `clear_graph_cache()` drops them.
+    _cache = weakref.WeakKeyDictionary()
+    _MAX_PER_FUNC = 4
+
+    @staticmethod
+    def _key(s):
+        c = s._ctrl
+        segs = tuple((int(sg.chunk_start), int(sg.numel), float(sg.rtol), float(sg.atol)) for sg in s.plan.segs)
+        return (type(s).__name__, str(s.y0.dtype), str(s.y0.device), int(s.layout.total), int(s.plan.chunk), segs,
+                c.safety, c.ifactor, c.dfactor, c.exponent, c.min_step, c.max_step, c.time_sign, int(c.n_norm_seg))
+
+    @classmethod
+    def acquire(cls, s, t0: float, dt: float) -> "_GraphStep":
+        try:
+            per_func = cls._cache.get(s.func.base_func)
+        except TypeError:           # func object cannot be weakly referenced: no reuse
+            return cls(s, t0, dt)
+        key = cls._key(s)
+        g = per_func.get(key) if per_func is not None else None
+        if g is not None and not g.in_use:
+            g.in_use = True
+            s.plan = g.plan         # read-backs must poll the buffers the captured kernels write
+            g.reset(s, t0, dt)
+            return g
+        g = cls(s, t0, dt)
+        if per_func is None:
+            try:
+                per_func = cls._cache[s.func.base_func] = {}
+            except TypeError:
+                return g
+        if key not in per_func and len(per_func) < cls._MAX_PER_FUNC:
+            per_func[key] = g
+        return g
+
+    def release(self) -> None:
+        self.in_use = False
 
     def body(self, s) -> None:
         func, kern, plan = s.func, s.kernels, s.plan
@@ -215,6 +264,11 @@ class _GraphStep:
         kern.arm_readback(s.plan)
         self.graph.replay()
         func.nfe += len(s._beta)
+
+
+def clear_graph_cache() -> None:
+    """Drop every captured trial-step graph kept for reuse (options={'hip_graph': True})."""
+    _GraphStep._cache.clear()
 
 
 class _DenseRecord:
@@ -367,18 +421,22 @@ class RKAdaptiveStepsizeODESolver:
         solution = torch.empty(len(t_host), self.layout.total, dtype=self.y0.dtype, device=self.y0.device)
         solution[0].copy_(self.y0)
         i, n_t = 1, len(t_host)
-        while i < n_t:
-            self._step_until(t_host[i])
-            # every output time inside the step just accepted is an interpolation of that step (rk_common.py:243-250):
-            # one launch per <= 16 of them (tdeq_dense_eval_multi) instead of one per output time
-            j = i + 1
-            while j < n_t and t_host[j] <= self.t1 and j - i < self._max_rows:
-                j += 1
-            self._interp_evaluate_rows(t_host[i:j], solution[i:j])
-            i = j
-        if self._g is not None:
-            # hipGraph mode: the graph's private pool backs the last step's buffers — let its kernels finish
-            torch.cuda.current_stream(self.y0.device).synchronize()
+        try:
+            while i < n_t:
+                self._step_until(t_host[i])
+                # every output time inside the step just accepted is an interpolation of that step
+                # (rk_common.py:243-250): one launch per <= 16 of them (tdeq_dense_eval_multi), not one per time
+                j = i + 1
+                while j < n_t and t_host[j] <= self.t1 and j - i < self._max_rows:
+                    j += 1
+                self._interp_evaluate_rows(t_host[i:j], solution[i:j])
+                i = j
+        finally:
+            if self._g is not None:
+                # hipGraph mode: the step's static buffers are about to be re-armed by the next solve that takes
+                # this (cached) graph — let the kernels that still read them finish, then hand the graph back
+                torch.cuda.current_stream(self.y0.device).synchronize()
+                self._g.release()
         return solution
 
     def _set_time_anchor(self, t: torch.Tensor) -> None:
@@ -734,7 +792,7 @@ class RKAdaptiveStepsizeODESolver:
         assert not self._y_nonfinite, "non-finite values in state `y`: {}".format(self.y1)
         g = self._g
         if g is None:
-            g = self._g = _GraphStep(self, t0, dt)
+            g = self._g = _GraphStep.acquire(self, t0, dt)
         g.run(self)
         accept_step, dt_next, _ratio, bad = kern.read_ctrl(self.plan)
         dt_signed = float(T(dt)) * func.sign
