@@ -163,4 +163,14 @@ def cnf_fwd_bwd():
 cnf_fwd_bwd()
 cnf_fwd_bwd()
 res["cfg5_cnf_adjoint"] = {"fwd_wall_s": state["cnf_fwd"], "bwd_wall_s": state["cnf_bwd"]}
+
+
+def cnf_fwd_graph():
+    x = z0.clone().requires_grad_(True)
+    return tda.odeint_adjoint(cnf, (x, torch.zeros(32768, 1, device=dev)), t5, atol=1e-5, rtol=1e-5, method="dopri5",
+                              options=dict(hip_graph=True))
+
+
+wg5, _ = timed(cnf_fwd_graph)
+res["cfg5_cnf_adjoint"]["fwd_wall_s_hip_graph"] = wg5
 print(json.dumps(res, indent=1))
