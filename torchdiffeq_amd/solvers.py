@@ -111,6 +111,11 @@ class _LockStep:
         return out[:n], out[n:2 * n], out[2 * n:]
 
 
+# hipGraph mode targets launch-latency-bound states; its stage kernel (run-time term count, scalar loads) is not the
+# bandwidth-tuned one, so beyond this size the eager path is used
+_GRAPH_MODE_MAX_ELEMENTS = 1 << 22
+
+
 class _CaptureFailed(RuntimeError):
     """The step body could not be captured into a hipGraph; no kernel of it has run."""
 
@@ -351,11 +356,13 @@ class RKAdaptiveStepsizeODESolver:
         self._lookahead = device_ctrl and os.environ.get("TDEQ_LOOKAHEAD", "1") != "0"
         # `hip_graph=True` (an extension, not a reference option): one captured hipGraph per trial step, see _GraphStep
         self.hip_graph = bool(hip_graph) and device_ctrl and y0.device.type == "cuda" \
-            and hasattr(self.kernels, "stage_combine_dev")
+            and hasattr(self.kernels, "stage_combine_dev") and self.layout.total <= _GRAPH_MODE_MAX_ELEMENTS
         if bool(hip_graph) and not self.hip_graph:
             warnings.warn("{}: hip_graph=True needs a builtin norm, at most {} state segments, no step_t / jump_t, a "
-                          "tableau with a fused error combine and a ROCm device; running the eager path".format(
-                              self.__class__.__name__, _native.TDEQ_INLINE_SEGMENTS))
+                          "tableau with a fused error combine, a ROCm device and a state of at most {} elements (larger "
+                          "states are bandwidth-bound: the eager path with its unrolled kernels is the fast one); "
+                          "running the eager path".format(self.__class__.__name__, _native.TDEQ_INLINE_SEGMENTS,
+                                                          _GRAPH_MODE_MAX_ELEMENTS))
         self._g = None
         if device_ctrl:
             c = _native.StepCtrl()
