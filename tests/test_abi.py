@@ -73,3 +73,26 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "rk_oracle" not in text, f
+
+
+def test_no_kernel_uses_scratch_memory(tmp_path):
+    """Cross-compile the device code (no GPU needed) and check that NO kernel needs private (scratch) memory: a
+    spilled argument block once cost the step-controller kernel +10 us (an address select between a device pointer
+    and a kernel-argument field made the compiler copy 840 B of arguments to scratch)."""
+    import re
+    import shutil
+    import subprocess
+    from torchdiffeq_amd import build as tbuild
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    asm = tmp_path / "tdeq.s"
+    flags = [f for f in tbuild.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([hipcc] + flags + ["-S", "--cuda-device-only", tbuild.SOURCES[0], "-o", str(asm)],
+                          stderr=subprocess.DEVNULL)
+    text = asm.read_text()
+    names = re.findall(r"\.amdhsa_kernel (\S+)", text)
+    sizes = [int(v) for v in re.findall(r"\.amdhsa_private_segment_fixed_size (\d+)", text)]
+    assert len(names) == len(sizes) and len(names) > 100
+    spilled = {n: s for n, s in zip(names, sizes) if s}
+    assert not spilled, spilled
