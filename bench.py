@@ -19,6 +19,8 @@ Extra objects in the JSON line:
                 fused partial-error store); its launches inside the TIMED region stamp HIP events with the dispatch's own
                 begin / end times (tdeq_stage_combine_timed -> hipExtLaunchKernelGGL) on the launch stream.
   solver_only   the step's solver kernels alone, back to back on the last step's stage tensors.
+  reference_style_eager_gpu   the reference's eager op sequence restated in stock PyTorch (oracle/eager_torch_port.py)
+                timed on the same GPU and state: what a user of the reference gets on an MI355X today.
   cpu_baseline  the CPU oracle (oracle/reference_solver.py + rk_oracle.c, OpenMP on all host cores) on
                 a bounded sample of the same workload (rank 0, N=1 only).
   rel_err       max rel-err of a full odeint(t=[0,1]) at this size vs the closed form y0 expm(A)^T.
@@ -110,6 +112,26 @@ def cpu_baseline(max_seconds=20.0):
     return {"value": 6 * steps / dt, "unit": "RK-stages/s", "cores": cores, "kind": "port",
             "sample": f"{steps} dopri5 trial steps ({6 * steps} RK stages) of the same 65536x128 fp32 workload, "
                       f"oracle/rk_oracle.c with OpenMP on {cores} threads + numpy GEMM, {dt:.1f} s"}
+
+
+def eager_gpu_baseline(field, y0, first_step, steps=12):
+    """The reference's own way of running this workload on a GPU — stock eager PyTorch-ROCm ops with 0-dim device
+    tensors for the time-like scalars (oracle/eager_torch_port.py, a restatement: the reference itself cannot
+    travel to the GPU box) — timed on the same MI355X, same state, same field."""
+    from oracle import eager_torch_port as ep
+    solver = ep.EagerAdaptiveRK(field, y0, 0.0, first_step, RTOL, ATOL, "dopri5")
+    for _ in range(3):
+        solver.adaptive_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solver.adaptive_step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": 6 * steps / dt, "unit": "RK-stages/s", "ms_per_step": 1e3 * dt / steps, "kind": "port",
+            "sample": f"{steps} dopri5 trial steps of the same 65536x128 fp32 workload through oracle/eager_torch_port.py "
+                      "(the reference's eager op sequence: stage-minor k tensor, ~220 ATen ops and ~19 host syncs "
+                      "per trial step) on this GPU"}
 
 
 def main():
@@ -295,6 +317,11 @@ def main():
             "solver_only": solver_only,
         }
         if world == 1 and not args.no_cpu_baseline:
+            try:
+                with torch.no_grad():
+                    out["reference_style_eager_gpu"] = eager_gpu_baseline(field, y0, 0.05)
+            except Exception as exc:      # an extra figure, never allowed to break the contract line
+                out["reference_style_eager_gpu"] = {"error": repr(exc)}
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

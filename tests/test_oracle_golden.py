@@ -370,3 +370,31 @@ def test_oracle_fused_end_of_step_pair_is_the_same_arithmetic():
         a = KERN.read_norms(plan)[0][0]
         KERN.error_norm(plan, y0, y1, [k[j] for j in eidx], ecoef, 0.0371)
         assert a == KERN.read_norms(plan)[0][0]
+
+
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+def test_eager_torch_port_follows_the_numpy_oracle(dname):
+    """oracle/eager_torch_port.py (the "reference-style eager PyTorch" timed by bench.py on the GPU) against the
+    numpy oracle on the same trial steps: same accept/reject sequence; step sizes to 3e-4 in fp32 (the embedded
+    error is a cancelling sum: torch.sum's association over the stage axis vs the oracle's left-to-right one moves it
+    by ~1e-4 relative, and the eager port accumulates its norm in T like the reference) and 1e-11 in fp64."""
+    from oracle import eager_torch_port as ep
+    dtype = np.float32 if dname == "f32" else np.float64
+    rng = np.random.default_rng(3)
+    A = (rng.standard_normal((8, 8)) / 3 - 0.3 * np.eye(8)).astype(dtype)
+    y0 = rng.standard_normal((20, 8)).astype(dtype)
+    field = orc.LinearField(A)
+    solver = orc.AdaptiveRK(lambda tt, y: field.f(tt, y.reshape(20, 8)).reshape(-1), y0.reshape(-1),
+                            orc.tableau("dopri5"), 1e-5, 1e-7, first_step=0.35)
+    solver.before_integrate(0.0)
+    At = torch.from_numpy(A.T.copy())
+    eager = ep.EagerAdaptiveRK(lambda t, y: y @ At, torch.from_numpy(y0.copy()), 0.0, 0.35, 1e-5, 1e-7)
+    for _ in range(12):
+        solver.adaptive_step()
+        eager.adaptive_step()
+        assert (eager.n_accepted, eager.n_rejected) == (solver.n_accept, solver.n_reject)
+        assert float(eager.dt) == pytest.approx(solver.dt, rel=3e-4 if dname == "f32" else 1e-11)
+        assert float(eager.t) == pytest.approx(solver.t1, rel=3e-4 if dname == "f32" else 1e-12)
+    tol = 1e-4 if dname == "f32" else 5e-12     # the states are compared at (slightly) different times in fp32
+    assert rel_err(eager.y.numpy().reshape(-1), solver.y1) < tol
+    assert solver.n_reject > 0          # the large first step exercises the reject branch
