@@ -247,3 +247,45 @@ def test_graph_is_reused_across_solves_of_the_same_func():
     assert len(_GraphStep._cache.get(f)) == 2
     tda.clear_graph_cache()
     assert _GraphStep._cache.get(f) is None
+
+
+def test_graph_cache_notices_reallocated_parameters():
+    """In-place parameter updates are seen by the captured graph; parameters that move to new storage (here: a
+    dtype round trip) lead to a fresh capture instead of a graph reading freed memory."""
+    from torchdiffeq_amd.solvers import _GraphStep
+    tda.clear_graph_cache()
+    torch.manual_seed(1)
+
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(5, 5).double().cuda()
+
+        def forward(self, t, y):
+            return torch.tanh(self.lin(y))
+
+    f = F()
+    y0 = torch.randn(9, 5, dtype=torch.float64, device="cuda")
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64, device="cuda")
+    kw = dict(method="dopri5", rtol=1e-7, atol=1e-9)
+
+    def both():
+        with torch.no_grad():
+            return tda.odeint(f, y0, t, options=dict(hip_graph=True), **kw), tda.odeint(f, y0, t, **kw)
+
+    yg, ye = both()
+    assert torch.equal(yg, ye)
+    first = next(iter(_GraphStep._cache.get(f).values()))
+    f.float().double()                      # same values, new storages
+    with torch.no_grad():
+        f.lin.weight.mul_(0.5)
+    yg, ye = both()
+    assert torch.equal(yg, ye)
+    entries = list(_GraphStep._cache.get(f).values())
+    assert len(entries) == 2 and entries[-1] is not first
+    for _ in range(6):                      # the cache stays bounded
+        f.float().double()
+        yg, ye = both()
+        assert torch.equal(yg, ye)
+    assert len(_GraphStep._cache.get(f)) <= _GraphStep._MAX_PER_FUNC
+    tda.clear_graph_cache()

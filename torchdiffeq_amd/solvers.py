@@ -189,8 +189,14 @@ class _GraphStep:
     def _key(s):
         c = s._ctrl
         segs = tuple((int(sg.chunk_start), int(sg.numel), float(sg.rtol), float(sg.atol)) for sg in s.plan.segs)
-        return (type(s).__name__, str(s.y0.dtype), str(s.y0.device), int(s.layout.total), int(s.plan.chunk), segs,
-                c.safety, c.ifactor, c.dfactor, c.exponent, c.min_step, c.max_step, c.time_sign, int(c.n_norm_seg))
+        key = (type(s).__name__, str(s.y0.dtype), str(s.y0.device), int(s.layout.total), int(s.plan.chunk), segs,
+               c.safety, c.ifactor, c.dfactor, c.exponent, c.min_step, c.max_step, c.time_sign, int(c.n_norm_seg))
+        base = s.func.base_func
+        if isinstance(base, torch.nn.Module):
+            # a captured graph reads the parameter STORAGES it saw: in-place updates are fine, re-allocated
+            # parameters (module.to(...), a re-built layer) must lead to a new capture
+            key += (tuple(p.data_ptr() for p in base.parameters()), tuple(b.data_ptr() for b in base.buffers()))
+        return key
 
     @classmethod
     def acquire(cls, s, t0: float, dt: float) -> "_GraphStep":
@@ -211,8 +217,14 @@ class _GraphStep:
                 per_func = cls._cache[s.func.base_func] = {}
             except TypeError:
                 return g
-        if key not in per_func and len(per_func) < cls._MAX_PER_FUNC:
-            per_func[key] = g
+        if key not in per_func:
+            if len(per_func) >= cls._MAX_PER_FUNC:       # evict the oldest entry that no running solve holds
+                for old_key, old in list(per_func.items()):
+                    if not old.in_use:
+                        del per_func[old_key]
+                        break
+            if len(per_func) < cls._MAX_PER_FUNC:
+                per_func[key] = g
         return g
 
     def release(self) -> None:
