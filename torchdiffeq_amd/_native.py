@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -256,11 +257,33 @@ class HipKernels:
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
 
-    @staticmethod
-    def _terms(ks: Sequence[torch.Tensor], coefs: Sequence[float]):
+    # Host-side argument marshalling is on the critical path of small / medium states.  The entry points copy the
+    # host arrays into the kernel-argument block before they return, so one pointer array per term count is reused
+    # (overwritten per call) and the coefficient arrays of the (immutable, few) tableau rows are built once.
+    # (ctypes releases the GIL during a call: the reused pointer arrays are per thread.)
+    _TLS = threading.local()
+    _COEF_ARRAYS: dict = {}
+
+    @classmethod
+    def _terms(cls, ks: Sequence[torch.Tensor], coefs: Sequence[float]):
         n = len(ks)
-        ptrs = (ctypes.c_void_p * n)(*[k.data_ptr() for k in ks])
-        cf = (ctypes.c_double * n)(*coefs)
+        if n > TDEQ_MAX_TERMS:
+            ptrs = (ctypes.c_void_p * n)(*[k.data_ptr() for k in ks])
+        else:
+            arrays = getattr(cls._TLS, "ptr_arrays", None)
+            if arrays is None:
+                arrays = cls._TLS.ptr_arrays = [(ctypes.c_void_p * m)() for m in range(TDEQ_MAX_TERMS + 1)]
+            ptrs = arrays[n]
+            for j in range(n):
+                ptrs[j] = ks[j].data_ptr()
+        if type(coefs) is tuple:
+            cf = cls._COEF_ARRAYS.get(coefs)
+            if cf is None:
+                if len(cls._COEF_ARRAYS) > 4096:      # not a tableau row cache any more: start over
+                    cls._COEF_ARRAYS.clear()
+                cf = cls._COEF_ARRAYS[coefs] = (ctypes.c_double * n)(*coefs)
+        else:
+            cf = (ctypes.c_double * n)(*coefs)
         return ptrs, cf, n
 
     def make_plan(self, segments, total, chunk, device) -> NormPlan:
