@@ -77,3 +77,43 @@ def test_cpu_state_fails_loudly():
     from torchdiffeq_amd._native import NativeLibraryError
     with pytest.raises(NativeLibraryError):
         tda.odeint(lambda t_, y_: -y_, torch.ones(3), torch.tensor([0.0, 1.0]))
+
+
+def test_solves_on_a_user_stream_match_the_default_stream():
+    """All launches go to torch's CURRENT stream: a solve issued inside `torch.cuda.stream(s)` (look-ahead path,
+    adjoint included) must give the default-stream result bit for bit."""
+    import torch
+    import torchdiffeq_amd as tda
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 8).double().cuda()
+
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = lin
+
+        def forward(self, t, y):
+            return torch.tanh(self.lin(y)) * torch.cos(t)
+
+    y0 = torch.randn(64, 8, dtype=torch.float64, device="cuda")
+    t = torch.tensor([0.0, 0.8, 2.0], dtype=torch.float64, device="cuda")
+
+    def run():
+        f = F()
+        f.zero_grad()
+        x = y0.clone().requires_grad_(True)
+        y = tda.odeint_adjoint(f, x, t, rtol=1e-7, atol=1e-9, method="dopri5")
+        y[-1].pow(2).sum().backward()
+        with torch.no_grad():
+            plain = tda.odeint(f, y0, t, rtol=1e-7, atol=1e-9, method="dopri8")
+        return y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), plain
+
+    ref = run()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
