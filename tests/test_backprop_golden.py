@@ -3,11 +3,11 @@ autograd node with a hand-written backward (torchdiffeq_amd/autodiff.py, tdeq_sc
 Gradients wrt y0, the field's parameters and `t` against the reference's autograd-through-eager-ops
 (tests/golden/backprop.npz, fp64).
 
-Tolerances: fixed-grid methods compute exactly the same discrete function as the reference -> 1e-9.  Adaptive
-methods: the reference also differentiates its FIRST step size through `_select_initial_step` (misc.py:36-77 is
-not under no_grad), a discretisation-error-sized contribution that this implementation (every dt a constant of
-the backward pass) leaves out, and noise-floor first steps shift later dts: agreement is at the
-level of the solve's own accuracy."""
+Tolerances: every method computes the same discrete function as the reference, including the reference's
+differentiable FIRST step size (`_select_initial_step`, misc.py:36-77, is not under no_grad: dt0 is a function of
+y0, f0 and f1 — torchdiffeq_amd.solvers._InitialStepShadow records the same graph) -> 1e-9 for the fixed-grid
+methods, 1e-8 for the adaptive ones (measured 1e-14 ... 8e-12 on the CPU host-logic run; the GPU evaluates the field
+with its own libm)."""
 import numpy as np
 import pytest
 import torch
@@ -15,10 +15,12 @@ import torch
 import torchdiffeq_amd as tda
 from _cases import T, load, rel_err
 
-CASES = [("dopri5", "dopri5", None, False, 2e-6), ("dopri8", "dopri8", None, False, 2e-6),
-         ("tsit5", "tsit5", None, False, 2e-6), ("bosh3", "bosh3", None, False, 1e-4),
-         ("fehlberg2", "fehlberg2", None, False, 2e-3), ("adaptive_heun", "adaptive_heun", None, False, 2e-3),
-         ("dopri5_rev", "dopri5", None, False, 2e-6), ("dopri5_tuple", "dopri5", None, True, 2e-6),
+# dopri8 at rtol 1e-8 takes steps whose error estimate is rounding noise: a field evaluated by the GPU's libm moves
+# the step sequence, the solution by 1e-9 and the gradients with it (CPU host-logic run: 8e-12)
+CASES = [("dopri5", "dopri5", None, False, 1e-8), ("dopri8", "dopri8", None, False, 1e-6),
+         ("tsit5", "tsit5", None, False, 1e-8), ("bosh3", "bosh3", None, False, 1e-8),
+         ("fehlberg2", "fehlberg2", None, False, 1e-8), ("adaptive_heun", "adaptive_heun", None, False, 1e-8),
+         ("dopri5_rev", "dopri5", None, False, 1e-8), ("dopri5_tuple", "dopri5", None, True, 1e-8),
          ("rk4_grid", "rk4", None, False, 1e-9), ("euler_grid", "euler", None, False, 1e-9),
          ("midpoint_step", "midpoint", dict(step_size=0.1), False, 1e-9),
          ("heun2_perturb", "heun2", dict(step_size=0.1, perturb=True), False, 1e-9),
@@ -49,7 +51,7 @@ def test_backprop_through_solver_matches_reference(dev, tag, method, opts, tup, 
         loss = sol[-1].pow(2).sum() + sol[1].sum()
     assert sol.requires_grad
     loss.backward()
-    assert rel_err(sol.detach(), z[f"bp_{tag}_y"]) < max(tol * 1e-2, 1e-12)
+    assert rel_err(sol.detach(), z[f"bp_{tag}_y"]) < max(tol * 1e-2, 1e-11)
     assert rel_err(y0.grad, z[f"bp_{tag}_g_y0"]) < tol
     for g, name in zip(p, ("g_W1", "g_b1", "g_W2")):
         assert rel_err(g.grad, z[f"bp_{tag}_{name}"]) < tol, name

@@ -15,10 +15,11 @@ so one `torch.autograd.Function` serves all of them:
 
 The forward value is produced by the SAME kernel as in no-grad mode (same rounding), the weights w_m are the
 T-rounded coefficients that kernel used, and the controller (error norm, accept/reject, next dt) is outside
-the graph exactly as in the reference (`_optimal_step_size` is `@torch.no_grad`, misc.py:85).  One deliberate
-difference: the reference's *first* step size is differentiable through `_select_initial_step` (misc.py:36-77
-is not under no_grad), which adds a discretisation-error-sized term to its gradients; here every step size
-is a constant of the backward pass.
+the graph exactly as in the reference (`_optimal_step_size` is `@torch.no_grad`, misc.py:85).  The one step size
+the reference does differentiate — the first, through `_select_initial_step` (misc.py:36-77 is not under no_grad) —
+is differentiable here too: `solvers._InitialStepShadow` records the heuristic's formulas with torch ops next to
+the kernel-evaluated values, and the first step's combines, stage times and interpolation carry that graph through
+their `dt_shadow` / time shadows.
 
 Time gradients (`t.requires_grad`): host doubles drive the kernels; a "shadow" 0-dim tensor with the autograd
 graph back to `t` accompanies each time-like scalar that can carry gradient, and `stitch` gives the tensor

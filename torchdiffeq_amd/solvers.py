@@ -288,9 +288,64 @@ def clear_graph_cache() -> None:
     _GraphStep._cache.clear()
 
 
+class _InitialStepShadow:
+    """Autograd graph of the starting step size (misc.py:36-77), for backprop through the solver.  The VALUES of the
+    heuristic come from the norm kernels (host scalars, `_select_initial_step`); this records the same formulas with
+    torch ops on the live tensors, taking the branches the host took, so that the first step size carries the
+    gradient the reference's does (its heuristic is not under no_grad).  Segment-wise: scale_s = atol_s + |y0|·rtol_s,
+    norm = max over segments of sqrt(mean(x²)) (misc.py:22-33)."""
+
+    def __init__(self, solver, y0, f0, h0_value: float, h0_is_const: bool):
+        s = self.s = solver
+        lay = s.layout
+        self.segs = [(off, n, rt, at) for off, n, rt, at in lay.segments(s.rtol, s.atol) if n > 0]
+        self.y0, self.f0 = y0, f0
+        self.scale = [at + y0[off:off + n].abs() * rt for off, n, rt, at in self.segs]
+        self.d0 = self._norm(y0)
+        self.d1 = self._norm(f0)
+        if h0_is_const:
+            self.h0 = torch.full((), h0_value, dtype=y0.dtype, device=y0.device)
+        else:
+            self.h0 = stitch(torch.full((), h0_value, dtype=y0.dtype, device=y0.device),
+                             (0.01 * self.d0 / self.d1).abs())
+        # y1 = y0 + h0 * f0 in solver time (f0 is the raw func output: the time sign rides on h0)
+        self.y1 = y0 + (self.h0 * s.func.sign) * f0
+
+    def _norm(self, x, diff=None):
+        vals = []
+        for (off, n, _, _), sc in zip(self.segs, self.scale):
+            v = x[off:off + n] if diff is None else x[off:off + n] - diff[off:off + n]
+            vals.append((v / sc).abs().pow(2).mean().sqrt())
+        return max(vals) if vals else torch.zeros((), dtype=x.dtype, device=x.device)
+
+    def time_shadow(self, anchor, sign: float):
+        """User-time graph of t0 + h0 for the heuristic's own evaluation of func."""
+        base = self.h0 if anchor is None else anchor + self.h0
+        return base * sign
+
+    def finish(self, f1, h1_is_floor: bool, d1_is_max: bool, h0_branch: bool, order: int, value: float):
+        """dt0 = min(100·h0, h1) with the branches the host took; returns a 0-dim fp64 tensor whose value is the
+        host's first step and whose graph is the heuristic's."""
+        d2 = (self._norm(f1, diff=self.f0) / self.h0).abs()
+        if h1_is_floor:
+            h1 = self.h0 * 1e-3       # (the constant 1e-6 floor carries no gradient either way)
+        else:
+            h1 = (0.01 / (self.d1 if d1_is_max else d2)) ** (1.0 / float(order + 1))
+        h1 = h1.abs()
+        dt0 = (100 * self.h0) if h0_branch else h1
+        dt0 = dt0.to(torch.float64)
+        if not dt0.requires_grad:
+            return None
+        return stitch(torch.full((), value, dtype=torch.float64, device=dt0.device), dt0)
+
+
 class _DenseRecord:
     """Data of the last accepted step, kept for lazy dense output (rk_common.py:363-369)."""
-    __slots__ = ("y0", "y1", "k", "dt_signed", "t0", "t1")
+    __slots__ = ("y0", "y1", "k", "dt_signed", "t0", "t1", "dt_shadow", "anchor")
+
+    def __init__(self):
+        self.dt_shadow = None     # graph of the step size (only the first step's, see _initial_step_shadow)
+        self.anchor = None        # time anchor (graph of the step's start time) when the step was taken
 
 
 class RKAdaptiveStepsizeODESolver:
@@ -376,6 +431,7 @@ class RKAdaptiveStepsizeODESolver:
                           "running the eager path".format(self.__class__.__name__, _native.TDEQ_INLINE_SEGMENTS,
                                                           _GRAPH_MODE_MAX_ELEMENTS))
         self._g = None
+        self._dt_shadow = None      # autograd graph of the current step size (the first, heuristic one only)
         if device_ctrl:
             c = _native.StepCtrl()
             c.safety, c.ifactor, c.dfactor = self.safety, self.ifactor, self.dfactor
@@ -530,6 +586,7 @@ class RKAdaptiveStepsizeODESolver:
 
     def _before_integrate(self, t_host: List[float]) -> None:
         t0 = t_host[0]
+        self._dt_shadow = None
         f0 = self.func.eval(t0, self.y0)
         if self.first_step is None:
             first_step = self._select_initial_step(t0, self.y0, f0)
@@ -544,6 +601,8 @@ class RKAdaptiveStepsizeODESolver:
         self._dense: Optional[_DenseRecord] = None
         self._t_end, self._pre = -math.inf, None    # event mode / direct stepping: no look-ahead
         self._g = None
+        if self.first_step is not None:
+            self._dt_shadow = None
 
         step_t = [] if self.step_t is None else sorted(v for v in self.step_t if v >= t0)
         jump_t = [] if self.jump_t is None else sorted(v for v in self.jump_t if v >= t0)
@@ -559,7 +618,13 @@ class RKAdaptiveStepsizeODESolver:
         T = self.np_dtype
         kern, plan = self.kernels, self.plan
         order = self.order - 1   # the reference passes `self.order - 1` (rk_common.py:217)
-        y0, f0 = y0.detach(), f0.detach()        # the step-size heuristic is a constant of the backward pass
+        # Values come from the kernels on detached data; when the solve is differentiated, the SAME formulas are
+        # recorded a second time with torch ops (`_initial_step_shadow`) only to carry the gradient: the reference's
+        # heuristic is not under no_grad, so its first step size is a differentiable function of y0, f0 and f1.
+        shadow_on = self.first_step is None and torch.is_grad_enabled() and \
+            (y0.requires_grad or f0.requires_grad or self._anchor is not None)
+        y0_g, f0_g = y0, f0
+        y0, f0 = y0.detach(), f0.detach()
         kern.init_norms(plan, 0, y0, f0, y0)
         s0, s1, bad = self._read_norms()
         self._y_nonfinite = any(b != 0 for b in bad)
@@ -570,10 +635,15 @@ class RKAdaptiveStepsizeODESolver:
         else:
             h0 = T(T(0.01) * d0) / d1
         h0 = abs(h0)
-        y1 = torch.empty_like(y0)
-        kern.stage_combine(y1, y0, [f0], [1.0], float(h0) * self.func.sign)
-        with torch.no_grad():
-            f1 = self.func.eval(t0 + float(h0), y1)
+        if shadow_on:
+            sh = _InitialStepShadow(self, y0_g, f0_g, float(h0), bool(d0 < 1e-5 or d1 < 1e-5))
+            f1_g = self.func.eval(t0 + float(h0), sh.y1, shadow=sh.time_shadow(self._anchor, self.func.sign))
+            f1 = f1_g.detach()
+        else:
+            y1 = torch.empty_like(y0)
+            kern.stage_combine(y1, y0, [f0], [1.0], float(h0) * self.func.sign)
+            with torch.no_grad():
+                f1 = self.func.eval(t0 + float(h0), y1)
         kern.init_norms(plan, 1, f1, f0, y0)
         s2, _, bad = self._read_norms()
         with np.errstate(all="ignore"):
@@ -583,7 +653,11 @@ class RKAdaptiveStepsizeODESolver:
             else:
                 h1 = T(T(0.01) / max(d1, d2)) ** T(1.0 / float(order + 1))
             h1 = abs(h1)
-            return float(min(T(100) * h0, h1))
+            first_step = float(min(T(100) * h0, h1))
+        if shadow_on:
+            self._dt_shadow = sh.finish(f1_g, bool(d1 <= 1e-15 and d2 <= 1e-15), bool(d1 >= d2),
+                                        bool(T(100) * h0 <= h1), order, first_step)
+        return first_step
 
     def _step_until(self, next_t: float) -> None:
         """Trial steps until next_t is inside the last accepted step (rk_common.py:243-249)."""
@@ -634,12 +708,22 @@ class RKAdaptiveStepsizeODESolver:
             "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(self.t0, t, self.t1)
         x = float(self.np_dtype((t - rec.t0) / (rec.t1 - rec.t0)))
         x_shadow = None
-        if self._anchor is not None:
-            # x = (t - t0_step) / (t1_step - t0_step): the step boundaries move with t[0], the width is a constant
-            x_shadow = ((t_shadow if t_shadow is not None else 0.0) - self._anchor) / (rec.t1 - rec.t0)
+        if rec.dt_shadow is not None:
+            # first step of a differentiated solve: x = (t - t0) / dt0 with dt0 a function of (y0, f0, f1) too
+            width = stitch(torch.full((), rec.t1 - rec.t0, dtype=torch.float64, device=rec.y0.device),
+                           rec.dt_shadow * self.func.sign)
+            num = torch.full((), t - rec.t0, dtype=torch.float64, device=rec.y0.device)
+            if t_shadow is not None:
+                num = num + (t_shadow - t_shadow.detach())
+            if rec.anchor is not None:
+                num = num - (rec.anchor - rec.anchor.detach())
+            x_shadow = num / width
+        elif rec.anchor is not None:
+            # x = (t - t0_step) / (t1_step - t0_step): the step boundaries move with the anchor, the width is a constant
+            x_shadow = ((t_shadow if t_shadow is not None else 0.0) - rec.anchor) / (rec.t1 - rec.t0)
         mid = self._c_mid
         return self.ops.dense_eval(rec.y0, rec.y1, rec.k, mid.idx, mid.coef, rec.dt_signed, x,
-                                   x_shadow=x_shadow, out=out)
+                                   dt_shadow=rec.dt_shadow, x_shadow=x_shadow, out=out)
 
     def _adaptive_step(self) -> None:
         """One trial step (rk_common.py:266-361)."""
@@ -676,6 +760,9 @@ class RKAdaptiveStepsizeODESolver:
         ops = self.ops
         row0 = self._beta[0]
         plain = not (torch.is_grad_enabled() and (y0.requires_grad or f0.requires_grad or self._anchor is not None))
+        # graph of this trial's step size: only the first, heuristic one has any (the controller is under no_grad)
+        dsh, self._dt_shadow = (None if plain or on_step_t or on_jump_t else self._dt_shadow), None
+        dsh_signed = None if dsh is None else dsh * func.sign
         lookahead = (self._lookahead and plain and func.callback_step is _null
                      and func.callback_accept_step is _null and func.callback_reject_step is _null)
         pre, self._pre = self._pre, None
@@ -694,8 +781,16 @@ class RKAdaptiveStepsizeODESolver:
                                         [func.user_time(t, p) for t, p in times])
                 stage_times = tbuf.unbind(0)
             else:
-                yi = ops.combine(y0, [f0], row0.coef, dt_signed)
-                stage_times = func.time_tensors(kern, times)
+                yi = ops.combine(y0, [f0], row0.coef, dt_signed, dsh_signed)
+                shadows = None
+                if dsh is not None:
+                    # t_i = t0 + alpha_i dt0 (t1 = t0 + dt0 for alpha_i = 1), in user time
+                    base = self._anchor
+                    shadows = []
+                    for i in range(len(self._beta)):
+                        inc = dsh if self._alpha_is_one[i] else float(self._alpha[i]) * dsh
+                        shadows.append((inc if base is None else base + inc) * func.sign)
+                stage_times = func.time_tensors(kern, times, shadows=shadows)
             k1 = func.eval_at(stage_times[0], yi)
         k: List[torch.Tensor] = [f0, k1]
         n_rows = len(self._beta)
@@ -709,7 +804,7 @@ class RKAdaptiveStepsizeODESolver:
                 yi, err_partial = torch.empty_like(y0), torch.empty_like(y0)
                 kern.stage_combine_err(yi, err_partial, y0, [k[j] for j in row.idx], row.coef, self._fuse[0], dt_signed)
             else:
-                yi = ops.combine(y0, [k[j] for j in row.idx], row.coef, dt_signed)
+                yi = ops.combine(y0, [k[j] for j in row.idx], row.coef, dt_signed, dsh_signed)
             k.append(func.eval_at(stage_times[i], yi))
         if fsal:
             y1 = yi
@@ -719,7 +814,7 @@ class RKAdaptiveStepsizeODESolver:
             y1, err_partial = torch.empty_like(y0), torch.empty_like(y0)
             kern.stage_combine_err(y1, err_partial, y0, [k[j] for j in sol.idx], sol.coef, self._fuse[0], dt_signed)
         else:
-            y1 = ops.combine(y0, [k[j] for j in self._c_sol.idx], self._c_sol.coef, dt_signed)
+            y1 = ops.combine(y0, [k[j] for j in self._c_sol.idx], self._c_sol.coef, dt_signed, dsh_signed)
         f1 = k[-1]
 
         # ---- error ratio (misc.py:80-82) ----
@@ -766,7 +861,12 @@ class RKAdaptiveStepsizeODESolver:
                 func.callback_accept_step(self._time_tensor(t0), y0, self._time_tensor(dt))
             rec = _DenseRecord()
             rec.y0, rec.y1, rec.k, rec.dt_signed, rec.t0, rec.t1 = y0, y1, k, dt_signed, t0, t1
+            rec.dt_shadow, rec.anchor = dsh_signed, self._anchor
             self._dense = rec
+            if dsh is not None:
+                # every later time of the solve is t0 + dt0 + constants: it moves with the first step size
+                self._anchor = dsh if self._anchor is None else self._anchor + dsh
+                func.set_time_anchor(self._anchor)
             if on_step_t and self.next_step_index != len(self._step_t) - 1:
                 self.next_step_index += 1
             if on_jump_t:
