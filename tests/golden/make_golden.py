@@ -504,9 +504,32 @@ def gen_backprop():
     save("backprop.npz", **arrays)
 
 
+def gen_tuple_tolerances():
+    """Tuple states with PER-COMPONENT tolerances (misc.py:115-123 `_tuple_tol`: rtol / atol become per-element
+    vectors, fp32 values widened to fp64, so the reference forms the error ratio in fp64 there)."""
+    arrays = {}
+    for dname, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        A = (rand(5, 5, seed=21) * 0.4 - 0.3 * torch.eye(5, dtype=torch.float64)).to(dtype)
+        ya, yb = rand(30, 5, seed=22).to(dtype), rand(7, seed=23).to(dtype)
+        t = torch.tensor([0.0, 0.7, 2.0], dtype=torch.float64)
+        count = [0]
+
+        def f(t_, y_):
+            count[0] += 1
+            return y_[0] @ A.T * torch.cos(t_), -y_[1] * 0.5
+
+        for tag, tt in (("fwd", t), ("rev", t.flip(0))):
+            count[0] = 0
+            sa, sb = torchdiffeq.odeint(f, (ya, yb), tt, rtol=(1e-5, 1e-3), atol=(1e-7, 1e-4), method="dopri5")
+            arrays[f"tt_{dname}_{tag}_ya"], arrays[f"tt_{dname}_{tag}_yb"] = sa, sb
+            arrays[f"tt_{dname}_{tag}_nfe"] = count[0]
+        arrays[f"tt_{dname}_A"], arrays[f"tt_{dname}_y0a"], arrays[f"tt_{dname}_y0b"] = A, ya, yb
+    save("tuple_tol.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
-                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop)]:
+                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances)]:
         if not only or name in only:
             fn()

@@ -308,3 +308,28 @@ def test_t_on_other_device_warns_and_default_method(dev):
     with torch.no_grad():
         y = tda.odeint(lambda t_, y_: -y_, y0, torch.tensor([0.0, 1.0], dtype=torch.float64), rtol=1e-9, atol=1e-12)
     assert y[-1, 0].item() == pytest.approx(math.exp(-1), rel=1e-8)      # default method = dopri5
+
+
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+@pytest.mark.parametrize("tag", ["fwd", "rev"])
+def test_tuple_state_with_per_component_tolerances(dev, dname, tag):
+    """misc.py:115-123: tupled rtol / atol apply per component (= per segment of the flat state).  fp64: the same
+    steps as the reference (1e-12).  fp32: the reference promotes the ratio to fp64 for vector tolerances, this
+    path forms it in fp32 — same NFE, agreement at fp32 rounding level."""
+    z = load("tuple_tol.npz")
+    A, ya, yb = (T(z[f"tt_{dname}_{k}"], dev) for k in ("A", "y0a", "y0b"))
+    t = torch.tensor([0.0, 0.7, 2.0], dtype=torch.float64, device=dev)
+    if tag == "rev":
+        t = t.flip(0)
+    count = [0]
+
+    def f(t_, y_):
+        count[0] += 1
+        return y_[0] @ A.T * torch.cos(t_), -y_[1] * 0.5
+
+    with torch.no_grad():
+        sa, sb = tda.odeint(f, (ya, yb), t, rtol=(1e-5, 1e-3), atol=(1e-7, 1e-4), method="dopri5")
+    assert count[0] == int(z[f"tt_{dname}_{tag}_nfe"])
+    tol = 1e-12 if dname == "f64" else 2e-6
+    assert rel_err(sa, z[f"tt_{dname}_{tag}_ya"]) < tol
+    assert rel_err(sb, z[f"tt_{dname}_{tag}_yb"]) < tol
