@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 11
+#define TDEQ_ABI_VERSION 12
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -225,6 +225,16 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale,
                     const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk,
                     int64_t n_chunks, double* out_sumsq, double* out_nonfinite, void* workspace, size_t workspace_bytes,
                     int dtype, void* stream);
+
+/*
+ * The quotients of tdeq_init_norms MATERIALISED, for a user-supplied norm callable (the reference hands its `norm`
+ * to _select_initial_step too, rk_common.py:217 -> misc.py:55-56,68):
+ *   mode 0: out0 = a / scale, out1 = b / scale          mode 1: out0 = (a - b) / scale      (out1 may be NULL)
+ * element-wise over the segments; the padding of a segmented layout is zero-filled.
+ */
+int tdeq_init_scaled(int mode, const void* a, const void* b, const void* yscale, const tdeq_segment* segs,
+                     const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, void* out0, void* out1,
+                     int dtype, void* stream);
 
 /*
  * Dense output, fused fit + evaluate (rk_common.py:363-369 + interp.py:1-48):

@@ -48,6 +48,7 @@ def load() -> ctypes.CDLL:
         "oracle_error_norm": [V, V, V, _c_void_pp, _c_double_p, I, D, ctypes.POINTER(Segment), I, I64, I64,
                               V, V, I],
         "oracle_init_norms": [I, V, V, V, ctypes.POINTER(Segment), I, I64, I64, V, V, I],
+        "oracle_init_scaled": [I, V, V, V, ctypes.POINTER(Segment), I, I64, I64, V, V, I],
         "oracle_dense_eval": [V, V, V, V, V, _c_void_pp, _c_double_p, I, D, D, I64, I],
         "oracle_interp_fit": [V, V, V, V, V, _c_void_pp, _c_double_p, I, D, I64, I],
         "oracle_rk4_38_stage": [I, V, V, V, V, V, V, D, I64, I],
@@ -155,6 +156,12 @@ class OracleKernels:
         _ok(self.lib.oracle_init_norms(mode, a.data_ptr(), b.data_ptr(), yscale.data_ptr(), plan.segs, plan.n_seg,
                                        plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr, _code(yscale.dtype)),
             "oracle_init_norms")
+
+    def init_scaled(self, plan, mode, a, b, yscale, out0, out1=None):
+        _ok(self.lib.oracle_init_scaled(mode, a.data_ptr(), b.data_ptr(), yscale.data_ptr(), plan.segs, plan.n_seg,
+                                        plan.chunk, plan.n_chunks, out0.data_ptr(),
+                                        None if out1 is None else out1.data_ptr(), _code(yscale.dtype)),
+            "oracle_init_scaled")
 
     def read_norms(self, plan) -> Tuple[List[float], List[float], List[float]]:
         v = plan.out.tolist()

@@ -628,3 +628,39 @@ int oracle_pack_segments(void* out, const void* const* src, const int64_t* chunk
     }
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * y0/scale, f0/scale, (f1 - f0)/scale of the initial-step heuristic, materialised for a user norm callable
+ * (misc.py:53-56, 68; CPU twin of tdeq_init_scaled).
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_INIT_SCALED(NAME, T, ABS)                                                                 \
+    static void NAME(int mode, const T* a, const T* b, const T* y, const oracle_segment* segs, int n_seg, \
+                     int64_t chunk, int64_t n_chunks, T* out0, T* out1) {                             \
+        for (int s = 0; s < n_seg; ++s) {                                                             \
+            const int64_t begin = segs[s].chunk_start * chunk;                                        \
+            const int64_t end = ((s + 1 < n_seg) ? segs[s + 1].chunk_start : n_chunks) * chunk;       \
+            const T rtol = (T)segs[s].rtol, atol = (T)segs[s].atol;                                   \
+            for (int64_t i = begin; i < end; ++i) {                                                   \
+                const int live = (i - begin) < segs[s].numel;                                         \
+                if (!live) { if (n_seg > 1) { out0[i] = 0; if (mode == 0) out1[i] = 0; } continue; }  \
+                const T scale = atol + ABS(y[i]) * rtol;                                              \
+                if (mode == 0) { out0[i] = a[i] / scale; out1[i] = b[i] / scale; }                    \
+                else out0[i] = (a[i] - b[i]) / scale;                                                 \
+            }                                                                                         \
+        }                                                                                             \
+    }
+DEF_INIT_SCALED(init_scaled_f32, float, fabsf)
+DEF_INIT_SCALED(init_scaled_f64, double, fabs)
+
+int oracle_init_scaled(int mode, const void* a, const void* b, const void* yscale, const oracle_segment* segs, int n_seg,
+                       int64_t chunk, int64_t n_chunks, void* out0, void* out1, int dtype) {
+    if ((mode != 0 && mode != 1) || !a || !b || !yscale || !segs || !out0 || (mode == 0 && !out1)) return -1;
+    if (dtype == ORACLE_F32)
+        init_scaled_f32(mode, (const float*)a, (const float*)b, (const float*)yscale, segs, n_seg, chunk, n_chunks,
+                        (float*)out0, (float*)out1);
+    else if (dtype == ORACLE_F64)
+        init_scaled_f64(mode, (const double*)a, (const double*)b, (const double*)yscale, segs, n_seg, chunk, n_chunks,
+                        (double*)out0, (double*)out1);
+    else return -1;
+    return 0;
+}

@@ -527,9 +527,73 @@ def gen_tuple_tolerances():
     save("tuple_tol.npz", **arrays)
 
 
+def gen_adjoint_time_dependent():
+    """Adjoint of a TIME-DEPENDENT field, with default and user-supplied norms.  Two reference behaviours are pinned
+    here: (i) vjp_t is formed in every backward evaluation even when `t` does not require grad (the in-place
+    `requires_grad_` of adjoint.py:84-88), so it takes part in the backward solve's norms and step sizes;
+    (ii) a user forward `norm` is also used by `_select_initial_step` (rk_common.py:217) and, through
+    `handle_adjoint_norm_`, on y / adj_y of the backward solve (adjoint.py:247-270)."""
+    arrays = {}
+    torch.manual_seed(5)
+    W = torch.randn(4, 4, dtype=torch.float64) * 0.6
+    b = torch.randn(4, dtype=torch.float64) * 0.1
+    ya = rand(6, 4, seed=31)
+    yb = rand(3, seed=32)
+    t = torch.tensor([0.0, 0.6, 1.4], dtype=torch.float64)
+    arrays.update(adjt_W=W, adjt_b=b, adjt_ya=ya, adjt_yb=yb, adjt_t=t)
+    for tup in (False, True):
+        for norm_tag in ("default", "usernorm", "usernorm_semi", "semi"):
+            lin = torch.nn.Linear(4, 4).double()
+            with torch.no_grad():
+                lin.weight.copy_(W)
+                lin.bias.copy_(b)
+            acc, rej, nfe = [], [], [0]
+
+            class F(torch.nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.lin = lin
+
+                def forward(self, t_, y_):
+                    nfe[0] += 1
+                    if tup:
+                        return torch.tanh(self.lin(y_[0])) * torch.cos(t_), -y_[1] * 0.3 * t_
+                    return torch.tanh(self.lin(y_)) * torch.cos(t_)
+
+                def callback_accept_step_adjoint(self, t0, y0, dt):
+                    acc.append(float(dt))
+
+                def callback_reject_step_adjoint(self, t0, y0, dt):
+                    rej.append(float(dt))
+
+            f = F()
+            a0 = ya.clone().requires_grad_(True)
+            b0 = yb.clone().requires_grad_(True)
+            y0 = (a0, b0) if tup else a0
+            opts, aopts = None, None
+            if norm_tag.startswith("usernorm"):
+                opts = dict(norm=(lambda y: max(y[0].abs().max(), y[1].abs().max())) if tup else (lambda y: y.abs().max()))
+            if norm_tag.endswith("semi"):
+                aopts = dict(norm="seminorm")
+            out = torchdiffeq.odeint_adjoint(f, y0, t, rtol=1e-6, atol=1e-8, method="dopri5", options=opts,
+                                             adjoint_options=aopts)
+            o = out[0] if tup else out
+            nfe_fwd = nfe[0]
+            (o[-1].pow(2).sum() + o[1].sum() + (out[1][-1].sum() if tup else 0.0)).backward()
+            key = f"adjt_{'tup' if tup else 'ten'}_{norm_tag}"
+            arrays[f"{key}_y"] = o
+            arrays[f"{key}_g_y0"] = a0.grad
+            arrays[f"{key}_g_W"] = lin.weight.grad
+            arrays[f"{key}_g_b"] = lin.bias.grad
+            arrays[f"{key}_nfe"] = np.array([nfe_fwd, nfe[0] - nfe_fwd])
+            arrays[f"{key}_acc"] = np.array(acc)
+            arrays[f"{key}_rej"] = np.array(rej)
+    save("adjoint_tdep.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
-                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances)]:
+                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent)]:
         if not only or name in only:
             fn()

@@ -333,3 +333,59 @@ def test_tuple_state_with_per_component_tolerances(dev, dname, tag):
     tol = 1e-12 if dname == "f64" else 2e-6
     assert rel_err(sa, z[f"tt_{dname}_{tag}_ya"]) < tol
     assert rel_err(sb, z[f"tt_{dname}_{tag}_yb"]) < tol
+
+
+@pytest.mark.parametrize("tup", [False, True], ids=["tensor", "tuple"])
+@pytest.mark.parametrize("norm_tag", ["default", "usernorm", "usernorm_semi", "semi"])
+def test_adjoint_time_dependent_field_and_user_norms(dev, tup, norm_tag):
+    """Adjoint of a time-dependent field against the reference (tests/golden/adjoint_tdep.npz): the backward solve
+    takes the reference's steps — same accepted / rejected step sizes, same NFE — because (i) the time VJP is formed
+    in every backward evaluation and enters the norms even when `t` needs no gradient, as in the reference, and
+    (ii) a user forward `norm` is used by the initial-step heuristic and on (y, adj_y) of the backward solve."""
+    z = load("adjoint_tdep.npz")
+    lin = torch.nn.Linear(4, 4).double()
+    with torch.no_grad():
+        lin.weight.copy_(T(z["adjt_W"], dev))
+        lin.bias.copy_(T(z["adjt_b"], dev))
+    acc, rej, nfe = [], [], [0]
+
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = lin
+
+        def forward(self, t_, y_):
+            nfe[0] += 1
+            if tup:
+                return torch.tanh(self.lin(y_[0])) * torch.cos(t_), -y_[1] * 0.3 * t_
+            return torch.tanh(self.lin(y_)) * torch.cos(t_)
+
+        def callback_accept_step_adjoint(self, t0, y0, dt):
+            acc.append(float(dt))
+
+        def callback_reject_step_adjoint(self, t0, y0, dt):
+            rej.append(float(dt))
+
+    f = F()
+    a0 = T(z["adjt_ya"], dev).clone().requires_grad_(True)
+    b0 = T(z["adjt_yb"], dev).clone().requires_grad_(True)
+    t = T(z["adjt_t"], dev)
+    opts = aopts = None
+    if norm_tag.startswith("usernorm"):
+        opts = dict(norm=(lambda y: max(y[0].abs().max(), y[1].abs().max())) if tup else (lambda y: y.abs().max()))
+    if norm_tag.endswith("semi"):
+        aopts = dict(norm="seminorm")
+    out = tda.odeint_adjoint(f, (a0, b0) if tup else a0, t, rtol=1e-6, atol=1e-8, method="dopri5", options=opts,
+                             adjoint_options=aopts)
+    o = out[0] if tup else out
+    nfe_fwd = nfe[0]
+    (o[-1].pow(2).sum() + o[1].sum() + (out[1][-1].sum() if tup else 0.0)).backward()
+    key = f"adjt_{'tup' if tup else 'ten'}_{norm_tag}"
+    assert [nfe_fwd, nfe[0] - nfe_fwd] == z[f"{key}_nfe"].tolist()
+    assert len(acc) == len(z[f"{key}_acc"]) and len(rej) == len(z[f"{key}_rej"])
+    # the embedded error is a cancelling sum (|err| ~ 1e-8 |k|): its association moves the ratio by ~1e-8 relative
+    assert np.allclose(acc, z[f"{key}_acc"], rtol=1e-6, atol=0)
+    assert rel_err(o.detach(), z[f"{key}_y"]) < 1e-12
+    assert rel_err(a0.grad, z[f"{key}_g_y0"]) < 1e-11
+    assert rel_err(lin.weight.grad, z[f"{key}_g_W"]) < 1e-11
+    assert rel_err(lin.bias.grad, z[f"{key}_g_b"]) < 1e-11

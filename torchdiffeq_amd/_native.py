@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 11
+TDEQ_ABI_VERSION = 12
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -91,6 +91,10 @@ ABI_SIGNATURES = {
                                        ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int,
                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_init_scaled": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_void_p]),
     "tdeq_dense_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
                                        ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
@@ -354,6 +358,14 @@ class HipKernels:
                                         plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
                                         plan.workspace.data_ptr(), plan.workspace_bytes,
                                         dtype_code(yscale.dtype), self._stream()), "tdeq_init_norms")
+
+    def init_scaled(self, plan: NormPlan, mode: int, a, b, yscale, out0, out1=None) -> None:
+        """a/scale, b/scale (mode 0) or (a-b)/scale (mode 1) materialised for a user norm (tdeq_init_scaled)."""
+        dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
+        _check(self.lib.tdeq_init_scaled(mode, a.data_ptr(), b.data_ptr(), yscale.data_ptr(), plan.segs, dev,
+                                         plan.n_seg, plan.chunk, plan.n_chunks, out0.data_ptr(),
+                                         None if out1 is None else out1.data_ptr(), dtype_code(yscale.dtype),
+                                         self._stream()), "tdeq_init_scaled")
 
     def read_norms(self, plan: NormPlan) -> Tuple[List[float], List[float], List[float]]:
         """(sumsq[0:n_seg], sumsq[n_seg:2n_seg], nonfinite[0:n_seg]) of the last norm launch."""

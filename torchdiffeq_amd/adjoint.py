@@ -49,13 +49,15 @@ class _AugmentedDynamics(OdeFunc):
         y_views, adj_views = views[1:1 + n_y], views[1 + n_y:1 + 2 * n_y]
         sign_f = fwd.sign            # forward solve in decreasing time: f_fwd(s, y) = -f(-s, y)
         with torch.enable_grad():
-            t_ = (t_user * sign_f if sign_f != 1.0 else t_user).detach()
-            if self.t_requires_grad:
-                t_.requires_grad_(True)
+            # The time VJP is ALWAYS formed, whether or not `t` requires grad: the reference means to skip it
+            # (adjoint.py:84-88) but its `t_.requires_grad_(True)` acts in place on the detached tensor it then hands
+            # to func, so vjp_t is computed there in every case — and, being a component of the augmented state, it
+            # takes part in the error norm and the initial-step heuristic of the backward solve.
+            t_ = (t_user * sign_f if sign_f != 1.0 else t_user).detach().requires_grad_(True)
             y_in = tuple(v.detach().requires_grad_(True) for v in y_views)
             f = fwd.base_func(t_, y_in if fwd.layout.is_tuple else y_in[0])
             f_list = list(f) if fwd.layout.is_tuple else [f]
-            wrt = ((t_,) if self.t_requires_grad else ()) + y_in + self.params
+            wrt = (t_,) + y_in + self.params
             # components of f that depend on nothing differentiable (e.g. f(t, y) = g(t)) contribute zero VJPs
             live = [(fi, ai) for fi, ai in zip(f_list, adj_views) if fi.requires_grad]
             if live:
@@ -63,10 +65,7 @@ class _AugmentedDynamics(OdeFunc):
                                             allow_unused=True)
             else:
                 grads = (None,) * len(wrt)
-        if self.t_requires_grad:
-            g_t, grads = grads[0], grads[1:]
-        else:
-            g_t = None
+        g_t, grads = grads[0], grads[1:]
         g_y, g_p = grads[:n_y], grads[n_y:]
 
         # one launch assembles [ -vjp_t | f | -vjp_y | -vjp_θ ] (signs for an ascending forward solve; absent
@@ -270,17 +269,34 @@ def find_parameters(module):
     return list(module.parameters())
 
 
-def handle_adjoint_norm_(adjoint_options, n_params: int) -> None:
+def handle_adjoint_norm_(adjoint_options, n_params: int, state_norm=None, layout: Optional[StateLayout] = None) -> None:
     """Choose the adjoint norm in place (adjoint.py:243-288): default = mixed norm over
-    (vjp_t, y, adj_y, every θ-adjoint); 'seminorm' drops the θ-adjoints; a callable is the user's."""
+    (vjp_t, y, adj_y, every θ-adjoint); 'seminorm' drops the θ-adjoints; a callable is the user's.
+    `state_norm` = the forward solve's norm when that is a USER callable (wrapped by check_inputs: flat forward
+    state -> scalar): the default and the seminorm then apply it to y and adj_y, as the reference does."""
     norm = adjoint_options.get("norm")
-    if norm is None:
-        adjoint_options["norm"] = BuiltinNorm(name="adjoint-mixed")
-    elif isinstance(norm, str):
-        if norm == "seminorm":
-            adjoint_options["norm"] = BuiltinNorm(n_skip_tail=n_params, name="adjoint-seminorm")
-        else:
-            raise ValueError(f"Unknown adjoint norm '{norm}'")
+    user_state_norm = state_norm is not None and not isinstance(state_norm, BuiltinNorm)
+    if norm is not None and not isinstance(norm, str):
+        return                                              # the user's own adjoint norm
+    if isinstance(norm, str) and norm != "seminorm":
+        raise ValueError(f"Unknown adjoint norm '{norm}'")
+    seminorm = norm == "seminorm"
+    if not user_state_norm:
+        adjoint_options["norm"] = BuiltinNorm(n_skip_tail=n_params, name="adjoint-seminorm") if seminorm \
+            else BuiltinNorm(name="adjoint-mixed")
+        return
+    n_y = layout.n_seg
+
+    def _adjoint_norm(tensors, _state_norm=state_norm, _lay=layout, _seminorm=seminorm):
+        # (t, *y components, *adj_y components, *θ-adjoints): the user's state norm sees y and adj_y the way the
+        # forward solve hands them to it
+        t, ys, adj = tensors[0], tensors[1:1 + n_y], tensors[1 + n_y:1 + 2 * n_y]
+        vals = [t.abs(), _state_norm(_lay.pack(list(ys))), _state_norm(_lay.pack(list(adj)))]
+        if not _seminorm:
+            vals += [p.abs().pow(2).mean().sqrt() for p in tensors[1 + 2 * n_y:] if p.numel() > 0]
+        return max(vals)
+
+    adjoint_options["norm"] = _adjoint_norm
 
 
 def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None,
@@ -324,10 +340,7 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
     if adjoint_method not in SOLVERS:
         raise ValueError('Invalid method "{}". Must be one of {}'.format(
             adjoint_method, '{"' + '", "'.join(SOLVERS.keys()) + '"}.'))
-    if not isinstance(ci.options["norm"], BuiltinNorm) and "norm" not in adjoint_options:
-        raise NotImplementedError("a user-supplied forward `norm` needs an explicit adjoint_options['norm'] "
-                                  "on the MI355X path")
-    handle_adjoint_norm_(adjoint_options, len(adjoint_params))
+    handle_adjoint_norm_(adjoint_options, len(adjoint_params), ci.options["norm"], ci.layout)
 
     layout = ci.layout
     y0_tensors = y0 if layout.is_tuple else (y0,)

@@ -829,6 +829,32 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, 
                              : launch_init<double>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, s);
 }
 
+int tdeq_init_scaled(int mode, const void* a, const void* b, const void* yscale, const tdeq_segment* segs,
+                     const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, void* out0, void* out1,
+                     int dtype, void* stream) {
+    if ((mode != 0 && mode != 1) || !a || !b || !yscale || !out0 || (mode == 0 && !out1) || bad_dtype(dtype))
+        return TDEQ_EINVAL;
+    SegTable st;
+    const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
+    if (e) return e;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 g((unsigned)st.n_chunks), blk(kBlock);
+    if (dtype == TDEQ_F32) {
+        InitScaledArgs<float> x{static_cast<const float*>(a), static_cast<const float*>(b),
+                                static_cast<const float*>(yscale), st, static_cast<float*>(out0),
+                                static_cast<float*>(out1)};
+        if (mode == 0) hipLaunchKernelGGL((init_scaled_kernel<float, 0>), g, blk, 0, s, x);
+        else hipLaunchKernelGGL((init_scaled_kernel<float, 1>), g, blk, 0, s, x);
+    } else {
+        InitScaledArgs<double> x{static_cast<const double*>(a), static_cast<const double*>(b),
+                                 static_cast<const double*>(yscale), st, static_cast<double*>(out0),
+                                 static_cast<double*>(out1)};
+        if (mode == 0) hipLaunchKernelGGL((init_scaled_kernel<double, 0>), g, blk, 0, s, x);
+        else hipLaunchKernelGGL((init_scaled_kernel<double, 1>), g, blk, 0, s, x);
+    }
+    return check_launch();
+}
+
 int tdeq_dense_eval(void* out, const void* y0, const void* y1, const void* f0, const void* f1,
                     const void* const* k, const double* coef, int n_terms, double dt, double x, int64_t n,
                     int dtype, void* stream) {

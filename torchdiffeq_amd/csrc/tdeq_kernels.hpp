@@ -486,6 +486,43 @@ __global__ __launch_bounds__(kBlock) void init_norms_kernel(const InitArgs<T> a)
     }
 }
 
+// The same quotients materialised for a USER norm callable (misc.py:53-56,68 with norm != rms): out0 = a/scale,
+// out1 = b/scale (MODE 0) or out0 = (a - b)/scale (MODE 1); padding of a segmented layout zero-filled.  Once per
+// solve, so a plain scalar loop per chunk.
+template <typename T>
+struct InitScaledArgs {
+    const T* a;
+    const T* b;
+    const T* y;
+    SegTable st;
+    T* out0;
+    T* out1;
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(kBlock) void init_scaled_kernel(const InitScaledArgs<T> a) {
+    const int64_t b = blockIdx.x;
+    const tdeq_segment seg = find_segment(a.st, b);
+    const int64_t base = b * a.st.chunk;
+    int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+    valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
+    const T rtol = (T)seg.rtol, atol = (T)seg.atol;
+    for (int64_t t = threadIdx.x; t < valid; t += kBlock) {
+        const T scale = atol + sabs(a.y[base + t]) * rtol;
+        if (MODE == 0) {
+            a.out0[base + t] = a.a[base + t] / scale;
+            a.out1[base + t] = a.b[base + t] / scale;
+        } else {
+            a.out0[base + t] = (a.a[base + t] - a.b[base + t]) / scale;
+        }
+    }
+    if (a.st.n_seg > 1)
+        for (int64_t t = valid + threadIdx.x; t < a.st.chunk; t += kBlock) {
+            a.out0[base + t] = (T)0;
+            if (MODE == 0) a.out1[base + t] = (T)0;
+        }
+}
+
 // Finalize: workgroup (s, q) adds the partials of segment s from array q in a fixed order.
 //   q < n_sum  -> out_sumsq[q*n_seg + s]      q == n_sum -> out_bad[s]
 struct FinalizeArgs {

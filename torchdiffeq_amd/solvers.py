@@ -625,11 +625,20 @@ class RKAdaptiveStepsizeODESolver:
             (y0.requires_grad or f0.requires_grad or self._anchor is not None)
         y0_g, f0_g = y0, f0
         y0, f0 = y0.detach(), f0.detach()
+        user_norm = not isinstance(self.norm, BuiltinNorm)
         kern.init_norms(plan, 0, y0, f0, y0)
         s0, s1, bad = self._read_norms()
         self._y_nonfinite = any(b != 0 for b in bad)
-        d0 = T(self._segment_norm(s0, bad))
-        d1 = T(self._segment_norm(s1, bad))
+        if user_norm:
+            # the reference hands ITS norm to the heuristic (rk_common.py:217): materialise the quotients and let the
+            # user's callable reduce them
+            q0, q1 = torch.empty_like(y0), torch.empty_like(y0)
+            kern.init_scaled(plan, 0, y0, f0, y0, q0, q1)
+            with torch.no_grad():
+                d0, d1 = T(abs(float(self.norm(q0)))), T(abs(float(self.norm(q1))))
+        else:
+            d0 = T(self._segment_norm(s0, bad))
+            d1 = T(self._segment_norm(s1, bad))
         if d0 < 1e-5 or d1 < 1e-5:
             h0 = T(1e-6)
         else:
@@ -644,10 +653,16 @@ class RKAdaptiveStepsizeODESolver:
             kern.stage_combine(y1, y0, [f0], [1.0], float(h0) * self.func.sign)
             with torch.no_grad():
                 f1 = self.func.eval(t0 + float(h0), y1)
-        kern.init_norms(plan, 1, f1, f0, y0)
-        s2, _, bad = self._read_norms()
+        if user_norm:
+            kern.init_scaled(plan, 1, f1, f0, y0, q0)
+            with torch.no_grad():
+                d2_num = T(abs(float(self.norm(q0))))
+        else:
+            kern.init_norms(plan, 1, f1, f0, y0)
+            s2, _, bad = self._read_norms()
+            d2_num = T(self._segment_norm(s2, bad))
         with np.errstate(all="ignore"):
-            d2 = abs(T(self._segment_norm(s2, bad)) / h0)
+            d2 = abs(d2_num / h0)
             if d1 <= 1e-15 and d2 <= 1e-15:
                 h1 = max(T(1e-6), T(h0 * T(1e-3)))
             else:
