@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 12
+#define TDEQ_ABI_VERSION 13
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -351,6 +351,35 @@ int tdeq_pack_segments(void* out, const void* const* src, const int64_t* chunk_s
 
 /* Writes n_vals scalars (converted to T) to consecutive elements of dst (stage times for func). */
 int tdeq_fill_scalars(void* dst, const double* vals, int n_vals, int dtype, void* stream);
+
+/*
+ * Adams–Bashforth(–Moulton) multistep steps of the fixed-grid solvers `explicit_adams`, `implicit_adams`
+ * (= `fixed_adams`), fixed_adams.py:164-228.  f_hist[j] = func output at t_{n-j} (newest first, separate
+ * contiguous tensors — the reference's deque `prev_f`), 1 <= n_terms <= TDEQ_MAX_TERMS (the reference uses 3..11).
+ *
+ * tdeq_adams_predict — one pass over the history:
+ *   dy    = (cb_0*f_0 + cb_1*f_1) + ...       `_dot_product(dt * bashforth_coeffs, prev_f)` (:205); the caller passes
+ *                                             cb_j = dt*b_j formed in fp64, rounded to T here (0-dim fp64 x T tensor)
+ *   y_out = y0 + dy                           (:213 / solvers.py:115)
+ *   delta = T(dt) * ((cm_0*f_0 + cm_1*f_1) + ...)   `dt * _dot_product(moulton_coeffs[1:], prev_f)` (:210), cm_j = m_{j+1}
+ * dy_out / delta_out / cm are given together (implicit method) or all NULL (explicit method).
+ *
+ * tdeq_adams_correct — one corrector iteration and its convergence test in one pass (:212-216, :189-192):
+ *   compute != 0:  dy = T(c)*f + delta (c = dt*m_0 formed in fp64 by the caller), dy_out = dy, y_out = y0 + dy
+ *   compute == 0:  dy is read from dy_out (test only; y_out, f, delta, y0 unused)
+ *   out_count[s]      = number of elements of segment s with NOT (|dy_old - dy| / (atol_s + rtol_s*max(|dy_old|,|dy|)) < 1)
+ *                       — `_has_converged` (l-inf norm of the error ratio < 1, misc.py:80-82) <=> all counts are 0
+ *   out_nonfinite[s]  = number of non-finite elements of dy in segment s
+ * Segment table, workspace (tdeq_workspace_bytes(n_chunks)) and result placement as for tdeq_error_norm; n = number of
+ * elements of every buffer (>= the end of the last segment; the padding of a segmented state is written, not counted).
+ */
+int tdeq_adams_predict(void* y_out, void* dy_out, void* delta_out, const void* y0, const void* const* f_hist,
+                       const double* cb, const double* cm, int n_terms, double dt, int64_t n, int dtype,
+                       void* stream);
+int tdeq_adams_correct(void* y_out, void* dy_out, const void* f, const void* delta, const void* dy_old,
+                       const void* y0, double c, int compute, const tdeq_segment* segs, const void* segs_dev,
+                       int n_seg, int64_t chunk, int64_t n_chunks, int64_t n, double* out_count,
+                       double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

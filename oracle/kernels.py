@@ -66,6 +66,8 @@ def load() -> ctypes.CDLL:
                                  _c_double_p, I, I64, I64, I],
         "oracle_scale_many": [_c_void_pp, V, _c_double_p, I, I64, I],
         "oracle_multi_dot": [V, _c_void_pp, I, I64, V, I],
+        "oracle_adams_predict": [V, V, V, V, _c_void_pp, _c_double_p, _c_double_p, I, D, I64, I],
+        "oracle_adams_correct": [V, V, V, V, V, V, D, I, ctypes.POINTER(Segment), I, I64, I64, I64, V, V, I],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -244,6 +246,20 @@ class OracleKernels:
         _ok(self.lib.oracle_multi_dot(g.data_ptr(), ptrs, n, g.numel(), out.data_ptr(), _code(g.dtype)),
             "oracle_multi_dot")
         return out
+
+    def adams_predict(self, y_out, y0, hist, cb, cm=None, dt=0.0, dy_out=None, delta_out=None):
+        ptrs, cbf, n = self._terms(hist, cb)
+        cmf = None if cm is None else (ctypes.c_double * n)(*cm)
+        p = lambda t: None if t is None else t.data_ptr()
+        _ok(self.lib.oracle_adams_predict(y_out.data_ptr(), p(dy_out), p(delta_out), y0.data_ptr(), ptrs, cbf, cmf, n,
+                                          dt, y0.numel(), _code(y0.dtype)), "oracle_adams_predict")
+
+    def adams_correct(self, plan, dy_out, dy_old, y_out=None, f=None, delta=None, y0=None, c=0.0, compute=True):
+        p = lambda t: None if t is None else t.data_ptr()
+        _ok(self.lib.oracle_adams_correct(p(y_out), dy_out.data_ptr(), p(f), p(delta), dy_old.data_ptr(), p(y0), c,
+                                          1 if compute else 0, plan.segs, plan.n_seg, plan.chunk, plan.n_chunks,
+                                          dy_out.numel(), plan.out_ptr, plan.bad_ptr, _code(dy_out.dtype)),
+            "oracle_adams_correct")
 
     def pack_segments(self, out, srcs, chunk_starts, numels, scales, chunk):
         n = len(srcs)

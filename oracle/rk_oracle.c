@@ -664,3 +664,107 @@ int oracle_init_scaled(int mode, const void* a, const void* b, const void* yscal
     else return -1;
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * Adams–Bashforth predictor and the constant part of the Adams–Moulton corrector (CPU twin of
+ * tdeq_adams_predict):
+ *   dy = _dot_product(dt * bashforth_coeffs, prev_f).type_as(y0)            fixed_adams.py:205
+ *        (`dt * bashforth_coeffs` is an fp64 vector; each entry is rounded to T when it multiplies f_j; Python's
+ *        `sum` adds the products left to right starting from the int 0)                fixed_adams.py:160-161
+ *   delta = dt * _dot_product(moulton_coeffs[1:], prev_f).type_as(y0)      fixed_adams.py:210 (dt rounded to T)
+ *   y0 + dy                                                                  fixed_adams.py:213, solvers.py:115
+ * The caller passes cb_j = dt*b_j (fp64) and cm_j = m_{j+1}.
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_ADAMS_PREDICT(NAME, T)                                                                    \
+    static void NAME(T* y_out, T* dy_out, T* delta_out, const T* y0, const T* const* f,               \
+                     const double* cb, const double* cm, int nt, double dt, int64_t n) {              \
+        T b[ORACLE_MAX_TERMS], m[ORACLE_MAX_TERMS];                                                   \
+        for (int j = 0; j < nt; ++j) { b[j] = (T)cb[j]; m[j] = cm ? (T)cm[j] : (T)0; }                \
+        const T dtT = (T)dt;                                                                          \
+        _Pragma("omp parallel for schedule(static)")                                                  \
+        for (int64_t i = 0; i < n; ++i) {                                                             \
+            T dy = b[0] * f[0][i];                                                                    \
+            for (int j = 1; j < nt; ++j) dy = dy + b[j] * f[j][i];                                    \
+            y_out[i] = y0[i] + dy;                                                                    \
+            if (dy_out) {                                                                             \
+                T sm = m[0] * f[0][i];                                                                \
+                for (int j = 1; j < nt; ++j) sm = sm + m[j] * f[j][i];                                \
+                dy_out[i] = dy;                                                                       \
+                delta_out[i] = dtT * sm;                                                              \
+            }                                                                                         \
+        }                                                                                             \
+    }
+DEF_ADAMS_PREDICT(adams_predict_f32, float)
+DEF_ADAMS_PREDICT(adams_predict_f64, double)
+
+int oracle_adams_predict(void* y_out, void* dy_out, void* delta_out, const void* y0, const void* const* f_hist,
+                         const double* cb, const double* cm, int n_terms, double dt, int64_t n, int dtype) {
+    if (!y_out || !y0 || !f_hist || !cb || n_terms < 1 || n_terms > ORACLE_MAX_TERMS) return -1;
+    if ((dy_out == NULL) != (delta_out == NULL) || (dy_out && !cm)) return -1;
+    if (dtype == ORACLE_F32)
+        adams_predict_f32((float*)y_out, (float*)dy_out, (float*)delta_out, (const float*)y0,
+                          (const float* const*)f_hist, cb, cm, n_terms, dt, n);
+    else if (dtype == ORACLE_F64)
+        adams_predict_f64((double*)y_out, (double*)dy_out, (double*)delta_out, (const double*)y0,
+                          (const double* const*)f_hist, cb, cm, n_terms, dt, n);
+    else return -1;
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * One Adams–Moulton corrector iteration + `_has_converged` (CPU twin of tdeq_adams_correct):
+ *   dy = (dt * moulton_coeffs[0] * f).type_as(y0) + delta                   fixed_adams.py:214
+ *        (`dt * moulton_coeffs[0]` is a 0-dim fp64 product — the caller passes it as c — rounded to T against f)
+ *   y0 + dy                                                                  fixed_adams.py:213 (next iteration) / y1
+ *   error_ratio = linf(|dy_old - dy| / (atol + rtol*max(|dy_old|,|dy|))) < 1 fixed_adams.py:189-192, misc.py:80-82
+ * reported as the per-segment COUNT of elements with not(ratio < 1): the boolean is "all counts are 0".
+ * ------------------------------------------------------------------------------------------------- */
+#define DEF_ADAMS_CORRECT(NAME, T, ABS, MAX)                                                          \
+    static void NAME(T* y_out, T* dy_out, const T* f, const T* delta, const T* dy_old, const T* y0,   \
+                     double c, int compute, const oracle_segment* segs, int n_seg, int64_t chunk,     \
+                     int64_t n_chunks, int64_t n, double* out_count, double* out_bad) {               \
+        const T cT = (T)c;                                                                            \
+        if (compute) {                                                                                \
+            _Pragma("omp parallel for schedule(static)")                                              \
+            for (int64_t i = 0; i < n; ++i) {                                                         \
+                const T d = cT * f[i] + delta[i];                                                     \
+                dy_out[i] = d;                                                                        \
+                y_out[i] = y0[i] + d;                                                                 \
+            }                                                                                         \
+        }                                                                                             \
+        for (int s = 0; s < n_seg; ++s) {                                                             \
+            const int64_t base = segs[s].chunk_start * chunk;                                         \
+            const T rtol = (T)segs[s].rtol, atol = (T)segs[s].atol;                                   \
+            double cnt = 0.0, bad = 0.0;                                                              \
+            _Pragma("omp parallel for schedule(static) reduction(+:cnt,bad)")                         \
+            for (int64_t t = 0; t < segs[s].numel; ++t) {                                             \
+                const T d0 = dy_old[base + t], d1 = dy_out[base + t];                                 \
+                const T e = ABS(d0 - d1);                                                             \
+                const T tol = atol + rtol * MAX(ABS(d0), ABS(d1));                                    \
+                const T r = e / tol;                                                                  \
+                if (!(r < (T)1)) cnt += 1.0;                                                          \
+                if (!isfinite((double)d1)) bad += 1.0;                                                \
+            }                                                                                         \
+            out_count[s] = cnt;                                                                       \
+            out_bad[s] = bad;                                                                         \
+        }                                                                                             \
+        (void)n_chunks;                                                                               \
+    }
+DEF_ADAMS_CORRECT(adams_correct_f32, float, fabsf, fmaxf)
+DEF_ADAMS_CORRECT(adams_correct_f64, double, fabs, fmax)
+
+int oracle_adams_correct(void* y_out, void* dy_out, const void* f, const void* delta, const void* dy_old,
+                         const void* y0, double c, int compute, const oracle_segment* segs, int n_seg, int64_t chunk,
+                         int64_t n_chunks, int64_t n, double* out_count, double* out_nonfinite, int dtype) {
+    if (!dy_out || !dy_old || !segs || !out_count || !out_nonfinite) return -1;
+    if (compute && (!y_out || !f || !delta || !y0)) return -1;
+    if (dtype == ORACLE_F32)
+        adams_correct_f32((float*)y_out, (float*)dy_out, (const float*)f, (const float*)delta, (const float*)dy_old,
+                          (const float*)y0, c, compute, segs, n_seg, chunk, n_chunks, n, out_count, out_nonfinite);
+    else if (dtype == ORACLE_F64)
+        adams_correct_f64((double*)y_out, (double*)dy_out, (const double*)f, (const double*)delta,
+                          (const double*)dy_old, (const double*)y0, c, compute, segs, n_seg, chunk, n_chunks, n,
+                          out_count, out_nonfinite);
+    else return -1;
+    return 0;
+}

@@ -591,9 +591,89 @@ def gen_adjoint_time_dependent():
     save("adjoint_tdep.npz", **arrays)
 
 
+def adams_field(A):
+    return lambda t, y: torch.cos(t) * (torch.sin(y) @ A.T) - 0.1 * y
+
+
+def gen_adams():
+    """Widening beyond §8(f): the Adams multistep methods of the reference's SOLVERS table (fixed_adams.py).
+    Coefficient tables, solves (grid / step_size / perturb / cubic / reverse / low max_order / one iteration with
+    its non-convergence warnings / fp64), NFE counts, a tuple state with per-component tolerances, gradients by
+    backprop through the solver and an event solve."""
+    import warnings
+    from torchdiffeq._impl import fixed_adams
+    arrays = {}
+    for k in range(1, 13):
+        arrays[f"bashforth_{k}"] = fixed_adams._BASHFORTH_DIVISOR[k]
+        arrays[f"moulton_{k}"] = fixed_adams._MOULTON_DIVISOR[k]
+    A, y0 = linear_problem(4, 8, torch.float32, seed=15)
+    t = torch.tensor([0.0, 0.33, 0.7, 1.0])
+    arrays.update(A=A, y0=y0, t=t)
+
+    class Count:
+        def __init__(self, fn):
+            self.fn, self.nfe = fn, 0
+
+        def __call__(self, t, y):
+            self.nfe += 1
+            return self.fn(t, y)
+
+    with torch.no_grad():
+        for method in ["explicit_adams", "implicit_adams"]:
+            f = adams_field(A)
+            f64 = adams_field(A.double())
+            cases = {
+                "grid": (f, y0, torch.linspace(0, 1, 41), {}),
+                "step": (f, y0, t, dict(step_size=0.02)),
+                "perturb": (f, y0, t, dict(step_size=0.02, perturb=True)),
+                "cubic": (f, y0, t, dict(step_size=0.02, interp="cubic")),
+                "rev": (f, y0, torch.tensor([1.0, 0.45, 0.0]), dict(step_size=0.025, interp="cubic")),
+                "order6": (f, y0, t, dict(step_size=0.02, max_order=6)),
+                "iters1": (f, y0, t, dict(step_size=0.02, max_iters=1)),
+                "f64": (f64, y0.double(), t.double(), dict(step_size=0.0125)),
+            }
+            for tag, (fn, y, tt, opts) in cases.items():
+                c = Count(fn)
+                with warnings.catch_warnings(record=True) as w:
+                    warnings.simplefilter("always")
+                    arrays[f"{method}_{tag}"] = torchdiffeq.odeint(c, y, tt, method=method, options=opts,
+                                                                   rtol=1e-6, atol=1e-8)
+                arrays[f"{method}_{tag}_nfe"] = c.nfe
+                arrays[f"{method}_{tag}_warnings"] = len(w)
+            # tuple state, per-component tolerances, fp64 time grid over an fp32 state
+            ft = lambda t, y: (torch.cos(t) * (torch.sin(y[0]) @ A.T), -y[1] * y[0].sum())
+            yt = (y0, torch.tensor([0.5, 0.25, 1.0]))
+            out = torchdiffeq.odeint(ft, yt, torch.linspace(0, 1, 31, dtype=torch.float64), method=method,
+                                     rtol=(1e-6, 1e-5), atol=(1e-8, 1e-7))
+            arrays[f"{method}_tuple0"], arrays[f"{method}_tuple1"] = out
+    # gradients by backprop through the solver (y0, t and the parameters of the field)
+    for method in ["explicit_adams", "implicit_adams"]:
+        torch.manual_seed(3)
+        lin = torch.nn.Linear(3, 3).double()
+        yg = rand(5, 3, seed=16).requires_grad_(True)
+        tg = torch.linspace(0, 1, 21, dtype=torch.float64).requires_grad_(True)
+        fg = lambda t, y: torch.tanh(lin(y)) * torch.cos(t)
+        y = torchdiffeq.odeint(fg, yg, tg, method=method, rtol=1e-6, atol=1e-8)
+        loss = y[-1].pow(2).sum() + y[7].sum()
+        g = torch.autograd.grad(loss, [yg, tg, lin.weight, lin.bias])
+        arrays[f"{method}_bp_w"], arrays[f"{method}_bp_b"] = lin.weight, lin.bias
+        arrays[f"{method}_bp_y0"] = yg
+        arrays[f"{method}_bp_y"] = y
+        for name, v in zip(["gy0", "gt", "gw", "gb"], g):
+            arrays[f"{method}_bp_{name}"] = v
+        # event: harmonic oscillator crossing y[0] = 0
+        fe = lambda t, y: torch.stack([y[1], -y[0]])
+        et, ys = torchdiffeq.odeint_event(fe, torch.tensor([1.0, 0.0], dtype=torch.float64),
+                                          torch.tensor(0.0, dtype=torch.float64), event_fn=lambda t, y: y[0],
+                                          method=method, options=dict(step_size=0.01), atol=1e-8)
+        arrays[f"{method}_event_t"], arrays[f"{method}_event_y"] = et, ys
+    save("adams.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
-                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent)]:
+                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
+                     ("adams", gen_adams)]:
         if not only or name in only:
             fn()

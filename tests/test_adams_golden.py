@@ -1,0 +1,170 @@
+"""Adams multistep methods of the reference's SOLVERS table — `explicit_adams`, `implicit_adams`, `fixed_adams`
+(fixed_adams.py:164-228) — against the reference's own outputs (tests/golden/adams.npz, written by
+tests/golden/make_golden.py::gen_adams running the reference).
+
+`dev` fixture as in test_methods_golden.py: "cuda" = the product on the MI355X (tdeq_adams_predict /
+tdeq_adams_correct), "cpu" = the product's host logic with the oracle substituted for the HIP kernels.  The
+methods contain no reduction other than the convergence test, which is an exact census, so with the same torch CPU
+code evaluating the field the results must be BIT-IDENTICAL to the reference's; on the GPU the field's cos / sin /
+GEMM differ from the CPU's by an ulp, hence a tolerance there."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import torchdiffeq_amd as tda
+from torchdiffeq_amd.tableaus import adams_coefficients
+from _cases import T, load, rel_err
+
+METHODS = ["explicit_adams", "implicit_adams"]
+
+
+def _field(A):
+    return lambda t, y: torch.cos(t) * (torch.sin(y) @ A.T) - 0.1 * y
+
+
+class _Count:
+    def __init__(self, fn):
+        self.fn, self.nfe = fn, 0
+
+    def __call__(self, t, y):
+        self.nfe += 1
+        return self.fn(t, y)
+
+
+def test_solver_table_has_the_adams_methods():
+    assert list(tda.SOLVERS)[11:14] == ["explicit_adams", "implicit_adams", "fixed_adams"]
+    assert tda.SOLVERS["fixed_adams"] is tda.SOLVERS["implicit_adams"]
+    assert issubclass(tda.SOLVERS["explicit_adams"], tda.SOLVERS["implicit_adams"])
+    assert tda.SOLVERS["implicit_adams"].order == 4
+
+
+def test_coefficients_bit_identical_to_the_reference_tables():
+    """Generated in exact rational arithmetic here; the reference divides integer tables (fixed_adams.py:10-156)."""
+    z = load("adams.npz")
+    for k in range(1, 13):
+        bash, moulton = adams_coefficients(k)
+        assert np.array_equal(np.array(bash), z[f"bashforth_{k}"]), k
+        if k > 1:      # the reference's order-1 Moulton entry is 1/11 (a typo it never uses: orders start at 4)
+            assert np.array_equal(np.array(moulton), z[f"moulton_{k}"]), k
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_solves_match_the_reference(dev, method):
+    z = load("adams.npz")
+    A, y0, t = T(z["A"], dev), T(z["y0"], dev), T(z["t"], dev)
+    f, f64 = _field(A), _field(A.double())
+    cases = {
+        "grid": (f, y0, torch.linspace(0, 1, 41), {}),
+        "step": (f, y0, t, dict(step_size=0.02)),
+        "perturb": (f, y0, t, dict(step_size=0.02, perturb=True)),
+        "cubic": (f, y0, t, dict(step_size=0.02, interp="cubic")),
+        "rev": (f, y0, torch.tensor([1.0, 0.45, 0.0]), dict(step_size=0.025, interp="cubic")),
+        "order6": (f, y0, t, dict(step_size=0.02, max_order=6)),
+        "iters1": (f, y0, t, dict(step_size=0.02, max_iters=1)),
+        "f64": (f64, y0.double(), t.double(), dict(step_size=0.0125)),
+    }
+    for tag, (fn, y, tt, opts) in cases.items():
+        c = _Count(fn)
+        with warnings.catch_warnings(record=True) as w, torch.no_grad():
+            warnings.simplefilter("always")
+            got = tda.odeint(c, y, tt, method=method, options=opts, rtol=1e-6, atol=1e-8)
+        ref = T(z[f"{method}_{tag}"], dev)
+        assert got.shape == ref.shape and got.dtype == ref.dtype
+        if dev == "cpu":
+            assert torch.equal(got, ref), tag
+            # same number of corrector iterations and the same non-convergence warnings as the reference
+            assert c.nfe == int(z[f"{method}_{tag}_nfe"]), tag
+            assert len(w) == int(z[f"{method}_{tag}_warnings"]), tag
+        else:
+            assert rel_err(got, ref) < (1e-12 if tag == "f64" else 2e-6), tag
+            assert abs(c.nfe - int(z[f"{method}_{tag}_nfe"])) <= 2, tag       # a borderline convergence test may flip
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_fixed_adams_alias_and_reference_defaults(dev, method):
+    """`fixed_adams` is the implicit method; without tolerances odeint passes its own defaults (1e-7, 1e-9)."""
+    z = load("adams.npz")
+    A, y0 = T(z["A"], dev), T(z["y0"], dev)
+    with torch.no_grad():
+        a = tda.odeint(_field(A), y0, torch.linspace(0, 1, 41), method="fixed_adams", rtol=1e-6, atol=1e-8)
+        b = tda.odeint(_field(A), y0, torch.linspace(0, 1, 41), method="implicit_adams", rtol=1e-6, atol=1e-8)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_tuple_state_with_per_component_tolerances(dev, method):
+    z = load("adams.npz")
+    A, y0 = T(z["A"], dev), T(z["y0"], dev)
+    ft = lambda t, y: (torch.cos(t) * (torch.sin(y[0]) @ A.T), -y[1] * y[0].sum())
+    yt = (y0, torch.tensor([0.5, 0.25, 1.0]))
+    with torch.no_grad():
+        out = tda.odeint(ft, yt, torch.linspace(0, 1, 31, dtype=torch.float64), method=method,
+                         rtol=(1e-6, 1e-5), atol=(1e-8, 1e-7))
+    for i in range(2):
+        ref = T(z[f"{method}_tuple{i}"], dev)
+        assert out[i].dtype == ref.dtype and out[i].shape == ref.shape
+        if dev == "cpu":
+            assert torch.equal(out[i], ref)
+        else:
+            assert rel_err(out[i], ref) < 2e-6
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_backprop_through_the_solver(dev, method):
+    """Gradients wrt y0, t and the field's parameters equal the reference's autograd-through-eager-ops result."""
+    z = load("adams.npz")
+    lin = torch.nn.Linear(3, 3).double().to(dev)
+    with torch.no_grad():
+        lin.weight.copy_(T(z[f"{method}_bp_w"], dev))
+        lin.bias.copy_(T(z[f"{method}_bp_b"], dev))
+    y0 = T(z[f"{method}_bp_y0"], dev).requires_grad_(True)
+    t = torch.linspace(0, 1, 21, dtype=torch.float64).requires_grad_(True)
+    y = tda.odeint(lambda t_, y_: torch.tanh(lin(y_)) * torch.cos(t_), y0, t, method=method, rtol=1e-6, atol=1e-8)
+    assert rel_err(y, z[f"{method}_bp_y"]) < 1e-13
+    loss = y[-1].pow(2).sum() + y[7].sum()
+    g = torch.autograd.grad(loss, [y0, t, lin.weight, lin.bias])
+    for name, v in zip(["gy0", "gt", "gw", "gb"], g):
+        ref = T(z[f"{method}_bp_{name}"])
+        assert float((v.cpu() - ref).abs().max()) < 1e-11 * max(1.0, float(ref.abs().max())), name
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_event_mode(dev, method):
+    z = load("adams.npz")
+    fe = lambda t, y: torch.stack([y[1], -y[0]])
+    et, ys = tda.odeint_event(fe, torch.tensor([1.0, 0.0], dtype=torch.float64),
+                              torch.tensor(0.0, dtype=torch.float64), event_fn=lambda t, y: y[0], method=method,
+                              options=dict(step_size=0.01), atol=1e-8)
+    assert abs(float(et) - float(z[f"{method}_event_t"])) < 1e-12
+    assert rel_err(ys, z[f"{method}_event_y"]) < 1e-12
+
+
+def test_adjoint_with_adams_methods(dev):
+    """odeint_adjoint accepts the Adams methods for the forward and the backward solve."""
+    torch.manual_seed(4)
+    lin = torch.nn.Linear(3, 3).double().to(dev)
+    params = tuple(lin.parameters())
+    f = lambda t_, y_: torch.tanh(lin(y_))
+    y0 = torch.randn(4, 3, dtype=torch.float64).to(dev).requires_grad_(True)
+    t = torch.linspace(0, 1, 41, dtype=torch.float64)
+    grads = {}
+    for method in ["dopri5", "explicit_adams", "implicit_adams"]:
+        y0.grad = None
+        y = tda.odeint_adjoint(f, y0, t, method=method, rtol=1e-9, atol=1e-11, adjoint_params=params)
+        y[-1].pow(2).sum().backward()
+        grads[method] = y0.grad.clone()
+    assert rel_err(grads["explicit_adams"], grads["dopri5"]) < 1e-5
+    assert rel_err(grads["implicit_adams"], grads["dopri5"]) < 1e-5
+
+
+def test_option_checks(dev):
+    y0, t = torch.ones(3), torch.linspace(0, 1, 5)
+    with pytest.raises(AssertionError, match="max_order must be at most"):
+        tda.odeint(lambda t_, y_: -y_, y0, t, method="implicit_adams", options=dict(max_order=13))
+    with pytest.warns(UserWarning, match="reduces to `rk4`"):
+        with torch.no_grad():
+            a = tda.odeint(lambda t_, y_: -y_, y0, t, method="implicit_adams", options=dict(max_order=3))
+            b = tda.odeint(lambda t_, y_: -y_, y0, t, method="rk4")
+    assert torch.equal(a, b)

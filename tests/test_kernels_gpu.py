@@ -457,3 +457,120 @@ def test_dense_eval_multi_rows_equal_single_calls(hip_kernels, oracle_kernels, d
         for q, x in enumerate(xs):
             hip_kernels.dense_eval(single, y0d, y1d, ksd[0], ksd[-1], [ksd[j] for j in mid.idx], mid.coef, -0.07, x)
             assert torch.equal(rows[q], single)
+
+
+# ---- Adams–Bashforth(–Moulton): tdeq_adams_predict / tdeq_adams_correct ----------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 255, 4099, 65536 + 7, 1 << 20])
+def test_adams_predict_bit_exact(hip_kernels, oracle_kernels, dtype, n):
+    from torchdiffeq_amd.tableaus import adams_coefficients
+    y0 = _rand(n, dtype, 1)
+    hist = [_rand(n, dtype, 20 + j) for j in range(14)]
+    y0d, histd = y0.cuda(), _dev(hist)
+    for order in (1, 3, 4, 7, 11, 14):
+        bash, _ = adams_coefficients(order)
+        _, moulton = adams_coefficients(order + 1)
+        for dt in (0.0371, -0.0123):
+            cb = [dt * b for b in bash]
+            # explicit: only y0 + dy
+            ref = torch.empty_like(y0)
+            oracle_kernels.adams_predict(ref, y0, hist[:order], cb)
+            out = torch.empty_like(y0d)
+            hip_kernels.adams_predict(out, y0d, histd[:order], cb)
+            assert torch.equal(out.cpu(), ref)
+            # implicit: dy and the corrector's constant part from the same pass
+            refs = [torch.empty_like(y0) for _ in range(3)]
+            oracle_kernels.adams_predict(refs[0], y0, hist[:order], cb, list(moulton[1:]), dt, dy_out=refs[1],
+                                         delta_out=refs[2])
+            outs = [torch.empty_like(y0d) for _ in range(3)]
+            hip_kernels.adams_predict(outs[0], y0d, histd[:order], cb, list(moulton[1:]), dt, dy_out=outs[1],
+                                      delta_out=outs[2])
+            for o, r in zip(outs, refs):
+                assert torch.equal(o.cpu(), r)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_adams_predict_unaligned(hip_kernels, oracle_kernels, dtype):
+    n = 10007
+    y0 = _rand(n, dtype, 1)
+    hist = [_rand(n, dtype, 30 + j) for j in range(5)]
+    cb, cm = [0.3, -0.2, 0.1, 0.05, -0.01], [0.5, 0.25, -0.125, 0.0625, 0.03]
+    refs = [torch.empty_like(y0) for _ in range(3)]
+    oracle_kernels.adams_predict(refs[0], y0, hist, cb, cm, 0.07, dy_out=refs[1], delta_out=refs[2])
+
+    def view(src, off):          # a view at an odd element offset -> scalar path
+        buf = torch.empty(n + 3, dtype=dtype).cuda()
+        v = buf[off:off + n]
+        v.copy_(src)
+        return v
+    histd = [view(h, 1 + j % 3) for j, h in enumerate(hist)]
+    outs = [view(torch.zeros(n, dtype=dtype), 1) for _ in range(3)]
+    hip_kernels.adams_predict(outs[0], view(y0, 1), histd, cb, cm, 0.07, dy_out=outs[1], delta_out=outs[2])
+    for o, r in zip(outs, refs):
+        assert torch.equal(o.cpu(), r)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 255, 4099, 65536 + 7, 1 << 20])
+@pytest.mark.parametrize("chunk", [1024, 2048])
+def test_adams_correct_single_segment(hip_kernels, oracle_kernels, dtype, n, chunk):
+    rtol, atol = 1e-3, 1e-4
+    pg, pc = _plan_pair(hip_kernels, oracle_kernels, [(0, n, rtol, atol)], n, chunk)
+    y0, f, delta = _rand(n, dtype, 1), _rand(n, dtype, 2), _rand(n, dtype, 3)
+    c = 0.0173
+    # dy_old close to the new value for most elements, far for a few: a non-trivial census
+    dy_ref_full = (f.double() * c + delta.double()).to(dtype)
+    noise = _rand(n, dtype, 4)
+    dy_old = dy_ref_full + noise * 1e-4 * (noise.abs() > 1.5)
+    y_ref, dy_ref = torch.empty_like(y0), torch.empty_like(y0)
+    oracle_kernels.adams_correct(pc, dy_ref, dy_old, y_out=y_ref, f=f, delta=delta, y0=y0, c=c)
+    cnt_ref, _, bad_ref = oracle_kernels.read_norms(pc)
+    y, dy = torch.empty_like(y0).cuda(), torch.empty_like(y0).cuda()
+    hip_kernels.adams_correct(pg, dy, dy_old.cuda(), y_out=y, f=f.cuda(), delta=delta.cuda(), y0=y0.cuda(), c=c)
+    cnt, _, bad = hip_kernels.read_norms(pg)
+    assert torch.equal(dy.cpu(), dy_ref) and torch.equal(y.cpu(), y_ref)
+    assert cnt == cnt_ref and bad == bad_ref == [0.0]        # an exact census: no tolerance
+    # census-only mode on the same pair
+    hip_kernels.adams_correct(pg, dy, dy_old.cuda(), compute=False)
+    cnt2, _, _ = hip_kernels.read_norms(pg)
+    assert cnt2 == cnt
+    # identical iterates -> converged; a NaN anywhere -> not converged (torch.max propagates NaN, NaN < 1 is false)
+    hip_kernels.adams_correct(pg, dy, dy, compute=False)
+    assert hip_kernels.read_norms(pg)[0] == [0.0]
+    dy_nan = dy.clone()
+    dy_nan[n // 2] = float("nan")
+    hip_kernels.adams_correct(pg, dy_nan, dy, compute=False)
+    cnt3, _, bad3 = hip_kernels.read_norms(pg)
+    assert cnt3 == [1.0] and bad3 == [1.0]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_adams_correct_segments_and_padding(hip_kernels, oracle_kernels, dtype):
+    chunk = 1024
+    numels = [5000, 1, 1024, 77, 3000]
+    offs, off = [], 0
+    for m in numels:
+        offs.append(off)
+        off += math.ceil(m / chunk) * chunk
+    total = off
+    segs = [(o, m, 10.0 ** -(i + 2), 10.0 ** -(i + 4)) for i, (o, m) in enumerate(zip(offs, numels))]
+    pg, pc = _plan_pair(hip_kernels, oracle_kernels, segs, total, chunk)
+    y0, f, delta = _rand(total, dtype, 1), _rand(total, dtype, 2), _rand(total, dtype, 3)
+    mask = torch.ones(total, dtype=torch.bool)
+    for o, m in zip(offs, numels):
+        mask[o:o + m] = False
+    for tns in (y0, f, delta):
+        tns[mask] = 0.0                       # the padding of a segmented state is zero in every input
+    c = -0.031
+    dy_full = (f.double() * c + delta.double()).to(dtype)
+    dy_old = dy_full * (1 + 3e-4 * _rand(total, dtype, 5))
+    dy_old[mask] = 0.0
+    y_ref, dy_ref = torch.empty_like(y0), torch.empty_like(y0)
+    oracle_kernels.adams_correct(pc, dy_ref, dy_old, y_out=y_ref, f=f, delta=delta, y0=y0, c=c)
+    cnt_ref, _, _ = oracle_kernels.read_norms(pc)
+    y, dy = torch.full_like(y0, 7.0).cuda(), torch.full_like(y0, 7.0).cuda()
+    hip_kernels.adams_correct(pg, dy, dy_old.cuda(), y_out=y, f=f.cuda(), delta=delta.cuda(), y0=y0.cuda(), c=c)
+    cnt, _, bad = hip_kernels.read_norms(pg)
+    assert torch.equal(dy.cpu(), dy_ref) and torch.equal(y.cpu(), y_ref)      # padding written (zeros) as well
+    assert cnt == cnt_ref and bad == [0.0] * len(numels)
+    assert 0 < sum(cnt) < sum(numels)      # tolerances differ per segment: a mixed census

@@ -17,8 +17,8 @@ FIXED = ["euler", "midpoint", "heun2", "heun3", "rk4"]
 
 def test_solver_table_matches_reference_explicit_methods():
     """Same keys, same order as the reference's table for the explicit RK family (odeint.py:19-30)."""
-    assert list(tda.SOLVERS) == ["dopri8", "dopri5", "tsit5", "bosh3", "fehlberg2", "adaptive_heun",
-                                 "euler", "midpoint", "heun2", "heun3", "rk4"]
+    assert list(tda.SOLVERS)[:11] == ["dopri8", "dopri5", "tsit5", "bosh3", "fehlberg2", "adaptive_heun",
+                                      "euler", "midpoint", "heun2", "heun3", "rk4"]
     assert [tda.SOLVERS[m].order for m in ADAPTIVE] == [5, 3, 2, 2]
     assert [tda.SOLVERS[m].order for m in FIXED] == [1, 2, 2, 3, 4]
 

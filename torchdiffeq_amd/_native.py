@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 12
+TDEQ_ABI_VERSION = 13
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -134,6 +134,14 @@ ABI_SIGNATURES = {
                                           ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_fill_scalars": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p]),
+    "tdeq_adams_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          _c_void_pp, _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_double,
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_adams_correct": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int,
+                                          ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                          ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
 }
 
 
@@ -518,6 +526,29 @@ class HipKernels:
         _check(self.lib.tdeq_multi_dot(g.data_ptr(), ptrs, n, g.numel(), out.data_ptr(), ws.data_ptr(), nbytes,
                                        dtype_code(g.dtype), self._stream()), "tdeq_multi_dot")
         return out
+
+    # -- Adams–Bashforth(–Moulton) -----------------------------------------------------------------
+    def adams_predict(self, y_out, y0, hist, cb, cm=None, dt: float = 0.0, dy_out=None, delta_out=None) -> None:
+        """y_out = y0 + sum_j T(cb_j) f_j [, dy_out = that sum, delta_out = T(dt) * sum_j T(cm_j) f_j] in one pass over
+        the history `hist` (newest first) — tdeq_adams_predict."""
+        ptrs, cbf, n = self._terms(hist, cb)
+        cmf = None if cm is None else (ctypes.c_double * n)(*cm)
+        p = lambda t: None if t is None else t.data_ptr()
+        _check(self.lib.tdeq_adams_predict(y_out.data_ptr(), p(dy_out), p(delta_out), y0.data_ptr(), ptrs, cbf, cmf, n,
+                                           dt, y0.numel(), dtype_code(y0.dtype), self._stream()), "tdeq_adams_predict")
+
+    def adams_correct(self, plan: NormPlan, dy_out, dy_old, y_out=None, f=None, delta=None, y0=None, c: float = 0.0,
+                      compute: bool = True) -> None:
+        """One corrector iteration (dy_out = T(c) f + delta, y_out = y0 + dy_out) fused with its convergence census;
+        compute=False: census of (dy_old, dy_out) only.  Read the per-segment counts with `read_norms(plan)`."""
+        p = lambda t: None if t is None else t.data_ptr()
+        dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
+        self._arm(plan, 1)
+        _check(self.lib.tdeq_adams_correct(p(y_out), dy_out.data_ptr(), p(f), p(delta), dy_old.data_ptr(), p(y0), c,
+                                           1 if compute else 0, plan.segs, dev, plan.n_seg, plan.chunk, plan.n_chunks,
+                                           dy_out.numel(), plan.out_ptr, plan.bad_ptr, plan.workspace.data_ptr(),
+                                           plan.workspace_bytes, dtype_code(dy_out.dtype), self._stream()),
+               "tdeq_adams_correct")
 
     def pack_segments(self, out, srcs, chunk_starts: Sequence[int], numels: Sequence[int], scales: Sequence[float],
                       chunk: int) -> None:

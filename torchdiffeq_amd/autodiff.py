@@ -174,6 +174,53 @@ class Ops:
         return self._record(lambda o: self.k.rk4_stage(stage, o, y0, k1, k2, k3, k4, dt), [y0] + ks, w,
                             [(dt_shadow, [0.0] + pattern)])
 
+    # -- Adams–Bashforth(–Moulton) --------------------------------------------------------------------
+    def _long_sum(self, xs, ws, scalars=()):
+        """weighted_sum over more terms than one launch takes: left to right, the running sum carried with weight 1."""
+        cap = 8                                                   # TDEQ_MAX_SUM_TERMS
+        acc = self.weighted_sum(xs[:cap], ws[:cap], [(sh, dw[:cap]) for sh, dw in scalars])
+        lo = cap
+        while lo < len(xs):
+            hi = lo + cap - 1
+            acc = self.weighted_sum([acc, *xs[lo:hi]], [1.0, *ws[lo:hi]],
+                                    [(sh, [0.0, *dw[lo:hi]]) for sh, dw in scalars])
+            lo = hi
+        return acc
+
+    def adams_predict(self, y0, hist, cb, cm, dt: float, dt_shadow: Scalar = None, db=None, out=None):
+        """(y0 + dy, dy, delta) with dy = sum_j T(cb_j) f_j and delta = T(dt) * sum_j T(cm_j) f_j (tdeq_adams_predict);
+        `cm is None` (explicit method): only y0 + dy.  `db` = d cb / d dt for the time gradient."""
+        implicit = cm is not None
+        if not _needs_graph((y0, *hist), (dt_shadow,)):
+            y = out if out is not None else torch.empty_like(y0)
+            if not implicit:
+                self.k.adams_predict(y, y0, hist, cb)
+                return y, None, None
+            dy, delta = torch.empty_like(y0), torch.empty_like(y0)
+            self.k.adams_predict(y, y0, hist, cb, cm, dt, dy_out=dy, delta_out=delta)
+            return y, dy, delta
+        # recorded path: the same sums through the generic linear nodes (same products, same order => same bits)
+        sc = [(dt_shadow, list(db))] if dt_shadow is not None else []
+        dy = self._long_sum(list(hist), list(cb), sc)
+        y = self.weighted_sum([y0, dy], [1.0, 1.0])
+        if not implicit:
+            return y, None, None
+        sm = self._long_sum(list(hist), list(cm))
+        delta = self.weighted_sum([sm], [dt], [(dt_shadow, [1.0])] if dt_shadow is not None else [])
+        return y, dy, delta
+
+    def adams_correct(self, plan, y0, f, delta, dy_old, c: float, dt_shadow: Scalar = None, m0: float = 0.0):
+        """(y0 + dy, dy) with dy = T(c) f + delta; the convergence census of (dy_old, dy) is left in `plan`
+        (tdeq_adams_correct)."""
+        if not _needs_graph((y0, f, delta, dy_old), (dt_shadow,)):
+            y, dy = torch.empty_like(y0), torch.empty_like(y0)
+            self.k.adams_correct(plan, dy, dy_old, y_out=y, f=f, delta=delta, y0=y0, c=c)
+            return y, dy
+        dy = self.weighted_sum([f, delta], [c, 1.0], [(dt_shadow, [m0, 0.0])] if dt_shadow is not None else [])
+        y = self.weighted_sum([y0, dy], [1.0, 1.0])
+        self.k.adams_correct(plan, dy.detach(), dy_old.detach(), compute=False)
+        return y, dy
+
     # -- interpolation --------------------------------------------------------------------------------
     def lerp(self, y0, y1, slope: float, slope_shadow: Scalar = None, out=None):
         """y0 + slope (y1 - y0)   (tdeq_lerp)."""

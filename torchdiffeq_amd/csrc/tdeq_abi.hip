@@ -655,6 +655,80 @@ int launch_pack(void* out, const void* const* src, const int64_t* chunk_start, c
     return check_launch();
 }
 
+// ---- Adams–Bashforth(–Moulton) -----------------------------------------------------------------------
+template <typename T, int NT>
+int launch_adams_predict(void* y_out, void* dy_out, void* delta_out, const void* y0, const void* const* f,
+                         const double* cb, const double* cm, double dt, int64_t n, hipStream_t s) {
+    AdamsPredictArgs<T, NT> a;
+    const bool implicit = dy_out != nullptr;
+    a.y_out = static_cast<T*>(y_out);
+    a.dy_out = static_cast<T*>(dy_out);
+    a.delta_out = static_cast<T*>(delta_out);
+    a.y0 = static_cast<const T*>(y0);
+    bool vec = aligned16(y_out) && aligned16(y0) && aligned16(dy_out) && aligned16(delta_out);
+    for (int j = 0; j < NT; ++j) {
+        a.f[j] = static_cast<const T*>(f[j]);
+        a.cb[j] = (T)cb[j];
+        a.cm[j] = implicit ? (T)cm[j] : (T)0;
+        vec = vec && aligned16(f[j]);
+    }
+    a.dt = (T)dt;
+    a.n = n;
+    constexpr int L = VecOf<T>::L;
+    const dim3 g(vec ? stream_grid(n / L, kBlock) : stream_grid(n, kBlock)), b(kBlock);
+    if (implicit) {
+        if (vec) hipLaunchKernelGGL((adams_predict_kernel<T, NT, true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((adams_predict_kernel<T, NT, true, false>), g, b, 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((adams_predict_kernel<T, NT, false, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((adams_predict_kernel<T, NT, false, false>), g, b, 0, s, a);
+    }
+    return check_launch();
+}
+
+template <typename T>
+int dispatch_adams_predict(void* y_out, void* dy_out, void* delta_out, const void* y0, const void* const* f,
+                           const double* cb, const double* cm, int nt, double dt, int64_t n, hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_adams_predict<T, N>(y_out, dy_out, delta_out, y0, f, cb, cm, dt, n, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
+template <typename T>
+int launch_adams_correct(void* y_out, void* dy_out, const void* f, const void* delta, const void* dy_old,
+                         const void* y0, double c, bool compute, const SegTable& st, int64_t n, double* out_count,
+                         double* out_bad, double* ws, hipStream_t s) {
+    AdamsCorrectArgs<T> a;
+    a.y_out = static_cast<T*>(y_out);
+    a.dy_out = static_cast<T*>(dy_out);
+    a.f = static_cast<const T*>(f);
+    a.delta = static_cast<const T*>(delta);
+    a.dy_old = static_cast<const T*>(dy_old);
+    a.y0 = static_cast<const T*>(y0);
+    a.c = (T)c;
+    a.n = n;
+    a.st = st;
+    a.part_count = ws;
+    a.part_bad = ws + 2 * st.n_chunks;
+    const bool vec = aligned16(y_out) && aligned16(dy_out) && aligned16(f) && aligned16(delta) && aligned16(dy_old) &&
+                     aligned16(y0);
+    const dim3 g((unsigned)st.n_chunks), b(kBlock);
+    if (compute) {
+        if (vec) hipLaunchKernelGGL((adams_correct_kernel<T, true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((adams_correct_kernel<T, true, false>), g, b, 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((adams_correct_kernel<T, false, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((adams_correct_kernel<T, false, false>), g, b, 0, s, a);
+    }
+    const int e = check_launch();
+    if (e) return e;
+    return launch_finalize(st, ws, 1, out_count, out_bad, s);
+}
+
 inline bool bad_dtype(int dtype) { return dtype != TDEQ_F32 && dtype != TDEQ_F64; }
 
 }  // namespace
@@ -1030,6 +1104,38 @@ int tdeq_fill_scalars(void* dst, const double* vals, int n_vals, int dtype, void
     a.dtype = dtype;
     hipLaunchKernelGGL(fill_scalars_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     return check_launch();
+}
+
+int tdeq_adams_predict(void* y_out, void* dy_out, void* delta_out, const void* y0, const void* const* f_hist,
+                       const double* cb, const double* cm, int n_terms, double dt, int64_t n, int dtype,
+                       void* stream) {
+    if (!y_out || !y0 || !f_hist || !cb || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if ((dy_out == nullptr) != (delta_out == nullptr)) return TDEQ_EINVAL;
+    if (dy_out && !cm) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!f_hist[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? dispatch_adams_predict<float>(y_out, dy_out, delta_out, y0, f_hist, cb, cm, n_terms, dt, n, s)
+                             : dispatch_adams_predict<double>(y_out, dy_out, delta_out, y0, f_hist, cb, cm, n_terms, dt, n, s);
+}
+
+int tdeq_adams_correct(void* y_out, void* dy_out, const void* f, const void* delta, const void* dy_old,
+                       const void* y0, double c, int compute, const tdeq_segment* segs, const void* segs_dev,
+                       int n_seg, int64_t chunk, int64_t n_chunks, int64_t n, double* out_count,
+                       double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    if (!dy_out || !dy_old || !out_count || !out_nonfinite || !workspace || n < 0 || bad_dtype(dtype))
+        return TDEQ_EINVAL;
+    if (compute && (!y_out || !f || !delta || !y0)) return TDEQ_EINVAL;
+    SegTable st;
+    const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
+    if (e) return e;
+    if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    return dtype == TDEQ_F32
+               ? launch_adams_correct<float>(y_out, dy_out, f, delta, dy_old, y0, c, compute != 0, st, n, out_count, out_nonfinite, ws, s)
+               : launch_adams_correct<double>(y_out, dy_out, f, delta, dy_old, y0, c, compute != 0, st, n, out_count, out_nonfinite, ws, s);
 }
 
 }  // extern "C"

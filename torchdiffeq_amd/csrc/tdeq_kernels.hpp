@@ -1289,4 +1289,149 @@ __global__ void fill_scalars_kernel(const FillArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Adams–Bashforth(–Moulton) multistep steps on a fixed grid (fixed_adams.py:196-223).  Same streaming
+// shape as the RK combines: up to 11 history tensors f_{n-j} (separate contiguous tensors, newest first)
+// are read ONCE per step and feed both the predictor and the constant part of the corrector:
+//   dy    = (cb_0*f_0 + cb_1*f_1) + ...     cb_j = fl_T(dt*b_j), dt*b_j formed in fp64 by the host (:205)
+//   y_out = y0 + dy                         (:213 first iteration; solvers.py:115 in the explicit method)
+//   delta = dt * ((cm_0*f_0 + cm_1*f_1) + ...)    cm_j = fl_T(m_{j+1}), dt rounded to T (:210)
+// Python's `sum` starts from the int 0, and 0 + v == v.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+struct AdamsPredictArgs {
+    T* y_out;
+    T* dy_out;      // IMPLICIT only
+    T* delta_out;   // IMPLICIT only
+    const T* y0;
+    const T* f[NT];
+    T cb[NT];
+    T cm[NT];
+    T dt;
+    int64_t n;
+};
+
+template <typename T, int NT, bool IMPLICIT, typename E>
+__device__ __forceinline__ void adams_predict_one(const AdamsPredictArgs<T, NT>& a, int64_t i) {
+    E fv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fv[j] = reinterpret_cast<const E*>(a.f[j])[i];
+    const E y0 = reinterpret_cast<const E*>(a.y0)[i];
+    E dy = fv[0] * a.cb[0];
+#pragma unroll
+    for (int j = 1; j < NT; ++j) dy = dy + fv[j] * a.cb[j];
+    reinterpret_cast<E*>(a.y_out)[i] = y0 + dy;
+    if (IMPLICIT) {
+        E sm = fv[0] * a.cm[0];
+#pragma unroll
+        for (int j = 1; j < NT; ++j) sm = sm + fv[j] * a.cm[j];
+        reinterpret_cast<E*>(a.dy_out)[i] = dy;
+        reinterpret_cast<E*>(a.delta_out)[i] = sm * a.dt;
+    }
+}
+
+template <typename T, int NT, bool IMPLICIT, bool VEC>
+__global__ __launch_bounds__(kBlock) void adams_predict_kernel(const AdamsPredictArgs<T, NT> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
+        adams_predict_one<T, NT, IMPLICIT, E>(a, i);
+    if (VEC) {
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) adams_predict_one<T, NT, IMPLICIT, T>(a, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adams–Moulton corrector iteration + its convergence test in ONE pass (fixed_adams.py:212-216, 189-192):
+//   dy    = c*f + delta                      c = fl_T(dt*m_0), dt*m_0 formed in fp64 by the host (:214)
+//   y_out = y0 + dy                          input of the next evaluation, and y1 once converged
+//   ratio = |dy_old - dy| / (atol + rtol*max(|dy_old|, |dy|))      (misc.py:80-82 with the l-inf norm)
+// The reference reduces `ratio` with abs().max() and tests `< 1`; that boolean equals "no element has
+// !(ratio < 1)" (NaN included: torch.max propagates NaN and NaN < 1 is false), so the kernel COUNTS those
+// elements per chunk and the usual finalize launch adds the counts: exact, order-independent.
+// One workgroup per chunk like the norm kernels; the padding of a segmented state is written (it is zero
+// in every input) but not counted.  COMPUTE = false: test only, dy is read from dy_out.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct AdamsCorrectArgs {
+    T* y_out;
+    T* dy_out;
+    const T* f;
+    const T* delta;
+    const T* dy_old;
+    const T* y0;
+    T c;
+    int64_t n;
+    SegTable st;
+    double* part_count;
+    double* part_bad;
+};
+
+template <typename T>
+__device__ __forceinline__ void adams_test(T d_old, T d_new, T rtol, T atol, bool counted, double& cnt, double& bad) {
+    const T e = sabs(d_old - d_new);
+    const T tol = atol + rtol * smax(sabs(d_old), sabs(d_new));
+    const T r = e / tol;
+    cnt += (counted && !(r < (T)1)) ? 1.0 : 0.0;
+    bad += (counted && !__builtin_isfinite(d_new)) ? 1.0 : 0.0;
+}
+
+template <typename T, bool COMPUTE, bool VEC>
+__global__ __launch_bounds__(kBlock) void adams_correct_kernel(const AdamsCorrectArgs<T> a) {
+    using V = typename VecOf<T>::type;
+    constexpr int L = VecOf<T>::L;
+    __shared__ double red[2 * (kBlock / kWave)];
+    const int64_t b = blockIdx.x;
+    const tdeq_segment seg = find_segment(a.st, b);
+    const int64_t base = b * a.st.chunk;
+    int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+    valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
+    int64_t lim = a.n - base;
+    lim = lim < 0 ? 0 : (lim > a.st.chunk ? a.st.chunk : lim);
+    if (!COMPUTE) lim = valid;
+    const T rtol = (T)seg.rtol, atol = (T)seg.atol;
+    double acc[2] = {0.0, 0.0};
+    int64_t t0 = 0;
+    if (VEC) {
+        const int64_t nv = lim / L;
+        for (int64_t i = threadIdx.x; i < nv; i += kBlock) {
+            const V d_old = reinterpret_cast<const V*>(a.dy_old + base)[i];
+            V d_new;
+            if (COMPUTE) {
+                const V fv = reinterpret_cast<const V*>(a.f + base)[i];
+                const V dl = reinterpret_cast<const V*>(a.delta + base)[i];
+                const V y0 = reinterpret_cast<const V*>(a.y0 + base)[i];
+                d_new = fv * a.c + dl;
+                reinterpret_cast<V*>(a.dy_out + base)[i] = d_new;
+                reinterpret_cast<V*>(a.y_out + base)[i] = y0 + d_new;
+            } else {
+                d_new = reinterpret_cast<const V*>(a.dy_out + base)[i];
+            }
+#pragma unroll
+            for (int q = 0; q < L; ++q) adams_test<T>(d_old[q], d_new[q], rtol, atol, i * L + q < valid, acc[0], acc[1]);
+        }
+        t0 = nv * L;
+    }
+    for (int64_t t = t0 + threadIdx.x; t < lim; t += kBlock) {
+        const T d_old = a.dy_old[base + t];
+        T d_new;
+        if (COMPUTE) {
+            d_new = a.f[base + t] * a.c + a.delta[base + t];
+            a.dy_out[base + t] = d_new;
+            a.y_out[base + t] = a.y0[base + t] + d_new;
+        } else {
+            d_new = a.dy_out[base + t];
+        }
+        adams_test<T>(d_old, d_new, rtol, atol, t < valid, acc[0], acc[1]);
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        a.part_count[b] = acc[0];
+        a.part_bad[b] = acc[1];
+    }
+}
+
 }  // namespace tdeq

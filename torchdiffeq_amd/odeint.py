@@ -5,13 +5,14 @@ from __future__ import annotations
 import torch
 
 from .misc import check_inputs, pack_differentiable
-from .solvers import (RK4, AdaptiveHeunSolver, Bosh3Solver, Dopri5Solver, Dopri8Solver, Euler, Fehlberg2, Heun2,
-                      Heun3, Midpoint, Tsit5Solver)
+from .solvers import (RK4, AdamsBashforth, AdamsBashforthMoulton, AdaptiveHeunSolver, Bosh3Solver, Dopri5Solver,
+                      Dopri8Solver, Euler, Fehlberg2, Heun2, Heun3, Midpoint, Tsit5Solver)
 
 # method name -> solver class.  Same protocol as the reference's table (odeint.py:19-46):
 #   SOLVERS[method](func=..., y0=..., rtol=..., atol=..., **options).integrate(t)
-# The names below are every explicit Runge–Kutta method of the reference's table, in its order; the
-# reference's other methods (implicit RK / Adams / scipy wrapper) are out of scope.
+# The names below are every explicit Runge–Kutta method and the Adams multistep methods of the reference's
+# table, in its order; the reference's other methods (implicit RK with dense Broyden solves, the scipy
+# wrapper) are out of scope.
 SOLVERS = {
     "dopri8": Dopri8Solver,
     "dopri5": Dopri5Solver,
@@ -24,6 +25,9 @@ SOLVERS = {
     "heun2": Heun2,
     "heun3": Heun3,
     "rk4": RK4,
+    "explicit_adams": AdamsBashforth,
+    "implicit_adams": AdamsBashforthMoulton,
+    "fixed_adams": AdamsBashforthMoulton,      # the reference's backward-compatible alias (odeint.py:41-43)
 }
 
 

@@ -10,12 +10,14 @@ ops and ≈19 device->host syncs per trial step.  Control flow a
   _select_initial_step / _compute_error_ratio / _optimal_step_size   misc.py:36-95
   _interp_fit / _interp_evaluate  interp.py:1-48 (fused, evaluated lazily: only for requested outputs)
   FixedGridODESolver / RK4      solvers.py:52-181, fixed_grid.py:24-29, rk_common.py:110-118
+  AdamsBashforth(Moulton)       fixed_adams.py:164-228
 
 with time-like scalars (t0, t1, dt, rtol, ...) as host doubles instead of 0-dim device tensors.
 """
 from __future__ import annotations
 
 import bisect
+import collections
 import contextlib
 import gc
 import math
@@ -31,7 +33,8 @@ from . import _native
 from .autodiff import Ops, stitch
 from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, find_event, handle_unused_kwargs, rms_norm)
 from .misc import _null_callback as _null
-from .tableaus import ADAPTIVE_HEUN, BOSH3, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau
+from .tableaus import (ADAPTIVE_HEUN, BOSH3, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau,
+                       adams_coefficients)
 
 
 def _nan_max(a: float, b: float) -> float:
@@ -1320,31 +1323,41 @@ class Heun3(FixedGridODESolver):
         return y1, k1
 
 
+def _rk4_38_step(solver, t0, dt, t1, y0, k1, y1_out, sh):
+    """One 3/8-rule step (rk_common.py:110-118); `k1` = func(t0, y0) when the caller already has it (the Adams
+    methods' start-up steps, fixed_adams.py:200), else it is evaluated here.  Returns (y1, k1)."""
+    func, ops = solver.func, solver.ops
+    scalar = type(t0)
+    third, two_thirds = 1 / 3, 2 / 3
+    dts = float(dt) * func.sign
+    stages = [(scalar(t0 + solver._tmul(scalar, dt, third)), Perturb.NONE),
+              (scalar(t0 + solver._tmul(scalar, dt, two_thirds)), Perturb.NONE),
+              (t1, solver._last_perturb())]
+    shadows = [sh.time(third), sh.time(two_thirds), sh.time(1.0)]
+    if k1 is None:
+        stages.insert(0, (t0, solver._first_perturb()))
+        shadows.insert(0, sh.time(0.0))
+    ts = func.time_tensors(solver.kernels, stages, shadows=shadows)
+    dsh = sh.dt_signed()
+    if k1 is None:
+        k1 = func.eval_at(ts[0], y0)
+        ts = ts[1:]
+    ya = ops.rk4_stage(1, y0, k1, None, None, None, dts, dsh)
+    k2 = func.eval_at(ts[0], ya)
+    yb = ops.rk4_stage(2, y0, k1, k2, None, None, dts, dsh)
+    k3 = func.eval_at(ts[1], yb)
+    yc = ops.rk4_stage(3, y0, k1, k2, k3, None, dts, dsh)
+    k4 = func.eval_at(ts[2], yc)
+    y1 = ops.rk4_stage(4, y0, k1, k2, k3, k4, dts, dsh, out=y1_out)
+    return y1, k1
+
+
 class RK4(FixedGridODESolver):
     """Fixed-grid 4th-order RK, 3/8 rule (fixed_grid.py:24-29 -> rk_common.py:110-118)."""
     order = 4
 
     def _step(self, t0, dt, t1, y0, y1_out, sh):
-        func, ops = self.func, self.ops
-        scalar = type(t0)
-        third, two_thirds = 1 / 3, 2 / 3
-        dts = float(dt) * func.sign
-        ts = func.time_tensors(self.kernels, [(t0, self._first_perturb()),
-                                              (scalar(t0 + self._tmul(scalar, dt, third)), Perturb.NONE),
-                                              (scalar(t0 + self._tmul(scalar, dt, two_thirds)), Perturb.NONE),
-                                              (t1, self._last_perturb())],
-                               shadows=[sh.time(0.0), sh.time(third), sh.time(two_thirds), sh.time(1.0)])
-        dsh = sh.dt_signed()
-        k1 = func.eval_at(ts[0], y0)
-        ya = ops.rk4_stage(1, y0, k1, None, None, None, dts, dsh)
-        k2 = func.eval_at(ts[1], ya)
-        yb = ops.rk4_stage(2, y0, k1, k2, None, None, dts, dsh)
-        k3 = func.eval_at(ts[2], yb)
-        yc = ops.rk4_stage(3, y0, k1, k2, k3, None, dts, dsh)
-        k4 = func.eval_at(ts[3], yc)
-        y1 = ops.rk4_stage(4, y0, k1, k2, k3, k4, dts, dsh, out=y1_out)
-        return y1, k1
-
+        return _rk4_38_step(self, t0, dt, t1, y0, None, y1_out, sh)
 
     # -- hipGraph mode --------------------------------------------------------------------------------
     def _graph_capable(self, t: torch.Tensor, time_grid: torch.Tensor) -> bool:
@@ -1419,6 +1432,102 @@ class RK4(FixedGridODESolver):
         return solution
 
 
+# ---------------------------------------------------------------------------------------------------
+# Adams–Bashforth(–Moulton) multistep methods on a fixed grid
+# ---------------------------------------------------------------------------------------------------
+_ADAMS_MIN_ORDER = 4
+_ADAMS_MAX_ORDER = 12
+_ADAMS_MAX_ITERS = 4
+
+
+class AdamsBashforthMoulton(FixedGridODESolver):
+    """`implicit_adams` / `fixed_adams` (fixed_adams.py:164-223): variable-order (up to `max_order`) Adams–Bashforth
+    predictor and, with `implicit=True`, an Adams–Moulton corrector solved by at most `max_iters` fixed-point
+    iterations; the first steps — until three past derivatives exist — are 3/8-rule RK4 steps.
+
+    The history `prev_f` is a deque of SEPARATE contiguous func outputs (newest first), read once per step by
+    tdeq_adams_predict (predictor sum, the corrector's constant part and y0 + dy in one pass: order+1 reads, 1 or 3
+    writes); each corrector iteration is ONE tdeq_adams_correct launch (new dy, next evaluation point and the
+    convergence census of `_has_converged`), with one polled read-back per iteration — the reference spends ~2·order
+    + 12 eager ops and a host sync there.  The method's quirks are kept: the corrected derivative never replaces
+    the predictor's in the history (`_update_history(t0, f)` finds `prev_t == t0`, :222), and a step whose iteration
+    did not converge warns and drops the OLDEST derivative (:219-221)."""
+    order = 4
+
+    def __init__(self, func, y0, rtol=1e-3, atol=1e-4, implicit=True, max_iters=_ADAMS_MAX_ITERS,
+                 max_order=_ADAMS_MAX_ORDER, dist_sync=None, **kwargs):
+        super().__init__(func, y0, rtol=rtol, atol=atol, **kwargs)
+        assert max_order <= _ADAMS_MAX_ORDER, "max_order must be at most {}".format(_ADAMS_MAX_ORDER)
+        if max_order < _ADAMS_MIN_ORDER:
+            warnings.warn("max_order is below {}, so the solver reduces to `rk4`.".format(_ADAMS_MIN_ORDER))
+        self.rtol, self.atol = rtol, atol
+        self.implicit = implicit
+        self.max_iters = max_iters
+        self.max_order = int(max_order)
+        self.prev_f = collections.deque(maxlen=self.max_order - 1)
+        self.prev_t = None
+        self._sync = _LockStep(dist_sync) if dist_sync is not None else None
+        self._plan = None
+
+    def _update_history(self, t, f) -> None:
+        if self.prev_t is None or self.prev_t != t:
+            self.prev_f.appendleft(f)
+            self.prev_t = t
+
+    def _converged(self) -> bool:
+        """`_has_converged` (fixed_adams.py:189-192) from the census of the last tdeq_adams_correct launch."""
+        counts, _, _ = self.kernels.read_norms(self._plan)
+        if self._sync is not None:      # sharded batch in lock step: every rank iterates until all have converged
+            counts = self._sync._allreduce(list(counts), self.device)
+        return not any(c != 0.0 for c in counts)
+
+    def _step(self, t0, dt, t1, y0, y1_out, sh):
+        func, ops = self.func, self.ops
+        f0 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
+        self._update_history(t0, f0)
+        order = min(len(self.prev_f), self.max_order - 1)
+        if order < _ADAMS_MIN_ORDER - 1:
+            y1, _ = _rk4_38_step(self, t0, dt, t1, y0, self.prev_f[0], y1_out, sh)
+            return y1, f0
+        sign = func.sign
+        dt64 = float(dt)
+        bash, _ = adams_coefficients(order)
+        hist = [self.prev_f[j] for j in range(order)]
+        cb = [dt64 * b * sign for b in bash]            # `dt * bashforth_coeffs` in fp64 (:205); the sign is exact
+        dsh = sh.dt_signed()
+        if not self.implicit:
+            y1, _, _ = ops.adams_predict(y0, hist, cb, None, 0.0, dsh, list(bash), out=y1_out)
+            return y1, f0
+        _, moulton = adams_coefficients(order + 1)
+        y, dy, delta = ops.adams_predict(y0, hist, cb, list(moulton[1:]), dt64 * sign, dsh, list(bash))
+        if self._plan is None:
+            self._plan = self.kernels.make_plan(self.layout.segments(self.rtol, self.atol), self.layout.total,
+                                                self.layout.chunk, self.device)
+        c = dt64 * moulton[0] * sign                      # `dt * moulton_coeffs[0]`: 0-dim fp32/fp64 x fp64 -> fp64 (:214)
+        last = self._last_perturb()
+        converged = False
+        for _ in range(self.max_iters):
+            f = func.eval(t1, y, last, shadow=sh.time(1.0))
+            y, dy = ops.adams_correct(self._plan, y0, f, delta, dy, c, dsh, moulton[0])
+            converged = self._converged()
+            if converged:
+                break
+        if not converged:
+            warnings.warn("Functional iteration did not converge. Solution may be incorrect.")
+            self.prev_f.pop()
+        self._update_history(t0, f)
+        return y, f0
+
+
+class AdamsBashforth(AdamsBashforthMoulton):
+    """`explicit_adams` (fixed_adams.py:226-228)."""
+
+    def __init__(self, func, y0, **kwargs):
+        super().__init__(func, y0, implicit=False, **kwargs)
+
+
 SOLVER_CLASSES = {"dopri8": Dopri8Solver, "dopri5": Dopri5Solver, "tsit5": Tsit5Solver, "bosh3": Bosh3Solver,
                   "fehlberg2": Fehlberg2, "adaptive_heun": AdaptiveHeunSolver, "euler": Euler,
-                  "midpoint": Midpoint, "heun2": Heun2, "heun3": Heun3, "rk4": RK4}
+                  "midpoint": Midpoint, "heun2": Heun2, "heun3": Heun3, "rk4": RK4,
+                  "explicit_adams": AdamsBashforth, "implicit_adams": AdamsBashforthMoulton,
+                  "fixed_adams": AdamsBashforthMoulton}

@@ -254,3 +254,39 @@ FEHLBERG2 = _fehlberg2()
 ADAPTIVE_HEUN = _adaptive_heun()
 
 ADAPTIVE_TABLEAUS = {t.name: t for t in (DOPRI8, DOPRI5, TSIT5, BOSH3, FEHLBERG2, ADAPTIVE_HEUN)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# Adams–Bashforth / Adams–Moulton weights (fixed_adams.py:10-152 holds them as integer tables over a common
+# divisor).  They are the integrals over one step of the Lagrange basis polynomials through the last k derivative
+# values (Bashforth: nodes t_n, t_{n-1}, ...; Moulton: t_{n+1}, t_n, ...), generated here in exact rational
+# arithmetic and rounded once — the same doubles as the reference's `numerator / divisor` (Python's int / int is
+# correctly rounded), checked against the reference's tables in tests/test_tableaus.py (golden/adams.npz).
+# ---------------------------------------------------------------------------------------------------
+def _lagrange_step_integrals(k: int, shift: int) -> Tuple[float, ...]:
+    from fractions import Fraction
+    out = []
+    for j in range(k):
+        poly = [Fraction(1)]                    # prod_{i != j} (u - x_i), x_i = shift - i, ascending powers of u
+        den = Fraction(1)
+        for i in range(k):
+            if i == j:
+                continue
+            root = Fraction(shift - i)
+            nxt = [Fraction(0)] * (len(poly) + 1)
+            for p, c in enumerate(poly):
+                nxt[p] -= root * c
+                nxt[p + 1] += c
+            poly = nxt
+            den *= Fraction(i - j)               # x_j - x_i
+        integral = sum(c / (p + 1) for p, c in enumerate(poly))      # over u in [0, 1]
+        out.append(float(integral / den))
+    return tuple(out)
+
+
+@functools.lru_cache(maxsize=None)
+def adams_coefficients(order: int) -> Tuple[Tuple[float, ...], Tuple[float, ...]]:
+    """(Bashforth weights, Moulton weights) of the given order, newest derivative first; 1 <= order <= 20."""
+    if not 1 <= order <= 20:
+        raise ValueError("Adams coefficients are available for orders 1..20")
+    return _lagrange_step_integrals(order, 0), _lagrange_step_integrals(order, 1)
