@@ -20,8 +20,9 @@ from _cases import T, load, rel_err
 METHODS = ["explicit_adams", "implicit_adams"]
 
 
-def _field(A):
-    return lambda t, y: torch.cos(t) * (torch.sin(y) @ A.T) - 0.1 * y
+def _field(t, y):
+    """Exactly rounded elementwise operations only (see make_golden.adams_field): the same bits on any CPU or GPU."""
+    return (1 - t * 0.5) * (y.roll(1, -1) * 0.3 - y * 0.2) - y * y * y * 0.01
 
 
 class _Count:
@@ -52,63 +53,59 @@ def test_coefficients_bit_identical_to_the_reference_tables():
 
 @pytest.mark.parametrize("method", METHODS)
 def test_solves_match_the_reference(dev, method):
+    """Bit-identical solutions, evaluation counts (= corrector iterations) and non-convergence warnings, on the
+    host-logic path and on the MI355X alike: the field consists of exactly rounded operations, so its values do not
+    depend on where it is evaluated and only the solver arithmetic is under test.  (A field with transcendental
+    functions or a GEMM differs by an ulp between machines, and the top-order fp32 Adams–Bashforth formula —
+    coefficients of magnitude 1e3 — amplifies that to 1e-3 in the solution: the method's own conditioning.)"""
     z = load("adams.npz")
-    A, y0, t = T(z["A"], dev), T(z["y0"], dev), T(z["t"], dev)
-    f, f64 = _field(A), _field(A.double())
+    y0, t = T(z["y0"], dev), T(z["t"], dev)
     cases = {
-        "grid": (f, y0, torch.linspace(0, 1, 41), {}),
-        "step": (f, y0, t, dict(step_size=0.02)),
-        "perturb": (f, y0, t, dict(step_size=0.02, perturb=True)),
-        "cubic": (f, y0, t, dict(step_size=0.02, interp="cubic")),
-        "rev": (f, y0, torch.tensor([1.0, 0.45, 0.0]), dict(step_size=0.025, interp="cubic")),
-        "order6": (f, y0, t, dict(step_size=0.02, max_order=6)),
-        "iters1": (f, y0, t, dict(step_size=0.02, max_iters=1)),
-        "f64": (f64, y0.double(), t.double(), dict(step_size=0.0125)),
+        "grid": (y0, torch.linspace(0, 1, 41, device="cpu").to(dev), {}),
+        "step": (y0, t, dict(step_size=0.02)),
+        "perturb": (y0, t, dict(step_size=0.02, perturb=True)),
+        "cubic": (y0, t, dict(step_size=0.02, interp="cubic")),
+        "rev": (y0, torch.tensor([1.0, 0.45, 0.0]), dict(step_size=0.025, interp="cubic")),
+        "order6": (y0, t, dict(step_size=0.02, max_order=6)),
+        "iters1": (y0, t, dict(step_size=0.02, max_iters=1)),
+        "f64": (y0.double(), t.double(), dict(step_size=0.0125)),
     }
-    for tag, (fn, y, tt, opts) in cases.items():
-        c = _Count(fn)
+    for tag, (y, tt, opts) in cases.items():
+        c = _Count(_field)
         with warnings.catch_warnings(record=True) as w, torch.no_grad():
             warnings.simplefilter("always")
             got = tda.odeint(c, y, tt, method=method, options=opts, rtol=1e-6, atol=1e-8)
         ref = T(z[f"{method}_{tag}"], dev)
         assert got.shape == ref.shape and got.dtype == ref.dtype
-        if dev == "cpu":
-            assert torch.equal(got, ref), tag
-            # same number of corrector iterations and the same non-convergence warnings as the reference
-            assert c.nfe == int(z[f"{method}_{tag}_nfe"]), tag
-            assert len(w) == int(z[f"{method}_{tag}_warnings"]), tag
-        else:
-            assert rel_err(got, ref) < (1e-12 if tag == "f64" else 2e-6), tag
-            assert abs(c.nfe - int(z[f"{method}_{tag}_nfe"])) <= 2, tag       # a borderline convergence test may flip
+        assert torch.equal(got, ref), tag
+        assert c.nfe == int(z[f"{method}_{tag}_nfe"]), tag
+        assert len(w) == int(z[f"{method}_{tag}_warnings"]), tag
 
 
 @pytest.mark.parametrize("method", METHODS)
 def test_fixed_adams_alias_and_reference_defaults(dev, method):
     """`fixed_adams` is the implicit method; without tolerances odeint passes its own defaults (1e-7, 1e-9)."""
     z = load("adams.npz")
-    A, y0 = T(z["A"], dev), T(z["y0"], dev)
+    y0 = T(z["y0"], dev)
     with torch.no_grad():
-        a = tda.odeint(_field(A), y0, torch.linspace(0, 1, 41), method="fixed_adams", rtol=1e-6, atol=1e-8)
-        b = tda.odeint(_field(A), y0, torch.linspace(0, 1, 41), method="implicit_adams", rtol=1e-6, atol=1e-8)
+        a = tda.odeint(_field, y0, torch.linspace(0, 1, 41), method="fixed_adams", rtol=1e-6, atol=1e-8)
+        b = tda.odeint(_field, y0, torch.linspace(0, 1, 41), method="implicit_adams", rtol=1e-6, atol=1e-8)
     assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("method", METHODS)
 def test_tuple_state_with_per_component_tolerances(dev, method):
     z = load("adams.npz")
-    A, y0 = T(z["A"], dev), T(z["y0"], dev)
-    ft = lambda t, y: (torch.cos(t) * (torch.sin(y[0]) @ A.T), -y[1] * y[0].sum())
+    y0 = T(z["y0"], dev)
+    ft = lambda t, y: (_field(t, y[0]), -y[1] * y[0][0, :3] * (1 + t))
     yt = (y0, torch.tensor([0.5, 0.25, 1.0]))
     with torch.no_grad():
-        out = tda.odeint(ft, yt, torch.linspace(0, 1, 31, dtype=torch.float64), method=method,
+        out = tda.odeint(ft, yt, torch.linspace(0, 1, 31, dtype=torch.float64, device="cpu").to(dev), method=method,
                          rtol=(1e-6, 1e-5), atol=(1e-8, 1e-7))
     for i in range(2):
         ref = T(z[f"{method}_tuple{i}"], dev)
         assert out[i].dtype == ref.dtype and out[i].shape == ref.shape
-        if dev == "cpu":
-            assert torch.equal(out[i], ref)
-        else:
-            assert rel_err(out[i], ref) < 2e-6
+        assert torch.equal(out[i], ref)
 
 
 @pytest.mark.parametrize("method", METHODS)
@@ -122,12 +119,12 @@ def test_backprop_through_the_solver(dev, method):
     y0 = T(z[f"{method}_bp_y0"], dev).requires_grad_(True)
     t = torch.linspace(0, 1, 21, dtype=torch.float64).requires_grad_(True)
     y = tda.odeint(lambda t_, y_: torch.tanh(lin(y_)) * torch.cos(t_), y0, t, method=method, rtol=1e-6, atol=1e-8)
-    assert rel_err(y, z[f"{method}_bp_y"]) < 1e-13
+    assert rel_err(y, z[f"{method}_bp_y"]) < 1e-10      # tanh / cos / GEMM: an ulp apart between machines, amplified
     loss = y[-1].pow(2).sum() + y[7].sum()
     g = torch.autograd.grad(loss, [y0, t, lin.weight, lin.bias])
     for name, v in zip(["gy0", "gt", "gw", "gb"], g):
         ref = T(z[f"{method}_bp_{name}"])
-        assert float((v.cpu() - ref).abs().max()) < 1e-11 * max(1.0, float(ref.abs().max())), name
+        assert float((v.cpu() - ref).abs().max()) < 1e-9 * max(1.0, float(ref.abs().max())), name
 
 
 @pytest.mark.parametrize("method", METHODS)
@@ -143,11 +140,14 @@ def test_event_mode(dev, method):
 
 def test_adjoint_with_adams_methods(dev):
     """odeint_adjoint accepts the Adams methods for the forward and the backward solve."""
-    torch.manual_seed(4)
+    g = torch.Generator(device="cpu").manual_seed(4)       # the same problem on every device
     lin = torch.nn.Linear(3, 3).double().to(dev)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(3, 3, generator=g, dtype=torch.float64, device="cpu") * 0.5)
+        lin.bias.copy_(torch.randn(3, generator=g, dtype=torch.float64, device="cpu") * 0.5)
     params = tuple(lin.parameters())
     f = lambda t_, y_: torch.tanh(lin(y_))
-    y0 = torch.randn(4, 3, dtype=torch.float64).to(dev).requires_grad_(True)
+    y0 = torch.randn(4, 3, generator=g, dtype=torch.float64, device="cpu").to(dev).requires_grad_(True)
     t = torch.linspace(0, 1, 41, dtype=torch.float64)
     grads = {}
     for method in ["dopri5", "explicit_adams", "implicit_adams"]:
@@ -155,8 +155,9 @@ def test_adjoint_with_adams_methods(dev):
         y = tda.odeint_adjoint(f, y0, t, method=method, rtol=1e-9, atol=1e-11, adjoint_params=params)
         y[-1].pow(2).sum().backward()
         grads[method] = y0.grad.clone()
-    assert rel_err(grads["explicit_adams"], grads["dopri5"]) < 1e-5
-    assert rel_err(grads["implicit_adams"], grads["dopri5"]) < 1e-5
+    # the methods' own accuracy at 40 steps (measured 1.0e-4 / 9.8e-10; the reference gives the same numbers)
+    assert rel_err(grads["explicit_adams"], grads["dopri5"]) < 1e-3
+    assert rel_err(grads["implicit_adams"], grads["dopri5"]) < 1e-7
 
 
 def test_option_checks(dev):

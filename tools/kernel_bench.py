@@ -36,6 +36,50 @@ def timed(fn, iters, warmup=3):
     return ms[len(ms) // 2] * 1e-3, ms[0] * 1e-3
 
 
+def adams_main(args, dtype, w):
+    """tdeq_adams_predict at the method's top order (11 history tensors) and tdeq_adams_correct, cold (rotating sets)."""
+    from torchdiffeq_amd.tableaus import adams_coefficients
+    n = args.batch * args.dim
+    dev = torch.device("cuda:0")
+    kern = _native.get_kernels(dev)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    order = 11
+    sets = []
+    for _ in range(args.sets):
+        hist = [torch.randn(n, generator=g, device=dev, dtype=dtype) for _ in range(order)]
+        y0 = torch.randn(n, generator=g, device=dev, dtype=dtype)
+        outs = [torch.empty(n, device=dev, dtype=dtype) for _ in range(4)]
+        sets.append((hist, y0, outs))
+    plan = kern.make_plan([(0, n, 1e-7, 1e-9)], n, args.chunk or _native.pick_chunk(n), dev)
+    bash, _ = adams_coefficients(order)
+    _, moulton = adams_coefficients(order + 1)
+    cb = [0.01 * b for b in bash]
+    results = []
+
+    def report(name, words, t_med, t_min):
+        by = words * n * w
+        results.append({"kernel": name, "words_per_elem": words, "bytes": by, "t_med_us": t_med * 1e6,
+                        "t_min_us": t_min * 1e6, "GBps_med": by / t_med / 1e9, "frac_of_8TBps": by / t_med / HBM_PEAK})
+        print(f"{name:34s} {words:3d} w/elem  {t_med*1e6:9.1f} us (min {t_min*1e6:8.1f})  "
+              f"{by/t_med/1e9:8.1f} GB/s  {100*by/t_med/HBM_PEAK:5.1f}% of 8 TB/s", flush=True)
+
+    def fn_explicit(it):
+        hist, y0, outs = sets[it % args.sets]
+        kern.adams_predict(outs[0], y0, hist, cb)
+    report("adams_predict explicit nt=11", order + 2, *timed(fn_explicit, args.iters))
+
+    def fn_implicit(it):
+        hist, y0, outs = sets[it % args.sets]
+        kern.adams_predict(outs[0], y0, hist, cb, list(moulton[1:]), 0.01, dy_out=outs[1], delta_out=outs[2])
+    report("adams_predict implicit nt=11", order + 4, *timed(fn_implicit, args.iters))
+
+    def fn_correct(it):
+        hist, y0, outs = sets[it % args.sets]
+        kern.adams_correct(plan, outs[3], outs[1], y_out=outs[0], f=hist[0], delta=outs[2], y0=y0, c=0.003)
+    report("adams_correct (+census+finalize)", 6, *timed(fn_correct, args.iters))
+    print(json.dumps({"n": n, "dtype": args.dtype, "method": "adams", "results": results}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=65536)
@@ -48,6 +92,8 @@ def main():
     args = ap.parse_args()
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     w = 4 if dtype == torch.float32 else 8
+    if args.method == "adams":
+        return adams_main(args, dtype, w)
     tab = DOPRI5 if args.method == "dopri5" else DOPRI8
     n = args.batch * args.dim
     dev = torch.device("cuda:0")
