@@ -672,10 +672,75 @@ def gen_adams():
     save("adams.npz", **arrays)
 
 
+IMPLICIT_METHODS = ["implicit_euler", "implicit_midpoint", "trapezoid", "radauIIA3", "gl4", "radauIIA5", "gl6",
+                    "sdirk2", "trbdf2"]
+
+
+def implicit_field(t, y):
+    """Exactly rounded elementwise operations only (see adams_field); moderately stiff linear part."""
+    return (1 - t * 0.5) * (y.roll(1, -1) * 0.3 - y * 2.0) - y * y * y * 0.01
+
+
+def gen_implicit():
+    """The implicit fixed-grid RK methods of the reference's SOLVERS table (fixed_grid_implicit.py, Broyden iterations
+    on a dense Jacobian in the reference): tableaus, solves with evaluation counts and warning counts, a tuple
+    state, an event solve."""
+    import warnings
+    from torchdiffeq._impl import fixed_grid_implicit as fgi
+    from torchdiffeq._impl.odeint import SOLVERS
+    arrays = {}
+    _, y0 = linear_problem(3, 6, torch.float32, seed=21)
+    t = torch.tensor([0.0, 0.33, 0.7, 1.0])
+    arrays.update(y0=y0, t=t)
+    arrays["solver_names"] = np.array(list(SOLVERS))
+
+    class Count:
+        def __init__(self, fn):
+            self.fn, self.nfe = fn, 0
+
+        def __call__(self, t, y):
+            self.nfe += 1
+            return self.fn(t, y)
+
+    with torch.no_grad():
+        for method in IMPLICIT_METHODS:
+            tab = SOLVERS[method].tableau
+            arrays[f"{method}_alpha"] = tab.alpha
+            arrays[f"{method}_beta_flat"] = torch.cat([b.reshape(-1) for b in tab.beta])
+            arrays[f"{method}_c_sol"] = tab.c_sol
+            arrays[f"{method}_order"] = SOLVERS[method].order
+            cases = {
+                "grid": (y0, torch.linspace(0, 1, 11), {}),
+                "step": (y0, t, dict(step_size=0.05)),
+                "perturb": (y0, t, dict(step_size=0.05, perturb=True)),
+                "cubic": (y0, t, dict(step_size=0.05, interp="cubic")),
+                "rev": (y0, torch.tensor([1.0, 0.45, 0.0]), dict(step_size=0.05)),
+                "iters2": (y0, t, dict(step_size=0.1, max_iters=2)),
+                "f64": (y0.double(), t.double(), dict(step_size=0.05)),
+            }
+            for tag, (y, tt, opts) in cases.items():
+                c = Count(implicit_field)
+                with warnings.catch_warnings(record=True) as w:
+                    warnings.simplefilter("always")
+                    arrays[f"{method}_{tag}"] = torchdiffeq.odeint(c, y, tt, method=method, options=opts)
+                arrays[f"{method}_{tag}_nfe"] = c.nfe
+                arrays[f"{method}_{tag}_warnings"] = len(w)
+            ft = lambda t, y: (implicit_field(t, y[0]), -y[1] * y[0][0, :3] * (1 + t))
+            yt = (y0.double(), torch.tensor([0.5, 0.25, 1.0], dtype=torch.float64))
+            out = torchdiffeq.odeint(ft, yt, torch.linspace(0, 1, 11, dtype=torch.float64), method=method)
+            arrays[f"{method}_tuple0"], arrays[f"{method}_tuple1"] = out
+            fe = lambda t, y: torch.stack([y[1], -y[0]])
+            et, ys = torchdiffeq.odeint_event(fe, torch.tensor([1.0, 0.0], dtype=torch.float64),
+                                              torch.tensor(0.0, dtype=torch.float64), event_fn=lambda t, y: y[0],
+                                              method=method, options=dict(step_size=0.05), atol=1e-8)
+            arrays[f"{method}_event_t"], arrays[f"{method}_event_y"] = et, ys
+    save("implicit.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
                      ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
-                     ("adams", gen_adams)]:
+                     ("adams", gen_adams), ("implicit", gen_implicit)]:
         if not only or name in only:
             fn()

@@ -5,14 +5,17 @@ from __future__ import annotations
 import torch
 
 from .misc import check_inputs, pack_differentiable
+from .implicit import (SDIRK2, TRBDF2, GaussLegendre4, GaussLegendre6, ImplicitEuler, ImplicitMidpoint, RadauIIA3,
+                       RadauIIA5, Trapezoid)
+from .scipy_wrapper import ScipyWrapperODESolver
 from .solvers import (RK4, AdamsBashforth, AdamsBashforthMoulton, AdaptiveHeunSolver, Bosh3Solver, Dopri5Solver,
                       Dopri8Solver, Euler, Fehlberg2, Heun2, Heun3, Midpoint, Tsit5Solver)
 
 # method name -> solver class.  Same protocol as the reference's table (odeint.py:19-46):
 #   SOLVERS[method](func=..., y0=..., rtol=..., atol=..., **options).integrate(t)
-# The names below are every explicit Runge–Kutta method and the Adams multistep methods of the reference's
-# table, in its order; the reference's other methods (implicit RK with dense Broyden solves, the scipy
-# wrapper) are out of scope.
+# Every name of the reference's table, in its order: the explicit Runge–Kutta methods (the hot path), the Adams
+# multistep methods, the implicit RK methods (matrix-free Broyden on the same kernels, implicit.py) and the
+# host-side SciPy bridge.
 SOLVERS = {
     "dopri8": Dopri8Solver,
     "dopri5": Dopri5Solver,
@@ -27,7 +30,17 @@ SOLVERS = {
     "rk4": RK4,
     "explicit_adams": AdamsBashforth,
     "implicit_adams": AdamsBashforthMoulton,
+    "implicit_euler": ImplicitEuler,
+    "implicit_midpoint": ImplicitMidpoint,
+    "trapezoid": Trapezoid,
+    "radauIIA3": RadauIIA3,
+    "gl4": GaussLegendre4,
+    "radauIIA5": RadauIIA5,
+    "gl6": GaussLegendre6,
+    "sdirk2": SDIRK2,
+    "trbdf2": TRBDF2,
     "fixed_adams": AdamsBashforthMoulton,      # the reference's backward-compatible alias (odeint.py:41-43)
+    "scipy_solver": ScipyWrapperODESolver,     # host-side SciPy bridge, not a HIP path (scipy_wrapper.py)
 }
 
 

@@ -290,3 +290,56 @@ def adams_coefficients(order: int) -> Tuple[Tuple[float, ...], Tuple[float, ...]
     if not 1 <= order <= 20:
         raise ValueError("Adams coefficients are available for orders 1..20")
     return _lagrange_step_integrals(order, 0), _lagrange_step_integrals(order, 1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Implicit Runge–Kutta tableaus of the fixed-grid implicit solvers (fixed_grid_implicit.py:10-140): published
+# collocation / DIRK coefficients (Gauss–Legendre, Radau IIA, Alexander's SDIRK2, TR-BDF2), written as the
+# closed forms in surds and evaluated in double — checked bit for bit against the reference's tensors in
+# tests/test_implicit_golden.py (golden/implicit.npz).
+# ---------------------------------------------------------------------------------------------------
+@dataclasses.dataclass(frozen=True)
+class ImplicitTableau:
+    name: str
+    order: int
+    alpha: Tuple[float, ...]
+    beta: Tuple[Tuple[float, ...], ...]   # full rows (FIRK) or lower-triangular rows incl. the diagonal (DIRK)
+    c_sol: Tuple[float, ...]
+    diagonal: bool                         # DIRK: stages solved one after the other
+
+
+def _implicit_tableaus():
+    # The reference takes its surds from torch.sqrt on 0-dim fp64 tensors (fixed_grid_implicit.py:5-8); for 2 that
+    # returns 1.414213562373095, one ulp below the correctly rounded math.sqrt(2.0) — kept, so that sdirk2 / trbdf2
+    # carry the reference's coefficients bit for bit.
+    r2, r3, r6, r15 = 1.414213562373095, math.sqrt(3.0), math.sqrt(6.0), math.sqrt(15.0)
+    tabs = [
+        ImplicitTableau("implicit_euler", 1, (1.0,), ((1.0,),), (1.0,), False),
+        ImplicitTableau("implicit_midpoint", 2, (1 / 2,), ((1 / 2,),), (1.0,), False),
+        ImplicitTableau("trapezoid", 2, (0.0, 1.0), ((0.0, 0.0), (1 / 2, 1 / 2)), (1 / 2, 1 / 2), False),
+        ImplicitTableau("radauIIA3", 3, (1 / 3, 1.0), ((5 / 12, -1 / 12), (3 / 4, 1 / 4)), (3 / 4, 1 / 4), False),
+        # NOTE the reference's gl4 abscissae: both entries are 1/2 - sqrt(3)/6 (fixed_grid_implicit.py:38) — kept
+        ImplicitTableau("gl4", 4, (1 / 2 - r3 / 6, 1 / 2 - r3 / 6),
+                        ((1 / 4, 1 / 4 - r3 / 6), (1 / 4 + r3 / 6, 1 / 4)), (1 / 2, 1 / 2), False),
+        ImplicitTableau("radauIIA5", 5, (2 / 5 - r6 / 10, 2 / 5 + r6 / 10, 1.0),
+                        ((11 / 45 - 7 * r6 / 360, 37 / 225 - 169 * r6 / 1800, -2 / 225 + r6 / 75),
+                         (37 / 225 + 169 * r6 / 1800, 11 / 45 + 7 * r6 / 360, -2 / 225 - r6 / 75),
+                         (4 / 9 - r6 / 36, 4 / 9 + r6 / 36, 1 / 9)),
+                        (4 / 9 - r6 / 36, 4 / 9 + r6 / 36, 1 / 9), False),
+        ImplicitTableau("gl6", 6, (1 / 2 - r15 / 10, 1 / 2, 1 / 2 + r15 / 10),
+                        ((5 / 36, 2 / 9 - r15 / 15, 5 / 36 - r15 / 30),
+                         (5 / 36 + r15 / 24, 2 / 9, 5 / 36 - r15 / 24),
+                         (5 / 36 + r15 / 30, 2 / 9 + r15 / 15, 5 / 36)),
+                        (5 / 18, 4 / 9, 5 / 18), False),
+    ]
+    g = (2.0 - r2) / 2.0
+    tabs.append(ImplicitTableau("sdirk2", 2, (g, 1.0), ((g,), (1 - g, g)), (1 - g, g), True))
+    g = 1.0 - r2 / 2.0
+    b = r2 / 4.0
+    tabs.append(ImplicitTableau("trbdf2", 2, (0.0, 2 * g, 1.0), ((0.0,), (g, g), (b, b, g)), (b, b, g), True))
+    return {t.name: t for t in tabs}
+
+
+import math  # noqa: E402  (used by the closed forms above)
+
+IMPLICIT_TABLEAUS = _implicit_tableaus()
