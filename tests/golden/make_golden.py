@@ -648,6 +648,10 @@ def gen_adams():
             out = torchdiffeq.odeint(ft, yt, torch.linspace(0, 1, 31, dtype=torch.float64), method=method,
                                      rtol=(1e-6, 1e-5), atol=(1e-8, 1e-7))
             arrays[f"{method}_tuple0"], arrays[f"{method}_tuple1"] = out
+            # 0-dim fp32 state: the fp64 coefficient tensors promote the history dot products to fp64
+            fs = lambda t, y: (1 - t * 0.5) * (y * -0.7) - y * y * y * 0.01
+            arrays[f"{method}_zerodim"] = torchdiffeq.odeint(fs, torch.tensor(1.5), torch.linspace(0, 1, 41),
+                                                             method=method, rtol=1e-6, atol=1e-8)
     # gradients by backprop through the solver (y0, t and the parameters of the field)
     for method in ["explicit_adams", "implicit_adams"]:
         torch.manual_seed(3)
@@ -734,6 +738,21 @@ def gen_implicit():
                                               torch.tensor(0.0, dtype=torch.float64), event_fn=lambda t, y: y[0],
                                               method=method, options=dict(step_size=0.05), atol=1e-8)
             arrays[f"{method}_event_t"], arrays[f"{method}_event_y"] = et, ys
+    # gradients of plain odeint (the reference backpropagates through its unrolled Broyden iterations)
+    for method in IMPLICIT_METHODS:
+        torch.manual_seed(3)
+        lin = torch.nn.Linear(3, 3).double()
+        yg = rand(5, 3, seed=22).requires_grad_(True)
+        tg = torch.linspace(0, 1, 6, dtype=torch.float64).requires_grad_(True)
+        fg = lambda t, y: torch.tanh(lin(y)) * torch.cos(t)
+        y = torchdiffeq.odeint(fg, yg, tg, method=method)
+        loss = y[-1].pow(2).sum() + y[3].sum()
+        g = torch.autograd.grad(loss, [yg, tg, lin.weight, lin.bias])
+        arrays[f"{method}_bp_w"], arrays[f"{method}_bp_b"] = lin.weight, lin.bias
+        arrays[f"{method}_bp_y0"] = yg
+        arrays[f"{method}_bp_y"] = y
+        for name, v in zip(["gy0", "gt", "gw", "gb"], g):
+            arrays[f"{method}_bp_{name}"] = v
     save("implicit.npz", **arrays)
 
 

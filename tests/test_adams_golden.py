@@ -110,6 +110,20 @@ def test_tuple_state_with_per_component_tolerances(dev, method):
 
 
 @pytest.mark.parametrize("method", METHODS)
+def test_zero_dim_fp32_state_promotion_quirk(dev, method):
+    """A 0-dim fp32 state multiplies the reference's 0-dim fp64 coefficients as 0-dim x 0-dim, which promotes to fp64:
+    `_dot_product` runs in fp64 and is rounded once (fixed_adams.py:205-214).  Reproduced bit for bit."""
+    z = load("adams.npz")
+    fs = lambda t, y: (1 - t * 0.5) * (y * -0.7) - y * y * y * 0.01
+    with torch.no_grad():
+        y = tda.odeint(fs, torch.tensor(1.5), torch.linspace(0, 1, 41, device="cpu").to(dev), method=method,
+                       rtol=1e-6, atol=1e-8)
+    ref = T(z[f"{method}_zerodim"], dev)
+    assert y.shape == ref.shape == (41,) and y.dtype == torch.float32
+    assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("method", METHODS)
 def test_backprop_through_the_solver(dev, method):
     """Gradients wrt y0, t and the field's parameters equal the reference's autograd-through-eager-ops result."""
     z = load("adams.npz")

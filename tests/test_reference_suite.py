@@ -1,4 +1,4 @@
-"""The reference's own test-suite, restated for the in-scope methods and run against torchdiffeq_amd:
+"""The reference's own test-suite, restated for every method of its SOLVERS table and run against torchdiffeq_amd:
 tests/odeint_tests.py, gradient_tests.py, norm_tests.py, api_tests.py and event_tests.py of rtqichen/torchdiffeq
 (cited per test).  Same problems (tests/problems.py: analytic solutions), same assertions and tolerances.
 
@@ -15,8 +15,14 @@ import torch
 import torchdiffeq_amd as tda
 
 ADAPTIVE_METHODS = ("adaptive_heun", "fehlberg2", "bosh3", "tsit5", "dopri5", "dopri8")
-FIXED_METHODS = ("euler", "midpoint", "heun2", "heun3", "rk4")
-METHODS = FIXED_METHODS + ADAPTIVE_METHODS
+# tests/problems.py:69-75
+FIXED_EXPLICIT_METHODS = ("euler", "midpoint", "heun2", "heun3", "rk4", "explicit_adams", "implicit_adams")
+FIXED_IMPLICIT_METHODS = ("implicit_euler", "implicit_midpoint", "trapezoid", "radauIIA3", "gl4", "radauIIA5", "gl6",
+                          "sdirk2", "trbdf2")
+FIXED_METHODS = FIXED_EXPLICIT_METHODS + FIXED_IMPLICIT_METHODS
+IMPLICIT_METHODS = FIXED_IMPLICIT_METHODS
+SCIPY_METHODS = ("scipy_solver",)
+METHODS = FIXED_METHODS + ADAPTIVE_METHODS + SCIPY_METHODS
 DTYPES = (torch.float32, torch.float64)
 
 
@@ -99,7 +105,12 @@ def test_solver_error_odeint(dev, method, dtype, reverse):
         kwargs = dict(rtol=1e-12, atol=1e-14)
     if method == "dopri8" and dtype == torch.float32:
         kwargs = dict(rtol=1e-7, atol=1e-7)
-    problems = tuple(PROBLEMS) if method in ADAPTIVE_METHODS else ("constant",)
+    if method in ADAPTIVE_METHODS:
+        problems = tuple(PROBLEMS)
+    elif method in IMPLICIT_METHODS:
+        problems = ("constant", "exp")
+    else:
+        problems = ("constant",)
     for ode in problems:
         if method in ("adaptive_heun", "bosh3"):
             eps = 4e-3
@@ -172,6 +183,8 @@ def test_jump_t(dev, method, dtype, adjoint):
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("method", FIXED_METHODS)
 def test_perturb(dev, method, dtype, adjoint):
+    if dtype == torch.float32 and method == "implicit_euler":
+        pytest.skip("skipped by the reference (odeint_tests.py:170-172: singular dense Jacobian there)")
     for perturb in (True, False):
         x0 = torch.tensor([1.0, 2.0], dtype=dtype, requires_grad=True)
         t = torch.tensor([0.0, 1.0])
@@ -268,7 +281,18 @@ def test_wrong_callback_warns(dev, method):
                 tda.odeint(f, x0, t, method=method)
 
 
-@pytest.mark.parametrize("method", [m for m in METHODS if m != "dopri8"])
+def test_wrong_callback_warns_scipy(dev):
+    """odeint_tests.py:302-309: the SciPy bridge supports no callback at all."""
+    x0, t = torch.tensor([1.0, 2.0]), torch.tensor([0.0, 1.0])
+    for name in ("callback_step", "callback_accept_step", "callback_reject_step"):
+        f = _NeuralF(width=10, oscillate=False)
+        setattr(f, name, lambda t0, y0, dt: None)
+        with pytest.warns(Warning):
+            with torch.no_grad():
+                tda.odeint(f, x0, t, method="scipy_solver")
+
+
+@pytest.mark.parametrize("method", [m for m in FIXED_METHODS + ADAPTIVE_METHODS if m != "dopri8"])
 @pytest.mark.parametrize("forward,adjoint", [(False, True), (True, False), (True, True)])
 def test_callback_step_counts(dev, method, forward, adjoint):
     f = _NeuralF(width=10, oscillate=False)
@@ -289,7 +313,9 @@ def test_callback_step_counts(dev, method, forward, adjoint):
             f.callback_accept_step_adjoint, f.callback_reject_step_adjoint = bump("aaccept"), bump("areject")
     x0, t = torch.tensor([1.0, 2.0]), torch.tensor([0.0, 1.0])
     kwargs = dict(options=dict(step_size=0.1)) if method in FIXED_METHODS else {}
-    xs = tda.odeint_adjoint(f, x0, t, method=method, **kwargs)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")       # implicit_adams at odeint's default tolerances may not converge in 4 iterations
+        xs = tda.odeint_adjoint(f, x0, t, method=method, **kwargs)
     if forward:
         if method in FIXED_METHODS:
             assert c["step"] == 10
@@ -491,7 +517,13 @@ def test_tuple_state_gradcheck(dev, method):
 # ---- gradient_tests.py:13-32 gradcheck, :34-87 adjoint vs odeint ------------------------------------------------
 @pytest.mark.parametrize("method", METHODS)
 def test_gradcheck_odeint_and_adjoint(dev, method):
-    f, y0, t_points, _ = construct_problem(device=dev, npts=4)
+    # npts = 4 keeps the test short; gl4 needs the reference's own 10 points: with its duplicated abscissa
+    # (fixed_grid_implicit.py:38) the continuous adjoint on a coarse grid misses the finite differences of the
+    # discrete solve by 1 % — in the reference exactly as here (same numbers)
+    f, y0, t_points, _ = construct_problem(device=dev, npts=10 if method == "gl4" else 4)
+    if method == "scipy_solver":      # gradient_tests.py:17-18: no gradients through SciPy; the adjoint still works
+        assert torch.autograd.gradcheck(lambda y0_, t_: tda.odeint_adjoint(f, y0_, t_, method=method), (y0, t_points))
+        return
     assert torch.autograd.gradcheck(lambda y0_, t_: tda.odeint(f, y0_, t_, method=method), (y0, t_points))
     assert torch.autograd.gradcheck(lambda y0_, t_: tda.odeint_adjoint(f, y0_, t_, method=method), (y0, t_points))
 
@@ -521,9 +553,16 @@ def test_adjoint_against_odeint(dev, ode, eps, t_grad):
 # ---- event_tests.py:14-48 / :50-63 -----------------------------------------------------------------------------
 @pytest.mark.parametrize("reverse", [False, True], ids=["fwd", "rev"])
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
-@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("method", [m for m in METHODS if m != "scipy_solver"])      # event_tests.py:20-22
 def test_event_odeint(dev, method, dtype, reverse):
-    tol = 5e-3 if method == "euler" else 1e-4
+    if method == "explicit_adams":
+        tol = 7e-2
+    elif method in ("euler", "implicit_euler"):
+        tol = 5e-3
+    elif method == "gl6":
+        tol = 2e-3
+    else:
+        tol = 1e-4
     for ode in ("constant", "sine"):
         f, y0, t_points, sol = construct_problem(dtype=dtype, device=dev, ode=ode, reverse=reverse)
         options = {"step_size": 0.01, "interp": "cubic"} if method in FIXED_METHODS else {}

@@ -21,8 +21,13 @@ or not `perturb` is set (rk_common.py:468-470 / :497-499); the convergence test 
 solve that converges only in its `max_iters`-th update still warns; a Python-float `dt` (event mode) is rounded
 through the default dtype (`torch.tensor(dt)`, rk_common.py:421-422).
 
-Gradients: backprop through these solvers is not recorded op by op (the reference differentiates its unrolled
-Broyden iterations); use `odeint_adjoint`, which needs only no-grad solves and supports every method.
+Gradients (plain `odeint` in grad mode).  The reference differentiates its unrolled Broyden iterations.  Here the
+stage equations are solved without a graph and the solution K* is attached to the graph by the implicit function
+theorem: the residual r(K*; y0, t, θ) is evaluated once more WITH a graph, and `_ImplicitCorrection` returns K* in
+forward and  grad_r = -J^{-T} g  in backward, where J = dr/dK at K* and the linear system is solved matrix-free by
+GMRES on vector-Jacobian products (autograd through `func` at the converged stage points).  That is the exact
+gradient of the converged solution — O(1) graph memory per step instead of one graph per Broyden iteration.
+`odeint_adjoint` works with every method as well (it needs only no-grad solves).
 """
 from __future__ import annotations
 
@@ -34,7 +39,7 @@ import numpy as np
 import torch
 
 from .misc import Perturb
-from .solvers import FixedGridODESolver
+from .solvers import _NO_SHADOW, FixedGridODESolver
 from .tableaus import IMPLICIT_TABLEAUS, ImplicitTableau
 
 _DOT_TERMS = 14          # TDEQ_MAX_TERMS vectors per tdeq_multi_dot launch
@@ -124,6 +129,62 @@ class _MatrixFreeBroyden:
         return K, converged
 
 
+def _gmres(matvec: Callable[[torch.Tensor], torch.Tensor], b: torch.Tensor, rtol: float, restart: int = 30,
+           max_restarts: int = 10) -> torch.Tensor:
+    """Restarted GMRES for A x = b with A given by `matvec`; vectors on the device, the small Hessenberg
+    least-squares problem on the host.  Used only by the backward pass of `_ImplicitCorrection`."""
+    x = torch.zeros_like(b)
+    bnorm = float(b.norm())
+    if bnorm == 0.0 or not math.isfinite(bnorm):
+        return x
+    for outer in range(max_restarts):
+        r = b - matvec(x) if outer else b.clone()
+        beta = float(r.norm())
+        if beta <= rtol * bnorm:
+            break
+        V = [r / beta]
+        H = np.zeros((restart + 1, restart))
+        y, done, m = np.zeros(0), False, 0
+        for j in range(restart):
+            w = matvec(V[j])
+            basis = torch.stack(V)
+            h = basis @ w
+            w = w - h @ basis
+            h2 = basis @ w                      # second Gram–Schmidt pass
+            w = w - h2 @ basis
+            H[:j + 1, j] = (h + h2).tolist()
+            hn = float(w.norm())
+            H[j + 1, j] = hn
+            m = j + 1
+            e1 = np.zeros(m + 1)
+            e1[0] = beta
+            y = np.linalg.lstsq(H[:m + 1, :m], e1, rcond=None)[0]
+            resid = float(np.linalg.norm(H[:m + 1, :m] @ y - e1))
+            if resid <= rtol * bnorm or hn <= 1e-300:
+                done = True
+                break
+            V.append(w / hn)
+        x = x + torch.as_tensor(y, dtype=b.dtype, device=b.device) @ torch.stack(V[:m])
+        if done:
+            break
+    return x
+
+
+class _ImplicitCorrection(torch.autograd.Function):
+    """forward: K* (the no-graph solution of r(K) = 0); backward: grad_r = -J^{-T} g with J = dr/dK at K* (implicit
+    function theorem), J^T v supplied by `vjp`."""
+
+    @staticmethod
+    def forward(ctx, r, K_star, vjp, rtol):
+        ctx.vjp, ctx.rtol = vjp, rtol
+        return K_star.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        lam = _gmres(ctx.vjp, g.contiguous(), ctx.rtol)
+        return -lam, None, None, None
+
+
 class FixedGridImplicitRKSolver(FixedGridODESolver):
     """FIRK (all stages coupled, rk_common.py:378-479) and DIRK (stage by stage, :482-558) drivers."""
     tableau: ImplicitTableau
@@ -154,17 +215,10 @@ class FixedGridImplicitRKSolver(FixedGridODESolver):
         return T(t0T + T(a * dtT)), Perturb.NONE
 
     def _step(self, t0, dt, t1, y0, y1_out, sh):
-        if torch.is_grad_enabled() and (y0.requires_grad or sh.dt_signed() is not None):
-            raise NotImplementedError(
-                "{}: backpropagation through the implicit solvers is not recorded; use odeint_adjoint (it supports "
-                "every method) or wrap the solve in torch.no_grad()".format(self.__class__.__name__))
-        func, kern = self.func, self.kernels
+        func, kern, ops = self.func, self.kernels, self.ops
         T = func.np_dtype
-        f0 = func.eval(t0, y0, self._first_perturb())
-        if f0.requires_grad:
-            raise NotImplementedError(
-                "{}: backpropagation through the implicit solvers is not recorded; use odeint_adjoint".format(
-                    self.__class__.__name__))
+        f0 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
+        graph = torch.is_grad_enabled() and (y0.requires_grad or f0.requires_grad or sh is not _NO_SHADOW)
         if isinstance(dt, float):
             dt = torch.tensor(dt).item()       # `torch.tensor(dt)`: a Python float passes through the default dtype
         t0T, dtT, t1T = T(t0), T(dt), T(t1)
@@ -173,20 +227,38 @@ class FixedGridImplicitRKSolver(FixedGridODESolver):
         stages = [self._stage(i, t0T, dtT, t1T) for i in range(n_st)]
         solver = _MatrixFreeBroyden(kern, self._tol, self.max_iters)
         n, stride = self._n, self._stride
+        y0_d, f0_d = y0.detach(), f0.detach()
+        gm_tol = 1e-6 if y0.dtype == torch.float32 else 1e-11
 
         def stage_input(ks: List[torch.Tensor], row: List[float]) -> torch.Tensor:
             nz = [(k, b) for k, b in zip(ks, row) if b != 0.0]
-            out = torch.empty_like(y0)
-            kern.stage_combine(out, y0, [k for k, _ in nz], [b for _, b in nz], dts)
+            out = torch.empty_like(y0_d)
+            kern.stage_combine(out, y0_d, [k for k, _ in nz], [b for _, b in nz], dts)
             return out
+
+        def stage_residual(i, st, ks, y_base, f_base, with_time):
+            """r_i = K_i - f(t_i, y_base + dt sum_j beta_ij K_j) through the recording front end (grad mode)."""
+            if st is None:                                   # stored slope: K_i = f0
+                return ops.weighted_sum([ks[i], f_base], [1.0, -1.0])
+            row = self._beta[i]
+            nz = [(k, b) for k, b in zip(ks, row) if b != 0.0]
+            yi = ops.combine(y_base, [k for k, _ in nz], [b for _, b in nz], dts, sh.dt_signed() if with_time else None)
+            a = 1.0 if st[1] is Perturb.PREV else float(self._alpha[i])
+            fi = func.eval(st[0], yi, st[1], shadow=sh.time(a) if with_time else None)
+            return ops.weighted_sum([ks[i], fi], [1.0, -1.0])
+
+        def warn_if(not_converged: bool) -> None:
+            if not_converged:
+                warnings.warn("Functional iteration did not converge. Solution may be incorrect.")
 
         if not self.tableau.diagonal:
             K = torch.zeros(n_st * stride, dtype=y0.dtype, device=y0.device)
             for i in range(n_st):
-                K[i * stride:i * stride + n].copy_(f0)
+                K[i * stride:i * stride + n].copy_(f0_d)
+            split = lambda Kf: [Kf[j * stride:j * stride + n] for j in range(n_st)]
 
             def residual(Kf: torch.Tensor) -> torch.Tensor:
-                ks = [Kf[j * stride:j * stride + n] for j in range(n_st)]
+                ks = split(Kf)
                 res = torch.zeros_like(Kf)
                 for i, st in enumerate(stages):
                     if st is None:
@@ -195,30 +267,59 @@ class FixedGridImplicitRKSolver(FixedGridODESolver):
                     kern.weighted_sum(res[i * stride:i * stride + n], [ks[i], fi], [1.0, -1.0])
                 return res
 
-            K, converged = solver.solve(K, residual)
-            if not converged:
-                warnings.warn("Functional iteration did not converge. Solution may be incorrect.")
-            ks = [K[j * stride:j * stride + n] for j in range(n_st)]
+            with torch.no_grad():
+                K, converged = solver.solve(K, residual)
+            warn_if(not converged)
+            if graph:
+                pad = [torch.zeros(stride - n, dtype=y0.dtype, device=y0.device)] if stride > n else []
+
+                def residual_graph(Kf, y_base, f_base, with_time):
+                    ks = split(Kf)
+                    pieces = []
+                    for i, st in enumerate(stages):
+                        pieces.append(stage_residual(i, st, ks, y_base, f_base, with_time))
+                        pieces.extend(pad)
+                    return torch.cat(pieces)
+
+                with torch.enable_grad():
+                    K_leaf = K.detach().requires_grad_(True)
+                    r_leaf = residual_graph(K_leaf, y0_d, f0_d, False)
+                    r = residual_graph(K.detach(), y0, f0, True)
+                vjp = lambda v: torch.autograd.grad(r_leaf, K_leaf, v, retain_graph=True)[0]
+                K = _ImplicitCorrection.apply(r, K.detach(), vjp, gm_tol) if r.requires_grad else K
+            ks = split(K)
+            if graph:       # stored-slope stages carry f0's graph directly as well (their residual row is K_i - f0)
+                ks = [k.contiguous() for k in ks]
         else:
-            ks = [f0] * n_st
+            ks = [f0 if graph else f0_d] * n_st
             for i, st in enumerate(stages):
                 if st is None:
                     continue
+                prev_d = [k.detach() for k in ks[:i]]
 
-                def residual(ki: torch.Tensor, i=i, st=st) -> torch.Tensor:
-                    fi = func.eval(st[0], stage_input(ks[:i] + [ki], self._beta[i]), st[1])
+                def residual(ki: torch.Tensor, i=i, st=st, prev_d=prev_d) -> torch.Tensor:
+                    fi = func.eval(st[0], stage_input(prev_d + [ki], self._beta[i]), st[1])
                     res = torch.empty_like(ki)
                     kern.weighted_sum(res, [ki, fi], [1.0, -1.0])
                     return res
 
-                ki, converged = solver.solve(ks[i], residual)
+                with torch.no_grad():
+                    ki, converged = solver.solve(ks[i].detach(), residual)
+                warn_if(not converged)
+                if graph:
+                    with torch.enable_grad():
+                        k_leaf = ki.detach().requires_grad_(True)
+                        r_leaf = stage_residual(i, st, prev_d + [k_leaf], y0_d, f0_d, False)
+                        r = stage_residual(i, st, list(ks[:i]) + [ki.detach()], y0, f0, True)
+                    vjp = lambda v, r_leaf=r_leaf, k_leaf=k_leaf: torch.autograd.grad(r_leaf, k_leaf, v,
+                                                                                      retain_graph=True)[0]
+                    if r.requires_grad:
+                        ki = _ImplicitCorrection.apply(r, ki.detach(), vjp, gm_tol)
                 ks = ks[:i] + [ki] + ks[i + 1:]
-                if not converged:
-                    warnings.warn("Functional iteration did not converge. Solution may be incorrect.")
         c_sol = [float(T(c)) for c in self.tableau.c_sol]
         nz = [(k, c) for k, c in zip(ks, c_sol) if c != 0.0]
-        y1 = y1_out if y1_out is not None else torch.empty_like(y0)
-        kern.stage_combine(y1, y0, [k for k, _ in nz], [c for _, c in nz], dts)
+        y1 = ops.combine(y0, [k for k, _ in nz], [c for _, c in nz], dts, sh.dt_signed(),
+                         out=None if graph else y1_out)
         return y1, f0
 
 

@@ -1468,6 +1468,64 @@ class AdamsBashforthMoulton(FixedGridODESolver):
         self.prev_t = None
         self._sync = _LockStep(dist_sync) if dist_sync is not None else None
         self._plan = None
+        # A 0-dim fp32 state meets the reference's fp64 coefficient tensors as 0-dim x 0-dim, which PyTorch promotes
+        # to fp64 (a dimensioned fp32 tensor would stay fp32): products and sums of `_dot_product` run in fp64 and are
+        # rounded once by `.type_as(y0)` — see _step_zero_dim.
+        self._zero_dim_f32 = (not self.layout.is_tuple and tuple(self.layout.shapes[0]) == ()
+                              and y0.dtype == torch.float32)
+
+    def _step_zero_dim(self, t1, y0, f0, hist, order, dt64, sh):
+        """The step for a 0-dim fp32 state with the reference's type promotion (fixed_adams.py:205-216): the history
+        dot products and `dt * m0 * f` are formed in fp64 (0-dim fp64 coefficient x 0-dim fp32 derivative promotes) and
+        rounded to fp32 once.  Same kernels, on fp64 copies of the one-element tensors."""
+        func, kern = self.func, self.kernels
+        sign = func.sign
+        bash, _ = adams_coefficients(order)
+        h64 = [h.double() for h in hist]
+
+        def dot64(coefs):            # left to right in fp64, then one rounding to fp32
+            acc = None
+            for lo in range(0, order, 7):
+                xs = ([acc] if acc is not None else []) + h64[lo:lo + 7]
+                ws = ([1.0] if acc is not None else []) + list(coefs[lo:lo + 7])
+                out = torch.empty_like(h64[0])
+                kern.weighted_sum(out, xs, ws)
+                acc = out
+            return acc.float()
+
+        def add(a, b):
+            out = torch.empty_like(a)
+            kern.weighted_sum(out, [a, b], [1.0, 1.0])
+            return out
+
+        dy = dot64([dt64 * b * sign for b in bash])
+        y = add(y0, dy)
+        if not self.implicit:
+            return y, f0
+        _, moulton = adams_coefficients(order + 1)
+        sm = dot64(list(moulton[1:]))
+        delta = torch.empty_like(sm)
+        kern.weighted_sum(delta, [sm], [dt64 * sign])
+        if self._plan is None:
+            self._plan = kern.make_plan(self.layout.segments(self.rtol, self.atol), self.layout.total,
+                                        self.layout.chunk, self.device)
+        c = dt64 * moulton[0] * sign
+        converged = False
+        for _ in range(self.max_iters):
+            f = func.eval(t1, y, self._last_perturb())
+            p64 = torch.empty_like(h64[0])
+            kern.weighted_sum(p64, [f.double()], [c])
+            dy_new = add(p64.float(), delta)
+            y = add(y0, dy_new)
+            kern.adams_correct(self._plan, dy_new, dy, compute=False)
+            dy = dy_new
+            converged = self._converged()
+            if converged:
+                break
+        if not converged:
+            warnings.warn("Functional iteration did not converge. Solution may be incorrect.")
+            self.prev_f.pop()
+        return y, f0
 
     def _update_history(self, t, f) -> None:
         if self.prev_t is None or self.prev_t != t:
@@ -1493,6 +1551,9 @@ class AdamsBashforthMoulton(FixedGridODESolver):
         dt64 = float(dt)
         bash, _ = adams_coefficients(order)
         hist = [self.prev_f[j] for j in range(order)]
+        if self._zero_dim_f32 and not (torch.is_grad_enabled() and (y0.requires_grad or hist[0].requires_grad
+                                                                     or sh is not _NO_SHADOW)):
+            return self._step_zero_dim(t1, y0, f0, hist, order, dt64, sh)
         cb = [dt64 * b * sign for b in bash]            # `dt * bashforth_coeffs` in fp64 (:205); the sign is exact
         dsh = sh.dt_signed()
         if not self.implicit:
