@@ -125,6 +125,31 @@ def test_batch_scale_state_the_dense_jacobian_could_not_hold(dev, method):
     assert rel_err(y[-1], torch.exp(-a)) < tol
 
 
+def test_rms_residual_test_for_large_fp32_states(dev):
+    """Opt-in `residual_norm="rms"`: at 2^18 fp32 unknowns per stage the reference's absolute 2-norm bound of 1e-6 sits
+    below the rounding floor of the residual, so every step would run all max_iters iterations; the RMS form of the
+    same bound converges in a few.  Same solution to fp32 rounding level."""
+    n = 1 << 18
+    a = torch.linspace(0.5, 3.0, n)
+    y0 = torch.ones(n)
+    t = torch.linspace(0, 1, 5)
+    calls = {"rms": 0, "l2": 0}
+
+    def make(tag):
+        def f(t_, y_):
+            calls[tag] += 1
+            return -a * y_
+        return f
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y_rms = tda.odeint(make("rms"), y0, t, method="radauIIA3", options=dict(residual_norm="rms"))
+        y_l2 = tda.odeint(make("l2"), y0, t, method="radauIIA3", options=dict(max_iters=12))
+    assert calls["rms"] < calls["l2"]            # l2 runs into its iteration cap at every step
+    assert rel_err(y_rms, y_l2) < 1e-5 and rel_err(y_rms[-1], torch.exp(-a)) < 1e-4
+    with pytest.raises(ValueError, match="residual_norm"):
+        tda.odeint(lambda t_, y_: -y_, torch.ones(3), t, method="gl4", options=dict(residual_norm="max"))
+
+
 def test_adjoint_with_implicit_methods(dev):
     """odeint_adjoint only needs no-grad solves, so the implicit methods serve as forward and backward method."""
     g = torch.Generator(device="cpu").manual_seed(7)
