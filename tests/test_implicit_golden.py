@@ -145,7 +145,7 @@ def test_rms_residual_test_for_large_fp32_states(dev):
         y_rms = tda.odeint(make("rms"), y0, t, method="radauIIA3", options=dict(residual_norm="rms"))
         y_l2 = tda.odeint(make("l2"), y0, t, method="radauIIA3", options=dict(max_iters=12))
     assert calls["rms"] < calls["l2"]            # l2 runs into its iteration cap at every step
-    assert rel_err(y_rms, y_l2) < 1e-5 and rel_err(y_rms[-1], torch.exp(-a)) < 1e-4
+    assert rel_err(y_rms, y_l2) < 1e-5 and rel_err(y_rms[-1], torch.exp(-a)) < 5e-3       # 4 steps of a 3rd-order method
     with pytest.raises(ValueError, match="residual_norm"):
         tda.odeint(lambda t_, y_: -y_, torch.ones(3), t, method="gl4", options=dict(residual_norm="max"))
 
