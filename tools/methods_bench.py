@@ -53,7 +53,7 @@ tt = torch.zeros((), device=dev)
 w_f, _ = timed(lambda: [f(tt, y0) for _ in range(200)])
 t_func = w_f / 200
 res = {"state": [B, D], "dtype": "f32", "func_us": t_func * 1e6}
-n_steps = 8
+n_steps = int(os.environ.get("TDEQ_BENCH_STEPS", "8"))
 t = torch.linspace(0.0, 1.0, n_steps + 1, device=dev)
 exact = y0.double() @ torch.linalg.matrix_exp(A.double()).T
 with torch.no_grad(), warnings.catch_warnings():
@@ -67,6 +67,8 @@ with torch.no_grad(), warnings.catch_warnings():
                               ("implicit_euler", {}, rms), ("implicit_midpoint", {}, rms), ("trapezoid", {}, rms),
                               ("radauIIA3", {}, rms), ("gl4", {}, rms), ("radauIIA5", {}, rms), ("gl6", {}, rms),
                               ("sdirk2", {}, rms), ("trbdf2", {}, rms)]:
+        if len(sys.argv) > 1 and method not in sys.argv[1:]:
+            continue
         f = Counting()
         w, y = timed(lambda: tda.odeint(f, y0, t[[0, -1]], method=method,
                                         options=dict(step_size=1.0 / n_steps, **extra), **kw))
