@@ -652,6 +652,31 @@ def gen_adams():
             fs = lambda t, y: (1 - t * 0.5) * (y * -0.7) - y * y * y * 0.01
             arrays[f"{method}_zerodim"] = torchdiffeq.odeint(fs, torch.tensor(1.5), torch.linspace(0, 1, 41),
                                                              method=method, rtol=1e-6, atol=1e-8)
+    # kernel-level vectors: the reference's own expressions (fixed_adams.py:205, :210, :213-215, :189-192) on random data
+    for dtype, tag in [(torch.float32, "f32"), (torch.float64, "f64")]:
+        n, order = 777, 7
+        hist = [rand(n, seed=30 + j, dtype=dtype) for j in range(order)]
+        y0k = rand(n, seed=29, dtype=dtype)
+        dt = torch.tensor(0.0371, dtype=dtype)
+        solver = fixed_adams.AdamsBashforthMoulton(lambda t, y: y, y0k, rtol=1e-3, atol=1e-4)
+        bash, moulton = solver.bashforth[order], solver.moulton[order + 1]
+        dy = fixed_adams._dot_product(dt * bash, hist).type_as(y0k)
+        delta = dt * fixed_adams._dot_product(moulton[1:], hist).type_as(y0k)
+        fnew = rand(n, seed=28, dtype=dtype)
+        dy_new = (dt * moulton[0] * fnew).type_as(y0k) + delta
+        # a second pair that is close to dy_new, so that the census is mixed
+        dy_close = dy_new * (1 + 2e-3 * rand(n, seed=27, dtype=dtype))
+        ratio = misc._compute_error_ratio(torch.abs(dy_close - dy_new), solver.rtol, solver.atol, dy_close, dy_new,
+                                          misc._linf_norm)
+        viol = ((torch.abs(dy_close - dy_new) / (solver.atol + solver.rtol * torch.max(dy_close.abs(), dy_new.abs())))
+                >= 1).sum()
+        arrays.update({f"kv_{tag}_hist": torch.stack(hist), f"kv_{tag}_y0": y0k, f"kv_{tag}_dt": dt,
+                       f"kv_{tag}_dy": dy, f"kv_{tag}_delta": delta, f"kv_{tag}_ypred": y0k + dy,
+                       f"kv_{tag}_f": fnew, f"kv_{tag}_dy_new": dy_new, f"kv_{tag}_y_new": y0k + dy_new,
+                       f"kv_{tag}_dy_close": dy_close, f"kv_{tag}_ratio": ratio, f"kv_{tag}_violations": viol,
+                       f"kv_{tag}_converged_far": solver._has_converged(dy, dy_new),
+                       f"kv_{tag}_converged_close": solver._has_converged(dy_close, dy_new),
+                       f"kv_{tag}_converged_same": solver._has_converged(dy_new, dy_new)})
     # gradients by backprop through the solver (y0, t and the parameters of the field)
     for method in ["explicit_adams", "implicit_adams"]:
         torch.manual_seed(3)

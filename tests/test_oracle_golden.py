@@ -398,3 +398,38 @@ def test_eager_torch_port_follows_the_numpy_oracle(dname):
     tol = 1e-4 if dname == "f32" else 5e-12     # the states are compared at (slightly) different times in fp32
     assert rel_err(eager.y.numpy().reshape(-1), solver.y1) < tol
     assert solver.n_reject > 0          # the large first step exercises the reject branch
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("f64", torch.float64)])
+def test_oracle_adams_kernels_pinned_to_the_reference_expressions(oracle_kernels, tag, dtype):
+    """oracle_adams_predict / oracle_adams_correct against outputs of the reference's own expressions
+    (fixed_adams.py:205, :210, :213-215 and `_has_converged` :189-192) on random vectors — golden/adams.npz `kv_*`."""
+    from torchdiffeq_amd.tableaus import adams_coefficients
+    z = load("adams.npz")
+    hist = [h.contiguous() for h in T(z[f"kv_{tag}_hist"])]
+    y0, dt = T(z[f"kv_{tag}_y0"]), float(z[f"kv_{tag}_dt"])
+    order = len(hist)
+    bash, _ = adams_coefficients(order)
+    _, moulton = adams_coefficients(order + 1)
+    y, dy, delta = torch.empty_like(y0), torch.empty_like(y0), torch.empty_like(y0)
+    oracle_kernels.adams_predict(y, y0, hist, [dt * b for b in bash], list(moulton[1:]), dt, dy_out=dy, delta_out=delta)
+    assert torch.equal(dy, T(z[f"kv_{tag}_dy"]))
+    assert torch.equal(delta, T(z[f"kv_{tag}_delta"]))
+    assert torch.equal(y, T(z[f"kv_{tag}_ypred"]))
+    y_only = torch.empty_like(y0)
+    oracle_kernels.adams_predict(y_only, y0, hist, [dt * b for b in bash])
+    assert torch.equal(y_only, y)
+    n = y0.numel()
+    plan = oracle_kernels.make_plan([(0, n, 1e-3, 1e-4)], n, 1024, None)
+    y_new, dy_new = torch.empty_like(y0), torch.empty_like(y0)
+    oracle_kernels.adams_correct(plan, dy_new, dy, y_out=y_new, f=T(z[f"kv_{tag}_f"]), delta=delta, y0=y0,
+                                 c=dt * moulton[0])
+    assert torch.equal(dy_new, T(z[f"kv_{tag}_dy_new"]))
+    assert torch.equal(y_new, T(z[f"kv_{tag}_y_new"]))
+    converged = lambda: oracle_kernels.read_norms(plan)[0] == [0.0]
+    assert converged() == bool(z[f"kv_{tag}_converged_far"])
+    oracle_kernels.adams_correct(plan, dy_new, T(z[f"kv_{tag}_dy_close"]), compute=False)
+    assert oracle_kernels.read_norms(plan)[0] == [float(z[f"kv_{tag}_violations"])]     # the exact census
+    assert converged() == bool(z[f"kv_{tag}_converged_close"])
+    oracle_kernels.adams_correct(plan, dy_new, dy_new, compute=False)
+    assert converged() == bool(z[f"kv_{tag}_converged_same"]) is True
