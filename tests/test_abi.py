@@ -55,6 +55,19 @@ def test_argument_errors_without_gpu():
     assert lib.tdeq_scale_many(ptrs, p, buf, 1, 0, 1, None) == 0
     assert lib.tdeq_dots_workspace_bytes(4096 * 3 + 1, 5) == 4 * 5 * 8
     assert lib.tdeq_multi_dot(p, ptrs, 1, 4, p, p, 0, 1, None) == -2                  # workspace too small
+    # Adams entry points (ABI v13)
+    assert lib.tdeq_adams_predict(None, None, None, p, ptrs, buf, None, 1, 0.1, 4, 1, None) == -1     # null y_out
+    assert lib.tdeq_adams_predict(p, p, None, p, ptrs, buf, buf, 1, 0.1, 4, 1, None) == -1            # dy without delta
+    assert lib.tdeq_adams_predict(p, p, p, p, ptrs, buf, None, 1, 0.1, 4, 1, None) == -1              # implicit without cm
+    assert lib.tdeq_adams_predict(p, None, None, p, ptrs, buf, None, 15, 0.1, 4, 1, None) == -1       # n_terms > 14
+    assert lib.tdeq_adams_predict(p, None, None, p, ptrs, buf, None, 1, 0.1, 0, 1, None) == 0         # empty state
+    seg = (_native.Segment * 1)(_native.Segment(0, 4, 1e-3, 1e-4))
+    assert lib.tdeq_adams_correct(None, p, None, None, p, None, 0.1, 1, seg, None, 1, 1024, 1, 4, p, p, p, 24, 1,
+                                  None) == -1                                                         # compute needs f, delta, y0
+    assert lib.tdeq_adams_correct(None, p, None, None, p, None, 0.1, 0, seg, None, 1, 1024, 1, 4, p, p, p, 8, 1,
+                                  None) == -2                                                         # workspace too small
+    assert lib.tdeq_adams_correct(None, p, None, None, p, None, 0.1, 0, seg, None, 1, 1000, 1, 4, p, p, p, 24, 1,
+                                  None) == -1                                                         # chunk not a multiple of 1024
 
 
 def test_cpu_state_is_rejected_loudly():
