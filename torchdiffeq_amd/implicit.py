@@ -33,7 +33,7 @@ from __future__ import annotations
 
 import math
 import warnings
-from typing import Callable, List, Optional
+from typing import Callable, List
 
 import numpy as np
 import torch

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import dataclasses
 import functools
+import math
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -340,6 +341,5 @@ def _implicit_tableaus():
     return {t.name: t for t in tabs}
 
 
-import math  # noqa: E402  (used by the closed forms above)
 
 IMPLICIT_TABLEAUS = _implicit_tableaus()
