@@ -1,0 +1,263 @@
+"""Differential fuzzing against the reference (build container only: imports /root/reference).
+
+  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop} [seed] [cases]
+
+Random states (0-dim .. 3-dim, tuples), dtypes, time grids (both directions), options and methods are solved by the
+reference and by torchdiffeq_amd (host logic over the CPU oracle kernels — the same code path the `dev="cpu"` tests
+use) and compared: bit for bit for the explicit fixed-grid and Adams methods, to the nonlinear solver's tolerance for
+the implicit RK methods, 1e-9 for the adaptive methods, 1e-9 / 1e-6 for gradients.  Test infrastructure, like oracle/.
+Last runs (round 1): fixed 550 cases, adaptive 200, adjoint 120, backprop 120 — no mismatch other than non-converged
+implicit solves (both libraries warn) and rounding-level iteration-count flips."""
+import random
+import sys
+import warnings
+
+import torch
+
+sys.path.insert(0, "/root/repo")
+sys.path.insert(0, "/root/reference")
+import torchdiffeq as ref  # noqa: E402
+import torchdiffeq_amd as tda  # noqa: E402
+from torchdiffeq_amd import _native  # noqa: E402
+from oracle.kernels import OracleKernels  # noqa: E402
+
+ok = OracleKernels()
+_native.get_kernels = lambda d: ok
+torch.set_num_threads(1)
+mode = sys.argv[1] if len(sys.argv) > 1 else "fixed"
+sys.argv = [sys.argv[0]] + sys.argv[2:]
+if len(sys.argv) < 3:
+    sys.argv += ["0", "100"][len(sys.argv) - 1:]
+
+if mode == "fixed":
+    seed = int(sys.argv[1]) if len(sys.argv)>1 else 0
+    n_cases = int(sys.argv[2]) if len(sys.argv)>2 else 200
+    rng = random.Random(seed)
+    FIXED = ['euler','midpoint','heun2','heun3','rk4','explicit_adams','implicit_adams','fixed_adams']
+    IMPL = ['implicit_euler','implicit_midpoint','trapezoid','radauIIA3','gl4','radauIIA5','gl6','sdirk2','trbdf2']
+    bad=0
+    for case in range(n_cases):
+        method = rng.choice(FIXED+IMPL)
+        dtype = rng.choice([torch.float32, torch.float64])
+        tdtype = rng.choice([dtype, torch.float64]) if rng.random()<0.3 else dtype
+        shape = rng.choice([(), (1,), (3,), (2,3), (4,1,2)])
+        is_tuple = rng.random()<0.25
+        rev = rng.random()<0.4
+        npts = rng.choice([2,3,5,9])
+        g = torch.Generator().manual_seed(rng.randrange(10**6))
+        y0 = torch.randn(shape, generator=g, dtype=torch.float64).to(dtype)
+        t = torch.sort(torch.rand(npts, generator=g, dtype=torch.float64)).values.to(tdtype)
+        if float((t[1:]-t[:-1]).min()) < 1e-3: continue
+        if rev: t = t.flip(0)
+        opts={}
+        r=rng.random()
+        if r<0.4: opts['step_size']=rng.choice([0.05,0.013,0.1,0.5])
+        elif r<0.5: opts['grid_constructor']=lambda f,y,tt: torch.cat([tt[:1], (tt[:1]+tt[-1:])/2, tt[-1:]]) 
+        if rng.random()<0.3: opts['perturb']=True
+        if rng.random()<0.3: opts['interp']='cubic'
+        if 'adams' in method:
+            if rng.random()<0.3: opts['max_order']=rng.choice([4,5,8,12,3])
+            if rng.random()<0.3 and method!='explicit_adams': opts['max_iters']=rng.choice([1,2,6])
+        if method in IMPL and rng.random()<0.3: opts['max_iters']=rng.choice([1,3,50])
+        lam = rng.choice([0.3,1.0,3.0])
+        if is_tuple:
+            y0b = torch.randn(2, generator=g, dtype=torch.float64).to(dtype)
+            f = lambda t_,y_: ((1-t_*0.5)*(y_[0]*(-lam)) - y_[0]*y_[0]*y_[0]*0.01 + y_[1].sum()*0.01, -y_[1]*0.5*(1+t_))
+            yy=(y0,y0b)
+        else:
+            f = lambda t_,y_: (1-t_*0.5)*(y_*(-lam)) - y_*y_*y_*0.01
+            yy=y0
+        kw={}
+        if rng.random()<0.5: kw=dict(rtol=rng.choice([1e-3,1e-6]), atol=rng.choice([1e-4,1e-8]))
+        res=[]
+        for lib in (ref,tda):
+            try:
+                with warnings.catch_warnings(record=True) as w, torch.no_grad():
+                    warnings.simplefilter('always')
+                    out = lib.odeint(f, yy, t, method=method, options=dict(opts), **kw)
+                res.append(('ok', out, len(w)))
+            except Exception as e:
+                res.append(('err', type(e).__name__+': '+str(e)[:80], 0))
+        a,b=res
+        desc=(method,str(dtype)[6:],str(tdtype)[6:],shape,is_tuple,rev,npts,{k:(v if not callable(v) else 'fn') for k,v in opts.items()},kw)
+        if a[0]!=b[0]:
+            bad+=1; print('STATUS MISMATCH', desc, a[0], a[1] if a[0]=='err' else '', b[0], b[1] if b[0]=='err' else ''); continue
+        if a[0]=='err':
+            if a[1].split(':')[0]!=b[1].split(':')[0]: bad+=1; print('ERR TYPE MISMATCH', desc, a[1], b[1])
+            continue
+        oa = a[1] if is_tuple else (a[1],); ob = b[1] if is_tuple else (b[1],)
+        tol = (1e-5 if dtype==torch.float32 else 1e-11) if method in IMPL else 0.0
+        for x,y in zip(oa,ob):
+            if x.dtype!=y.dtype or x.shape!=y.shape:
+                bad+=1; print('META MISMATCH', desc, x.dtype,y.dtype,x.shape,y.shape); break
+            d = float((x-y).abs().max()/ (x.abs().max()+1e-30)) if x.numel() else 0.0
+            nanmismatch = bool((torch.isnan(x)!=torch.isnan(y)).any())
+            if (d>tol and not (d!=d)) or nanmismatch:
+                bad+=1; print('VALUE MISMATCH', desc, d); break
+        if a[2]!=b[2]:
+            print('warn count differs', desc, a[2], b[2])
+    print('done', n_cases, 'bad', bad)
+elif mode == "adaptive":
+    seed = int(sys.argv[1]); n_cases=int(sys.argv[2])
+    rng = random.Random(seed)
+    AD = ['dopri5','dopri8','tsit5','bosh3','fehlberg2','adaptive_heun']
+    bad=0
+    for case in range(n_cases):
+        method=rng.choice(AD); dtype=torch.float64
+        shape=rng.choice([(),(1,),(3,),(2,3),(17,5)])
+        is_tuple=rng.random()<0.3; rev=rng.random()<0.4; npts=rng.choice([2,3,6,15])
+        g=torch.Generator().manual_seed(rng.randrange(10**6))
+        y0=torch.randn(shape,generator=g,dtype=torch.float64)
+        t=torch.sort(torch.rand(npts,generator=g,dtype=torch.float64)*3).values
+        if float((t[1:]-t[:-1]).min())<1e-3: continue
+        if rev: t=t.flip(0)
+        opts={}
+        if rng.random()<0.2: opts['first_step']=rng.choice([0.01,0.2])
+        if rng.random()<0.2: opts['max_step']=rng.choice([0.05,0.3])
+        if rng.random()<0.15: opts['min_step']=rng.choice([1e-3,0.05])
+        if rng.random()<0.2: opts['safety']=0.8; opts['ifactor']=5.0; opts['dfactor']=0.3
+        if rng.random()<0.2:
+            lo,hi=float(t.min()),float(t.max())
+            opts[rng.choice(['step_t','jump_t'])]=torch.tensor([lo+(hi-lo)*0.37, lo+(hi-lo)*0.71],dtype=torch.float64)
+        lam=rng.choice([0.3,1.0,3.0])
+        if is_tuple:
+            y0b=torch.randn(2,generator=g,dtype=torch.float64)
+            f=lambda t_,y_: (torch.sin(t_*2)*y_[0]*lam - y_[0]**3*0.1 + y_[1].sum()*0.01, -y_[1]*0.5*(1+t_))
+            yy=(y0,y0b)
+        else:
+            f=lambda t_,y_: torch.sin(t_*2)*y_*lam - y_**3*0.1
+            yy=y0
+        kw=dict(rtol=rng.choice([1e-4,1e-7,1e-9]),atol=rng.choice([1e-6,1e-9,1e-11]))
+        res=[]
+        for lib in (ref,tda):
+            n=[0]
+            def ff(t_,y_):
+                n[0]+=1; return f(t_,y_)
+            try:
+                with warnings.catch_warnings(record=True) as w, torch.no_grad():
+                    warnings.simplefilter('always')
+                    out=lib.odeint(ff,yy,t,method=method,options=dict(opts),**kw)
+                res.append(('ok',out,n[0]))
+            except Exception as e:
+                res.append(('err',type(e).__name__+': '+str(e)[:80],n[0]))
+        a,b=res
+        desc=(method,shape,is_tuple,rev,npts,{k:(v.tolist() if torch.is_tensor(v) else v) for k,v in opts.items()},kw)
+        if a[0]!=b[0]: bad+=1; print('STATUS',desc,a[:2] if a[0]=='err' else 'ok',b[:2] if b[0]=='err' else 'ok'); continue
+        if a[0]=='err':
+            if a[1].split(':')[0]!=b[1].split(':')[0]: bad+=1; print('ERRTYPE',desc,a[1],b[1])
+            continue
+        oa=a[1] if is_tuple else (a[1],); ob=b[1] if is_tuple else (b[1],)
+        for x,y in zip(oa,ob):
+            d=float((x-y).abs().max()/(x.abs().max()+1e-30))
+            if d>1e-9 or x.shape!=y.shape: bad+=1; print('VALUE',desc,d,a[2],b[2]); break
+        else:
+            if a[2]!=b[2]: print('nfe differs',desc,a[2],b[2])
+    print('done',n_cases,'bad',bad)
+elif mode == "adjoint":
+    seed=int(sys.argv[1]); n_cases=int(sys.argv[2])
+    rng=random.Random(seed)
+    M=['euler','rk4','explicit_adams','implicit_adams','implicit_midpoint','gl4','radauIIA5','sdirk2','trbdf2','dopri5','bosh3']
+    bad=0
+    for case in range(n_cases):
+        method=rng.choice(M); amethod=rng.choice([None,None,rng.choice(M)])
+        tgrad=rng.random()<0.4; rev=rng.random()<0.3; is_tuple=rng.random()<0.25
+        npts=rng.choice([2,3,6])
+        sd=rng.randrange(10**6)
+        res=[]
+        for lib in (ref,tda):
+            torch.manual_seed(sd)
+            lin=torch.nn.Linear(3,3).double()
+            y0=torch.randn(4,3,dtype=torch.float64).requires_grad_(True)
+            y0b=torch.randn(2,dtype=torch.float64).requires_grad_(True)
+            t=torch.sort(torch.rand(npts,dtype=torch.float64)).values
+            if float((t[1:]-t[:-1]).min())<0.02: res=None; break
+            if rev: t=t.flip(0)
+            t=t.detach().requires_grad_(tgrad)
+            class F(torch.nn.Module):
+                def __init__(s): super().__init__(); s.lin=lin
+                def forward(s,t_,y_):
+                    if is_tuple: return (torch.tanh(s.lin(y_[0]))*torch.cos(t_)+y_[1].sum()*0.1, -y_[1]*0.5)
+                    return torch.tanh(s.lin(y_))*torch.cos(t_)
+            yy=(y0,y0b) if is_tuple else y0
+            opts={} if method in('dopri5','bosh3') else {'step_size':0.05}
+            kw={}
+            if amethod is not None:
+                kw['adjoint_method']=amethod
+                kw['adjoint_options']={} if amethod in('dopri5','bosh3') else {'step_size':0.05}
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    out=lib.odeint_adjoint(F(),yy,t,method=method,options=opts,rtol=1e-7,atol=1e-9,**kw)
+                    o=out[0] if is_tuple else out
+                    loss=(o[-1]**2).sum()+ (out[1].sum() if is_tuple else 0)
+                    ins=[y0,*lin.parameters()]+([y0b] if is_tuple else [])+([t] if tgrad else [])
+                    g=torch.autograd.grad(loss,ins,allow_unused=True)
+                res.append(('ok',[o.detach()]+[x if x is not None else torch.zeros(1,dtype=torch.float64) for x in g]))
+            except Exception as e:
+                res.append(('err',type(e).__name__+': '+str(e)[:100]))
+        if res is None: continue
+        a,b=res
+        desc=(method,amethod,tgrad,rev,is_tuple,npts)
+        if a[0]!=b[0]: bad+=1; print('STATUS',desc,a[1] if a[0]=='err' else 'ok',b[1] if b[0]=='err' else 'ok'); continue
+        if a[0]=='err': continue
+        impl = any(m in ('implicit_midpoint','gl4','radauIIA5','sdirk2','trbdf2') for m in (method,amethod) if m)
+        tol = 1e-6 if impl else 1e-9
+        for i,(x,y) in enumerate(zip(a[1],b[1])):
+            d=float((x-y).abs().max()/(x.abs().max()+1e-12))
+            if d>tol: bad+=1; print('VALUE',desc,i,d); break
+    print('done',n_cases,'bad',bad)
+elif mode == "backprop":
+    seed=int(sys.argv[1]); n_cases=int(sys.argv[2])
+    rng=random.Random(seed)
+    M=['euler','rk4','explicit_adams','implicit_adams','implicit_midpoint','gl4','radauIIA5','sdirk2','trbdf2','dopri5','bosh3']
+    bad=0
+    for case in range(n_cases):
+        method=rng.choice(M); amethod=None
+        tgrad=rng.random()<0.4; rev=rng.random()<0.3; is_tuple=rng.random()<0.25
+        npts=rng.choice([2,3,6])
+        sd=rng.randrange(10**6)
+        res=[]
+        for lib in (ref,tda):
+            torch.manual_seed(sd)
+            lin=torch.nn.Linear(3,3).double()
+            y0=torch.randn(4,3,dtype=torch.float64).requires_grad_(True)
+            y0b=torch.randn(2,dtype=torch.float64).requires_grad_(True)
+            t=torch.sort(torch.rand(npts,dtype=torch.float64)).values
+            if float((t[1:]-t[:-1]).min())<0.02: res=None; break
+            if rev: t=t.flip(0)
+            t=t.detach().requires_grad_(tgrad)
+            class F(torch.nn.Module):
+                def __init__(s): super().__init__(); s.lin=lin
+                def forward(s,t_,y_):
+                    if is_tuple: return (torch.tanh(s.lin(y_[0]))*torch.cos(t_)+y_[1].sum()*0.1, -y_[1]*0.5)
+                    return torch.tanh(s.lin(y_))*torch.cos(t_)
+            yy=(y0,y0b) if is_tuple else y0
+            opts={} if method in('dopri5','bosh3') else {'step_size':0.05}
+            kw={}
+            if amethod is not None:
+                kw['adjoint_method']=amethod
+                kw['adjoint_options']={} if amethod in('dopri5','bosh3') else {'step_size':0.05}
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    out=lib.odeint(F(),yy,t,method=method,options=opts,rtol=1e-7,atol=1e-9)
+                    o=out[0] if is_tuple else out
+                    loss=(o[-1]**2).sum()+ (out[1].sum() if is_tuple else 0)
+                    ins=[y0,*lin.parameters()]+([y0b] if is_tuple else [])+([t] if tgrad else [])
+                    g=torch.autograd.grad(loss,ins,allow_unused=True)
+                res.append(('ok',[o.detach()]+[x if x is not None else torch.zeros(1,dtype=torch.float64) for x in g]))
+            except Exception as e:
+                res.append(('err',type(e).__name__+': '+str(e)[:100]))
+        if res is None: continue
+        a,b=res
+        desc=(method,amethod,tgrad,rev,is_tuple,npts)
+        if a[0]!=b[0]: bad+=1; print('STATUS',desc,a[1] if a[0]=='err' else 'ok',b[1] if b[0]=='err' else 'ok'); continue
+        if a[0]=='err': continue
+        impl = any(m in ('implicit_midpoint','gl4','radauIIA5','sdirk2','trbdf2') for m in (method,amethod) if m)
+        tol = 1e-6 if impl else 1e-9
+        for i,(x,y) in enumerate(zip(a[1],b[1])):
+            d=float((x-y).abs().max()/(x.abs().max()+1e-12))
+            if d>tol: bad+=1; print('VALUE',desc,i,d); break
+    print('done',n_cases,'bad',bad)
+else:
+    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop")
