@@ -45,8 +45,8 @@ class _AugmentedDynamics(OdeFunc):
 
     def call_base(self, t_user: torch.Tensor, aug: torch.Tensor) -> torch.Tensor:
         fwd, lay, n_y = self.fwd, self.layout, self.n_y
-        views = lay.unpack(aug)
-        y_views, adj_views = views[1:1 + n_y], views[1 + n_y:1 + 2 * n_y]
+        views = lay.unpack(aug, lo=1, hi=1 + 2 * n_y)       # only y and adj_y are read: [vjp_t | y | adj_y | θ-adjoints]
+        y_views, adj_views = views[:n_y], views[n_y:]
         sign_f = fwd.sign            # forward solve in decreasing time: f_fwd(s, y) = -f(-s, y)
         with torch.enable_grad():
             # The time VJP is ALWAYS formed, whether or not `t` requires grad: the reference means to skip it
@@ -76,8 +76,8 @@ class _AugmentedDynamics(OdeFunc):
         pieces = [g_t] + f_list + list(g_y) + list(g_p)
         scales = [-1.0] + [s_f] * n_y + [s_a] * (len(g_y) + len(g_p))
         out = lay.pack_fused(self.kernels(), pieces, self.dtype, self.device, scales)
-        o = lay.unpack(out)
         if self.sync:
+            o = lay.unpack(out)
             # lock-step mode: the time- and parameter-VJPs are sums over the batch, i.e. over the shards — add them
             # up now (one all-reduce of 1 + P words) so that these segments of the state are replicated, exactly
             # the whole-batch solve's, and enter its error norm

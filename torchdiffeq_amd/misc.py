@@ -143,10 +143,12 @@ class StateLayout:
                               [1.0] * n if scales is None else list(scales), self.chunk)
         return out
 
-    def unpack(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Tuple[torch.Tensor, ...]:
-        """Views of the components of `flat[..., total]` shaped (*lead, *shape)."""
+    def unpack(self, flat: torch.Tensor, lead: Tuple[int, ...] = (), lo: int = 0,
+               hi: Optional[int] = None) -> Tuple[torch.Tensor, ...]:
+        """Views of the components [lo, hi) of `flat[..., total]` shaped (*lead, *shape) (a view costs ~7 us of host
+        time: callers on a per-evaluation path ask only for the segments they read)."""
         return tuple(flat[..., off:off + n].view((*lead, *shape))
-                     for off, n, shape in zip(self.offsets, self.numels, self.shapes))
+                     for off, n, shape in zip(self.offsets[lo:hi], self.numels[lo:hi], self.shapes[lo:hi]))
 
     def segments(self, rtol, atol) -> List[Tuple[int, int, float, float]]:
         """[(offset, numel, rtol, atol)] with scalar or per-component tolerances (misc.py:115-123)."""
