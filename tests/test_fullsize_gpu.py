@@ -180,3 +180,38 @@ def test_kernels_beyond_2_31_elements(hip_kernels):
     hip_kernels.error_norm_partial(plan, epart, y0, y1, [k0], [5e-4], dt)
     _, _, bad = hip_kernels.read_norms(plan)
     assert bad == [1.0]
+
+
+def test_adams_full_size_closed_form_and_linearity():
+    """The Adams methods at the cfg2 state (65536 x 128 fp32): closed form, and linearity in y0 for a linear field —
+    solve(a*y0) == a*solve(y0) to rounding, a size-independent property of every step formula."""
+    A, y0 = _linear(65536, 128, torch.float32)
+    At = A.T.contiguous()
+    f = lambda t, y: y @ At
+    t = torch.tensor([0.0, 1.0]).cuda()
+    exact = y0.double() @ torch.linalg.matrix_exp(A.double()).T
+    with torch.no_grad():
+        for method, kw, tol in [("explicit_adams", dict(options=dict(step_size=1 / 64, max_order=6)), 1e-5),
+                                ("implicit_adams", dict(options=dict(step_size=1 / 32), rtol=1e-5, atol=1e-7), 1e-5)]:
+            y = tda.odeint(f, y0, t, method=method, **kw)[-1]
+            assert rel_err(y, exact) < tol, method
+            y2 = tda.odeint(f, y0 * 2.0, t, method=method, **kw)[-1]
+            assert rel_err(y2, y * 2.0) < 1e-6, method       # scaling by 2 is exact in fp32: only the census can differ
+
+
+def test_implicit_rk_full_size_matrix_free():
+    """gl4 at the cfg2 state: 2 x 8.4M unknowns per step — the reference's dense Broyden matrix would have 2.8e14
+    entries.  Closed form; the opt-in RMS residual test keeps the iteration count at a handful."""
+    A, y0 = _linear(65536, 128, torch.float32)
+    At = A.T.contiguous()
+    calls = [0]
+
+    def f(t, y):
+        calls[0] += 1
+        return y @ At
+    with torch.no_grad():
+        y = tda.odeint(f, y0, torch.tensor([0.0, 1.0]).cuda(), method="gl4",
+                       options=dict(step_size=0.125, residual_norm="rms"))[-1]
+    exact = y0.double() @ torch.linalg.matrix_exp(A.double()).T
+    assert rel_err(y, exact) < 1e-5
+    assert calls[0] < 8 * (1 + 2 * 12)          # a handful of Broyden iterations per step, not max_iters = 100
