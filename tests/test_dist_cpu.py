@@ -161,6 +161,45 @@ def test_lockstep_world2_equals_single_process(tmp_path):
         assert torch.equal(a, b)
 
 
+def _adams_lockstep_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    _patch_backend()
+    from torchdiffeq_amd import dist as tdist
+    tdist.init_from_env(backend="gloo")
+    f, y0 = _make(torch.float64)
+    f = _CountingModule(f)
+    t = torch.linspace(0, 1, 21, dtype=torch.float64)
+    shard = tdist.shard_batch(y0).clone()
+    with torch.no_grad():
+        y = tdist.odeint_sharded(f, shard, t, rtol=1e-7, atol=1e-9, method="implicit_adams")
+    torch.save(dict(y=y, nfe=f.nfe, rows=tdist.shard_rows(11, rank, world)), os.path.join(out_dir, f"ad{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_implicit_adams_lockstep_world2_equals_single_process(tmp_path):
+    """The corrector's convergence census is all-reduced in lock-step mode: every shard runs the whole-batch number
+    of iterations per step, so rows and evaluation counts equal the single-process solve EXACTLY (the census is an
+    integer count — no rounding in the cross-rank sum)."""
+    import torchdiffeq_amd as tda
+    world = 2
+    port = 30300 + (os.getpid() % 300)
+    mp.spawn(_adams_lockstep_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"ad{r}.pt"), weights_only=False) for r in range(world)]
+    _patch_backend()
+    f, y0 = _make(torch.float64)
+    f = _CountingModule(f)
+    with torch.no_grad():
+        y = tda.odeint(f, y0, torch.linspace(0, 1, 21, dtype=torch.float64), rtol=1e-7, atol=1e-9,
+                       method="implicit_adams")
+    for r in range(world):
+        assert res[r]["nfe"] == f.nfe
+        assert torch.equal(res[r]["y"], y[:, res[r]["rows"]])
+
+
 def test_shard_rows_cover_batch():
     from torchdiffeq_amd.dist import shard_rows
     for n in (1, 7, 8, 65536):
