@@ -580,3 +580,39 @@ def test_event_adjoint(dev):
     assert rel_error(sol[-1], y.detach()) < 1e-4 and rel_error(t_points[-1].detach(), t.detach()) < 1e-4
     t.backward(retain_graph=True)      # the adjoint-mode backward code must still run
     y.sum().backward()
+
+
+# ---- gradient_tests.py:89-135 TestCompareAdjointGradient (incl. the SciPy bridge as the adjoint's solver) --------
+@pytest.mark.parametrize("t_grad", [True, False])
+@pytest.mark.parametrize("method,eps", [("dopri5", (3e-4, 1e-4, 2e-3)), ("scipy_solver", (3e-4, 1e-4, 2e-3))])
+def test_compare_adjoint_gradient_against_dopri5(dev, method, eps, t_grad):
+    class Odefunc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.A = torch.nn.Parameter(torch.tensor([[-0.1, 2.0], [-2.0, -0.1]]))
+            self.unused_module = torch.nn.Linear(2, 5)
+
+        def forward(self, t, y):
+            return torch.mm(y ** 3, self.A)
+
+    def problem():
+        return (Odefunc().to(dev), torch.tensor([[2.0, 0.0]], requires_grad=True),
+                torch.linspace(0.0, 25.0, 10).requires_grad_(t_grad))
+
+    func, y0, t_points = problem()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ys = tda.odeint_adjoint(func, y0, t_points, method=method)
+        g = torch.Generator().manual_seed(0)
+        gradys = (torch.rand(ys.shape, generator=g, device="cpu") * 0.1).to(dev)
+        ys.backward(gradys)
+    adj = (y0.grad, t_points.grad if t_grad else None, func.A.grad)
+    assert float(func.unused_module.weight.grad.abs().max()) == 0
+    assert float(func.unused_module.bias.grad.abs().max()) == 0
+    func, y0, t_points = problem()
+    ys = tda.odeint(func, y0, t_points, method="dopri5")
+    ys.backward(gradys)
+    assert float((y0.grad - adj[0]).abs().max()) < eps[0]
+    if t_grad:
+        assert float((t_points.grad - adj[1]).abs().max()) < eps[1]
+    assert float((func.A.grad - adj[2]).abs().max()) < eps[2]
