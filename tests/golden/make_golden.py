@@ -781,10 +781,47 @@ def gen_implicit():
     save("implicit.npz", **arrays)
 
 
+def gen_detest():
+    """The reference's integration benchmark (tests/DETEST/run.py) as a parity fixture: 24 classic non-stiff problems
+    solved over [0, 20] by the reference with dopri5 (tol 1e-3, 1e-6, 1e-9), tsit5 and dopri8 — solutions, evaluation
+    counts.  The problem definitions are restated in tests/_detest.py and checked here against the reference's own."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    sys.path.insert(0, "/root/reference/tests/DETEST")
+    import _detest
+    import detest as ref_detest
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)        # the reference's run.py works in double
+    arrays = {}
+    try:
+        for name, (field, y0) in _detest.problems().items():
+            rf, rinit, _ = getattr(ref_detest, name)()
+            rt0, ry0 = rinit()
+            assert torch.equal(ry0.double().reshape(y0.shape), y0), name
+            for tt in (0.0, 0.7, 3.1):
+                probe = y0 + 0.01 * (tt + 1)
+                assert torch.allclose(field(torch.tensor(tt), probe), rf(torch.tensor(tt), probe).double(), rtol=1e-14,
+                                      atol=1e-15), name
+            t = torch.tensor([0.0, 20.0])
+            for method, tol in [("dopri5", 1e-3), ("dopri5", 1e-6), ("dopri5", 1e-9), ("tsit5", 1e-6),
+                                ("dopri8", 1e-9)]:
+                nfe = [0]
+
+                def f(t_, y_):
+                    nfe[0] += 1
+                    return field(t_, y_)
+                with torch.no_grad():
+                    y = torchdiffeq.odeint(f, y0, t, rtol=tol, atol=tol, method=method)[1]
+                key = f"{name}_{method}_{tol:g}"
+                arrays[key], arrays[key + "_nfe"] = y, nfe[0]
+    finally:
+        torch.set_default_dtype(prev)
+    save("detest.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
                      ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
-                     ("adams", gen_adams), ("implicit", gen_implicit)]:
+                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest)]:
         if not only or name in only:
             fn()
