@@ -1,9 +1,10 @@
 """torchdiffeq_amd — MI355X-native explicit Runge–Kutta ODE solvers behind the torchdiffeq API.
 
 Drop-in surface for the reference's hot path (torchdiffeq/__init__.py:1-5, scope: SURVEY.md §8):
-`odeint`, `odeint_adjoint`, `odeint_event`, `odeint_dense` and the `SOLVERS` plugin table for every
-explicit Runge–Kutta method of the reference.  The state-sized
-arithmetic runs in hand-written gfx950 HIP kernels (libtdeq_hip.so, C-ABI in include/tdeq_hip.h).
+`odeint`, `odeint_adjoint`, `odeint_event`, `odeint_dense` and the `SOLVERS` plugin table with every method name
+of the reference (explicit Runge–Kutta = the hot path; Adams multistep and implicit RK on the same kernels; the
+SciPy bridge).  The state-sized arithmetic runs in hand-written gfx950 HIP kernels (libtdeq_hip.so, C-ABI in
+include/tdeq_hip.h).
 """
 from .odeint import SOLVERS, odeint, odeint_dense, odeint_event
 from .adjoint import odeint_adjoint
