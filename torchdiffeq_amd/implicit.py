@@ -268,12 +268,15 @@ class FixedGridImplicitRKSolver(FixedGridODESolver):
 
             def residual(Kf: torch.Tensor) -> torch.Tensor:
                 ks = split(Kf)
-                res = torch.zeros_like(Kf)
+                res = torch.empty_like(Kf)
                 for i, st in enumerate(stages):
-                    if st is None:
+                    if st is None:                       # stored slope: this block of the residual is identically zero
+                        res[i * stride:(i + 1) * stride].zero_()
                         continue
                     fi = func.eval(st[0], stage_input(ks, self._beta[i]), st[1])
                     kern.weighted_sum(res[i * stride:i * stride + n], [ks[i], fi], [1.0, -1.0])
+                    if stride > n:
+                        res[i * stride + n:(i + 1) * stride].zero_()      # alignment padding of the stacked unknown
                 return res
 
             with torch.no_grad():
