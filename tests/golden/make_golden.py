@@ -652,6 +652,13 @@ def gen_adams():
             fs = lambda t, y: (1 - t * 0.5) * (y * -0.7) - y * y * y * 0.01
             arrays[f"{method}_zerodim"] = torchdiffeq.odeint(fs, torch.tensor(1.5), torch.linspace(0, 1, 41),
                                                              method=method, rtol=1e-6, atol=1e-8)
+    # 0-dim fp32 state on an fp64 time grid: `dt * f` promotes to fp64 and the rest of the solve runs in fp64
+    fs = lambda t, y: (1 - t * 0.5) * (y * -0.7) - y * y * y * 0.01
+    with torch.no_grad():
+        for method in ["euler", "midpoint", "heun3", "rk4", "explicit_adams", "implicit_adams"]:
+            arrays[f"zerodim64_{method}"] = torchdiffeq.odeint(fs, torch.tensor(1.5),
+                                                               torch.linspace(0, 1, 21, dtype=torch.float64),
+                                                               method=method, rtol=1e-6, atol=1e-8)
     # kernel-level vectors: the reference's own expressions (fixed_adams.py:205, :210, :213-215, :189-192) on random data
     for dtype, tag in [(torch.float32, "f32"), (torch.float64, "f64")]:
         n, order = 777, 7

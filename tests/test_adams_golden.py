@@ -123,6 +123,19 @@ def test_zero_dim_fp32_state_promotion_quirk(dev, method):
     assert torch.equal(y, ref)
 
 
+@pytest.mark.parametrize("method", ["euler", "midpoint", "heun3", "rk4", "explicit_adams", "implicit_adams"])
+def test_zero_dim_fp32_state_on_fp64_grid_runs_in_fp64_like_the_reference(dev, method):
+    """`dt` (0-dim fp64) x `f` (0-dim fp32) promotes: after the first evaluation the reference's solve is fp64 and only
+    the stored rows are fp32 (odeint._zero_dim_promotion).  Bit for bit."""
+    z = load("adams.npz")
+    fs = lambda t, y: (1 - t * 0.5) * (y * -0.7) - y * y * y * 0.01
+    with torch.no_grad():
+        y = tda.odeint(fs, torch.tensor(1.5), torch.linspace(0, 1, 21, dtype=torch.float64, device="cpu").to(dev),
+                       method=method, rtol=1e-6, atol=1e-8)
+    ref = T(z[f"zerodim64_{method}"], dev)
+    assert y.dtype == torch.float32 and torch.equal(y, ref)
+
+
 @pytest.mark.parametrize("method", METHODS)
 def test_backprop_through_the_solver(dev, method):
     """Gradients wrt y0, t and the field's parameters equal the reference's autograd-through-eager-ops result."""

@@ -44,6 +44,31 @@ SOLVERS = {
 }
 
 
+_PROMOTING_METHODS = ("euler", "midpoint", "heun2", "heun3", "rk4", "explicit_adams", "implicit_adams", "fixed_adams")
+
+
+def _zero_dim_promotion(func, y0, t, method, options, event_fn):
+    """A type-promotion artefact of the reference, reproduced: a 0-dim fp32 state on an fp64 time grid.  In the
+    explicit fixed-grid and Adams steps `dt` (0-dim fp64) multiplies `f` (0-dim fp32) — two 0-dim tensors promote by
+    dtype, so `dy`, `y1` and every later stage are fp64: after the very first evaluation (t and y still fp32) the
+    whole solve runs in fp64 and only the stored outputs are rounded to fp32 (solvers.py:104-127, rk_common.py:110-157,
+    fixed_adams.py:196-223).  Returned: the func to integrate in fp64, or None when the case does not apply (also with
+    `perturb`, whose first evaluation time the reference perturbs in fp32, and with step callbacks)."""
+    if not (event_fn is None and isinstance(y0, torch.Tensor) and y0.dim() == 0 and y0.dtype == torch.float32
+            and isinstance(t, torch.Tensor) and t.dtype == torch.float64 and method in _PROMOTING_METHODS):
+        return None
+    if (options or {}).get("perturb") or getattr(func, "callback_step", None) is not None:
+        return None
+    first = [True]
+
+    def promoted(t_, y_):
+        if first[0]:
+            first[0] = False
+            return func(t_.to(torch.float32), y_.to(torch.float32)).to(torch.float64)
+        return func(t_, y_)
+    return promoted
+
+
 def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None):
     """Integrate dy/dt = func(t, y), y(t[0]) = y0, returning y at every time in `t`.
 
@@ -59,6 +84,9 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
     hand-written backward (autodiff.py), so the result can be backpropagated *through* the solver like the
     reference's; `odeint_adjoint` gives the same gradients in O(1) memory.
     """
+    promoted = _zero_dim_promotion(func, y0, t, method, options, event_fn)
+    if promoted is not None:
+        return odeint(promoted, y0.double(), t, rtol=rtol, atol=atol, method=method, options=options).to(y0.dtype)
     ci = check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS)
     y0_flat = ci.y0_flat
     if torch.is_grad_enabled():
