@@ -9,7 +9,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def load(name):
-    return np.load(os.path.join(GOLDEN, name))
+    """The arrays of a golden file as a dict (read eagerly: no file handle is left for the GC to warn about)."""
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        return {k: z[k] for k in z.files}
 
 
 def T(a, device="cpu"):

@@ -80,7 +80,8 @@ def test_solves_match_the_reference(dev, method):
         assert got.shape == ref.shape and got.dtype == ref.dtype
         assert torch.equal(got, ref), tag
         assert c.nfe == int(z[f"{method}_{tag}_nfe"]), tag
-        assert len(w) == int(z[f"{method}_{tag}_warnings"]), tag
+        n_warn = sum("did not converge" in str(x.message) for x in w)      # (a ResourceWarning of another test may land here)
+        assert n_warn == int(z[f"{method}_{tag}_warnings"]), tag
 
 
 @pytest.mark.parametrize("method", METHODS)

@@ -76,7 +76,8 @@ def test_solves_match_the_reference(dev, method):
         # a residual norm within rounding of the stopping tolerance may cost one more / one fewer iteration
         # (each costs one evaluation per stage); measured: identical counts for every case
         assert abs(c.nfe - int(z[f"{method}_{tag}_nfe"])) <= 2 * len(IMPLICIT_TABLEAUS[method].alpha), tag
-        assert len(w) == int(z[f"{method}_{tag}_warnings"]), tag
+        n_warn = sum("did not converge" in str(x.message) for x in w)      # (a ResourceWarning of another test may land here)
+        assert n_warn == int(z[f"{method}_{tag}_warnings"]), tag
 
 
 @pytest.mark.parametrize("method", METHODS)
