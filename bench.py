@@ -1,35 +1,58 @@
 #!/usr/bin/env python
 """bench.py — BASELINE.json's headline metric on the MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload linear|adjoint] [--scaling weak|strong]
 
-Workload (BASELINE.json configs[1]): dopri5, linear field dy/dt = A y, state
-65536 x 128 fp32 per GPU, rtol 1e-7 / atol 1e-9 (reference defaults), synthetic seeded data.
-One "step" = one dopri5 trial step of the adaptive solver = 6 RK stages: 6 `stage_combine` launches
-interleaved with 6 evaluations of the field (a 65536x128x128 GEMM run by PyTorch-ROCm), one fused
-`error_norm` launch, one read-back of the error sum and the host step controller.  The state is
-resident in HBM before the timed region.  value = RK stages per second over all ranks (weak scaling:
-every rank integrates its own 65536-row shard with its own accept/reject loop, no data-path
-collective — SURVEY.md §8e).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself as N ranks (one process per GPU,
+`python -m torch.distributed.run ... bench.py`, rendezvous on 127.0.0.1, backend nccl = RCCL); under
+`torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* itself.  Rank r owns GPU r.
+`TDEQ_DIST_BACKEND=gloo` runs the N > 1 control flow on a box with fewer GPUs than ranks (ranks share devices).
 
-Extra objects in the JSON line:
-  roofline      dominant kernel = stage_combine with 5 stage terms (tableau row 5: read 5 k_j + y0, write
-                y_i = 7 words/element = 234.9 MB per launch at this size; row 6 is the same kernel plus the
-                fused partial-error store); its launches inside the TIMED region stamp HIP events with the dispatch's own
-                begin / end times (tdeq_stage_combine_timed -> hipExtLaunchKernelGGL) on the launch stream.
+Workloads
+  linear   (default) BASELINE.json configs[1] / SURVEY.md §8d cfg2 — the configuration the metric is quoted on:
+           dopri5, dy/dt = A y, state 65536 x 128 fp32 per GPU, rtol 1e-7 / atol 1e-9, synthetic seeded data.
+           One "step" = one dopri5 trial step of the adaptive solver = 6 RK stages: 6 `stage_combine` launches
+           interleaved with 6 evaluations of the field (a 65536x128x128 GEMM run by PyTorch-ROCm), one fused
+           `error_norm` launch, one read-back and the host step controller.  State resident in HBM before the timed
+           region.  Weak scaling by default (every rank integrates its own 65536-row shard with its own accept/reject
+           loop, no data-path collective — SURVEY.md §8e); `--scaling strong` splits the ONE 65536-row batch.
+  adjoint  BASELINE.json configs[2] / cfg3 — odeint_adjoint, MLP 64-256-256-64, 65536 x 64 fp32, rtol 1e-5 /
+           atol 1e-7, loss sum(y(1)^2); rows sharded over the ranks, parameter gradients summed by ONE all-reduce
+           (RCCL over xGMI) at the end of backward (torchdiffeq_amd.dist.odeint_adjoint_sharded).  One "step" = one
+           forward + backward pass; value = RK stages (forward + backward solves) per second.
+
+Timing: W warm-up steps, then 5 blocks of exactly K steps each, every block bracketed by a barrier +
+torch.cuda.synchronize(); per block the MAX over ranks; `value` / `ms_per_step` are the MEDIAN block (min / max in
+`blocks`).
+
+Extra objects in the JSON line (linear workload):
+  roofline      dominant kernel = stage_combine with 5 stage terms (tableau row 5: read 5 k_j + y0, write y_i =
+                7 words/element = 234.9 MB per launch; row 6 is the same kernel plus the fused partial-error store);
+                `achieved`/`frac` = IN SITU: its launches inside the timed region, each stamped by the dispatch itself
+                (tdeq_stage_combine_timed -> hipExtLaunchKernelGGL start/stop events) — every launch when K <= 50,
+                every 4th otherwise; the stage tensors were written by `func` just before, so part of the reads is
+                served by the 256 MiB Infinity Cache.  `cold` = the same kernel on 4 rotating buffer sets (940 MB
+                > 256 MiB), i.e. every byte from HBM.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes
+                committed under profiles/ (`traffic_source`; counters cannot be read from inside this process).
   solver_only   the step's solver kernels alone, back to back on the last step's stage tensors.
-  reference_style_eager_gpu   the reference's eager op sequence restated in stock PyTorch (oracle/eager_torch_port.py)
-                timed on the same GPU and state: what a user of the reference gets on an MI355X today.
-  cpu_baseline  the CPU oracle (oracle/reference_solver.py + rk_oracle.c, OpenMP on all host cores) on
-                a bounded sample of the same workload (rank 0, N=1 only).
-  rel_err       max rel-err of a full odeint(t=[0,1]) at this size vs the closed form y0 expm(A)^T.
+  shard_regime  (N = 1) what one GPU does on a 1/8 shard of the batch — the per-rank work of an 8-GPU strong-scaling
+                run: 8192 x 128 linear trial steps (host-driven, look-ahead, hip_graph) and the 8192 x 64 adjoint pass.
+  strong, adjoint  (N > 1) the same ranks on the strong-scaling split of cfg2 and on cfg3 with its all-reduce.
+  rel_err_vs_reference  full odeint(t=[0,1]) of cfg2 vs the REFERENCE's own result on these inputs
+                (tests/golden/fullsize_cfg2.npz, sample rows; rank 0), next to rel_err vs the closed form.
+  reference_style_eager_gpu   the reference's eager op sequence restated in stock PyTorch on the same GPU.
+  cpu_baseline  the CPU oracle (a port: the reference itself cannot travel to the GPU box) on a bounded sample, on
+                rank 0 at N = 1, with BASELINE.md's figure for the real reference on 8 cores beside it.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -38,14 +61,21 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BATCH, DIM = 65536, 128
 RTOL, ATOL = 1e-7, 1e-9
+ADJ_BATCH, ADJ_DIM = 65536, 64
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_BLOCKS = 5
 
 
-def make_problem(device, seed_offset=0):
-    """SURVEY.md §8(d) cfg2 synthetic inputs (per-rank seed offset for the weak-scaling shards)."""
+# ---------------------------------------------------------------------------------------------------
+# problems
+# ---------------------------------------------------------------------------------------------------
+def make_problem(device, seed_offset=0, rows=None):
+    """cfg2 synthetic inputs (per-rank seed offset for the weak-scaling shards; `rows` = strong-scaling shard of
+    rank 0's batch)."""
     g = torch.Generator().manual_seed(0)
     G = torch.randn(DIM, DIM, generator=g, dtype=torch.float64) / DIM ** 0.5
     A = (0.5 * (G - G.T) - 0.1 * torch.eye(DIM, dtype=torch.float64)).float()
@@ -53,19 +83,52 @@ def make_problem(device, seed_offset=0):
     # other ranks draw their own 65536 rows from generator seed = rank.
     gy = g if seed_offset == 0 else torch.Generator().manual_seed(seed_offset)
     y0 = torch.randn(BATCH, DIM, generator=gy, dtype=torch.float64).float()
+    if rows is not None:
+        y0 = y0[rows].contiguous()
     return A.to(device), y0.to(device)
+
+
+def dist_sync(world):
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world, device):
+    if world == 1:
+        return x
+    v = torch.tensor([x], device=device, dtype=torch.float64)
+    torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX)
+    return float(v.item())
+
+
+def timed_blocks(step_fn, steps, warmup, world, device, n_blocks=N_BLOCKS):
+    """W warm-up calls, then n_blocks blocks of exactly `steps` calls; per block barrier + synchronize on both sides
+    and the max over ranks.  Returns the per-block seconds."""
+    for _ in range(warmup):
+        step_fn()
+    blocks = []
+    for _ in range(n_blocks):
+        dist_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        blocks.append(max_over_ranks(time.perf_counter() - t0, world, device))
+    return blocks
 
 
 class EventTimedKernels:
     """Forwards to HipKernels; while `armed`, the dominant kernel's launches go through tdeq_stage_combine_timed,
     whose dispatch stamps a pair of HIP events with its own begin / end timestamps (hipExtLaunchKernelGGL)."""
 
-    EVERY = 4      # an event-stamped dispatch costs a few microseconds of pipeline: sample every 4th launch
-
-    def __init__(self, inner, dominant_terms, n_events):
+    def __init__(self, inner, dominant_terms, n_events, every):
         self._seen = 0
         self._inner = inner
         self._nt = dominant_terms
+        self.every = every         # an event-stamped dispatch costs a few microseconds of pipeline
         self.armed = False
         self.events = []
         # events are created (and recorded once: torch creates the hipEvent_t lazily) before the timed region
@@ -82,7 +145,7 @@ class EventTimedKernels:
     def stage_combine(self, out, y0, ks, coefs, dt):
         if self.armed and len(ks) == self._nt:
             self._seen += 1
-            if self._seen % self.EVERY == 0 and self._pool:
+            if self._seen % self.every == 0 and self._pool:
                 e0, e1 = self._pool.pop()
                 self._inner.stage_combine_timed(out, y0, ks, coefs, dt, e0, e1)
                 self.events.append((e0, e1))
@@ -90,9 +153,11 @@ class EventTimedKernels:
         self._inner.stage_combine(out, y0, ks, coefs, dt)
 
 
+# ---------------------------------------------------------------------------------------------------
+# baselines
+# ---------------------------------------------------------------------------------------------------
 def cpu_baseline(max_seconds=20.0):
     """Oracle (port of the reference algorithm) timed on this host's cores on a bounded sample."""
-    import numpy as np
     from oracle import reference_solver as orc
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
@@ -111,7 +176,13 @@ def cpu_baseline(max_seconds=20.0):
     dt = time.perf_counter() - t0
     return {"value": 6 * steps / dt, "unit": "RK-stages/s", "cores": cores, "kind": "port",
             "sample": f"{steps} dopri5 trial steps ({6 * steps} RK stages) of the same 65536x128 fp32 workload, "
-                      f"oracle/rk_oracle.c with OpenMP on {cores} threads + numpy GEMM, {dt:.1f} s"}
+                      f"oracle/rk_oracle.c with OpenMP on {cores} threads + numpy GEMM, {dt:.1f} s",
+            "why_a_port": "the reference is a Python package mounted only in the build container (/root/reference); it "
+                          "does not exist on the GPU box, so the CPU leg there is the committed restatement of its "
+                          "algorithm (oracle/, pinned to the reference's outputs by tests/test_oracle_golden.py)",
+            "reference_8core": {"value": 3.08, "unit": "RK-stages/s", "cores": 8, "kind": "reference",
+                                "source": "BASELINE.md §2: rtqichen/torchdiffeq v0.2.5 itself, this workload at full "
+                                          "size, torch CPU on the build container's 8-core Xeon (21.44 s for NFE 68)"}}
 
 
 def eager_gpu_baseline(field, y0, first_step, steps=12):
@@ -134,19 +205,440 @@ def eager_gpu_baseline(field, y0, first_step, steps=12):
                       "per trial step) on this GPU"}
 
 
+# ---------------------------------------------------------------------------------------------------
+# linear workload (cfg2)
+# ---------------------------------------------------------------------------------------------------
+def make_stepper(field, y0, hip_graph=False, lookahead=None):
+    """A Dopri5Solver in the middle of a long solve (no output time ahead — where the look-ahead first stage
+    applies), ready for `_trial_step()` calls."""
+    from torchdiffeq_amd.misc import OdeFunc, StateLayout, rms_norm
+    from torchdiffeq_amd.solvers import Dopri5Solver
+    layout = StateLayout([y0.shape], False)
+    func = OdeFunc(field, layout, 1.0, y0.dtype, y0.device)
+    prev = os.environ.get("TDEQ_LOOKAHEAD")
+    if lookahead is not None:
+        os.environ["TDEQ_LOOKAHEAD"] = "1" if lookahead else "0"
+    try:
+        solver = Dopri5Solver(func=func, y0=y0.reshape(-1), rtol=RTOL, atol=ATOL, norm=rms_norm, hip_graph=hip_graph)
+    finally:
+        if lookahead is not None:
+            if prev is None:
+                os.environ.pop("TDEQ_LOOKAHEAD", None)
+            else:
+                os.environ["TDEQ_LOOKAHEAD"] = prev
+    solver._before_integrate([0.0])
+    solver._t_end = float("inf")
+    return solver
+
+
+def time_steps(solver, steps, warmup, world, device, n_blocks=N_BLOCKS):
+    with torch.no_grad():
+        blocks = timed_blocks(solver._trial_step, steps, warmup, world, device, n_blocks)
+        if solver._g is not None:
+            torch.cuda.synchronize()
+            solver._g.release()
+    return blocks
+
+
+def block_stats(blocks, steps):
+    ms = sorted(1e3 * b / steps for b in blocks)
+    return {"median": statistics.median(ms), "min": ms[0], "max": ms[-1], "n_blocks": len(ms), "steps_per_block": steps}
+
+
+def solver_only_rate(solver, device):
+    """the 6 stage_combine launches + error_norm (+ finalize) of one dopri5 step on the k tensors
+    of the last timed step, no func, HIP events around REPS back-to-back passes."""
+    rec = solver._dense
+    kern = solver.kernels._inner if hasattr(solver.kernels, "_inner") else solver.kernels
+    ks, y0s = rec.k, rec.y0
+    outs = [torch.empty_like(y0s) for _ in range(2)]
+    REPS = 30
+    fuse = solver._fuse
+    epart = torch.empty_like(y0s)
+    last = len(solver._beta) - 1
+    la = bool(solver._lookahead and fuse is not None)
+    tnext = torch.empty(len(solver._beta), dtype=y0s.dtype, device=device)
+
+    def one_pass():
+        # exactly the solver's launch sequence for one trial step, minus func (and, without look-ahead, the
+        # stage-time fill)
+        for i, row in enumerate(solver._beta):
+            if i == 0 and la:
+                kern.stage_combine_sel(outs[0], rec.y1, ks[-1], y0s, ks[0], row.coef[0], solver.plan)
+            elif i == last and fuse is not None:
+                kern.stage_combine_err(outs[i & 1], epart, y0s, [ks[j] for j in row.idx], row.coef, fuse[0],
+                                       rec.dt_signed)
+            else:
+                kern.stage_combine(outs[i & 1], y0s, [ks[j] for j in row.idx], row.coef, rec.dt_signed)
+        if la:
+            solver._ctrl.t0, solver._ctrl.dt = rec.t0, rec.t1 - rec.t0
+            kern.error_norm_partial_ctrl(solver.plan, epart, y0s, rec.y1, [ks[j] for j in fuse[1]], fuse[2],
+                                         rec.dt_signed, solver._ctrl, tnext)
+        elif fuse is not None:
+            kern.error_norm_partial(solver.plan, epart, y0s, rec.y1, [ks[j] for j in fuse[1]], fuse[2], rec.dt_signed)
+        else:
+            kern.error_norm(solver.plan, y0s, rec.y1, [ks[j] for j in solver._c_err.idx], solver._c_err.coef,
+                            rec.dt_signed)
+    for _ in range(3):
+        one_pass()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REPS):
+        one_pass()
+    e1.record()
+    torch.cuda.synchronize()
+    solver.plan.expect = ()     # the passes' results are not read back
+    t_step = e0.elapsed_time(e1) * 1e-3 / REPS
+    n = y0s.numel()
+    # SURVEY.md §8(d) counts 32 + 8 = 40 words per element for a dopri5 step; the end-of-step fusion moves
+    # 37 (3+4+5+6+7+8 for the six combines, 4 for the norm) — both rates are reported.
+    moved = (37 if fuse is not None else 40) * n * 4
+    survey = 40 * n * 4
+    return {"stages_per_s": 6 / t_step, "us_per_step": 1e6 * t_step,
+            "bytes_moved_per_step": moved, "GBps_moved": moved / t_step / 1e9,
+            "frac_of_hbm_peak_moved": moved / t_step / 1e9 / HBM_PEAK_GBPS,
+            "survey_algorithmic_bytes_per_step": survey, "GBps_survey_bytes": survey / t_step / 1e9,
+            "note": "the solver's own launch sequence for one dopri5 trial step (stage_combine_sel + 4 "
+                    "stage_combine + stage_combine_err + error_norm_partial + controller finalize) back "
+                    "to back, no func; the 7 k tensors (235 MB) + y0/y1 fit the 256 MiB Infinity Cache "
+                    "only partly"}
+
+
+def cold_dominant_kernel(kern, n, device, sets=4, launches=24):
+    """The dominant kernel (5 stage terms, 7 words per element) on `sets` rotating buffer sets whose total size
+    exceeds the 256 MiB Infinity Cache several times: every read comes from HBM.  Timed per launch by the dispatch's
+    own start/stop events."""
+    g = torch.Generator(device="cpu").manual_seed(1)
+    bufs = []
+    for _ in range(sets):
+        y0 = torch.randn(n, generator=g).to(device)
+        ks = [torch.randn(n, generator=g).to(device) for _ in range(5)]
+        bufs.append((y0, ks, torch.empty(n, device=device)))
+    coefs = [0.1, -0.2, 0.3, 0.25, -0.15]
+    for y0, ks, out in bufs:                    # first touch
+        kern.stage_combine(out, y0, ks, coefs, 0.1)
+    torch.cuda.synchronize()
+    evs = []
+    for i in range(launches):
+        y0, ks, out = bufs[i % sets]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        kern.stage_combine_timed(out, y0, ks, coefs, 0.1, e0, e1)
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in evs]
+    avg = sum(ms) / len(ms)
+    bytes_per_launch = 7 * n * 4
+    ach = bytes_per_launch / (avg * 1e-3) / 1e9
+    return {"achieved": ach, "frac": ach / HBM_PEAK_GBPS, "avg_launch_ms": avg, "launches_timed": len(ms),
+            "buffer_sets": sets, "working_set_bytes": sets * 7 * n * 4,
+            "note": "same kernel, rotating buffer sets larger than the 256 MiB Infinity Cache: all reads from HBM"}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (tools/profile_gpu.sh)."""
+    for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
+        try:
+            kernels = json.load(open(pmc_path))["kernels"]
+            hit = [v for k, v in kernels.items() if k.startswith("tdeq::stage_combine_kernel<float, 5,")]
+            if hit:
+                return hit[0]["hbm_bytes_per_launch"], os.path.relpath(pmc_path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def reference_rel_err(y_end):
+    """max rel-err of y(1) vs the REFERENCE's result on the same inputs (sample rows of tests/golden/fullsize_cfg2.npz)."""
+    import _fullsize as fs
+    z = fs.load("cfg2")
+    rows = torch.from_numpy(z["rows"]).to(y_end.device)
+    return fs.sample_rel_err(y_end[rows], z["y_end_rows"], z["y_end_absmax"]), int(z["nfe"])
+
+
+def shard_regime_linear(device, steps=100, warmup=20):
+    """One GPU on the 8192 x 128 shard (1/8 of cfg2): ms per trial step on the three step paths."""
+    A, y0 = make_problem(device, rows=slice(0, BATCH // 8))
+    At = A.T.contiguous()
+    field = lambda t, y: y @ At
+    out = {"state": f"{BATCH // 8} x {DIM} fp32 (1/8 of cfg2)", "steps_per_block": steps}
+    for name, kw in (("host_driven", dict(lookahead=False)), ("lookahead", dict(lookahead=True)),
+                     ("hip_graph", dict(hip_graph=True))):
+        try:
+            solver = make_stepper(field, y0, **kw)
+            blocks = time_steps(solver, steps, warmup, 1, device, n_blocks=3)
+            st = block_stats(blocks, steps)
+            out[name] = {"ms_per_step": st["median"], "min": st["min"], "max": st["max"],
+                         "stages_per_s_of_the_shard": 6e3 / st["median"]}
+        except Exception as exc:
+            out[name] = {"error": repr(exc)}
+    return out
+
+
+def run_linear(args, rank, world, device):
+    import torchdiffeq_amd as tda
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        from torchdiffeq_amd.dist import shard_rows
+        A, y0 = make_problem(device, rows=shard_rows(BATCH, rank, world))
+    else:
+        A, y0 = make_problem(device, seed_offset=rank)
+    At = A.T.contiguous()
+    field = lambda t, y: y @ At
+    n = y0.numel()
+
+    # ---- parity at full size: whole odeint vs the closed form and vs the reference's own result ----
+    rel_err = rel_err_ref = ref_nfe = odeint_wall = None
+    nfe = [0]
+
+    def counted(t, y):
+        nfe[0] += 1
+        return y @ At
+    with torch.no_grad():
+        t_wall = time.perf_counter()
+        y_end = tda.odeint(counted, y0, torch.tensor([0.0, 1.0], device=device), rtol=RTOL, atol=ATOL, method="dopri5")[-1]
+        torch.cuda.synchronize()
+        odeint_wall = time.perf_counter() - t_wall
+        exact = y0.double() @ torch.linalg.matrix_exp(A.double()).T
+        rel_err = float((y_end.double() - exact).abs().max() / exact.abs().max())
+        if rank == 0 and not strong:
+            try:
+                rel_err_ref, ref_nfe = reference_rel_err(y_end)
+            except Exception as exc:
+                rel_err_ref = repr(exc)
+        del exact
+
+    # ---- timed region ----
+    auto_graph = strong and n <= (1 << 21) and os.environ.get("TDEQ_BENCH_GRAPH", "1") != "0"
+    solver = make_stepper(field, y0, hip_graph=auto_graph)
+    every = 1 if args.steps <= 50 else 4
+    timed = EventTimedKernels(solver.kernels, dominant_terms=5, n_events=N_BLOCKS * args.steps // every + 1, every=every)
+    solver.kernels = timed
+    solver.ops.k = timed        # the elementwise kernels are issued through solver.ops
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            solver._trial_step()
+        timed.armed = True
+        blocks = timed_blocks(solver._trial_step, args.steps, 0, world, device)
+        timed.armed = False
+    st = block_stats(blocks, args.steps)
+    ms_per_step = st["median"]
+    # weak: every rank did its own stages; strong: a stage of the global batch is done when every shard's is
+    value = 6e3 / ms_per_step * (1 if strong else world)
+
+    out = None
+    if rank == 0:
+        kernel_ms = [a.elapsed_time(b) for a, b in timed.events]
+        avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        bytes_per_launch = 7 * n * 4
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kernel_ms else None
+        traffic, traffic_src = pmc_traffic() if n == BATCH * DIM else (None, None)
+        out = {
+            "metric": "dopri5 RK-stages/sec at batch=65536x dim=128 (end-to-end adaptive trial steps incl. func, "
+                      "error norm, read-back and host controller)",
+            "value": value, "unit": "RK-stages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: dopri5 adaptive, linear ODE dy/dt=Ay, batch=65536 x "
+                                   "dim=128 fp32 " + ("in total, rows split over the GPUs" if strong else "per GPU")
+                                   + ", rtol=1e-7 atol=1e-9",
+                       "global_batch": BATCH if strong else BATCH * world, "rows_per_gpu": y0.shape[0], "dim": DIM,
+                       "parallelism": f"batch-sharded x{world}", "accepted": solver.n_accepted,
+                       "rejected": solver.n_rejected, "lookahead": bool(solver._lookahead),
+                       "hip_graph": bool(solver.hip_graph),
+                       "backend": torch.distributed.get_backend() if world > 1 else None},
+            "blocks": {"ms_per_step": st, "value_is": "median block"},
+            "rel_err_vs_reference": rel_err_ref,
+            "rel_err_vs_reference_definition": "max|y - y_ref| over the sample rows / max|y_ref| of odeint(t=[0,1]) at "
+                                               "full size, y_ref = rtqichen/torchdiffeq v0.2.5 on the same inputs "
+                                               "(tests/golden/fullsize_cfg2.npz; rank 0's shard = SURVEY cfg2)",
+            "nfe": nfe[0], "reference_nfe": ref_nfe,
+            "rel_err": rel_err,
+            "rel_err_definition": "max|y - y_exact| / max|y_exact| vs the closed form y0 @ expm(A)^T (the reference's "
+                                  "own fp32 result scores 2.2-2.8e-6 on this)",
+            "odeint_t01_wall_s": odeint_wall,
+        }
+        if n == BATCH * DIM:
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "stage_combine_kernel<float, 5, 1, true>", "achieved": achieved,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                "frac_is": "in situ (stage tensors freshly written by func; partly Infinity-Cache resident) — see `cold`",
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+                "timing": "HIP events stamped by the dispatch itself (hipExtLaunchKernelGGL start/stop) on the launch "
+                          f"stream, every {'launch' if every == 1 else '4th launch'} of this kernel in the timed blocks",
+                "launches_timed": len(kernel_ms), "traffic": traffic,
+                "traffic_source": (traffic_src + " (rocprofv3 --pmc passes of this same command, replayed — not "
+                                   "measured in this run)") if traffic_src else None}
+            try:
+                out["roofline"]["cold"] = cold_dominant_kernel(timed._inner, n, device)
+            except Exception as exc:
+                out["roofline"]["cold"] = {"error": repr(exc)}
+            try:
+                out["solver_only"] = solver_only_rate(solver, device)
+            except Exception as exc:      # never let the extra figure break the contract line
+                out["solver_only"] = {"error": repr(exc)}
+    if solver._g is not None:
+        torch.cuda.synchronize()
+        solver._g.release()
+    return out, field, y0
+
+
+# ---------------------------------------------------------------------------------------------------
+# adjoint workload (cfg3)
+# ---------------------------------------------------------------------------------------------------
+class AllReduceProbe:
+    """Counts and times torch.distributed.all_reduce calls (device-synchronised on both sides) while active."""
+
+    def __init__(self):
+        self.calls, self.bytes, self.seconds = 0, 0, 0.0
+        self._orig = None
+
+    def __enter__(self):
+        import torch.distributed as dist
+        self._orig = dist.all_reduce
+
+        def probed(tensor, *a, **kw):
+            if tensor.is_cuda:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = self._orig(tensor, *a, **kw)
+            if tensor.is_cuda:
+                torch.cuda.synchronize()
+            self.seconds += time.perf_counter() - t0
+            self.calls += 1
+            self.bytes += tensor.numel() * tensor.element_size()
+            return r
+        dist.all_reduce = probed
+        return self
+
+    def __exit__(self, *exc):
+        import torch.distributed as dist
+        dist.all_reduce = self._orig
+
+
+def adjoint_pass(world, rank, device, rows_per_rank, steps, warmup, group_forced=False):
+    """cfg3 on this rank's `rows_per_rank` rows: K forward + backward passes through odeint_adjoint_sharded."""
+    import _fullsize as fs
+    from torchdiffeq_amd import dist as tdist
+    field, y0_all = fs.cfg3_problem()
+    if rows_per_rank * world <= ADJ_BATCH:
+        lo = rank * rows_per_rank
+        y0 = y0_all[lo:lo + rows_per_rank].clone()
+    else:       # weak scaling: every rank its own 65536 rows (rank 0 = the survey's)
+        y0 = y0_all if rank == 0 else torch.randn(rows_per_rank, ADJ_DIM, generator=torch.Generator().manual_seed(rank))
+    field = field.to(device)
+    y0 = y0.to(device)
+    t = torch.tensor([0.0, 1.0], device=device)
+    params = list(field.parameters())
+    stats = {}
+    group = torch.distributed.group.WORLD if (world > 1 or group_forced) else None
+
+    def one():
+        for p in params:
+            p.grad = None
+        x = y0.clone().requires_grad_(True)
+        field.nfe = 0
+        y = tdist.odeint_adjoint_sharded(field, x, t, group=group, rtol=1e-5, atol=1e-7, method="dopri5")
+        stats["nfe_fwd"], field.nfe = field.nfe, 0
+        y[-1].pow(2).sum().backward()
+        stats["nfe_bwd"] = field.nfe
+    blocks = timed_blocks(one, steps, warmup, world, device, n_blocks=3)
+    # one more instrumented pass: forward / backward split and the all-reduce on its own clock
+    dist_sync(world)
+    with AllReduceProbe() as probe:
+        for p in params:
+            p.grad = None
+        x = y0.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        y = tdist.odeint_adjoint_sharded(field, x, t, group=group, rtol=1e-5, atol=1e-7, method="dopri5")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        y[-1].pow(2).sum().backward()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    st = block_stats(blocks, steps)
+    stages = (stats["nfe_fwd"] - 2) + (stats["nfe_bwd"] - 2)
+    grad_norm = float(torch.cat([p.grad.reshape(-1) for p in params]).double().norm())
+    return {"rows_per_gpu": rows_per_rank, "ms_per_pass": st["median"], "blocks": st,
+            "fwd_ms": 1e3 * max_over_ranks(t1 - t0, world, device),
+            "bwd_ms_incl_allreduce": 1e3 * max_over_ranks(t2 - t1, world, device),
+            "nfe_fwd": stats["nfe_fwd"], "nfe_bwd": stats["nfe_bwd"], "rk_stages_per_pass": stages,
+            "allreduce": {"calls": probe.calls, "bytes": probe.bytes, "ms": 1e3 * probe.seconds,
+                          "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                          "what": "parameter adjoints: the contiguous tail of the flat augmented state, one call "
+                                  "(reference: adj_params = aug_state[3:], adjoint.py:150-153)"},
+            "param_grad_l2": grad_norm}
+
+
+def run_adjoint(args, rank, world, device):
+    strong = args.scaling == "strong"
+    rows = ADJ_BATCH // world if strong else ADJ_BATCH
+    r = adjoint_pass(world, rank, device, rows, args.steps, args.warmup)
+    if rank != 0:
+        return None
+    # strong: a stage of the global batch is done when every shard's is; weak: ranks' stages add up
+    value = r["rk_stages_per_pass"] / (r["ms_per_pass"] * 1e-3) * (1 if strong else world)
+    return {
+        "metric": "odeint_adjoint RK-stages/sec (dopri5 forward + augmented backward solve, incl. func, its VJPs and "
+                  "the parameter-gradient all-reduce)",
+        "value": value, "unit": "RK-stages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_pass"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2]: odeint_adjoint, MLP 64-256-256-64 (P=98,880), batch=65536 x "
+                               "dim=64 fp32 " + ("in total, rows split over the GPUs" if strong else "per GPU")
+                               + ", rtol=1e-5 atol=1e-7, loss sum(y(1)^2)",
+                   "global_batch": ADJ_BATCH if strong else ADJ_BATCH * world, "rows_per_gpu": rows,
+                   "parallelism": f"batch-sharded x{world}, one all-reduce of the parameter adjoints per backward"},
+        "adjoint": r,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------
+# launch
+# ---------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` as a plain command: start N ranks of this script under torch.distributed.run."""
+    env = dict(os.environ)
+    visible = torch.cuda.device_count()
+    if args.gpus > visible and not env.get("TDEQ_DIST_BACKEND"):
+        # RCCL refuses two ranks on one GPU; say so in the line instead of dying without one
+        env["TDEQ_DIST_BACKEND"] = "gloo"
+        env["TDEQ_BENCH_NOTE"] = f"{args.gpus} ranks on {visible} visible GPU(s): ranks share devices, backend gloo"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=("linear", "adjoint"), default="linear")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the contract line's own measurement")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.workload == "linear" else 5
+    if args.warmup is None:
+        args.warmup = 20 if args.workload == "linear" else 2
 
-    from torchdiffeq_amd import _native, dist as tdist
-    from torchdiffeq_amd.misc import OdeFunc, StateLayout, rms_norm
-    from torchdiffeq_amd.solvers import Dopri5Solver
-    import torchdiffeq_amd as tda
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
+    from torchdiffeq_amd import dist as tdist
     # TDEQ_DIST_BACKEND=gloo lets the N>1 control flow be smoke-tested on a 1-GPU box (ranks share the device;
     # RCCL itself refuses two ranks on one GPU).  Unset, the backend is nccl (= RCCL) and rank r owns GPU r.
     rank, world, local_rank = tdist.init_from_env(backend=os.environ.get("TDEQ_DIST_BACKEND") or None)
@@ -155,174 +647,62 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    A, y0 = make_problem(device, seed_offset=rank)
-    At = A.T.contiguous()
-    field = lambda t, y: y @ At
-
-    # ---- parity at full size: whole odeint vs the closed form (size-independent property) ----
-    with torch.no_grad():
-        t_wall = time.perf_counter()
-        y_end = tda.odeint(field, y0, torch.tensor([0.0, 1.0], device=device), rtol=RTOL, atol=ATOL, method="dopri5")[-1]
-        torch.cuda.synchronize()
-        odeint_wall = time.perf_counter() - t_wall
-        exact = y0.double() @ torch.linalg.matrix_exp(A.double()).T
-        rel_err = float((y_end.double() - exact).abs().max() / exact.abs().max())
-
-    # ---- timed region: K trial steps of the adaptive solver ----
-    layout = StateLayout([y0.shape], False)
-    func = OdeFunc(field, layout, 1.0, y0.dtype, device)
-    solver = Dopri5Solver(func=func, y0=y0.reshape(-1), rtol=RTOL, atol=ATOL, norm=rms_norm)
-    timed = EventTimedKernels(solver.kernels, dominant_terms=5, n_events=args.steps // EventTimedKernels.EVERY + 1)
-    solver.kernels = timed
-    solver.ops.k = timed        # the elementwise kernels are issued through solver.ops
-    with torch.no_grad():
-        solver._before_integrate([0.0])
-        # the timed trial steps are steps in the middle of a long solve (no output time ahead), which is where the
-        # solver's look-ahead first stage applies (solvers.py: only the last steps before the final output time of
-        # an `integrate` call are driven without it)
-        solver._t_end = float("inf")
-        for _ in range(args.warmup):
-            solver._adaptive_step()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        timed.armed = True
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            solver._adaptive_step()
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        elapsed = time.perf_counter() - t0
-        timed.armed = False
-    if world > 1:
-        el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(el.item())
-
-    # ---- solver-only rate: the 6 stage_combine launches + error_norm (+ finalize) of one
-    # dopri5 step on the k tensors of the last timed step, no func, HIP events around REPS back-to-back passes.
-    solver_only = None
-    try:
-        rec = solver._dense
-        kern = solver.kernels._inner
-        ks, y0s = rec.k, rec.y0
-        outs = [torch.empty_like(y0s) for _ in range(2)]
-        REPS = 30
-
-        fuse = solver._fuse
-        epart = torch.empty_like(y0s)
-        last = len(solver._beta) - 1
-
-        la = bool(solver._lookahead and fuse is not None)
-        tnext = torch.empty(len(solver._beta), dtype=y0s.dtype, device=device)
-
-        def one_pass():
-            # exactly the solver's launch sequence for one trial step, minus func (and, without look-ahead, the
-            # stage-time fill)
-            for i, row in enumerate(solver._beta):
-                if i == 0 and la:
-                    kern.stage_combine_sel(outs[0], rec.y1, ks[-1], y0s, ks[0], row.coef[0], solver.plan)
-                elif i == last and fuse is not None:
-                    kern.stage_combine_err(outs[i & 1], epart, y0s, [ks[j] for j in row.idx], row.coef, fuse[0],
-                                           rec.dt_signed)
-                else:
-                    kern.stage_combine(outs[i & 1], y0s, [ks[j] for j in row.idx], row.coef, rec.dt_signed)
-            if la:
-                solver._ctrl.t0, solver._ctrl.dt = rec.t0, rec.t1 - rec.t0
-                kern.error_norm_partial_ctrl(solver.plan, epart, y0s, rec.y1, [ks[j] for j in fuse[1]], fuse[2],
-                                             rec.dt_signed, solver._ctrl, tnext)
-            elif fuse is not None:
-                kern.error_norm_partial(solver.plan, epart, y0s, rec.y1, [ks[j] for j in fuse[1]], fuse[2], rec.dt_signed)
-            else:
-                kern.error_norm(solver.plan, y0s, rec.y1, [ks[j] for j in solver._c_err.idx], solver._c_err.coef,
-                                rec.dt_signed)
-        for _ in range(3):
-            one_pass()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(REPS):
-            one_pass()
-        e1.record()
-        torch.cuda.synchronize()
-        solver.plan.expect = ()     # the passes' results are not read back
-        t_step = e0.elapsed_time(e1) * 1e-3 / REPS
-        # SURVEY.md §8(d) counts 32 + 8 = 40 words per element for a dopri5 step; the end-of-step fusion moves
-        # 37 (3+4+5+6+7+8 for the six combines, 4 for the norm) — both rates are reported.
-        moved = (37 if fuse is not None else 40) * BATCH * DIM * 4
-        survey = 40 * BATCH * DIM * 4
-        solver_only = {"stages_per_s": 6 / t_step, "us_per_step": 1e6 * t_step,
-                       "bytes_moved_per_step": moved, "GBps_moved": moved / t_step / 1e9,
-                       "frac_of_hbm_peak_moved": moved / t_step / 1e9 / HBM_PEAK_GBPS,
-                       "survey_algorithmic_bytes_per_step": survey, "GBps_survey_bytes": survey / t_step / 1e9,
-                       "note": "the solver's own launch sequence for one dopri5 trial step (stage_combine_sel + 4 "
-                               "stage_combine + stage_combine_err + error_norm_partial + controller finalize) back "
-                               "to back, no func; the 7 k tensors (235 MB) + y0/y1 fit the 256 MiB Infinity Cache "
-                               "only partly"}
-    except Exception as exc:      # never let the extra figure break the contract line
-        solver_only = {"error": repr(exc)}
-
-    n = BATCH * DIM
-    # dispatch begin -> end of each timed launch (the same interval rocprofv3's kernel trace reports)
-    kernel_ms = [a.elapsed_time(b) for a, b in timed.events]
-    avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-    bytes_per_launch = 7 * n * 4
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kernel_ms else None
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile_gpu.sh ->
-    # profiles/<tag>_pmc_hbm.json; counters cannot be collected from inside this process).
-    traffic = None
-    import glob
-    for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
-        try:
-            kernels = json.load(open(pmc_path))["kernels"]
-            hit = [v for k, v in kernels.items() if k.startswith("tdeq::stage_combine_kernel<float, 5,")]
-            if hit:
-                traffic = hit[0]["hbm_bytes_per_launch"]
-                break
-        except Exception:
-            continue
-
-    if rank == 0:
-        out = {
-            "metric": "dopri5 RK-stages/sec at batch=65536x dim=128 (end-to-end adaptive trial steps incl. func, "
-                      "error norm, read-back and host controller)",
-            "value": 6 * args.steps * world / elapsed,
-            "unit": "RK-stages/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: dopri5 adaptive, linear ODE dy/dt=Ay, batch=65536 x "
-                                   "dim=128 fp32 per GPU, rtol=1e-7 atol=1e-9",
-                       "global_batch": BATCH * world, "dim": DIM, "parallelism": f"batch-sharded x{world}",
-                       "accepted": solver.n_accepted, "rejected": solver.n_rejected,
-                       "lookahead": bool(solver._lookahead)},
-            "rel_err": rel_err,
-            "rel_err_definition": "max|y - y_exact| / max|y_exact| of odeint(t=[0,1]) at full size vs y0 @ expm(A)^T "
-                                  "(the reference's own fp32 result scores 2.2-2.6e-6 on this, SURVEY.md §7)",
-            "odeint_t01_wall_s": odeint_wall,
-            "roofline": {"bound": "hbm", "kernel": "stage_combine_kernel<float, 5, 1, true>",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
-                         "timing": "HIP events stamped by the dispatch itself (hipExtLaunchKernelGGL start/stop) on "
-                                   "the launch stream, every 4th launch of this kernel in the timed region",
-                         "launches_timed": len(kernel_ms), "traffic": traffic},
-            "solver_only": solver_only,
-        }
-        if world == 1 and not args.no_cpu_baseline:
+    if args.workload == "adjoint":
+        out = run_adjoint(args, rank, world, device)
+    else:
+        out, field, y0 = run_linear(args, rank, world, device)
+        extras = not args.no_extras
+        if extras and world > 1:
+            # the same ranks on the other regime and on the workload that communicates (short runs)
+            other = argparse.Namespace(**vars(args))
+            other.scaling = "strong" if args.scaling == "weak" else "weak"
+            other.steps, other.warmup = min(args.steps, 100), min(args.warmup, 20)
+            try:
+                o2, _, _ = run_linear(other, rank, world, device)
+                if rank == 0:
+                    out[other.scaling] = {k: o2[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "blocks")}
+            except Exception as exc:
+                if rank == 0:
+                    out[other.scaling] = {"error": repr(exc)}
+            adj = {}
+            for mode, rows in (("strong", ADJ_BATCH // world), ("weak", ADJ_BATCH)):
+                try:
+                    r = adjoint_pass(world, rank, device, rows, 3, 1)
+                    if rank == 0:
+                        r["rk_stages_per_s"] = r["rk_stages_per_pass"] / (r["ms_per_pass"] * 1e-3) * \
+                            (1 if mode == "strong" else world)
+                        adj[mode] = r
+                except Exception as exc:
+                    adj[mode] = {"error": repr(exc)}
+            if rank == 0:
+                out["adjoint"] = adj
+        if extras and world == 1 and rank == 0:
+            try:
+                out["shard_regime"] = {"linear": shard_regime_linear(device),
+                                       "adjoint": adjoint_pass(1, 0, device, ADJ_BATCH // 8, 3, 1)}
+                full = out["ms_per_step"]
+                la = out["shard_regime"]["linear"]
+                best = min(v["ms_per_step"] for v in la.values() if isinstance(v, dict) and "ms_per_step" in v)
+                la["full_size_ms_per_step"] = full
+                la["speedup_of_best_over_full_size"] = full / best
+                la["note"] = "per-rank work of an 8-GPU strong-scaling run of cfg2; >= 6 would mean the north star's " \
+                             "6x at 8 GPUs holds for a fixed global batch"
+            except Exception as exc:
+                out["shard_regime"] = {"error": repr(exc)}
+            try:
+                out["adjoint_full"] = adjoint_pass(1, 0, device, ADJ_BATCH, 3, 1)
+            except Exception as exc:
+                out["adjoint_full"] = {"error": repr(exc)}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
             try:
                 with torch.no_grad():
                     out["reference_style_eager_gpu"] = eager_gpu_baseline(field, y0, 0.05)
             except Exception as exc:      # an extra figure, never allowed to break the contract line
                 out["reference_style_eager_gpu"] = {"error": repr(exc)}
             out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        if os.environ.get("TDEQ_BENCH_NOTE"):
+            out["note"] = os.environ["TDEQ_BENCH_NOTE"]
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

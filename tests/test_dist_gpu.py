@@ -1,0 +1,61 @@
+"""The multi-GPU path's collectives through RCCL on the GPU box (the 1-GPU lease can only run world
+size 1, so the process group is handed over explicitly and nothing is short-circuited) and the device guard."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_rccl_world1_allreduce_tail_and_lockstep():
+    """tests/_rccl_world1.py in its own process (own process group; a hung collective cannot stall the suite)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_world1.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_self_launches_two_ranks_gloo():
+    """`python bench.py --gpus 2` as a plain command (no torchrun wrapper): it re-launches itself as 2 ranks; with
+    fewer GPUs than ranks the ranks share the device over gloo and the line says so.  One JSON line with n_gpus 2,
+    the strong-scaling object and the adjoint object with its all-reduce."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    if torch.cuda.device_count() < 2:
+        env["TDEQ_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "10",
+                        "--warmup", "3"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["strong"]["value"] > 0
+    ar = out["adjoint"]["strong"]["allreduce"]
+    assert ar["calls"] == 1 and ar["bytes"] >= 4 * 98880
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+def test_state_on_a_non_current_device():
+    """y0 on cuda:1 while cuda:0 is the current device: the kernels must go to cuda:1's stream (device guard)."""
+    import torchdiffeq_amd as tda
+    torch.cuda.set_device(0)
+    A = (torch.randn(32, 32) / 6 - 0.1 * torch.eye(32))
+    y0 = torch.randn(256, 32)
+    t = torch.tensor([0.0, 1.0])
+    outs = []
+    for dev in ("cuda:0", "cuda:1"):
+        Ad = A.to(dev)
+        with torch.no_grad():
+            outs.append(tda.odeint(lambda tt, y: y @ Ad.T, y0.to(dev), t.to(dev), rtol=1e-6, atol=1e-8).cpu())
+        lin = torch.nn.Linear(32, 32).to(dev)
+        x = y0.to(dev).requires_grad_(True)
+        tda.odeint_adjoint(lambda tt, y: lin(y), x, t.to(dev), adjoint_params=tuple(lin.parameters()))[-1].sum().backward()
+        assert torch.isfinite(x.grad).all()
+    assert torch.cuda.current_device() == 0
+    assert torch.equal(outs[0], outs[1])

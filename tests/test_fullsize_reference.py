@@ -1,0 +1,186 @@
+"""BASELINE.json's configurations at FULL size against the REFERENCE ITSELF: tests/golden/fullsize_*.npz hold what
+rtqichen/torchdiffeq v0.2.5 produced on the very same inputs (tests/golden/make_golden_fullsize.py: accepted /
+rejected step sequences through its callbacks, evaluation counts, sample rows of the solution and of dL/dy0, every
+parameter gradient).  BASELINE.json's parity metric — max rel-err vs reference odeint — is evaluated on the sample
+rows (rows 0..31, every 64th, the last 32), normalised by the reference's max|y| over all rows.
+
+Tolerances (stated per test): fp32 at rtol 1e-7 sits on the rounding-noise floor — the reference differs from
+ITSELF by 3.9e-6 there when only its CPU thread count changes — so 1e-5 is the bound, as in
+BASELINE.json; evaluation counts equal; step sizes to 1 % where the error estimate is above the fp32 rounding
+floor, wider (stated and explained at the assert) where it is not.
+
+GPU tests; `TDEQ_FULLSIZE_CPU=1` additionally runs them in the build container with the CPU oracle substituted for
+the kernels (host-logic check before spending GPU minutes; takes minutes)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import torchdiffeq_amd as tda
+import _fullsize as fs
+
+_CPU_TOO = os.environ.get("TDEQ_FULLSIZE_CPU") == "1"
+
+
+@pytest.fixture(params=[pytest.param("cpu", marks=pytest.mark.skipif(not _CPU_TOO, reason="TDEQ_FULLSIZE_CPU=1 only")),
+                        pytest.param("cuda", marks=pytest.mark.gpu)])
+def device(request, monkeypatch, oracle_kernels):
+    if request.param == "cpu":
+        from torchdiffeq_amd import _native
+        monkeypatch.setattr(_native, "get_kernels", lambda device: oracle_kernels)
+    return torch.device(request.param)
+
+
+def _solve_linear(case, B, D, dtype, method, device, with_callbacks):
+    z = fs.load(case)
+    A, y0 = fs.linear_problem(B, D, dtype)
+    assert np.array_equal(y0[:4].numpy(), z["y0_rows"]) and np.array_equal(A[:2].numpy(), z["A_rows"]), \
+        "the seeded inputs differ from the ones the reference was run on"
+    At = A.T.contiguous().to(device)
+    nfe = [0]
+
+    def field(t, y):
+        nfe[0] += 1
+        return y @ At
+    rec = fs.Recorder(field) if with_callbacks else None
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64 if dtype == torch.float64 else torch.float32, device=device)
+    rtol, atol = [float(v) for v in z["tol"]]
+    with torch.no_grad():
+        y = tda.odeint(field, y0.to(device), t, rtol=rtol, atol=atol, method=method)
+    return z, y[-1], nfe[0], rec
+
+
+@pytest.mark.parametrize("case,B", [("cfg2", 65536), ("cfg2_shard", 8192)])
+def test_cfg2_vs_reference(case, B, device):
+    """cfg2 (and its 1/8 shard): dopri5, dy/dt = Ay, fp32, rtol 1e-7 / atol 1e-9.  Reference: NFE 68, 11 accepted."""
+    # the default path (look-ahead controller on the device), then the callback-driven host loop for the steps
+    z, y_end, nfe, _ = _solve_linear(case, B, 128, torch.float32, "dopri5", device, with_callbacks=False)
+    err = fs.sample_rel_err(y_end[torch.from_numpy(z["rows"]).to(device)], z["y_end_rows"], z["y_end_absmax"])
+    assert err < 1e-5, err
+    assert nfe == int(z["nfe"])
+    z, y_end2, nfe2, rec = _solve_linear(case, B, 128, torch.float32, "dopri5", device, with_callbacks=True)
+    assert nfe2 == int(z["nfe"])
+    # step sizes: 3 % here, not 1 % — at rtol 1e-7 the fp32 error estimate of the early (small) steps is rounding
+    # noise, so the ratio fed to the controller depends on the summation order (the reference itself moves its dt by
+    # 0.3 % when only its thread count changes; measured against this fixture: <= 1.6 %, re-converging)
+    ok, msg = fs.steps_match(rec.acc, z["accepted"], rel=3e-2)
+    assert ok, msg
+    assert len(rec.rej) == len(z["rejected"])
+    # look-ahead and host-driven loops take the same decisions: same solution to fp32 rounding of dt
+    assert fs.sample_rel_err(y_end2, y_end, z["y_end_absmax"]) < 1e-6
+
+
+def test_cfg4_vs_reference(device):
+    """cfg4: dopri8, 16384 x 512 fp64, rtol 1e-9 / atol 1e-11.  Reference: NFE 67 = 2 + 13*5, 5 accepted.
+    dopri8's embedded error estimate is a 9-term cancelling sum; at the first (heuristic, tiny) step it is pure
+    rounding noise — ATen's blocked summation order vs the kernels' left-to-right order give different noise, so
+    the second step size differs; from there the sequences re-converge.  Solution bound: the solve's own
+    accuracy class (rtol 1e-9 on |y| ~ 4)."""
+    z, y_end, nfe, _ = _solve_linear("cfg4", 16384, 512, torch.float64, "dopri8", device, with_callbacks=False)
+    err = fs.sample_rel_err(y_end[torch.from_numpy(z["rows"]).to(device)], z["y_end_rows"], z["y_end_absmax"])
+    assert err < 1e-9, err
+    assert abs(nfe - int(z["nfe"])) <= 13, (nfe, int(z["nfe"]))
+
+
+def _run_cfg3(case, rows, device, with_callbacks):
+    z = fs.load(case)
+    field, y0 = fs.cfg3_problem(rows)
+    assert np.array_equal(y0[:4].numpy(), z["y0_rows"])
+    for i, p in enumerate(field.net.parameters()):
+        assert np.array_equal(p.detach().numpy(), z[f"p{i}"]), "layer initialisation differs from the reference run"
+    field = field.to(device)
+    rec = fs.Recorder(field) if with_callbacks else None
+    x = y0.to(device).requires_grad_(True)
+    t = torch.tensor([0.0, 1.0], device=device)
+    y = tda.odeint_adjoint(field, x, t, rtol=1e-5, atol=1e-7, method="dopri5")
+    nfe_fwd, field.nfe = field.nfe, 0
+    y[-1].pow(2).sum().backward()
+    return z, field, x, y[-1].detach(), nfe_fwd, field.nfe, rec
+
+
+@pytest.mark.parametrize("case,rows", [("cfg3", None), ("cfg3_shard", slice(0, 8192))])
+def test_cfg3_adjoint_vs_reference(case, rows, device):
+    """cfg3 (and its 1/8 shard): odeint_adjoint, MLP 64-256-256-64, fp32, rtol 1e-5 / atol 1e-7, loss sum(y(1)^2).
+    Reference: forward NFE 20 (3 accepted), backward NFE 74 (12 accepted; shard: 68, 11 accepted)."""
+    z, field, x, y_end, nfe_fwd, nfe_bwd, _ = _run_cfg3(case, rows, device, with_callbacks=False)
+    idx = torch.from_numpy(z["rows"]).to(device)
+    assert fs.sample_rel_err(y_end[idx], z["y_end_rows"], z["y_end_absmax"]) < 1e-5
+    assert fs.sample_rel_err(x.grad[idx], z["grad_y0_rows"], z["grad_y0_absmax"]) < 1e-4
+    for i, p in enumerate(field.net.parameters()):
+        ref = torch.from_numpy(z[f"grad_p{i}"])
+        assert float((p.grad.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4, i
+    assert nfe_fwd == int(z["nfe_fwd"])
+    assert nfe_bwd == int(z["nfe_bwd"]), (nfe_bwd, int(z["nfe_bwd"]))
+    z, field, x, _, nfe_fwd, nfe_bwd, rec = _run_cfg3(case, rows, device, with_callbacks=True)
+    ok, msg = fs.steps_match(rec.acc, z["accepted"])
+    assert ok, "forward: " + msg
+    # Backward solve: same NUMBER of accepted steps and evaluations; step sizes only to 60 %.  The backward solve
+    # starts from a tiny heuristic step (1.4e-5: the parameter adjoints start at zero) and grows it by the factor
+    # 0.9 / ratio^(1/5) with ratio ~ 3e-4 — an fp32 error estimate that is pure rounding noise.  Measured with the
+    # reference alone: 8 CPU threads instead of 1 move ITS accepted step sizes by up to 30 % (1/8 shard) / 19 % (full
+    # size), same count; in fp64 every one of these steps grows by exactly ifactor = 10.  The first two steps (before the noise
+    # enters) agree to 0.2 %, and the gradients above agree to 1e-4.
+    # Against the kernels (fp64 norm accumulation, left-to-right error sum — slightly LESS noise than ATen's fp32
+    # blocked sums, hence systematically larger steps): shard <= 21 %, full size <= 55 %, same count, same NFE.
+    ok, msg = fs.steps_match(rec.acc_adj, z["accepted_adjoint"], rel=0.6)
+    assert ok, "backward: " + msg
+    ok, msg = fs.steps_match(rec.acc_adj[:2], z["accepted_adjoint"][:2], rel=5e-2)
+    assert ok, "backward, first two steps: " + msg
+    assert len(rec.rej) == len(z["rejected"]) and len(rec.rej_adj) == len(z["rejected_adjoint"])
+
+
+@pytest.mark.parametrize("trace", ["closed", "autograd"])
+def test_cfg5_cnf_adjoint_vs_reference(trace, device):
+    """cfg5 as BASELINE.json writes it: CNF (examples/cnf.py model at its seeded init), state (z[32768,2],
+    logp[32768,1]), t: 10 -> 0, dopri5 + adjoint, rtol = atol = 1e-5, loss mean(logp) - sum(z^2)/100.  The reference
+    run used the example's own per-dimension autograd trace; "autograd" restates that loop, "closed" is the same
+    quantity in closed form.  Reference: forward NFE 44 (5 accepted, 2 rejected), backward 11 accepted."""
+    z = fs.load("cfg5")
+    z0, logp0 = fs.cfg5_problem()
+    assert np.array_equal(z0[:4].numpy(), z["z0_rows"])
+    cnf = fs.ExampleCNF([z[f"p{i}"] for i in range(6)], trace=trace).to(device)
+    rec = fs.Recorder(cnf)
+    x = z0.to(device).requires_grad_(True)
+    t = torch.tensor([10.0, 0.0], device=device)
+    zt, lp = tda.odeint_adjoint(cnf, (x, logp0.to(device)), t, atol=1e-5, rtol=1e-5, method="dopri5")
+    nfe_fwd, cnf.nfe = cnf.nfe, 0
+    loss = lp[-1].mean() - zt[-1].pow(2).sum() / 100
+    loss.backward()
+    idx = torch.from_numpy(z["rows"]).to(device)
+    assert fs.sample_rel_err(zt[-1][idx], z["z_end_rows"], z["z_end_absmax"]) < 1e-4
+    assert fs.sample_rel_err(lp[-1][idx], z["logp_end_rows"], z["logp_end_absmax"]) < 1e-4
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
+    assert fs.sample_rel_err(x.grad[idx], z["grad_z0_rows"], z["grad_z0_absmax"]) < 1e-3
+    for i, p in enumerate(cnf.parameters()):
+        ref = torch.from_numpy(z[f"grad_p{i}"])
+        assert float((p.grad.cpu() - ref).abs().max() / ref.abs().max()) < 1e-3, i
+    assert nfe_fwd == int(z["nfe_fwd"]), nfe_fwd
+    ok, msg = fs.steps_match(rec.acc, z["accepted"])
+    assert ok, "forward: " + msg
+    assert len(rec.rej) == len(z["rejected"])
+    # Backward: the same 11 accepted steps; sizes to 35 % and at most one extra rejected trial step (6 evaluations) —
+    # the fp32 error estimate of this backward solve sits on the rounding floor (see test_cfg3_adjoint_vs_reference),
+    # and with the closed-form trace one trial step lands at an error ratio within rounding of 1 and flips to a reject.
+    ok, msg = fs.steps_match(rec.acc_adj, z["accepted_adjoint"], rel=0.35)
+    assert ok, "backward: " + msg
+    assert len(rec.rej_adj) <= len(z["rejected_adjoint"]) + 1
+    assert cnf.nfe == int(z["nfe_bwd"]) + 6 * (len(rec.rej_adj) - len(z["rejected_adjoint"])), cnf.nfe
+
+
+def test_cfg5_hutchinson_trace_variant(device):
+    """The benchmark-side Hutchinson variant of cfg5 (one fixed Rademacher probe).  In two dimensions e^T J e =
+    tr J + (J01 + J10) e0 e1, so the estimator is unbiased but not exact: z(t1) does not depend on the trace at all
+    and must match the reference; logp differs by the probe's cross term (bounded here, not pinned)."""
+    z = fs.load("cfg5")
+    z0, logp0 = fs.cfg5_problem()
+    cnf = fs.ExampleCNF([z[f"p{i}"] for i in range(6)], trace="hutchinson").to(device)
+    x = z0.to(device).requires_grad_(True)
+    t = torch.tensor([10.0, 0.0], device=device)
+    zt, lp = tda.odeint_adjoint(cnf, (x, logp0.to(device)), t, atol=1e-5, rtol=1e-5, method="dopri5")
+    (lp[-1].mean() - zt[-1].pow(2).sum() / 100).backward()
+    idx = torch.from_numpy(z["rows"]).to(device)
+    assert fs.sample_rel_err(zt[-1][idx], z["z_end_rows"], z["z_end_absmax"]) < 1e-3
+    assert torch.isfinite(lp[-1]).all() and torch.isfinite(x.grad).all()
+    assert all(torch.isfinite(p.grad).all() for p in cnf.parameters())
+    assert abs(float(lp[-1].mean()) - float(torch.from_numpy(z["logp_end_rows"]).mean())) < 0.5

@@ -6,7 +6,9 @@ the library is missing or the state does not live on a ROCm device.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import functools
 import math
 import os
 import threading
@@ -567,6 +569,26 @@ class HipKernels:
         arr = (ctypes.c_double * n)(*vals)
         _check(self.lib.tdeq_fill_scalars(dst.data_ptr(), arr, n, dtype_code(dst.dtype), self._stream()),
                "tdeq_fill_scalars")
+
+
+def device_guard(device):
+    """Context that makes `device` the current HIP device.  Every launch goes to `torch.cuda.current_stream()` — the
+    CURRENT device's stream — and a kernel cannot be launched into another device's stream, so each entry point of the
+    package runs under this guard: a state on `cuda:1` is integrated on cuda:1's stream whatever the caller's current
+    device is.  Free when the device already is the current one (and for the CPU tensors of the host-logic tests)."""
+    device = torch.device(device)
+    if device.type != "cuda" or device.index is None or device.index == torch.cuda.current_device():
+        return contextlib.nullcontext()
+    return torch.cuda.device(device)
+
+
+def on_state_device(method):
+    """Decorator for solver entry points (`integrate*`): run under `device_guard(self.y0.device)`."""
+    @functools.wraps(method)
+    def guarded(self, *args, **kwargs):
+        with device_guard(self.y0.device):
+            return method(self, *args, **kwargs)
+    return guarded
 
 
 _KERNELS: Optional[HipKernels] = None

@@ -22,6 +22,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 import torch.nn as nn
 
+from ._native import device_guard
 from .misc import (ALL_ADJOINT_CALLBACK_NAMES, ALL_CALLBACK_NAMES, BuiltinNorm, OdeFunc, Perturb, StateLayout,
                    check_inputs, pack_differentiable)
 from .odeint import SOLVERS
@@ -107,7 +108,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
         ctx.t_requires_grad = cfg["t_requires_grad"]
         event_fn = cfg.get("event_fn")
         ctx.event_mode = event_fn is not None
-        with torch.no_grad():
+        with torch.no_grad(), device_guard(y0_flat.device):
             solver = SOLVERS[cfg["method"]](func=cfg["func"], y0=y0_flat.detach(), rtol=cfg["rtol"],
                                             atol=cfg["atol"], **cfg["options"])
             if event_fn is None:
@@ -125,7 +126,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grad_outputs):
-        with torch.no_grad():
+        with torch.no_grad(), device_guard(ctx.func.device):
             fwd: OdeFunc = ctx.func
             fwd_layout = fwd.layout
             # Event mode: backpropagate as if integrating up to the event time; NOT through the event time
@@ -173,7 +174,9 @@ class OdeintAdjointMethod(torch.autograd.Function):
             group = options.pop("dist_group", None)
             sync = options.pop("dist_sync", None)
             options.pop("dist_replicated", None)
-            if options.pop("hip_graph", False):
+            requested = options.pop("hip_graph", False)
+            options["hip_graph"] = False          # also overrides a process-wide TDEQ_HIP_GRAPH default
+            if requested and requested != "auto":
                 # the augmented dynamics call torch.autograd.grad from inside the autograd engine's own thread;
                 # capturing that into a hipGraph crashes the capture (measured) — never attempted
                 warnings.warn("adjoint_options['hip_graph'] is ignored: the backward solve evaluates autograd inside "
@@ -301,8 +304,9 @@ def handle_adjoint_norm_(adjoint_options, n_params: int, state_norm=None, layout
 
 def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None,
                    adjoint_rtol=None, adjoint_atol=None, adjoint_method=None, adjoint_options=None,
-                   adjoint_params=None):
-    """Same signature, defaults and errors as the reference `odeint_adjoint` (adjoint.py:156-223)."""
+                   adjoint_params=None, _adjoint_extra=None):
+    """Same signature, defaults and errors as the reference `odeint_adjoint` (adjoint.py:156-223).
+    (`_adjoint_extra`: private — keys torchdiffeq_amd.dist merges into the inferred adjoint options.)"""
     if adjoint_params is None and not isinstance(func, nn.Module):
         raise ValueError("func must be an instance of nn.Module to specify the adjoint parameters; alternatively they "
                          "can be specified explicitly via the `adjoint_params` argument. If there are no parameters "
@@ -322,6 +326,8 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
             if options is not None else {}
     else:
         adjoint_options = adjoint_options.copy()
+    if _adjoint_extra:
+        adjoint_options.update(_adjoint_extra)
 
     if adjoint_params is None:
         adjoint_params = tuple(find_parameters(func))

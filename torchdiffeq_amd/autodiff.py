@@ -31,6 +31,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+from torch.autograd.function import once_differentiable
 
 Scalar = Optional[torch.Tensor]          # shadow of a time-like scalar (0-dim, requires grad) or None
 
@@ -79,6 +80,7 @@ class _LinearOp(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable      # the backward runs raw HIP kernels: double backward raises instead of being silently wrong
     def backward(ctx, g):
         spec, ns = ctx.spec, ctx.n_scalars
         kern = spec.kernels

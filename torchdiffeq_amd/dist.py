@@ -64,7 +64,7 @@ def odeint_sharded(func, y0_shard, t, *, group=None, sync_steps=True, **kwargs):
     ("lock step"): the per-segment error sums are added over the ranks — one all-reduce of 3·n_seg doubles per
     trial step, latency-bound on xGMI — so every shard takes exactly the step sequence of the whole-batch solve
     and its rows come out as in a single-device run (adaptive methods; fixed grids are in lock step anyway)."""
-    if sync_steps and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if sync_steps and dist.is_initialized() and (dist.get_world_size(group) > 1 or group is not None):
         options = dict(kwargs.pop("options", None) or {})
         options["dist_sync"] = True if group is None else group
         kwargs["options"] = options
@@ -81,16 +81,22 @@ def odeint_adjoint_sharded(func, y0_shard, t, *, group=None, sync_steps=False, *
     parameter-VJPs are all-reduced at every evaluation (1 + P words), which makes every rank integrate the
     whole-batch adjoint system with the whole-batch step sequence: gradients equal the single-device ones to
     rounding, at the price of one small collective per evaluation and per trial step."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or group is not None):
+        # (an explicitly given group is honoured at world size 1 too: the collectives then run through the backend —
+        # how the RCCL path is exercised on a one-GPU box)
         g = True if group is None else group
-        inherited = {k: v for k, v in (kwargs.get("options") or {}).items() if k not in ("norm", "hip_graph")}
-        adjoint_options = dict(kwargs.pop("adjoint_options", None) or inherited)
+        extra = {"dist_sync": g} if sync_steps else {"dist_group": g}
+        user_options = kwargs.get("options")
         if sync_steps:
-            options = dict(kwargs.pop("options", None) or {})
+            options = dict(user_options or {})
             options["dist_sync"] = g
             kwargs["options"] = options
-            adjoint_options["dist_sync"] = g
+        if kwargs.get("adjoint_options") is not None:
+            kwargs["adjoint_options"] = {**kwargs["adjoint_options"], **extra}
+        elif user_options is None:
+            kwargs["adjoint_options"] = dict(extra)       # nothing for odeint_adjoint to infer from
         else:
-            adjoint_options["dist_group"] = g
-        kwargs["adjoint_options"] = adjoint_options
+            # odeint_adjoint infers (and validates) adjoint_options from `options` as always; the dist keys are
+            # merged in after that, so its ValueError for `adjoint_method != method` with `options` still fires
+            kwargs["_adjoint_extra"] = extra
     return odeint_adjoint(func, y0_shard, t, **kwargs)

@@ -180,6 +180,7 @@ class _ImplicitCorrection(torch.autograd.Function):
         return K_star.clone()
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         lam = _gmres(ctx.vjp, g.contiguous(), ctx.rtol)
         return -lam, None, None, None

@@ -269,17 +269,38 @@ class OdeFunc:
         t_user = self.time_tensor(self.user_time(t, perturb), shadow)
         return self.call_base(t_user, y_flat)
 
+    def _conform(self, f, shape: torch.Size, what: str) -> torch.Tensor:
+        """func's output as the kernels need it: on the state's device, with the state's element count.  An output
+        that only broadcasts to the state shape (0-dim, [1], a row ...) is expanded, as `y0 + dt * f` does in the
+        reference (rk_common.py:79); anything else raises here instead of being read out of bounds by a kernel."""
+        if not isinstance(f, torch.Tensor):
+            raise TypeError("func must return a Tensor{}; got {}".format(what, type(f).__name__))
+        if f.device != self.device:
+            raise RuntimeError("func returned a tensor on '{}'{} but the state lives on '{}'".format(
+                f.device, what, self.device))
+        if f.shape != shape and f.numel() != shape.numel():
+            try:
+                f = f.expand(shape)
+            except RuntimeError:
+                raise RuntimeError("func returned shape {}{} which does not broadcast to the state shape {}".format(
+                    tuple(f.shape), what, tuple(shape))) from None
+        return f
+
     def call_base(self, t_user: torch.Tensor, y_flat: torch.Tensor) -> torch.Tensor:
         lay = self.layout
         grad = torch.is_grad_enabled()
         if lay.is_tuple:
             f = self.base_func(t_user, lay.unpack(y_flat))
+            if len(f) != lay.n_seg:
+                raise RuntimeError("func returned {} components for a state of {}".format(len(f), lay.n_seg))
+            f = tuple(self._conform(f_, shape, " (component {})".format(i))
+                      for i, (f_, shape) in enumerate(zip(f, lay.shapes)))
             if grad and any(f_.requires_grad for f_ in f):
                 out = pack_differentiable(lay, f, self.dtype)     # backprop through the solver
             else:
                 out = lay.pack_fused(self.kernels(), f, self.dtype, self.device)
         else:
-            f = self.base_func(t_user, y_flat.view(lay.shapes[0]))
+            f = self._conform(self.base_func(t_user, y_flat.view(lay.shapes[0])), lay.shapes[0], "")
             if f.dtype != self.dtype:
                 f = f.to(self.dtype)
             out = f.reshape(-1)

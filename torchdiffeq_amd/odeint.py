@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import torch
 
+from ._native import device_guard
 from .misc import check_inputs, pack_differentiable
 from .implicit import (SDIRK2, TRBDF2, GaussLegendre4, GaussLegendre6, ImplicitEuler, ImplicitMidpoint, RadauIIA3,
                        RadauIIA5, Trapezoid)
@@ -93,14 +94,15 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
         y0_list = y0 if ci.layout.is_tuple else (y0,)
         if any(y_.requires_grad for y_ in y0_list):
             y0_flat = pack_differentiable(ci.layout, y0_list)        # backprop through the solver (autodiff.py)
-    solver = SOLVERS[ci.method](func=ci.func, y0=y0_flat, rtol=ci.rtol, atol=ci.atol, **ci.options)
-    if ci.event_fn is None:
-        solution = solver.integrate(ci.t)
-    else:
-        event_t, solution = solver.integrate_until_event(ci.t[0], ci.event_fn)
-        event_t = event_t.to(ci.t)
-        if ci.t_is_reversed:
-            event_t = -event_t
+    with device_guard(y0_flat.device):       # kernels go to the state's device, whatever the caller's current one is
+        solver = SOLVERS[ci.method](func=ci.func, y0=y0_flat, rtol=ci.rtol, atol=ci.atol, **ci.options)
+        if ci.event_fn is None:
+            solution = solver.integrate(ci.t)
+        else:
+            event_t, solution = solver.integrate_until_event(ci.t[0], ci.event_fn)
+            event_t = event_t.to(ci.t)
+            if ci.t_is_reversed:
+                event_t = -event_t
     if ci.layout.is_tuple:
         solution = ci.layout.unpack(solution, (len(ci.t),))
     else:
@@ -119,7 +121,7 @@ def odeint_dense(func, y0, t0, t1, *, rtol=1e-7, atol=1e-9, method=None, options
     `tdeq_weighted_sum` launch over the 5 planes of the step that contains `t_eval`."""
     assert torch.is_tensor(y0)
     t = torch.tensor([t0, t1]).to(t0)
-    with torch.no_grad():
+    with torch.no_grad(), device_guard(y0.device):
         ci = check_inputs(func, y0, t, rtol, atol, method, options, None, SOLVERS)
         assert ci.method == "dopri5"
         solver = Dopri5Solver(func=ci.func, y0=ci.y0_flat, rtol=ci.rtol, atol=ci.atol, **ci.options)
@@ -142,7 +144,8 @@ def odeint_dense(func, y0, t0, t1, *, rtol=1e-7, atol=1e-9, method=None, options
             w.append(float(xp))
         planes = coeffs[idx - 1]
         out = torch.empty(planes.shape[1], dtype=planes.dtype, device=planes.device)
-        kernels.weighted_sum(out, list(planes.unbind(0)), w)
+        with device_guard(planes.device):
+            kernels.weighted_sum(out, list(planes.unbind(0)), w)
         return out.view(shape)
 
     dense_output_fn.times = times
@@ -151,81 +154,50 @@ def odeint_dense(func, y0, t0, t1, *, rtol=1e-7, atol=1e-9, method=None, options
 
 
 def odeint_event(func, y0, t0, *, event_fn, reverse_time=False, odeint_interface=odeint, **kwargs):
-    """Solve until `event_fn(t, y)` crosses zero; returns `(event_t, solution)` with gradients linked through
-    the event time by the implicit function theorem (odeint.py:160-231).  Parameters of the event function
-    must be part of the state to receive gradients, as in the reference."""
-    if reverse_time:
-        t = torch.cat([t0.reshape(-1), t0.reshape(-1).detach() - 1.0])
-    else:
-        t = torch.cat([t0.reshape(-1), t0.reshape(-1).detach() + 1.0])
+    """Solve from `t0` until `event_fn(t, y)` crosses zero; returns `(event_t, solution)` whose gradients see the
+    event time as a function of the trajectory (same contract as odeint.py:160-231: parameters of the event
+    function must be part of the state to receive gradients).
 
+    The solve itself returns a detached event time t* and the state y* = y(t*) attached to the solve's graph.  The
+    event is defined by c(t*, y(t*)) = 0, so by the implicit function theorem a perturbation dy of the trajectory at
+    t* moves the event time by  dt* = -(dc/dy . dy) / (dc/dt + dc/dy . f)  and the state at the (moved) event by
+    dy + f dt*.  Both are attached here as first-order corrections with value ZERO on the flat state,
+
+        t_out = t* - <c_y, y - stop_grad(y)> / (c_t + <c_y, f>)          y_out = y + f (t_out - t*),
+
+    built from ordinary differentiable tensor ops — no dedicated autograd node: autograd derives the backward
+    (dL/dy = g_y - c_y (g_t + <g_y, f>) / (c_t + <c_y, f>)) from these two lines."""
+    t0_row = t0.reshape(-1)
+    t = torch.cat([t0_row, t0_row.detach() + (-1.0 if reverse_time else 1.0)])
     event_t, solution = odeint_interface(func, y0, t, event_fn=event_fn, **kwargs)
 
-    # the flat-state views of func / event_fn (dummy tolerances: nothing is solved here)
+    # flat-state views of func and event_fn in (ascending) solver time (dummy tolerances: nothing is solved here)
     ci = check_inputs(func, y0, t, 0.0, 0.0, None, None, event_fn, SOLVERS)
-    layout = ci.layout
-    if layout.is_tuple:
-        state_t = _pack_rows(layout, [s[-1] for s in solution])
-    else:
-        state_t = solution[-1].reshape(-1)
+    layout, flat_func, flat_event = ci.layout, ci.func, ci.event_fn
+    y_event = pack_differentiable(layout, [s[-1] for s in solution]) if layout.is_tuple else solution[-1].reshape(-1)
+    time_sign = -1.0 if reverse_time else 1.0
+    ts_value = (event_t.detach() * time_sign) if reverse_time else event_t.detach()      # t* in solver time
 
-    # event_fn takes the negated time when the solve runs in reverse
-    if reverse_time:
-        event_t = -event_t
-    event_t, state_t = ImplicitFnGradientRerouting.apply(ci.func, ci.event_fn, event_t, state_t)
-    if reverse_time:
-        event_t = -event_t
+    # first-order data at the event: f(t*, y*), dc/dt, dc/dy (all constants of the correction below)
+    y_const = y_event.detach()
+    with torch.no_grad(), device_guard(y_const.device):
+        f_event = flat_func(ts_value, y_const)
+    with torch.enable_grad():
+        ts_leaf, y_leaf = ts_value.clone().requires_grad_(True), y_const.clone().requires_grad_(True)
+        c = flat_event(ts_leaf, y_leaf)
+        c_t, c_y = torch.autograd.grad(c, (ts_leaf, y_leaf), torch.ones_like(c), allow_unused=True)
+    c_t = torch.zeros_like(ts_value) if c_t is None else c_t
+    c_y = torch.zeros_like(y_const) if c_y is None else c_y
+    # rate of change of c along the trajectory; the tiny offset keeps a grazing event (rate 0) finite, as the
+    # reference's guard does
+    rate = c_t + torch.dot(c_y, f_event) + 1e-12
+
+    ts_out = ts_value - torch.dot(c_y, y_event - y_const) / rate
+    y_out = y_event + f_event * (ts_out - ts_value)
+    event_t = (ts_out * time_sign if reverse_time else ts_out).reshape(event_t.shape).to(event_t.dtype)
 
     if layout.is_tuple:
-        state_parts = layout.unpack(state_t)
-        solution = tuple(torch.cat([s[:-1], s_t[None]], dim=0) for s, s_t in zip(solution, state_parts))
+        solution = tuple(torch.cat([s[:-1], part[None]], dim=0) for s, part in zip(solution, layout.unpack(y_out)))
     else:
-        solution = torch.cat([solution[:-1], state_t.view(layout.shapes[0])[None]], dim=0)
+        solution = torch.cat([solution[:-1], y_out.view(layout.shapes[0])[None]], dim=0)
     return event_t, solution
-
-
-def _pack_rows(layout, rows):
-    """Differentiable flat (chunk-padded) state from per-component tensors."""
-    pieces = []
-    for i, r in enumerate(rows):
-        pieces.append(r.reshape(-1))
-        end = layout.offsets[i + 1] if i + 1 < layout.n_seg else layout.total
-        pad = end - (layout.offsets[i] + layout.numels[i])
-        if pad:
-            pieces.append(torch.zeros(pad, dtype=r.dtype, device=r.device))
-    return torch.cat(pieces)
-
-
-class ImplicitFnGradientRerouting(torch.autograd.Function):
-    """Identity on (event_t, state_t) whose backward routes dL/d(event_t) into dL/d(state_t):
-    with c(t, y) = 0 defining the event, dt*/dy = -(dc/dy) / (dc/dt + dc/dy . f)   (odeint.py:199-231)."""
-
-    @staticmethod
-    def forward(ctx, func, event_fn, event_t, state_t):
-        ctx.func = func
-        ctx.event_fn = event_fn
-        ctx.save_for_backward(event_t, state_t)
-        return event_t.detach(), state_t.detach()
-
-    @staticmethod
-    def backward(ctx, grad_t, grad_state):
-        func, event_fn = ctx.func, ctx.event_fn
-        event_t, state_t = ctx.saved_tensors
-        event_t = event_t.detach().clone().requires_grad_(True)
-        state_t = state_t.detach().clone().requires_grad_(True)
-
-        with torch.no_grad():
-            f_val = func(event_t.detach(), state_t.detach())      # wrapped func: solver time, sign applied
-        with torch.enable_grad():
-            c = event_fn(event_t, state_t)
-            par_dt, dstate = torch.autograd.grad(c, (event_t, state_t), torch.ones_like(c), allow_unused=True)
-        par_dt = torch.zeros_like(event_t) if par_dt is None else par_dt
-        dstate = torch.zeros_like(state_t) if dstate is None else dstate
-
-        # total derivative of the event function along the trajectory, at the event
-        dcdt = par_dt + torch.sum(dstate * f_val)
-        # the final state's gradient also moves the final time, as in a regular odeint call
-        grad_t = grad_t + torch.sum(grad_state * f_val)
-        dstate = dstate * (-grad_t / (dcdt + 1e-12)).reshape_as(c)
-        grad_state = grad_state + dstate
-        return None, None, None, grad_state

@@ -23,6 +23,7 @@ class ScipyWrapperODESolver:
         unused_kwargs.pop("eps", None)
         unused_kwargs.pop("dist_sync", None)
         unused_kwargs.pop("dist_replicated", None)
+        unused_kwargs.pop("hip_graph", None)          # host-side solver: nothing to capture
         handle_unused_kwargs(self, unused_kwargs)
         del unused_kwargs
         if not isinstance(func, OdeFunc):

@@ -119,6 +119,25 @@ class _LockStep:
 _GRAPH_MODE_MAX_ELEMENTS = 1 << 22
 
 
+# `hip_graph="auto"`: capture only where a trial step costs launch latency rather than bandwidth (measured on the
+# MI355X, profiles/r02_shard_regime.json: the captured step wins up to ~2M elements and loses beyond)
+_GRAPH_AUTO_MAX_ELEMENTS = 1 << 21
+
+
+def _graph_request(hip_graph):
+    """(wanted, auto) from the `hip_graph` solver option: True / False, "auto", or None = the process-wide default
+    taken from the environment variable TDEQ_HIP_GRAPH ("0" — the default —, "1" or "auto")."""
+    if hip_graph is None:
+        hip_graph = {"0": False, "": False, "1": True, "auto": "auto"}.get(os.environ.get("TDEQ_HIP_GRAPH", "0").lower())
+        if hip_graph is None:
+            raise ValueError("TDEQ_HIP_GRAPH must be 0, 1 or auto")
+    if isinstance(hip_graph, str):
+        if hip_graph.lower() != "auto":
+            raise ValueError("hip_graph must be True, False or 'auto'")
+        return True, True
+    return bool(hip_graph), False
+
+
 class _CaptureFailed(RuntimeError):
     """The step body could not be captured into a hipGraph; no kernel of it has run."""
 
@@ -359,7 +378,7 @@ class RKAdaptiveStepsizeODESolver:
     def __init__(self, func: OdeFunc, y0: torch.Tensor, rtol, atol, min_step=0, max_step=float("inf"),
                  first_step=None, step_t=None, jump_t=None, safety=0.9, ifactor=10.0, dfactor=0.2,
                  max_num_steps=2 ** 31 - 1, dtype=torch.float64, norm=None, dist_sync=None, dist_replicated=(),
-                 hip_graph=False, **unused_kwargs):
+                 hip_graph=None, **unused_kwargs):
         handle_unused_kwargs(self, unused_kwargs)
         del unused_kwargs
         if not isinstance(func, OdeFunc):
@@ -425,9 +444,14 @@ class RKAdaptiveStepsizeODESolver:
                        and self.step_t is None and self.jump_t is None and self._sync is None)
         self._lookahead = device_ctrl and os.environ.get("TDEQ_LOOKAHEAD", "1") != "0"
         # `hip_graph=True` (an extension, not a reference option): one captured hipGraph per trial step, see _GraphStep
-        self.hip_graph = bool(hip_graph) and device_ctrl and y0.device.type == "cuda" \
-            and hasattr(self.kernels, "stage_combine_dev") and self.layout.total <= _GRAPH_MODE_MAX_ELEMENTS
-        if bool(hip_graph) and not self.hip_graph:
+        # "auto" = only where it pays (states up to _GRAPH_AUTO_MAX_ELEMENTS) and silently; never the built-in default,
+        # because a captured func runs in Python only while the graph is being built: per-evaluation Python side
+        # effects (an evaluation counter, data-dependent branches) are not replayed — the user has to vouch for that
+        wanted, auto = _graph_request(hip_graph)
+        self.hip_graph = wanted and device_ctrl and y0.device.type == "cuda" \
+            and hasattr(self.kernels, "stage_combine_dev") \
+            and self.layout.total <= (_GRAPH_AUTO_MAX_ELEMENTS if auto else _GRAPH_MODE_MAX_ELEMENTS)
+        if wanted and not auto and not self.hip_graph:
             warnings.warn("{}: hip_graph=True needs a builtin norm, at most {} state segments, no step_t / jump_t, a "
                           "tableau with a fused error combine, a ROCm device and a state of at most {} elements (larger "
                           "states are bandwidth-bound: the eager path with its unrolled kernels is the fast one); "
@@ -484,6 +508,7 @@ class RKAdaptiveStepsizeODESolver:
         return torch.tensor(value, dtype=torch.float64, device=self.y0.device)
 
     # -- integrate ---------------------------------------------------------------------------------
+    @_native.on_state_device
     def integrate(self, t: torch.Tensor) -> torch.Tensor:
         """solution[len(t), total] with solution[0] = y0 (solvers.py:28-35)."""
         t_host = t.detach().to(torch.float64).cpu().tolist()
@@ -527,6 +552,7 @@ class RKAdaptiveStepsizeODESolver:
         return torch.is_grad_enabled() and (self.y0.requires_grad or self._anchor is not None or
                                             self.f1.requires_grad)
 
+    @_native.on_state_device
     def integrate_dense(self, t: torch.Tensor):
         """Integrate over [t[0], t[-1]] keeping the dense output of EVERY accepted step (odeint.py:124-147):
         returns (times, coeffs) with `times` the n_steps + 1 accepted step boundaries (host doubles) and
@@ -556,6 +582,7 @@ class RKAdaptiveStepsizeODESolver:
                                                                  device=self.y0.device)
         return times, coeffs
 
+    @_native.on_state_device
     def integrate_until_event(self, t0: torch.Tensor, event_fn):
         """(event_t, solution[2, total]): step until `event_fn(t, y)` changes sign, then bisect on the last
         step's dense output (solvers.py:44-49, rk_common.py:252-264, event_handling.py:5-20)."""
@@ -683,19 +710,24 @@ class RKAdaptiveStepsizeODESolver:
         while next_t > self.t1:
             assert n_steps < self.max_num_steps, \
                 "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
-            if self.hip_graph and self._graph_step_ok():
-                try:
-                    self._graph_trial_step()
-                except _CaptureFailed as exc:
-                    # a failed capture executes nothing: the static buffers still hold the current state, continue
-                    # with the eager path from it
-                    warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({}); continuing with "
-                                  "the eager path".format(exc))
-                    self.hip_graph = False
-                    self._adaptive_step()
-            else:
-                self._adaptive_step()
+            self._trial_step()
             n_steps += 1
+
+    def _trial_step(self) -> None:
+        """One trial step by the path this solve runs on: a hipGraph replay (hip_graph mode, small states) or the
+        eager launch sequence."""
+        if self.hip_graph and self._graph_step_ok():
+            try:
+                self._graph_trial_step()
+            except _CaptureFailed as exc:
+                # a failed capture executes nothing: the static buffers still hold the current state, continue
+                # with the eager path from it
+                warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({}); continuing with "
+                              "the eager path".format(exc))
+                self.hip_graph = False
+                self._adaptive_step()
+        else:
+            self._adaptive_step()
 
     def _advance(self, next_t: float, out: Optional[torch.Tensor], t_shadow=None) -> torch.Tensor:
         """Step until next_t is inside the last accepted step, then return y(next_t) (written into `out` if
@@ -1005,11 +1037,12 @@ class FixedGridODESolver(object):
     order: int
 
     def __init__(self, func: OdeFunc, y0: torch.Tensor, step_size=None, grid_constructor=None,
-                 interp="linear", perturb=False, hip_graph=False, **unused_kwargs):
+                 interp="linear", perturb=False, hip_graph=None, **unused_kwargs):
         self.atol = unused_kwargs.pop("atol")
         # `hip_graph=True` (an extension, not a reference option): replay one captured hipGraph per grid interval
-        # instead of launching a step's kernels one by one — see RK4._integrate_graph
-        self.hip_graph = bool(hip_graph)
+        # instead of launching a step's kernels one by one — see RK4._integrate_graph.  "auto": where it applies
+        # (rk4, small states), without the warning otherwise.
+        self.hip_graph, self._graph_auto = _graph_request(hip_graph)
         unused_kwargs.pop("rtol", None)
         unused_kwargs.pop("norm", None)
         unused_kwargs.pop("dist_sync", None)          # fixed grids are in lock step by construction
@@ -1078,6 +1111,7 @@ class FixedGridODESolver(object):
         return Perturb.PREV if self.perturb else Perturb.NONE
 
     # -- integrate -----------------------------------------------------------------------------------
+    @_native.on_state_device
     def integrate(self, t: torch.Tensor) -> torch.Tensor:
         func, ops = self.func, self.ops
         time_grid = self.grid_constructor(func, self.y0, t)
@@ -1085,11 +1119,13 @@ class FixedGridODESolver(object):
         if self.interp not in ("linear", "cubic"):
             raise ValueError(f"Unknown interpolation method {self.interp}")
         if self.hip_graph:
-            if self._graph_capable(t, time_grid):
+            if self._graph_capable(t, time_grid) and not (self._graph_auto and
+                                                          self.layout.total > _GRAPH_AUTO_MAX_ELEMENTS):
                 return self._integrate_graph(t)
-            warnings.warn("{}: hip_graph=True needs the rk4 method, the output times as the grid, linear "
-                          "interpolation, no callback, no autograd graph and a ROCm device; running the eager "
-                          "path".format(self.__class__.__name__))
+            if not self._graph_auto:
+                warnings.warn("{}: hip_graph=True needs the rk4 method, the output times as the grid, linear "
+                              "interpolation, no callback, no autograd graph and a ROCm device; running the eager "
+                              "path".format(self.__class__.__name__))
         # host copies, in the grid's own dtype (dt = t1 - t0 is formed in t.dtype: solvers.py:112)
         grid = time_grid.detach().cpu().numpy()
         tt = t.detach().cpu().numpy()
@@ -1152,6 +1188,7 @@ class FixedGridODESolver(object):
     def _graph_capable(self, t: torch.Tensor, time_grid: torch.Tensor) -> bool:
         return False
 
+    @_native.on_state_device
     def integrate_until_event(self, t0: torch.Tensor, event_fn):
         """Fixed steps of `step_size` until the event function changes sign, then bisection on the linear /
         cubic interpolant of that step (solvers.py:129-164).  Times are kept in the state dtype (:132)."""
