@@ -525,6 +525,8 @@ __global__ __launch_bounds__(kBlock) void init_scaled_kernel(const InitScaledArg
 
 // Finalize: workgroup (s, q) adds the partials of segment s from array q in a fixed order.
 //   q < n_sum  -> out_sumsq[q*n_seg + s]      q == n_sum -> out_bad[s]
+constexpr int kFinBatch = 8;
+
 struct FinalizeArgs {
     const double* part[3];   // part[n_sum] is the non-finite counter array
     SegTable st;
@@ -538,9 +540,19 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_kernel(const FinalizeArg
     const int s = blockIdx.x, q = blockIdx.y;
     const int64_t c0 = get_segment(a.st, s).chunk_start;
     const int64_t c1 = (s + 1 < a.st.n_seg) ? get_segment(a.st, s + 1).chunk_start : a.st.n_chunks;
-    const double* p = a.part[q];
+    const double* __restrict__ p = a.part[q];
     double acc[1] = {0.0};
-    for (int64_t i = c0 + threadIdx.x; i < c1; i += kBlock) acc[0] += p[i];
+    // kFinBatch loads in flight per lane, added in index order (the same sum as one load per iteration, bit for bit,
+    // without paying one memory round trip per partial — the finalize step is on the serial path of every trial step)
+    int64_t i = c0 + threadIdx.x;
+    for (; i + (kFinBatch - 1) * kBlock < c1; i += kFinBatch * kBlock) {
+        double v[kFinBatch];
+#pragma unroll
+        for (int u = 0; u < kFinBatch; ++u) v[u] = p[i + u * kBlock];
+#pragma unroll
+        for (int u = 0; u < kFinBatch; ++u) acc[0] += v[u];
+    }
+    for (; i < c1; i += kBlock) acc[0] += p[i];
     block_sum<1>(acc, red);
     if (threadIdx.x == 0) {
         if (q < a.n_sum) a.out_sumsq[(int64_t)q * a.st.n_seg + s] = acc[0];
@@ -616,9 +628,25 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         const int64_t c0 = a.st.inl[s].chunk_start;
         const int64_t c1 = (s + 1 < n_seg) ? a.st.inl[s + 1].chunk_start : a.st.n_chunks;
         double acc[2] = {0.0, 0.0};
-        for (int64_t i = c0 + threadIdx.x; i < c1; i += kBlock) {
-            acc[0] += a.part_sumsq[i];
-            acc[1] += a.part_bad[i];
+        const double* __restrict__ ps = a.part_sumsq;
+        const double* __restrict__ pb = a.part_bad;
+        int64_t i = c0 + threadIdx.x;
+        for (; i + (kFinBatch - 1) * kBlock < c1; i += kFinBatch * kBlock) {     // batched loads, same sum order
+            double v[kFinBatch], w[kFinBatch];
+#pragma unroll
+            for (int u = 0; u < kFinBatch; ++u) {
+                v[u] = ps[i + u * kBlock];
+                w[u] = pb[i + u * kBlock];
+            }
+#pragma unroll
+            for (int u = 0; u < kFinBatch; ++u) {
+                acc[0] += v[u];
+                acc[1] += w[u];
+            }
+        }
+        for (; i < c1; i += kBlock) {
+            acc[0] += ps[i];
+            acc[1] += pb[i];
         }
         block_sum<2>(acc, red);
         if (threadIdx.x == 0) {
