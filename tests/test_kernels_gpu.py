@@ -574,3 +574,58 @@ def test_adams_correct_segments_and_padding(hip_kernels, oracle_kernels, dtype):
     assert torch.equal(dy.cpu(), dy_ref) and torch.equal(y.cpu(), y_ref)      # padding written (zeros) as well
     assert cnt == cnt_ref and bad == [0.0] * len(numels)
     assert 0 < sum(cnt) < sum(numels)      # tolerances differ per segment: a mixed census
+
+
+# ---------------------------------------------------------------------------------------------------
+# hipGraph-mode kernels: step size read from device memory
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [5, 4099, (1 << 17) - 3, 1 << 17, (1 << 17) + 5, (1 << 20) + 1])
+@pytest.mark.parametrize("offset", [0, 1])
+def test_stage_combine_dev_equals_host_dt_kernels(hip_kernels, dtype, n, offset):
+    """tdeq_stage_combine_dev (dt = ctrl_dev[1] on the device; run-time-term kernel below 2^17 elements, the
+    templated 16-byte-per-lane kernel from there on; `offset` = a view that is not 16-byte aligned -> scalar path)
+    must give the bits of tdeq_stage_combine / tdeq_stage_combine_err with the same dt in the kernel arguments —
+    which are pinned to the oracle above.  Every dopri5 and dopri8 row."""
+    dev = torch.device("cuda:0")
+    dt = -0.0371 if offset else 0.0371
+    T = np.float32 if dtype == torch.float32 else np.float64
+    plan = hip_kernels.make_plan([(0, n, 1e-5, 1e-7)], n, 1024, dev)
+    plan.ctrl_dev.copy_(torch.tensor([1.0, float(T(dt)), 0.0, abs(dt)], dtype=torch.float64))
+    for tab in (DOPRI5, DOPRI8):
+        S = len(tab.alpha)
+        y0 = _rand(n, dtype, 1, offset).cuda()
+        ks = [_rand(n, dtype, 10 + j, offset).cuda() for j in range(S + 1)]
+        c_err = SparseRow.from_dense(tab.c_error)
+        for row in tab.beta_rows():
+            kk = [ks[j] for j in row.idx]
+            ref, out = torch.empty_like(y0), torch.empty_like(y0)
+            hip_kernels.stage_combine(ref, y0, kk, row.coef, float(T(dt)))
+            hip_kernels.stage_combine_dev(out, None, y0, kk, row.coef, None, plan)
+            assert torch.equal(out, ref), (tab.name if hasattr(tab, "name") else S, len(kk))
+            ecoef = [0.37 * (j + 1) for j in range(len(kk))]
+            ref_e, out_e = torch.empty_like(y0), torch.empty_like(y0)
+            hip_kernels.stage_combine_err(ref, ref_e, y0, kk, row.coef, ecoef, float(T(dt)))
+            hip_kernels.stage_combine_dev(out, out_e, y0, kk, row.coef, ecoef, plan)
+            assert torch.equal(out, ref) and torch.equal(out_e, ref_e)
+        del c_err
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,offset", [(7, 0), (4099, 0), (4099, 1), ((1 << 18) + 3, 0)])
+def test_step_commit(hip_kernels, dtype, n, offset):
+    """tdeq_step_commit: on accept (y_prev, f_prev) <- (y_cur, f_cur), (y_cur, f_cur) <- (y1, f1); on reject nothing."""
+    dev = torch.device("cuda:0")
+    plan = hip_kernels.make_plan([(0, n, 1e-5, 1e-7)], n, 1024, dev)
+    bufs = [_rand(n, dtype, 20 + j, offset).cuda() for j in range(6)]
+    for accept in (0.0, 1.0):
+        y_prev, f_prev, y_cur, f_cur, y1, f1 = [b.clone() for b in bufs]
+        if offset:      # clones are aligned: rebuild unaligned views
+            y_prev, f_prev, y_cur, f_cur, y1, f1 = [torch.cat([b.new_zeros(1), b])[1:] for b in
+                                                    (y_prev, f_prev, y_cur, f_cur, y1, f1)]
+        plan.ctrl_dev.copy_(torch.tensor([accept, 0.1, 0.0, 0.1], dtype=torch.float64))
+        hip_kernels.step_commit(y_prev, f_prev, y_cur, f_cur, y1, f1, plan)
+        exp = [bufs[2], bufs[3], bufs[4], bufs[5]] if accept else [bufs[0], bufs[1], bufs[2], bufs[3]]
+        for got, want in zip((y_prev, f_prev, y_cur, f_cur), exp):
+            assert torch.equal(got, want)
+        assert torch.equal(y1, bufs[4]) and torch.equal(f1, bufs[5])

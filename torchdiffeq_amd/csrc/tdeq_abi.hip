@@ -297,9 +297,50 @@ int dispatch_error_partial(const void* partial, const void* y0, const void* y1, 
     return TDEQ_EINVAL;
 }
 
+template <typename T, int NT>
+int launch_combine_devdt(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
+                         const double* err_coef, const double* dt_dev, int64_t n, hipStream_t s) {
+    CombineDevTArgs<T, NT> a;
+    a.c.out = static_cast<T*>(out);
+    a.c.y0 = static_cast<const T*>(y0);
+    a.err_out = static_cast<T*>(err_out);
+    bool vec = aligned16(out) && aligned16(y0) && aligned16(err_out);
+    for (int j = 0; j < NT; ++j) {
+        a.c.k[j] = static_cast<const T*>(k[j]);
+        a.c.c[j] = (T)coef[j];
+        a.e[j] = err_out ? (T)err_coef[j] : (T)0;
+        vec = vec && aligned16(k[j]);
+    }
+    a.c.n = n;
+    a.dt_dev = dt_dev;
+    constexpr int L = VecOf<T>::L;
+    const dim3 g(vec ? stream_grid(n / L, kBlock) : stream_grid(n, kBlock)), b(kBlock);
+    if (err_out) {
+        if (vec) hipLaunchKernelGGL((combine_devdt_kernel<T, NT, true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((combine_devdt_kernel<T, NT, false, true>), g, b, 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((combine_devdt_kernel<T, NT, true, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((combine_devdt_kernel<T, NT, false, false>), g, b, 0, s, a);
+    }
+    return check_launch();
+}
+
+// States below this size are launch-latency-bound: the run-time-term-count kernel (one instantiation, smallest code)
+// is as fast there; above it the unrolled 16-byte-per-lane form wins (profiles/r02_shard_regime.json).
+constexpr int64_t kDevCombineTunedFrom = 1 << 17;
+
 template <typename T>
 int launch_combine_dev(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
                        const double* err_coef, int nt, const double* dt_dev, int64_t n, hipStream_t s) {
+    if (n >= kDevCombineTunedFrom) {
+        switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_combine_devdt<T, N>(out, err_out, y0, k, coef, err_coef, dt_dev, n, s);
+            TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+            TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+        }
+        return TDEQ_EINVAL;
+    }
     CombineDevArgs<T> a;
     a.out = static_cast<T*>(out);
     a.err_out = static_cast<T*>(err_out);
@@ -328,7 +369,11 @@ int launch_commit(void* y_prev, void* f_prev, void* y_cur, void* f_cur, const vo
     a.f1 = static_cast<const T*>(f1);
     a.ctrl_dev = ctrl_dev;
     a.n = n;
-    hipLaunchKernelGGL((step_commit_kernel<T>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    const bool vec = aligned16(y_prev) && aligned16(f_prev) && aligned16(y_cur) && aligned16(f_cur) && aligned16(y1) &&
+                     aligned16(f1);
+    constexpr int L = VecOf<T>::L;
+    if (vec) hipLaunchKernelGGL((step_commit_kernel<T, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((step_commit_kernel<T, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
     return check_launch();
 }
 

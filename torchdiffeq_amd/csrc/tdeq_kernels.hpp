@@ -755,6 +755,65 @@ __global__ __launch_bounds__(kBlock) void combine_dev_kernel(const CombineDevArg
     }
 }
 
+// The bandwidth-shaped form of the same operation for states that are no longer launch-bound (r02): term count a
+// template parameter (streams unrolled, register-resident), one 16-byte element per lane, coefficients formed once per
+// lane as fl_T(fl_T(coef_j) * fl_T(dt)) from the device-resident step size — the rounding sequence of stage_combine /
+// stage_combine_err and of combine_dev_kernel, so all three agree bit for bit.
+template <typename T, int NT>
+struct CombineDevTArgs {
+    CombineArgs<T, NT> c;    // c.c[j] = fl_T(coef_j) (NOT yet times dt)
+    T* err_out;              // ERR only
+    T e[NT];                 // fl_T(err_coef_j)
+    const double* dt_dev;    // sign * T(dt)
+};
+
+template <typename T, int NT, bool VEC, bool ERR>
+__global__ __launch_bounds__(kBlock) void combine_devdt_kernel(const CombineDevTArgs<T, NT> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const T dtT = (T)*a.dt_dev;
+    T c[NT], e[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        c[j] = a.c.c[j] * dtT;
+        e[j] = ERR ? a.e[j] * dtT : (T)0;
+    }
+    const int64_t ne = a.c.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const E* __restrict__ y0 = reinterpret_cast<const E*>(a.c.y0);
+    E* __restrict__ out = reinterpret_cast<E*>(a.c.out);
+    E* __restrict__ eo = reinterpret_cast<E*>(a.err_out);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
+        E kk[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.c.k[j])[i];
+        E acc = kk[0] * c[0];
+#pragma unroll
+        for (int j = 1; j < NT; ++j) acc = acc + kk[j] * c[j];
+        out[i] = y0[i] + acc;
+        if (ERR) {
+            E err = kk[0] * e[0];
+#pragma unroll
+            for (int j = 1; j < NT; ++j) err = err + kk[j] * e[j];
+            eo[i] = err;
+        }
+    }
+    if (VEC) {   // scalar tail (n % L elements)
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.c.n) {
+            T acc = a.c.k[0][t] * c[0];
+            T err = a.c.k[0][t] * e[0];
+#pragma unroll
+            for (int j = 1; j < NT; ++j) {
+                acc = acc + a.c.k[j][t] * c[j];
+                err = err + a.c.k[j][t] * e[j];
+            }
+            a.c.out[t] = a.c.y0[t] + acc;
+            if (ERR) a.err_out[t] = err;
+        }
+    }
+}
+
 template <typename T>
 struct CommitArgs {
     T* y_prev;
@@ -767,15 +826,34 @@ struct CommitArgs {
     int64_t n;
 };
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(kBlock) void step_commit_kernel(const CommitArgs<T> a) {
     if (a.ctrl_dev[0] == 0.0) return;
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.n / L;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
-        a.y_prev[i] = a.y_cur[i];
-        a.f_prev[i] = a.f_cur[i];
-        a.y_cur[i] = a.y1[i];
-        a.f_cur[i] = a.f1[i];
+    E* __restrict__ yp = reinterpret_cast<E*>(a.y_prev);
+    E* __restrict__ fp = reinterpret_cast<E*>(a.f_prev);
+    E* __restrict__ yc = reinterpret_cast<E*>(a.y_cur);
+    E* __restrict__ fc = reinterpret_cast<E*>(a.f_cur);
+    const E* __restrict__ y1 = reinterpret_cast<const E*>(a.y1);
+    const E* __restrict__ f1 = reinterpret_cast<const E*>(a.f1);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
+        const E a0 = yc[i], a1 = fc[i], a2 = y1[i], a3 = f1[i];
+        yp[i] = a0;
+        fp[i] = a1;
+        yc[i] = a2;
+        fc[i] = a3;
+    }
+    if (VEC) {
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) {
+            a.y_prev[t] = a.y_cur[t];
+            a.f_prev[t] = a.f_cur[t];
+            a.y_cur[t] = a.y1[t];
+            a.f_cur[t] = a.f1[t];
+        }
     }
 }
 
