@@ -339,7 +339,10 @@ def cold_dominant_kernel(kern, n, device, sets=4, launches=24):
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (tools/profile_gpu.sh)."""
-    for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
+    import re
+    paths = [q for q in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json"))
+             if re.fullmatch(r"r\d+[a-z]?_pmc_hbm\.json", os.path.basename(q))]      # profiles of THIS command only
+    for pmc_path in sorted(paths, reverse=True):
         try:
             kernels = json.load(open(pmc_path))["kernels"]
             hit = [v for k, v in kernels.items() if k.startswith("tdeq::stage_combine_kernel<float, 5,")]

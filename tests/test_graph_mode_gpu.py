@@ -289,3 +289,56 @@ def test_graph_cache_notices_reallocated_parameters():
         assert torch.equal(yg, ye)
     assert len(_GraphStep._cache.get(f)) <= _GraphStep._MAX_PER_FUNC
     tda.clear_graph_cache()
+
+
+def test_graph_cache_notices_rebound_closure_tensors_and_plain_attributes():
+    """the captured-step cache must not replay a graph that reads tensors the func no longer uses.  A
+    closure whose variable is bound to a NEW tensor, a Module with a plain (unregistered) tensor attribute that is
+    re-assigned, and a user-bumped `hip_graph_token` each lead to a fresh capture; in-place updates do not need one."""
+    tda.clear_graph_cache()
+    torch.manual_seed(2)
+    y0 = torch.randn(7, 4, dtype=torch.float64, device="cuda")
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64, device="cuda")
+    kw = dict(method="dopri5", rtol=1e-7, atol=1e-9)
+    box = {"A": torch.randn(4, 4, dtype=torch.float64, device="cuda") * 0.3}
+
+    def make():
+        A = box["A"]
+        return lambda tt, y: torch.tanh(y @ A)
+
+    class Plain(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.W = box["A"].clone()        # plain attribute: not a Parameter, not a buffer
+
+        def forward(self, tt, y):
+            return torch.tanh(y @ self.W)
+
+    mod = Plain()
+    with torch.no_grad():
+        for step in range(3):
+            f = make()
+            yg = tda.odeint(f, y0, t, options=dict(hip_graph=True), **kw)
+            assert torch.equal(yg, tda.odeint(f, y0, t, **kw))
+            ym = tda.odeint(mod, y0, t, options=dict(hip_graph=True), **kw)
+            assert torch.equal(ym, tda.odeint(mod, y0, t, **kw))
+            box["A"] = torch.randn(4, 4, dtype=torch.float64, device="cuda") * 0.3      # NEW storage
+            mod.W = box["A"].clone()
+        # in-place update of a held tensor: same storage, the replayed graph sees the new values
+        f = make()
+        y1 = tda.odeint(f, y0, t, options=dict(hip_graph=True), **kw)
+        box["A"].mul_(0.5)
+        y2 = tda.odeint(f, y0, t, options=dict(hip_graph=True), **kw)
+        assert torch.equal(y2, tda.odeint(f, y0, t, **kw)) and not torch.equal(y1, y2)
+        # the token: same object, same storages, but the user says it computes something else now
+        mode = {"k": 1.0}
+
+        def g(tt, y):
+            return torch.tanh(y @ box["A"]) * mode["k"]
+        g.hip_graph_token = 0
+        ya = tda.odeint(g, y0, t, options=dict(hip_graph=True), **kw)
+        mode["k"] = -1.0
+        g.hip_graph_token = 1
+        yb = tda.odeint(g, y0, t, options=dict(hip_graph=True), **kw)
+        assert torch.equal(yb, tda.odeint(g, y0, t, **kw)) and not torch.equal(ya, yb)
+    tda.clear_graph_cache()

@@ -10,12 +10,12 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $REPO/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace_stdout.log 2>&1
 echo "trace rc=$?"
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch_stdout.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/pmc_fetch_stdout.log 2>&1
 echo "pmc fetch rc=$?"
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_write_stdout.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/pmc_write_stdout.log 2>&1
 echo "pmc write rc=$?"
 cd $REPO
 find $OUT -name "*.csv" | head -30

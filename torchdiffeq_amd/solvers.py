@@ -138,6 +138,48 @@ def _graph_request(hip_graph):
     return bool(hip_graph), False
 
 
+def _held_tensor_ptrs(fn, _depth=0):
+    """Storage addresses of the tensors a func object visibly holds: an nn.Module's parameters, buffers and plain
+    tensor attributes (all submodules); a function's closure cells, defaults and the module-level tensors its body
+    names; a bound method's owner; a
+    functools.partial's arguments.  Part of the captured-step cache key (see _GraphStep._key)."""
+    ptrs = []
+    if isinstance(fn, torch.nn.Module):
+        ptrs += [p.data_ptr() for p in fn.parameters()] + [b.data_ptr() for b in fn.buffers()]
+        for m in fn.modules():
+            ptrs += [v.data_ptr() for v in m.__dict__.values() if isinstance(v, torch.Tensor)]
+        return tuple(ptrs)
+    if _depth > 2:
+        return ()
+    owner = getattr(fn, "__self__", None)
+    if owner is not None and not isinstance(owner, type):
+        ptrs += _held_tensor_ptrs(owner, _depth + 1) if isinstance(owner, torch.nn.Module) else \
+            [v.data_ptr() for v in getattr(owner, "__dict__", {}).values() if isinstance(v, torch.Tensor)]
+    inner = getattr(fn, "__func__", fn)
+    held = [c.cell_contents for c in (getattr(inner, "__closure__", None) or ()) if _cell_is_set(c)]
+    held += list(getattr(inner, "__defaults__", None) or ())
+    code, glob = getattr(inner, "__code__", None), getattr(inner, "__globals__", None)
+    if code is not None and glob is not None:        # module-level tensors / modules the body names
+        held += [glob[n] for n in code.co_names if isinstance(glob.get(n), (torch.Tensor, torch.nn.Module))]
+    held += list(getattr(fn, "args", ())) + list((getattr(fn, "keywords", None) or {}).values())     # functools.partial
+    if getattr(fn, "func", None) is not None and callable(fn.func):
+        held.append(fn.func)
+    for v in held:
+        if isinstance(v, torch.Tensor):
+            ptrs.append(v.data_ptr())
+        elif isinstance(v, torch.nn.Module) or callable(v):
+            ptrs += _held_tensor_ptrs(v, _depth + 1)
+    return tuple(ptrs)
+
+
+def _cell_is_set(cell) -> bool:
+    try:
+        cell.cell_contents
+        return True
+    except ValueError:
+        return False
+
+
 class _CaptureFailed(RuntimeError):
     """The step body could not be captured into a hipGraph; no kernel of it has run."""
 
@@ -213,11 +255,11 @@ class _GraphStep:
         segs = tuple((int(sg.chunk_start), int(sg.numel), float(sg.rtol), float(sg.atol)) for sg in s.plan.segs)
         key = (type(s).__name__, str(s.y0.dtype), str(s.y0.device), int(s.layout.total), int(s.plan.chunk), segs,
                c.safety, c.ifactor, c.dfactor, c.exponent, c.min_step, c.max_step, c.time_sign, int(c.n_norm_seg))
-        base = s.func.base_func
-        if isinstance(base, torch.nn.Module):
-            # a captured graph reads the parameter STORAGES it saw: in-place updates are fine, re-allocated
-            # parameters (module.to(...), a re-built layer) must lead to a new capture
-            key += (tuple(p.data_ptr() for p in base.parameters()), tuple(b.data_ptr() for b in base.buffers()))
+        # A captured graph reads the STORAGES it saw: in-place updates are fine, anything re-allocated (module.to(...),
+        # a re-built layer, a closure variable bound to a new tensor) must lead to a new capture — so every tensor the
+        # func object can be seen to hold goes into the key; a user-supplied `hip_graph_token` attribute of func (any
+        # hashable: bump it when func changes what it computes) does too.
+        key += (_held_tensor_ptrs(s.func.base_func), getattr(s.func.base_func, "hip_graph_token", None))
         return key
 
     @classmethod
