@@ -1,0 +1,82 @@
+"""Round-1 advisor findings, pinned: func outputs are validated / broadcast before any kernel reads them, double
+backward through the kernel-backed autograd nodes raises instead of returning wrong numbers, and the sharded adjoint
+keeps `odeint_adjoint`'s own option validation."""
+import pytest
+import torch
+
+import torchdiffeq_amd as tda
+
+
+def test_broadcastable_func_output_is_expanded(dev):
+    """The reference computes `y0 + dt * f` with broadcasting (rk_common.py:79): a 0-dim or [1]-shaped derivative is
+    valid for any state shape.  Here it is expanded before the kernels read `numel` elements."""
+    y0 = torch.tensor([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]], dtype=torch.float64)
+    t = torch.tensor([0.0, 0.5, 2.0], dtype=torch.float64)
+    with torch.no_grad():
+        for method in ("dopri5", "rk4"):
+            y = tda.odeint(lambda tt, yy: torch.tensor(1.5, dtype=torch.float64, device=yy.device), y0, t, method=method)
+            assert torch.allclose(y[-1].cpu(), y0 + 3.0, atol=1e-12)
+            y = tda.odeint(lambda tt, yy: yy.new_tensor([1.0, 0.0, -1.0]), y0, t, method=method)      # a row
+            assert torch.allclose(y[-1].cpu(), y0 + torch.tensor([2.0, 0.0, -2.0], dtype=torch.float64), atol=1e-12)
+
+
+def test_wrong_sized_func_output_raises(dev):
+    y0 = torch.ones(4, 3, dtype=torch.float64)
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="does not broadcast"):
+            tda.odeint(lambda tt, yy: yy[:2], y0, t)
+        with pytest.raises(RuntimeError, match="components"):
+            tda.odeint(lambda tt, yy: (yy[0],), (y0, y0.clone()), t)
+        with pytest.raises(RuntimeError, match="does not broadcast"):
+            tda.odeint(lambda tt, yy: (yy[0], yy[1][:1, :2]), (y0, y0.clone()), t)
+        with pytest.raises(TypeError):
+            tda.odeint(lambda tt, yy: 1.0, y0, t)
+
+
+@pytest.mark.gpu
+def test_func_output_on_another_device_raises():
+    y0 = torch.ones(4, 3, device="cuda")
+    t = torch.tensor([0.0, 1.0], device="cuda")
+    with torch.no_grad(), pytest.raises(RuntimeError, match="lives on"):
+        tda.odeint(lambda tt, yy: yy.cpu(), y0, t)
+
+
+def test_double_backward_through_the_solver_raises(dev):
+    """The backward of a kernel-backed node runs raw HIP kernels (autodiff._LinearOp): it is marked
+    once_differentiable, so a Hessian-vector product through plain `odeint` fails loudly."""
+    y0 = torch.tensor([0.3, -0.7], dtype=torch.float64, requires_grad=True)
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64)
+    y = tda.odeint(lambda tt, yy: torch.sin(yy) * 2.0, y0, t, method="dopri5")
+    (g,) = torch.autograd.grad(y[-1].sum(), y0, create_graph=True)
+    assert torch.isfinite(g).all()
+    with pytest.raises(RuntimeError, match="once_differentiable|differentiated twice|twice"):
+        g.sum().backward()
+
+
+def test_sharded_adjoint_keeps_option_validation(cpu_backend):
+    """dist.odeint_adjoint_sharded must not defeat odeint_adjoint's ValueError for `adjoint_method != method` with
+    `options` given and no `adjoint_options` (adjoint.py:175 of the reference)."""
+    import torch.distributed as dist
+    from torchdiffeq_amd import dist as tdist
+    import os
+    import tempfile
+    lin = torch.nn.Linear(3, 3).double()
+    y0 = torch.randn(4, 3, dtype=torch.float64, requires_grad=True)
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64)
+    with tempfile.TemporaryDirectory() as d:
+        dist.init_process_group(backend="gloo", init_method="file://" + os.path.join(d, "rdv"), rank=0, world_size=1)
+        try:
+            with pytest.raises(ValueError, match="cannot infer"):
+                tdist.odeint_adjoint_sharded(lambda tt, yy: lin(yy), y0, t, group=dist.group.WORLD, method="dopri5",
+                                             adjoint_method="rk4", options=dict(first_step=0.1),
+                                             adjoint_params=tuple(lin.parameters()))
+            # forward-method options are NOT forwarded to a different adjoint solver when the user gave both
+            y = tdist.odeint_adjoint_sharded(lambda tt, yy: lin(yy), y0, t, group=dist.group.WORLD, method="dopri5",
+                                             adjoint_method="rk4", options=dict(first_step=0.1),
+                                             adjoint_options=dict(step_size=0.05),
+                                             adjoint_params=tuple(lin.parameters()))
+            y[-1].sum().backward()
+            assert torch.isfinite(y0.grad).all() and all(torch.isfinite(p.grad).all() for p in lin.parameters())
+        finally:
+            dist.destroy_process_group()

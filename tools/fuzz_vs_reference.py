@@ -9,6 +9,7 @@ the implicit RK methods, 1e-9 for the adaptive methods, 1e-9 / 1e-6 for gradient
 Last runs (round 1): fixed 1050 cases, adaptive 400, adjoint 220, backprop 120, event 100 — no mismatch other than
 non-converged implicit solves (both libraries warn), rounding-level iteration-count flips, dopri8's noise-level first
 step and the 0-dim fp32 state on an fp64 grid together with `perturb`."""
+import os
 import random
 import sys
 import warnings
@@ -130,10 +131,12 @@ elif mode == "adaptive":
             yy=y0
         kw=dict(rtol=rng.choice([1e-4,1e-7,1e-9]),atol=rng.choice([1e-6,1e-9,1e-11]))
         res=[]
+        import time as _time
         for lib in (ref,tda):
             n=[0]
             def ff(t_,y_):
                 n[0]+=1; return f(t_,y_)
+            _t0=_time.perf_counter()
             try:
                 with warnings.catch_warnings(record=True) as w, torch.no_grad():
                     warnings.simplefilter('always')
@@ -141,6 +144,8 @@ elif mode == "adaptive":
                 res.append(('ok',out,n[0]))
             except Exception as e:
                 res.append(('err',type(e).__name__+': '+str(e)[:80],n[0]))
+            if os.environ.get('FUZZ_VERBOSE'):
+                print('case',case,lib.__name__,method,'nfe',n[0],'%.1fs'%(_time.perf_counter()-_t0),flush=True)
         a,b=res
         desc=(method,shape,is_tuple,rev,npts,{k:(v.tolist() if torch.is_tensor(v) else v) for k,v in opts.items()},kw)
         if a[0]!=b[0]: bad+=1; print('STATUS',desc,a[:2] if a[0]=='err' else 'ok',b[:2] if b[0]=='err' else 'ok'); continue

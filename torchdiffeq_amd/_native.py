@@ -267,8 +267,17 @@ class HipKernels:
             plan.expect = ((0, n_sum * n), (2 * n, 3 * n + (4 if ctrl else 0)))
 
     # -- helpers ---------------------------------------------------------------------------------
-    @staticmethod
-    def _stream() -> int:
+    # The raw hipStream_t of the CURRENT device's current torch stream.  `torch.cuda.current_stream().cuda_stream`
+    # gives the same value but costs 4–8 us of host time per call (device-index resolution, an `is_available()` probe
+    # that reads os.environ, a Stream object) — seven calls per trial step, 12–17 % of the host time of a launch-bound
+    # step (tools/host_profile2.py, r02); the C accessors below cost ~0.2 us.
+    _raw_stream = staticmethod(getattr(torch._C, "_cuda_getCurrentRawStream", None))
+    _cur_device = staticmethod(getattr(torch._C, "_cuda_getDevice", None))
+
+    @classmethod
+    def _stream(cls) -> int:
+        if cls._raw_stream is not None and cls._cur_device is not None:
+            return cls._raw_stream(cls._cur_device())
         return torch.cuda.current_stream().cuda_stream
 
     # Host-side argument marshalling is on the critical path of small / medium states.  The entry points copy the

@@ -889,12 +889,16 @@ class RKAdaptiveStepsizeODESolver:
         fsal = self.tableau.fsal_solution
         builtin_norm = isinstance(self.norm, BuiltinNorm)
         err_partial = None
+        nograd = not torch.is_grad_enabled()      # no-grad solves (the adjoint's two solves, inference): no graph checks
         for i in range(1, n_rows):
             row = self._beta[i]
             if i == n_rows - 1 and fsal and self._fuse is not None and builtin_norm and \
-                    not (torch.is_grad_enabled() and (y0.requires_grad or k[-1].requires_grad)):
+                    (nograd or not (y0.requires_grad or k[-1].requires_grad)):
                 yi, err_partial = torch.empty_like(y0), torch.empty_like(y0)
                 kern.stage_combine_err(yi, err_partial, y0, [k[j] for j in row.idx], row.coef, self._fuse[0], dt_signed)
+            elif nograd:
+                yi = torch.empty_like(y0)
+                kern.stage_combine(yi, y0, [k[j] for j in row.idx], row.coef, dt_signed)
             else:
                 yi = ops.combine(y0, [k[j] for j in row.idx], row.coef, dt_signed, dsh_signed)
             k.append(func.eval_at(stage_times[i], yi))
