@@ -15,9 +15,9 @@ def test_broadcastable_func_output_is_expanded(dev):
     with torch.no_grad():
         for method in ("dopri5", "rk4"):
             y = tda.odeint(lambda tt, yy: torch.tensor(1.5, dtype=torch.float64, device=yy.device), y0, t, method=method)
-            assert torch.allclose(y[-1].cpu(), y0 + 3.0, atol=1e-12)
+            assert torch.allclose(y[-1].cpu(), (y0 + 3.0).cpu(), atol=1e-12)
             y = tda.odeint(lambda tt, yy: yy.new_tensor([1.0, 0.0, -1.0]), y0, t, method=method)      # a row
-            assert torch.allclose(y[-1].cpu(), y0 + torch.tensor([2.0, 0.0, -2.0], dtype=torch.float64), atol=1e-12)
+            assert torch.allclose(y[-1].cpu(), (y0 + y0.new_tensor([2.0, 0.0, -2.0])).cpu(), atol=1e-12)
 
 
 def test_wrong_sized_func_output_raises(dev):

@@ -43,6 +43,27 @@ class _AugmentedDynamics(OdeFunc):
         self.n_y = fwd.layout.n_seg
         self.sync_group = None       # lock-step sharded solve: batch-summed outputs are all-reduced per evaluation
         self.sync = False
+        # hipGraph capture of the backward solve (see `backward`): the parameter VJPs must not touch the parameters' own
+        # AccumulateGrad nodes — those were created on the default stream by the user's forward pass and are kept alive
+        # by the very graph whose backward is running; autograd would synchronise the capturing stream with the
+        # default stream and the capture dies (measured: a segfault inside hipGraph capture).  Captured evaluations
+        # therefore run func through `torch.func.functional_call` on fresh leaf ALIASES of the parameters (same
+        # storage: in-place optimizer updates are seen by every replay).  Possible when func is an nn.Module and every
+        # adjoint parameter is one of its parameters.
+        self.proxy_names = None
+        self.use_proxy = False
+        base = fwd.base_func
+        if isinstance(base, nn.Module):
+            by_id = {}
+            for name, p in base.named_parameters(remove_duplicate=False):
+                by_id.setdefault(id(p), name)
+            if all(id(p) in by_id for p in self.params):
+                self.proxy_names = [by_id[id(p)] for p in self.params]
+
+    def graph_key(self):
+        """What a captured trial step of these dynamics depends on beyond the user's func (solvers._GraphStep._key)."""
+        return ("adjoint", self.fwd.sign, tuple(p.data_ptr() for p in self.params),
+                tuple(tuple(sh) for sh in self.fwd.layout.shapes))
 
     def call_base(self, t_user: torch.Tensor, aug: torch.Tensor) -> torch.Tensor:
         fwd, lay, n_y = self.fwd, self.layout, self.n_y
@@ -56,9 +77,15 @@ class _AugmentedDynamics(OdeFunc):
             # takes part in the error norm and the initial-step heuristic of the backward solve.
             t_ = (t_user * sign_f if sign_f != 1.0 else t_user).detach().requires_grad_(True)
             y_in = tuple(v.detach().requires_grad_(True) for v in y_views)
-            f = fwd.base_func(t_, y_in if fwd.layout.is_tuple else y_in[0])
+            y_arg = y_in if fwd.layout.is_tuple else y_in[0]
+            if self.use_proxy:
+                leaves = tuple(p.detach().requires_grad_(True) for p in self.params)
+                f = torch.func.functional_call(fwd.base_func, dict(zip(self.proxy_names, leaves)), (t_, y_arg))
+            else:
+                leaves = self.params
+                f = fwd.base_func(t_, y_arg)
             f_list = list(f) if fwd.layout.is_tuple else [f]
-            wrt = (t_,) + y_in + self.params
+            wrt = (t_,) + y_in + leaves
             # components of f that depend on nothing differentiable (e.g. f(t, y) = g(t)) contribute zero VJPs
             live = [(fi, ai) for fi, ai in zip(f_list, adj_views) if fi.requires_grad]
             if live:
@@ -174,13 +201,23 @@ class OdeintAdjointMethod(torch.autograd.Function):
             group = options.pop("dist_group", None)
             sync = options.pop("dist_sync", None)
             options.pop("dist_replicated", None)
-            requested = options.pop("hip_graph", False)
-            options["hip_graph"] = False          # also overrides a process-wide TDEQ_HIP_GRAPH default
-            if requested and requested != "auto":
-                # the augmented dynamics call torch.autograd.grad from inside the autograd engine's own thread;
-                # capturing that into a hipGraph crashes the capture (measured) — never attempted
-                warnings.warn("adjoint_options['hip_graph'] is ignored: the backward solve evaluates autograd inside "
-                              "func and cannot be captured into a hipGraph")
+            # `hip_graph` passes through to the backward solver: one trial step of the AUGMENTED system — S evaluations
+            # of func with `torch.autograd.grad` behind each, the segment packing, the combines, the segmented norm +
+            # controller — is captured and replayed like a forward step (capturing autograd from inside the engine's
+            # worker thread works once the parameter VJPs stay off the parameters' own AccumulateGrad nodes — see
+            # _AugmentedDynamics.__init__; that was r01's crash).  Not with lock-step sharding: the per-
+            # evaluation all-reduce does not belong in a graph.
+            if sync is not None:
+                options["hip_graph"] = False
+            from .solvers import _graph_request
+            wanted, auto = _graph_request(options.get("hip_graph"))
+            if wanted and aug_func.proxy_names is None:
+                if not auto and "hip_graph" in ctx.adjoint_options:
+                    warnings.warn("hip_graph: the adjoint's backward solve can only be captured when func is an "
+                                  "nn.Module and every adjoint parameter is one of its parameters; running it eagerly")
+                options["hip_graph"] = False
+            elif wanted:
+                aug_func.use_proxy = True
             if sync is not None:
                 # lock-step backward solve: [vjp_t | θ-adjoints] replicated (all-reduced per evaluation), y / adj_y
                 # sharded; the norm sums are added over ranks (solvers._LockStep)
@@ -321,9 +358,7 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
         raise ValueError("If `adjoint_method != method` then we cannot infer `adjoint_options` from `options`. So as "
                          "`options` has been passed then `adjoint_options` must be passed as well.")
     if adjoint_options is None:
-        # `hip_graph` (an extension) is not inherited: the backward dynamics run autograd inside `func`
-        adjoint_options = {k: v for k, v in options.items() if k not in ("norm", "hip_graph")} \
-            if options is not None else {}
+        adjoint_options = {k: v for k, v in options.items() if k != "norm"} if options is not None else {}
     else:
         adjoint_options = adjoint_options.copy()
     if _adjoint_extra:

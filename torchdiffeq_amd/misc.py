@@ -223,6 +223,11 @@ class OdeFunc:
             self._kernels = _native.get_kernels(self.device)
         return self._kernels
 
+    def graph_key(self):
+        """Extra identity of this wrapper for the captured-step cache (subclasses that compute more than
+        `base_func` — the adjoint's augmented dynamics — say what else a captured step depends on)."""
+        return ()
+
     def set_time_anchor(self, anchor) -> None:
         """`anchor` = t[0] in solver time (a 0-dim tensor in the autograd graph of `t`) or None.  Every time the
         adaptive solvers hand to func is t[0] + constants, so its gradient flows to this anchor

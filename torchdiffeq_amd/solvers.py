@@ -259,7 +259,8 @@ class _GraphStep:
         # a re-built layer, a closure variable bound to a new tensor) must lead to a new capture — so every tensor the
         # func object can be seen to hold goes into the key; a user-supplied `hip_graph_token` attribute of func (any
         # hashable: bump it when func changes what it computes) does too.
-        key += (_held_tensor_ptrs(s.func.base_func), getattr(s.func.base_func, "hip_graph_token", None))
+        key += (_held_tensor_ptrs(s.func.base_func), getattr(s.func.base_func, "hip_graph_token", None),
+                type(s.func).__name__, s.func.graph_key())
         return key
 
     @classmethod
