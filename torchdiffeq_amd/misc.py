@@ -117,11 +117,12 @@ class StateLayout:
 
     def pack_fused(self, kernels, pieces: Sequence[Optional[torch.Tensor]], dtype, device,
                    scales: Optional[Sequence[float]] = None) -> torch.Tensor:
-        """`pack` as ONE kernel launch (tdeq_pack_segments): piece s (None = zeros) times scales[s] (+-1) into
-        segment s of a fresh flat buffer, padding zero-filled.  Falls back to `pack` for layouts the kernel does not
-        take (a single unpadded segment, more than TDEQ_INLINE_SEGMENTS segments)."""
+        """`pack` as ONE kernel launch per <= TDEQ_INLINE_SEGMENTS consecutive segments (tdeq_pack_segments): piece s
+        (None = zeros) times scales[s] (+-1) into segment s of a fresh flat buffer, padding zero-filled.  A model with
+        40 parameter tensors packs its augmented state in 3 launches instead of ~90 copy / neg / zero ops.  Falls back
+        to `pack` for a single unpadded segment."""
         n = self.n_seg
-        if n == 1 or n > _native.TDEQ_INLINE_SEGMENTS or os.environ.get("TDEQ_PACK_FUSED", "1") == "0":
+        if n == 1 or os.environ.get("TDEQ_PACK_FUSED", "1") == "0":
             neg = [sc < 0 for sc in scales] if scales is not None else ()
             filled = [torch.zeros(m, dtype=dtype, device=device) if t is None else t
                       for t, m in zip(pieces, self.numels)]
@@ -139,8 +140,17 @@ class StateLayout:
                 raise RuntimeError(f"func returned a component with {t.numel()} elements where the state has {m}")
             srcs.append(t if t.is_contiguous() else t.contiguous())
         out = torch.empty(self.total, dtype=dtype, device=device)
-        kernels.pack_segments(out, srcs, [off // self.chunk for off in self.offsets], self.numels,
-                              [1.0] * n if scales is None else list(scales), self.chunk)
+        scales = [1.0] * n if scales is None else list(scales)
+        G = _native.TDEQ_INLINE_SEGMENTS
+        if n <= G:
+            kernels.pack_segments(out, srcs, [off // self.chunk for off in self.offsets], self.numels, scales,
+                                  self.chunk)
+            return out
+        for a in range(0, n, G):           # consecutive segments span a contiguous, chunk-aligned range of `out`
+            b = min(a + G, n)
+            lo, hi = self.offsets[a], (self.offsets[b] if b < n else self.total)
+            kernels.pack_segments(out[lo:hi], srcs[a:b], [(off - lo) // self.chunk for off in self.offsets[a:b]],
+                                  self.numels[a:b], scales[a:b], self.chunk)
         return out
 
     def unpack(self, flat: torch.Tensor, lead: Tuple[int, ...] = (), lo: int = 0,
