@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 13
+#define TDEQ_ABI_VERSION 14
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -178,7 +178,9 @@ int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void*
  *       ratio, t0'} (device or pinned host memory, read by the host loop); ctrl_dev[4] = {accept, sign * T(dt'),
  *       t0', dt'} (device memory, read by tdeq_stage_combine_sel and by the hipGraph-mode kernels);
  *       next_times[n_times] (device memory, element type T) = the 0-dim time tensors the next trial step hands to
- *       func.  n_seg <= TDEQ_INLINE_SEGMENTS.  state_in_dev != 0 (hipGraph mode, below): ctrl->t0 / ctrl->dt and
+ *       func.  More than TDEQ_INLINE_SEGMENTS segments (segs_dev required, as for tdeq_error_norm): the sums come
+ *       from the parallel per-segment finalize launch and the one-workgroup controller runs on them (one launch
+ *       more; same sums, same decision).  state_in_dev != 0 (hipGraph mode, below): ctrl->t0 / ctrl->dt and
  *       the `dt` argument are ignored — the trial step's (t0, dt) are ctrl_dev[2..3] and the error coefficients are
  *       scaled by ctrl_dev[1], all left there by the previous call (or by the host before the first one).
  *
@@ -189,10 +191,11 @@ int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void*
  *       Bit-identical to the host-driven tdeq_stage_combine call it replaces.
  */
 int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const void* y1, const void* const* k,
-                                 const double* coef, int n_terms, double dt, const tdeq_segment* segs, int n_seg,
-                                 int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite,
-                                 const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev, void* next_times,
-                                 int state_in_dev, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+                                 const double* coef, int n_terms, double dt, const tdeq_segment* segs,
+                                 const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
+                                 double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev,
+                                 void* next_times, int state_in_dev, void* workspace, size_t workspace_bytes,
+                                 int dtype, void* stream);
 int tdeq_stage_combine_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej,
                            double coef, const double* ctrl_dev, int64_t n, int dtype, void* stream);
 

@@ -580,7 +580,7 @@ int oracle_error_norm_partial_ctrl(const void* err_partial, const void* y0, cons
                                    int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite,
                                    const oracle_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev, void* next_times,
                                    int dtype) {
-    if (!ctrl || !out_ctrl || !ctrl_dev || !next_times || n_seg > 16) return -1;
+    if (!ctrl || !out_ctrl || !ctrl_dev || !next_times) return -1;   /* any number of segments (the host loops) */
     if (ctrl->n_times < 1 || ctrl->n_times > ORACLE_MAX_STAGE_TIMES) return -1;
     const int e = oracle_error_norm_partial(err_partial, y0, y1, k, coef, n_terms, dt, segs, n_seg, chunk, n_chunks,
                                             out_sumsq, out_nonfinite, dtype);

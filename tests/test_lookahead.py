@@ -271,3 +271,54 @@ def test_lookahead_under_every_readback_mode(hip_kernels, monkeypatch):
         outs.append((y.cpu(), f.nfe))
     assert outs[0][1] == outs[1][1] == outs[2][1]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n_seg,skip_tail,plant_nan", [(17, 0, False), (40, 0, False), (40, 37, False), (23, 0, True)])
+def test_controller_kernel_many_segments(hip_kernels, oracle_kernels, dtype, n_seg, skip_tail, plant_nan):
+    """More segments than the inline table holds (r02, ABI 14): per-segment sums by the parallel finalize launch,
+    controller on them.  Sums equal tdeq_error_norm_partial's bit for bit; ratio / accept / t0' equal the oracle's
+    controller on those sums (a max over segments: order-independent; NaN wins); seminorm (`n_norm_seg` < n_seg) too."""
+    chunk = 1024
+    g = torch.Generator().manual_seed(n_seg)
+    numels = [int(v) for v in torch.randint(1, 3 * chunk, (n_seg,), generator=g)]
+    numels[1] = 5 * chunk + 17                      # one big segment
+    offs, off = [], 0
+    for m in numels:
+        offs.append(off)
+        off += -(-m // chunk) * chunk
+    total = off
+    segs = [(o, m, 1e-6 * (1 + i % 3), 1e-8) for i, (o, m) in enumerate(zip(offs, numels))]
+    y0 = torch.randn(total, generator=g, dtype=torch.float64).to(dtype)
+    y1 = y0 + 0.01 * torch.randn(total, generator=g, dtype=torch.float64).to(dtype)
+    part = (torch.randn(total, generator=g, dtype=torch.float64) * 3e-7).to(dtype)
+    k6 = (torch.randn(total, generator=g, dtype=torch.float64) * 1e-7).to(dtype)
+    if plant_nan:
+        part[offs[20] + 3] = float("nan")
+    plan_d = hip_kernels.make_plan(segs, total, chunk, torch.device("cuda:0"))
+    plan_o = oracle_kernels.make_plan(segs, total, chunk, None)
+    assert plan_d.segs_dev is not None
+    np_dtype = np.float32 if dtype == torch.float32 else np.float64
+    c = _ctrl(0.37, 0.0123, 5, DOPRI5, 1.0, 0.0, math.inf, np_dtype=np_dtype)
+    c.n_norm_seg = n_seg - skip_tail
+    dts = float(np_dtype(0.0123))
+    tn_d = torch.empty(c.n_times, dtype=dtype, device="cuda")
+    yd, y1d, pd, kd = y0.cuda(), y1.cuda(), part.cuda(), k6.cuda()
+    hip_kernels.error_norm_partial_ctrl(plan_d, pd, yd, y1d, [kd], [0.025], dts, c, tn_d)
+    accept, dt_next, ratio, bad = hip_kernels.read_ctrl(plan_d)
+    full = hip_kernels._read_out(plan_d)
+    sums_ctrl, t0_next = full[:n_seg], full[3 * n_seg + 3]
+    hip_kernels.error_norm_partial(plan_d, pd, yd, y1d, [kd], [0.025], dts)
+    sums_plain, _, bad_plain = hip_kernels.read_norms(plan_d)
+    assert np.array_equal(np.array(sums_ctrl), np.array(sums_plain), equal_nan=True)
+    assert bad == bad_plain          # (the census counts non-finite STATE entries; a NaN error shows up in the sums)
+    tn_o = torch.empty(c.n_times, dtype=dtype)
+    out_ctrl, ctrl_dev_o = oracle_kernels.step_controller(plan_o, sums_plain, c, tn_o, dtype)
+    assert accept == (out_ctrl[0] != 0.0)
+    assert np.array_equal([ratio, t0_next], [out_ctrl[2], out_ctrl[3]], equal_nan=True)
+    if plant_nan and skip_tail == 0:
+        assert math.isnan(ratio) and not accept
+    if not math.isnan(out_ctrl[1]):
+        assert abs(dt_next - out_ctrl[1]) <= 4 * np.spacing(abs(out_ctrl[1]))
+    assert torch.allclose(tn_d.cpu().double(), tn_o.double(), rtol=1e-6 if dtype == torch.float32 else 1e-14, equal_nan=True)

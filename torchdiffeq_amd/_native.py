@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 13
+TDEQ_ABI_VERSION = 14
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -75,7 +75,7 @@ ABI_SIGNATURES = {
                                                ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_error_norm_partial_ctrl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
                                                     _c_double_p, ctypes.c_int, ctypes.c_double,
-                                                    ctypes.POINTER(Segment), ctypes.c_int, ctypes.c_int64,
+                                                    ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                                     ctypes.POINTER(StepCtrl), ctypes.c_void_p, ctypes.c_void_p,
                                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
@@ -424,7 +424,8 @@ class HipKernels:
         cf = (ctypes.c_double * max(n, 1))(*coefs)
         self._arm(plan, 1, ctrl=True)
         _check(self.lib.tdeq_error_norm_partial_ctrl(
-            err_partial.data_ptr(), y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, plan.segs, plan.n_seg, plan.chunk,
+            err_partial.data_ptr(), y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, plan.segs,
+            plan.segs_dev.data_ptr() if plan.segs_dev is not None else None, plan.n_seg, plan.chunk,
             plan.n_chunks, plan.out_ptr, plan.bad_ptr, ctypes.byref(ctrl), plan.ctrl_ptr, plan.ctrl_dev.data_ptr(),
             next_times.data_ptr(), 1 if state_in_dev else 0, plan.workspace.data_ptr(), plan.workspace_bytes,
             dtype_code(y0.dtype), self._stream()), "tdeq_error_norm_partial_ctrl")

@@ -250,6 +250,14 @@ int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, doub
     a.ctrl_dev = cb.ctrl_dev;
     a.next_times = cb.next_times;
     a.state_in_dev = cb.state_in_dev;
+    a.presummed = 0;
+    if (st.n_seg > TDEQ_INLINE_SEGMENTS) {
+        // more segments than the inline table holds: the per-segment sums by the parallel finalize (one workgroup per
+        // segment, segment table from device memory), then the one-workgroup controller on those sums
+        const int e = launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
+        if (e) return e;
+        a.presummed = 1;
+    }
     hipLaunchKernelGGL(norm_finalize_ctrl_kernel, dim3(1), dim3(kBlock), 0, s, a);
     return check_launch();
 }
@@ -875,20 +883,20 @@ int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void*
 }
 
 int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const void* y1, const void* const* k,
-                                 const double* coef, int n_terms, double dt, const tdeq_segment* segs, int n_seg,
-                                 int64_t chunk, int64_t n_chunks, double* out_sumsq, double* out_nonfinite,
-                                 const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev, void* next_times,
-                                 int state_in_dev, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+                                 const double* coef, int n_terms, double dt, const tdeq_segment* segs,
+                                 const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
+                                 double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev,
+                                 void* next_times, int state_in_dev, void* workspace, size_t workspace_bytes,
+                                 int dtype, void* stream) {
     if (!err_partial || !y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype))
         return TDEQ_EINVAL;
     if (!ctrl || !out_ctrl || !ctrl_dev || !next_times) return TDEQ_EINVAL;
     if (n_terms < 0 || n_terms > 2 || (n_terms > 0 && (!k || !coef))) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
-    if (n_seg > TDEQ_INLINE_SEGMENTS) return TDEQ_EINVAL;
     if (ctrl->n_times < 1 || ctrl->n_times > TDEQ_MAX_STAGE_TIMES || ctrl->n_norm_seg < 0 || ctrl->n_norm_seg > n_seg)
         return TDEQ_EINVAL;
     SegTable st;
-    const int e = fill_segtable(st, segs, nullptr, n_seg, chunk, n_chunks);
+    const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
     if (e) return e;
     if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -580,6 +580,8 @@ struct CtrlArgs {
     double* ctrl_dev;         // [4] = {accept, sign * T(dt'), t0', dt'}  device
     void* next_times;         // [n_times] of T                          device
     int state_in_dev;         // hipGraph mode: the trial step's (t0, dt) are ctrl_dev[2..3], not c.t0 / c.dt
+    int presummed;            // n_seg > TDEQ_INLINE_SEGMENTS: norm_finalize_kernel (one workgroup per segment) has
+                              // already written out_sumsq / out_bad; this kernel only runs the controller on them
 };
 
 __device__ __forceinline__ double ctl_nan_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
@@ -624,7 +626,37 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
     __shared__ double seg_val[2][TDEQ_INLINE_SEGMENTS];
     __shared__ double next_step[2];     // {t0', dt'} broadcast to the lanes that form the stage times
     const int n_seg = a.st.n_seg;
-    for (int s = 0; s < n_seg; ++s) {
+    if (a.presummed) {
+        // Many segments (an adjoint state with more than 13 parameter tensors): the per-segment sums come from the
+        // parallel finalize launch; ratio = max_s sqrt(sum_s / numel_s) is order-independent (a max; NaN wins), so
+        // it is formed by all lanes — each lane its segments, then one block reduction — with the value the serial
+        // loop below would give.
+        double part[2] = {0.0, 0.0};          // {max over this lane's segments, 1 if any of them is NaN}
+        for (int s = threadIdx.x; s < a.c.n_norm_seg && s < n_seg; s += kBlock) {
+            const int64_t numel = get_segment(a.st, s).numel;
+            if (numel == 0) continue;
+            const double v = __builtin_sqrt(a.out_sumsq[s] / (double)numel);
+            if (v != v) part[1] = 1.0;
+            else part[0] = v > part[0] ? v : part[0];
+        }
+        // block max of part[0] (wave shuffles + LDS) and block sum of the NaN flags
+        double m = part[0];
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const double o = __shfl_down(m, off, kWave);
+            m = o > m ? o : m;
+        }
+        double flag[1] = {part[1]};
+        __shared__ double wmax[kBlock / kWave];
+        if ((threadIdx.x & (kWave - 1)) == 0) wmax[threadIdx.x / kWave] = m;
+        block_sum<1>(flag, red);              // (contains the __syncthreads that also publishes wmax)
+        if (threadIdx.x == 0) {
+            double mm = wmax[0];
+            for (int w = 1; w < kBlock / kWave; ++w) mm = wmax[w] > mm ? wmax[w] : mm;
+            seg_val[0][0] = flag[0] != 0.0 ? __builtin_nan("") : mm;
+        }
+        __syncthreads();
+    }
+    for (int s = 0; s < n_seg && !a.presummed; ++s) {
         const int64_t c0 = a.st.inl[s].chunk_start;
         const int64_t c1 = (s + 1 < n_seg) ? a.st.inl[s + 1].chunk_start : a.st.n_chunks;
         double acc[2] = {0.0, 0.0};
@@ -665,7 +697,8 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         const double step_dt = a.state_in_dev ? dev_dt : arg_dt;
         // error ratio: max over segments of sqrt(mean), rounded to T (misc.py:22-33, 80-82)
         double val = 0.0;
-        for (int s = 0; s < c.n_norm_seg && s < n_seg; ++s) {
+        if (a.presummed) val = seg_val[0][0];
+        for (int s = 0; s < c.n_norm_seg && s < n_seg && !a.presummed; ++s) {
             const int64_t numel = a.st.inl[s].numel;
             if (numel == 0) continue;
             val = ctl_nan_max(val, __builtin_sqrt(seg_val[0][s] / (double)numel));
@@ -708,7 +741,7 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         if (a.is_f32) static_cast<float*>(a.next_times)[i] = ctl_stage_time<float>(c, next_step[0], next_step[1], i);
         else static_cast<double*>(a.next_times)[i] = ctl_stage_time<double>(c, next_step[0], next_step[1], i);
     }
-    if (i < n_seg) {
+    if (i < n_seg && !a.presummed) {
         a.out_sumsq[i] = seg_val[0][i];
         a.out_bad[i] = seg_val[1][i];
     }

@@ -482,7 +482,6 @@ class RKAdaptiveStepsizeODESolver:
         # trial step's first stage and func evaluation are enqueued before the decision has been read back.
         n_norm_seg = self.layout.n_seg - (self.norm.n_skip_tail if isinstance(self.norm, BuiltinNorm) else 0)
         device_ctrl = (self._fuse is not None and isinstance(self.norm, BuiltinNorm)
-                       and self.layout.n_seg <= _native.TDEQ_INLINE_SEGMENTS
                        and len(self._beta) <= _native.TDEQ_MAX_STAGE_TIMES and n_norm_seg >= 0
                        and self.step_t is None and self.jump_t is None and self._sync is None)
         self._lookahead = device_ctrl and os.environ.get("TDEQ_LOOKAHEAD", "1") != "0"
@@ -495,11 +494,10 @@ class RKAdaptiveStepsizeODESolver:
             and hasattr(self.kernels, "stage_combine_dev") \
             and self.layout.total <= (_GRAPH_AUTO_MAX_ELEMENTS if auto else _GRAPH_MODE_MAX_ELEMENTS)
         if wanted and not auto and not self.hip_graph:
-            warnings.warn("{}: hip_graph=True needs a builtin norm, at most {} state segments, no step_t / jump_t, a "
-                          "tableau with a fused error combine, a ROCm device and a state of at most {} elements (larger "
-                          "states are bandwidth-bound: the eager path with its unrolled kernels is the fast one); "
-                          "running the eager path".format(self.__class__.__name__, _native.TDEQ_INLINE_SEGMENTS,
-                                                          _GRAPH_MODE_MAX_ELEMENTS))
+            warnings.warn("{}: hip_graph=True needs a builtin norm, no step_t / jump_t, a tableau with a fused error "
+                          "combine, a ROCm device and a state of at most {} elements (larger states are "
+                          "bandwidth-bound: the eager path with its unrolled kernels is the fast one); running the "
+                          "eager path".format(self.__class__.__name__, _GRAPH_MODE_MAX_ELEMENTS))
         self._g = None
         self._dt_shadow = None      # autograd graph of the current step size (the first, heuristic one only)
         if device_ctrl:
