@@ -521,8 +521,11 @@ class AllReduceProbe:
         dist.all_reduce = self._orig
 
 
-def adjoint_pass(world, rank, device, rows_per_rank, steps, warmup, group_forced=False):
-    """cfg3 on this rank's `rows_per_rank` rows: K forward + backward passes through odeint_adjoint_sharded."""
+def adjoint_pass(world, rank, device, rows_per_rank, steps, warmup, group_forced=False, graph=False):
+    """cfg3 on this rank's `rows_per_rank` rows: K forward + backward passes through odeint_adjoint_sharded.
+    graph=True: options={'hip_graph': 'auto'} (forward and, inherited, backward solve as captured trial steps where the
+    state is small enough); the field's own Python evaluation counter does not run during replays, so the evaluation
+    counts of such a pass are not reported."""
     import _fullsize as fs
     from torchdiffeq_amd import dist as tdist
     field, y0_all = fs.cfg3_problem()
@@ -537,17 +540,21 @@ def adjoint_pass(world, rank, device, rows_per_rank, steps, warmup, group_forced
     params = list(field.parameters())
     stats = {}
     group = torch.distributed.group.WORLD if (world > 1 or group_forced) else None
+    extra = {"options": {"hip_graph": "auto"}} if graph else {}
 
     def one():
         for p in params:
             p.grad = None
         x = y0.clone().requires_grad_(True)
         field.nfe = 0
-        y = tdist.odeint_adjoint_sharded(field, x, t, group=group, rtol=1e-5, atol=1e-7, method="dopri5")
+        y = tdist.odeint_adjoint_sharded(field, x, t, group=group, rtol=1e-5, atol=1e-7, method="dopri5", **extra)
         stats["nfe_fwd"], field.nfe = field.nfe, 0
         y[-1].pow(2).sum().backward()
         stats["nfe_bwd"] = field.nfe
     blocks = timed_blocks(one, steps, warmup, world, device, n_blocks=3)
+    if graph:
+        st = block_stats(blocks, steps)
+        return {"rows_per_gpu": rows_per_rank, "ms_per_pass": st["median"], "blocks": st, "options": extra["options"]}
     # one more instrumented pass: forward / backward split and the all-reduce on its own clock
     dist_sync(world)
     with AllReduceProbe() as probe:
@@ -555,7 +562,7 @@ def adjoint_pass(world, rank, device, rows_per_rank, steps, warmup, group_forced
             p.grad = None
         x = y0.clone().requires_grad_(True)
         t0 = time.perf_counter()
-        y = tdist.odeint_adjoint_sharded(field, x, t, group=group, rtol=1e-5, atol=1e-7, method="dopri5")
+        y = tdist.odeint_adjoint_sharded(field, x, t, group=group, rtol=1e-5, atol=1e-7, method="dopri5", **extra)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         y[-1].pow(2).sum().backward()
@@ -677,12 +684,20 @@ def main():
                         adj[mode] = r
                 except Exception as exc:
                     adj[mode] = {"error": repr(exc)}
+            try:        # the strong split once more with captured trial steps (forward and backward solve)
+                r = adjoint_pass(world, rank, device, ADJ_BATCH // world, 3, 2, graph=True)
+                if rank == 0:
+                    adj["strong_hip_graph_auto"] = r
+            except Exception as exc:
+                adj["strong_hip_graph_auto"] = {"error": repr(exc)}
             if rank == 0:
                 out["adjoint"] = adj
         if extras and world == 1 and rank == 0:
             try:
                 out["shard_regime"] = {"linear": shard_regime_linear(device),
-                                       "adjoint": adjoint_pass(1, 0, device, ADJ_BATCH // 8, 3, 1)}
+                                       "adjoint": adjoint_pass(1, 0, device, ADJ_BATCH // 8, 3, 1),
+                                       "adjoint_hip_graph_auto": adjoint_pass(1, 0, device, ADJ_BATCH // 8, 3, 2,
+                                                                              graph=True)}
                 full = out["ms_per_step"]
                 la = out["shard_regime"]["linear"]
                 best = min(v["ms_per_step"] for v in la.values() if isinstance(v, dict) and "ms_per_step" in v)
