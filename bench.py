@@ -608,6 +608,31 @@ def run_adjoint(args, rank, world, device):
 # ---------------------------------------------------------------------------------------------------
 # launch
 # ---------------------------------------------------------------------------------------------------
+class _Watchdog:
+    """Fires once after `seconds`: rank 0 prints the JSON line built so far (marked `extras_timed_out`), then the
+    process exits with status 0 without waiting for anything (os._exit: a hung collective cannot be joined)."""
+
+    def __init__(self, seconds, rank, out):
+        import threading
+        self._timer = threading.Timer(seconds, self._fire, args=(rank, out))
+        self._timer.daemon = True
+        self._timer.start()
+
+    @staticmethod
+    def _fire(rank, out):
+        if rank == 0 and out is not None:
+            try:
+                line = dict(out)
+                line["extras_timed_out"] = True
+                print(json.dumps(line, default=repr), flush=True)
+            except Exception:
+                pass
+        os._exit(0)
+
+    def cancel(self):
+        self._timer.cancel()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -662,6 +687,10 @@ def main():
     else:
         out, field, y0 = run_linear(args, rank, world, device)
         extras = not args.no_extras
+        # The contract line is measured; everything below only adds objects to it.  If an extra hangs (a collective
+        # that never completes on some node), every rank's watchdog fires after the same delay: rank 0 prints the
+        # line as far as it got and all ranks leave — the scaling run keeps its number.
+        watchdog = _Watchdog(float(os.environ.get("TDEQ_BENCH_EXTRAS_TIMEOUT", "300")), rank, out)
         if extras and world > 1:
             # the same ranks on the other regime and on the workload that communicates (short runs)
             other = argparse.Namespace(**vars(args))
@@ -718,6 +747,8 @@ def main():
             except Exception as exc:      # an extra figure, never allowed to break the contract line
                 out["reference_style_eager_gpu"] = {"error": repr(exc)}
             out["cpu_baseline"] = cpu_baseline()
+    if args.workload != "adjoint":
+        watchdog.cancel()
     if rank == 0:
         if os.environ.get("TDEQ_BENCH_NOTE"):
             out["note"] = os.environ["TDEQ_BENCH_NOTE"]
