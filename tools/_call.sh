@@ -1,5 +1,11 @@
-mkdir -p gpurun_out/r02i
-timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -12 > gpurun_out/r02i/gpu_tests.txt; cat gpurun_out/r02i/gpu_tests.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 600 python bench.py > gpurun_out/r02i/bench_line.json 2> gpurun_out/r02i/bench.err; echo "bench rc=$?"; tail -2 gpurun_out/r02i/bench.err
-TDEQ_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 50 --warmup 10 > gpurun_out/r02i/bench_n2_gloo.json 2>> gpurun_out/r02i/bench.err; echo "bench2 rc=$?"
+mkdir -p gpurun_out/r02j
+export TMPDIR=/tmp
+REPO=$PWD
+cd /tmp
+for arr in serial split2_skew; do
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/r02j/tr_$arr -o t -- python $REPO/tools/overlap_probe.py $arr > $REPO/gpurun_out/r02j/$arr.log 2>&1
+python $REPO/tools/trace_gaps.py $(find $REPO/gpurun_out/r02j/tr_$arr -name "*kernel_trace.csv" | head -1) 3000 > $REPO/gpurun_out/r02j/overlap_trace_$arr.json
+python -c "
+import json; o=json.load(open('$REPO/gpurun_out/r02j/overlap_trace_$arr.json')); print('$arr', {k:o[k] for k in ('dispatches','span_us','busy_us','gap_us','us_with_two_or_more_kernels_in_flight')})"
+rm -rf $REPO/gpurun_out/r02j/tr_$arr
+done

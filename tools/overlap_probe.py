@@ -134,8 +134,11 @@ def time_graph(graph, reps=200):
 
 res = {"state": f"{B} x {D} fp32", "unit": "us per trial step (6 combines + 7 GEMMs + error norm), hipGraph replay"}
 ref = None
-for name, n_parts, skew in (("serial", 1, False), ("split2", 2, False), ("split2_skew", 2, True),
-                            ("split4", 4, False), ("split4_skew", 4, True), ("split8_skew", 8, True)):
+ARRANGEMENTS = (("serial", 1, False), ("split2", 2, False), ("split2_skew", 2, True),
+                ("split4", 4, False), ("split4_skew", 4, True), ("split8_skew", 8, True))
+if len(sys.argv) > 1:          # one arrangement only (for a rocprofv3 kernel trace of it: do the chains really overlap?)
+    ARRANGEMENTS = tuple(a for a in ARRANGEMENTS if a[0] in sys.argv[1:])
+for name, n_parts, skew in ARRANGEMENTS:
     try:
         with torch.no_grad():
             graph, keep, parts = capture(n_parts, skew)
