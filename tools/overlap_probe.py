@@ -10,6 +10,8 @@ norm) into a hipGraph in several arrangements and times replays:
     split2        two half-batch chains forked / joined inside the graph, started together
     split2_skew   the same, chain B released only after chain A's first combine (so A's GEMM meets B's combine)
     split4        four quarter-batch chains
+    seq2/4/8      the row blocks one after the other (temporal blocking: does a block's working set in the Infinity
+                  Cache make its kernels faster than the fixed costs of smaller kernels make them slower?)
 
 All arrangements compute the same values (the split ones on row blocks).  Prints one JSON object."""
 import json
@@ -74,6 +76,12 @@ def capture(n_parts, skew):
         if n_parts == 1:
             keep.append(chain(*parts[0]))
             return
+        if skew == "seq":
+            # temporal blocking: the row blocks one AFTER the other on one stream — each block's working set
+            # (9 state-sized tensors / n_parts) then fits the 256 MiB Infinity Cache
+            for part in parts:
+                keep.append(chain(*part))
+            return
         cur = torch.cuda.current_stream()
         prev_first = None
         for s, part in zip(sides, parts):
@@ -135,7 +143,8 @@ def time_graph(graph, reps=200):
 res = {"state": f"{B} x {D} fp32", "unit": "us per trial step (6 combines + 7 GEMMs + error norm), hipGraph replay"}
 ref = None
 ARRANGEMENTS = (("serial", 1, False), ("split2", 2, False), ("split2_skew", 2, True),
-                ("split4", 4, False), ("split4_skew", 4, True), ("split8_skew", 8, True))
+                ("split4", 4, False), ("split4_skew", 4, True), ("split8_skew", 8, True),
+                ("seq2", 2, "seq"), ("seq4", 4, "seq"), ("seq8", 8, "seq"))
 if len(sys.argv) > 1:          # one arrangement only (for a rocprofv3 kernel trace of it: do the chains really overlap?)
     ARRANGEMENTS = tuple(a for a in ARRANGEMENTS if a[0] in sys.argv[1:])
 for name, n_parts, skew in ARRANGEMENTS:
