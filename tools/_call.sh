@@ -1,1 +1,1 @@
-timeout 300 python tools/overlap_probe.py serial seq2 seq4 seq8 2>&1 | grep -v amdgpu
+timeout 300 python tools/host_profile3.py 2>&1 | grep -v amdgpu | head -60

@@ -286,6 +286,7 @@ class HipKernels:
     # (ctypes releases the GIL during a call: the reused pointer arrays are per thread.)
     _TLS = threading.local()
     _COEF_ARRAYS: dict = {}
+    _PACK_TABLES: dict = {}
 
     @classmethod
     def _terms(cls, ks: Sequence[torch.Tensor], coefs: Sequence[float]):
@@ -568,9 +569,15 @@ class HipKernels:
         their chunk-aligned segment starts, times +-1; padding zero-filled.  One launch (tdeq_pack_segments)."""
         n = len(srcs)
         ptrs = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in srcs])
-        cs = (ctypes.c_int64 * n)(*chunk_starts)
-        nm = (ctypes.c_int64 * n)(*numels)
-        sc = (ctypes.c_double * n)(*scales)
+        # the three constant tables of a layout are converted once (keyed by identity-stable tuples)
+        key = (tuple(chunk_starts), tuple(numels), tuple(scales))
+        tabs = self._PACK_TABLES.get(key)
+        if tabs is None:
+            if len(self._PACK_TABLES) > 1024:
+                self._PACK_TABLES.clear()
+            tabs = self._PACK_TABLES[key] = ((ctypes.c_int64 * n)(*chunk_starts), (ctypes.c_int64 * n)(*numels),
+                                             (ctypes.c_double * n)(*scales))
+        cs, nm, sc = tabs
         _check(self.lib.tdeq_pack_segments(out.data_ptr(), ptrs, cs, nm, sc, n, chunk, out.numel() // chunk,
                                            dtype_code(out.dtype), self._stream()), "tdeq_pack_segments")
 

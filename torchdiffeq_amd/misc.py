@@ -92,6 +92,8 @@ class StateLayout:
             self.offsets.append(off)
             off += max(1, math.ceil(n / self.chunk)) * self.chunk if len(self.shapes) > 1 else n
         self.total = max(off, 1) if len(self.shapes) > 1 else (self.numels[0] if self.numels else 0)
+        self._chunk_starts = None                      # built on first use by pack_fused
+        self._unit_scales = (1.0,) * len(self.shapes)
 
     @property
     def n_seg(self) -> int:
@@ -127,25 +129,27 @@ class StateLayout:
             filled = [torch.zeros(m, dtype=dtype, device=device) if t is None else t
                       for t, m in zip(pieces, self.numels)]
             return self.pack(filled, dtype=dtype, negate=neg if any(neg) else ())
+        # (per-evaluation path of the adjoint's backward solve: the kernel needs only addresses, so no detach / reshape
+        # views are made — each costs 1–2 us of host time per piece — and the constant tables are built once)
         srcs = []
         for t, m in zip(pieces, self.numels):
             if t is None or m == 0:
                 srcs.append(None)
                 continue
-            t = t.detach()
             if t.dtype != dtype:
-                t = t.to(dtype)
-            t = t.reshape(-1)
+                t = t.detach().to(dtype)
             if t.numel() != m:
                 raise RuntimeError(f"func returned a component with {t.numel()} elements where the state has {m}")
             srcs.append(t if t.is_contiguous() else t.contiguous())
         out = torch.empty(self.total, dtype=dtype, device=device)
-        scales = [1.0] * n if scales is None else list(scales)
         G = _native.TDEQ_INLINE_SEGMENTS
         if n <= G:
-            kernels.pack_segments(out, srcs, [off // self.chunk for off in self.offsets], self.numels, scales,
-                                  self.chunk)
+            if self._chunk_starts is None:
+                self._chunk_starts = [off // self.chunk for off in self.offsets]
+            kernels.pack_segments(out, srcs, self._chunk_starts, self.numels,
+                                  self._unit_scales if scales is None else scales, self.chunk)
             return out
+        scales = self._unit_scales if scales is None else list(scales)
         for a in range(0, n, G):           # consecutive segments span a contiguous, chunk-aligned range of `out`
             b = min(a + G, n)
             lo, hi = self.offsets[a], (self.offsets[b] if b < n else self.total)
