@@ -174,7 +174,29 @@ def cpu_baseline(max_seconds=20.0):
         solver.adaptive_step()
         steps += 1
     dt = time.perf_counter() - t0
+    torch_cpu = None
+    try:
+        # the reference's OWN op sequence on torch's CPU path (oracle/eager_torch_port.py: stage-minor k, ~220 ATen
+        # ops per trial step, 0-dim tensor scalars) on this host's cores — the closest thing to "the reference on
+        # this box's CPU" that can travel; bounded to a few trial steps
+        from oracle import eager_torch_port as ep
+        torch.set_num_threads(cores)
+        At_cpu = torch.from_numpy(A).T.contiguous()
+        eager = ep.EagerAdaptiveRK(lambda tt, y: y @ At_cpu, torch.from_numpy(y0), 0.0, 0.05, RTOL, ATOL, "dopri5")
+        with torch.no_grad():
+            eager.adaptive_step()
+            n_e, t1 = 0, time.perf_counter()
+            while n_e < 6 and time.perf_counter() - t1 < 12.0:
+                eager.adaptive_step()
+                n_e += 1
+            dte = time.perf_counter() - t1
+        torch_cpu = {"value": 6 * n_e / dte, "unit": "RK-stages/s", "cores": cores, "kind": "port",
+                     "sample": f"{n_e} dopri5 trial steps of the same workload through the reference's eager op "
+                               f"sequence on torch CPU tensors ({cores} threads), {dte:.1f} s"}
+    except Exception as exc:
+        torch_cpu = {"error": repr(exc)}
     return {"value": 6 * steps / dt, "unit": "RK-stages/s", "cores": cores, "kind": "port",
+            "reference_op_sequence_on_torch_cpu": torch_cpu,
             "sample": f"{steps} dopri5 trial steps ({6 * steps} RK stages) of the same 65536x128 fp32 workload, "
                       f"oracle/rk_oracle.c with OpenMP on {cores} threads + numpy GEMM, {dt:.1f} s",
             "why_a_port": "the reference is a Python package mounted only in the build container (/root/reference); it "
