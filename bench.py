@@ -180,7 +180,10 @@ def cpu_baseline(max_seconds=20.0):
         # ops per trial step, 0-dim tensor scalars) on this host's cores — the closest thing to "the reference on
         # this box's CPU" that can travel; bounded to a few trial steps
         from oracle import eager_torch_port as ep
-        torch.set_num_threads(cores)
+        # torch's CPU ops on 33 MB tensors are fastest at 8-16 threads on the GPU box's 256-thread host (measured,
+        # seconds per trial step: 8: 0.58, 16: 0.55, 32: 0.75, 64: 1.2, 128: 2.2, 256: 11.8)
+        tthreads = min(cores, 16)
+        torch.set_num_threads(tthreads)
         At_cpu = torch.from_numpy(A).T.contiguous()
         eager = ep.EagerAdaptiveRK(lambda tt, y: y @ At_cpu, torch.from_numpy(y0), 0.0, 0.05, RTOL, ATOL, "dopri5")
         with torch.no_grad():
@@ -190,9 +193,10 @@ def cpu_baseline(max_seconds=20.0):
                 eager.adaptive_step()
                 n_e += 1
             dte = time.perf_counter() - t1
-        torch_cpu = {"value": 6 * n_e / dte, "unit": "RK-stages/s", "cores": cores, "kind": "port",
+        torch_cpu = {"value": 6 * n_e / dte, "unit": "RK-stages/s", "cores": tthreads, "kind": "port",
                      "sample": f"{n_e} dopri5 trial steps of the same workload through the reference's eager op "
-                               f"sequence on torch CPU tensors ({cores} threads), {dte:.1f} s"}
+                               f"sequence on torch CPU tensors ({tthreads} threads: the fastest setting on this "
+                               f"host), {dte:.1f} s"}
     except Exception as exc:
         torch_cpu = {"error": repr(exc)}
     return {"value": 6 * steps / dt, "unit": "RK-stages/s", "cores": cores, "kind": "port",
