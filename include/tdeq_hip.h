@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 14
+#define TDEQ_ABI_VERSION 15
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -198,6 +198,22 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
                                  int dtype, void* stream);
 int tdeq_stage_combine_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej,
                            double coef, const double* ctrl_dev, int64_t n, int dtype, void* stream);
+
+/*
+ * The controller alone, on per-segment sums that already sit in DEVICE memory — the lock-step mode of a batch-sharded
+ * solve (no counterpart in the reference, which has no distributed code): every rank runs tdeq_error_norm_partial
+ * into device buffers, the n_seg sums (+ non-finite counters) are all-reduced over the ranks ON THE DEVICE (RCCL over
+ * xGMI, no host round trip), and this entry point then takes the same decision on every rank:
+ *   ratio = max_s sqrt(sums[s] / segs[s].numel) over the first n_norm_seg segments — `segs[s].numel` must hold the
+ *   GLOBAL element counts (summed over the ranks) — then accept / dt_next / next stage times exactly as
+ *   tdeq_error_norm_partial_ctrl.  sums / nonfinite are mirrored to out_sumsq / out_nonfinite (device or pinned host
+ *   memory) for the host's bookkeeping; the other outputs as tdeq_error_norm_partial_ctrl.  Only `numel` of the
+ *   segment table is read (segs_dev required beyond TDEQ_INLINE_SEGMENTS segments).
+ */
+int tdeq_step_controller(const double* sums, const double* nonfinite, const tdeq_segment* segs, const void* segs_dev,
+                         int n_seg, double* out_sumsq, double* out_nonfinite, const tdeq_step_ctrl* ctrl,
+                         double* out_ctrl, double* ctrl_dev, void* next_times, int state_in_dev, int dtype,
+                         void* stream);
 
 /*
  * hipGraph mode of the adaptive solvers (small states, where a trial step is launch-latency-bound): ONE captured

@@ -76,6 +76,14 @@ def main():
     assert calls["n"] - n0 > 10 and calls["cuda"] == calls["n"], calls
     for a, b in zip(base, lock):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), "lock-step adjoint differs at world size 1"
+    # (2b) the same with the host-side reduction (TDEQ_LOOKAHEAD=0: sums -> host -> tensor -> all_reduce): the device-
+    #      resident path above (finalize -> RCCL all-reduce on the device buffer -> tdeq_step_controller) must take the
+    #      same steps
+    os.environ["TDEQ_LOOKAHEAD"] = "0"
+    lock_host = grads(tdist.odeint_adjoint_sharded, group=dist.group.WORLD, sync_steps=True)
+    os.environ.pop("TDEQ_LOOKAHEAD")
+    for a, b in zip(lock, lock_host):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), "device-resident and host-side lock step differ"
     # (3) forward-only lock step
     with torch.no_grad():
         y_plain = tda.odeint(f, y0, t, rtol=1e-6, atol=1e-8)

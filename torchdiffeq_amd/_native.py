@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 14
+TDEQ_ABI_VERSION = 15
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
@@ -80,6 +80,10 @@ ABI_SIGNATURES = {
                                                     ctypes.POINTER(StepCtrl), ctypes.c_void_p, ctypes.c_void_p,
                                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                     ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_step_controller": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Segment), ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.POINTER(StepCtrl), ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_stage_combine_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
                                               _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_void_p]),
@@ -430,6 +434,20 @@ class HipKernels:
             plan.n_chunks, plan.out_ptr, plan.bad_ptr, ctypes.byref(ctrl), plan.ctrl_ptr, plan.ctrl_dev.data_ptr(),
             next_times.data_ptr(), 1 if state_in_dev else 0, plan.workspace.data_ptr(), plan.workspace_bytes,
             dtype_code(y0.dtype), self._stream()), "tdeq_error_norm_partial_ctrl")
+
+    def step_controller(self, plan: NormPlan, sums_plan: NormPlan, numel_plan: NormPlan, ctrl: StepCtrl, next_times,
+                        dtype: torch.dtype, state_in_dev: bool = False) -> None:
+        """The controller alone (tdeq_step_controller) on the per-segment sums in `sums_plan.out` (DEVICE memory: a
+        plan made with pinned=False, filled by a norm launch and all-reduced over the ranks of a lock-step sharded
+        solve), with the element counts of `numel_plan`'s segment table (the GLOBAL counts); results land in `plan`
+        like those of `error_norm_partial_ctrl` — read with `read_ctrl(plan)`."""
+        assert not sums_plan.pinned and sums_plan.n_seg == plan.n_seg == numel_plan.n_seg
+        self._arm(plan, 1, ctrl=True)
+        _check(self.lib.tdeq_step_controller(
+            sums_plan.out_ptr, sums_plan.bad_ptr, numel_plan.segs,
+            numel_plan.segs_dev.data_ptr() if numel_plan.segs_dev is not None else None, plan.n_seg, plan.out_ptr,
+            plan.bad_ptr, ctypes.byref(ctrl), plan.ctrl_ptr, plan.ctrl_dev.data_ptr(), next_times.data_ptr(),
+            1 if state_in_dev else 0, dtype_code(dtype), self._stream()), "tdeq_step_controller")
 
     def read_ctrl(self, plan: NormPlan) -> Tuple[bool, float, float, List[float]]:
         """(accept, dt_next, error_ratio, nonfinite[0:n_seg]) of the last `error_norm_partial_ctrl` launch."""

@@ -251,6 +251,8 @@ int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, doub
     a.next_times = cb.next_times;
     a.state_in_dev = cb.state_in_dev;
     a.presummed = 0;
+    a.in_sumsq = nullptr;
+    a.in_bad = nullptr;
     if (st.n_seg > TDEQ_INLINE_SEGMENTS) {
         // more segments than the inline table holds: the per-segment sums by the parallel finalize (one workgroup per
         // segment, segment table from device memory), then the one-workgroup controller on those sums
@@ -905,6 +907,37 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
     return dtype == TDEQ_F32
                ? dispatch_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s)
                : dispatch_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s);
+}
+
+int tdeq_step_controller(const double* sums, const double* nonfinite, const tdeq_segment* segs, const void* segs_dev,
+                         int n_seg, double* out_sumsq, double* out_nonfinite, const tdeq_step_ctrl* ctrl,
+                         double* out_ctrl, double* ctrl_dev, void* next_times, int state_in_dev, int dtype,
+                         void* stream) {
+    if (!sums || !nonfinite || !segs || !out_sumsq || !out_nonfinite || !ctrl || !out_ctrl || !ctrl_dev ||
+        !next_times || bad_dtype(dtype))
+        return TDEQ_EINVAL;
+    if (ctrl->n_times < 1 || ctrl->n_times > TDEQ_MAX_STAGE_TIMES || ctrl->n_norm_seg < 0 || ctrl->n_norm_seg > n_seg)
+        return TDEQ_EINVAL;
+    SegTable st;
+    const int e = fill_segtable(st, segs, segs_dev, n_seg, TDEQ_CHUNK_QUANTUM, 1);   // only numel is read
+    if (e) return e;
+    CtrlArgs a;
+    a.part_sumsq = nullptr;
+    a.part_bad = nullptr;
+    a.st = st;
+    a.c = *ctrl;
+    a.is_f32 = dtype == TDEQ_F32 ? 1 : 0;
+    a.out_sumsq = out_sumsq;
+    a.out_bad = out_nonfinite;
+    a.out_ctrl = out_ctrl;
+    a.ctrl_dev = ctrl_dev;
+    a.next_times = next_times;
+    a.state_in_dev = state_in_dev ? 1 : 0;
+    a.presummed = 1;
+    a.in_sumsq = sums;
+    a.in_bad = nonfinite;
+    hipLaunchKernelGGL(norm_finalize_ctrl_kernel, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch();
 }
 
 int tdeq_stage_combine_dev(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,

@@ -582,6 +582,8 @@ struct CtrlArgs {
     int state_in_dev;         // hipGraph mode: the trial step's (t0, dt) are ctrl_dev[2..3], not c.t0 / c.dt
     int presummed;            // n_seg > TDEQ_INLINE_SEGMENTS: norm_finalize_kernel (one workgroup per segment) has
                               // already written out_sumsq / out_bad; this kernel only runs the controller on them
+    const double* in_sumsq;   // presummed only, may be null: the sums come from THESE device arrays (a lock-step
+    const double* in_bad;     // sharded solve has all-reduced them over the ranks) and are mirrored to out_sumsq / out_bad
 };
 
 __device__ __forceinline__ double ctl_nan_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
@@ -631,11 +633,17 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         // parallel finalize launch; ratio = max_s sqrt(sum_s / numel_s) is order-independent (a max; NaN wins), so
         // it is formed by all lanes — each lane its segments, then one block reduction — with the value the serial
         // loop below would give.
+        const double* sums = a.in_sumsq ? a.in_sumsq : a.out_sumsq;
+        if (a.in_sumsq)
+            for (int s = threadIdx.x; s < n_seg; s += kBlock) {
+                a.out_sumsq[s] = a.in_sumsq[s];
+                a.out_bad[s] = a.in_bad[s];
+            }
         double part[2] = {0.0, 0.0};          // {max over this lane's segments, 1 if any of them is NaN}
         for (int s = threadIdx.x; s < a.c.n_norm_seg && s < n_seg; s += kBlock) {
             const int64_t numel = get_segment(a.st, s).numel;
             if (numel == 0) continue;
-            const double v = __builtin_sqrt(a.out_sumsq[s] / (double)numel);
+            const double v = __builtin_sqrt(sums[s] / (double)numel);
             if (v != v) part[1] = 1.0;
             else part[0] = v > part[0] ? v : part[0];
         }

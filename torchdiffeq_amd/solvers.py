@@ -103,6 +103,17 @@ class _LockStep:
         mine = [0 if (i in self.replicated and self.rank != 0) else int(n) for i, n in enumerate(numels)]
         return [int(round(x)) for x in self._allreduce([float(m) for m in mine], device)]
 
+    def reduce_device(self, buf: torch.Tensor, n: int) -> None:
+        """In-place all-reduce of a norm plan's DEVICE result words [n sums | n (second sum) | n non-finite counters]
+        — RCCL over xGMI on the buffer the finalize kernel wrote, no host round trip; replicated segments are taken
+        from rank 0 only."""
+        if self.rank != 0 and self.replicated:
+            if getattr(self, "_zero_idx", None) is None or self._zero_idx.device != buf.device:
+                idx = [q * n + s for s in self.replicated for q in range(3)]
+                self._zero_idx = torch.tensor(idx, dtype=torch.int64, device=buf.device)
+            buf.index_fill_(0, self._zero_idx, 0.0)
+        self.dist.all_reduce(buf[:3 * n], op=self.dist.ReduceOp.SUM, group=self.group)
+
     def reduce(self, s0, s1, bad, device):
         n = len(s0)
         if self.rank != 0:
@@ -481,16 +492,27 @@ class RKAdaptiveStepsizeODESolver:
         # the loop stays here, but the scalar decision of a trial step is also taken on the device so that the next
         # trial step's first stage and func evaluation are enqueued before the decision has been read back.
         n_norm_seg = self.layout.n_seg - (self.norm.n_skip_tail if isinstance(self.norm, BuiltinNorm) else 0)
+        # (lock-step sharding: only when the collective runs on device buffers — backend nccl = RCCL —, where the sums
+        # are all-reduced between the norm's finalize and the controller kernel without leaving the GPU)
+        sync_dev = self._sync is not None and self._sync.on_device and y0.device.type == "cuda" \
+            and hasattr(self.kernels, "step_controller")
         device_ctrl = (self._fuse is not None and isinstance(self.norm, BuiltinNorm)
                        and len(self._beta) <= _native.TDEQ_MAX_STAGE_TIMES and n_norm_seg >= 0
-                       and self.step_t is None and self.jump_t is None and self._sync is None)
+                       and self.step_t is None and self.jump_t is None and (self._sync is None or sync_dev))
+        self._plan_dev = self._plan_glob = None
+        if device_ctrl and self._sync is not None:
+            segs = self.layout.segments(rtol, atol)
+            self._plan_dev = _native.NormPlan(segs, self.layout.total, self.layout.chunk, y0.device, pinned=False)
+            self._plan_glob = self.kernels.make_plan([(off, gn, rt, at) for (off, _, rt, at), gn in
+                                                      zip(segs, self._numels)], self.layout.total,
+                                                     self.layout.chunk, y0.device)
         self._lookahead = device_ctrl and os.environ.get("TDEQ_LOOKAHEAD", "1") != "0"
         # `hip_graph=True` (an extension, not a reference option): one captured hipGraph per trial step, see _GraphStep
         # "auto" = only where it pays (states up to _GRAPH_AUTO_MAX_ELEMENTS) and silently; never the built-in default,
         # because a captured func runs in Python only while the graph is being built: per-evaluation Python side
         # effects (an evaluation counter, data-dependent branches) are not replayed — the user has to vouch for that
         wanted, auto = _graph_request(hip_graph)
-        self.hip_graph = wanted and device_ctrl and y0.device.type == "cuda" \
+        self.hip_graph = wanted and device_ctrl and self._sync is None and y0.device.type == "cuda" \
             and hasattr(self.kernels, "stage_combine_dev") \
             and self.layout.total <= (_GRAPH_AUTO_MAX_ELEMENTS if auto else _GRAPH_MODE_MAX_ELEMENTS)
         if wanted and not auto and not self.hip_graph:
@@ -918,8 +940,16 @@ class RKAdaptiveStepsizeODESolver:
             ctrl = self._ctrl
             ctrl.t0, ctrl.dt = t0, dt
             tnext = torch.empty(ctrl.n_times, dtype=y0.dtype, device=y0.device)
-            kern.error_norm_partial_ctrl(self.plan, err_partial, y0, y1, [k[j] for j in self._fuse[1]], self._fuse[2],
-                                         dt_signed, ctrl, tnext)
+            if self._sync is None:
+                kern.error_norm_partial_ctrl(self.plan, err_partial, y0, y1, [k[j] for j in self._fuse[1]],
+                                             self._fuse[2], dt_signed, ctrl, tnext)
+            else:
+                # lock step: this rank's sums -> device buffer, all-reduce over the ranks on the device, the
+                # controller on the global sums (global element counts): every rank takes the whole-batch decision
+                kern.error_norm_partial(self._plan_dev, err_partial, y0, y1, [k[j] for j in self._fuse[1]],
+                                        self._fuse[2], dt_signed)
+                self._sync.reduce_device(self._plan_dev.out, self.plan.n_seg)
+                kern.step_controller(self.plan, self._plan_dev, self._plan_glob, ctrl, tnext, y0.dtype)
             if t1 < self._t_end:
                 # accepted or rejected, another trial step follows: enqueue its first stage and func evaluation now
                 yi_n = torch.empty_like(y0)
