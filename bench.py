@@ -234,7 +234,7 @@ def eager_gpu_baseline(field, y0, first_step, steps=12):
 # ---------------------------------------------------------------------------------------------------
 # linear workload (cfg2)
 # ---------------------------------------------------------------------------------------------------
-def make_stepper(field, y0, hip_graph=False, lookahead=None):
+def make_stepper(field, y0, hip_graph=False, lookahead=None, dist_sync=None):
     """A Dopri5Solver in the middle of a long solve (no output time ahead — where the look-ahead first stage
     applies), ready for `_trial_step()` calls."""
     from torchdiffeq_amd.misc import OdeFunc, StateLayout, rms_norm
@@ -245,7 +245,8 @@ def make_stepper(field, y0, hip_graph=False, lookahead=None):
     if lookahead is not None:
         os.environ["TDEQ_LOOKAHEAD"] = "1" if lookahead else "0"
     try:
-        solver = Dopri5Solver(func=func, y0=y0.reshape(-1), rtol=RTOL, atol=ATOL, norm=rms_norm, hip_graph=hip_graph)
+        solver = Dopri5Solver(func=func, y0=y0.reshape(-1), rtol=RTOL, atol=ATOL, norm=rms_norm, hip_graph=hip_graph,
+                              dist_sync=dist_sync)
     finally:
         if lookahead is not None:
             if prev is None:
@@ -729,6 +730,25 @@ def main():
             except Exception as exc:
                 if rank == 0:
                     out[other.scaling] = {"error": repr(exc)}
+            try:
+                # lock-step mode (every shard takes the whole-batch step sequence): one all-reduce of 3 doubles per
+                # trial step, on the device with RCCL (finalize -> all-reduce -> tdeq_step_controller)
+                A_, y0_ = make_problem(device, seed_offset=rank)
+                At_ = A_.T.contiguous()
+                ls = make_stepper(lambda t, y: y @ At_, y0_, dist_sync=torch.distributed.group.WORLD)
+                stl = block_stats(time_steps(ls, min(args.steps, 100), min(args.warmup, 20), world, device, n_blocks=3),
+                                  min(args.steps, 100))
+                if rank == 0:
+                    out["lockstep"] = {"ms_per_step": stl["median"], "blocks": stl, "scaling": "weak",
+                                       "value": 6e3 / stl["median"] * world, "unit": "RK-stages/s",
+                                       "lookahead": bool(ls._lookahead),
+                                       "collective": "all_reduce of the 3 norm words per trial step, "
+                                                     + ("on the device (RCCL)" if ls._plan_dev is not None else
+                                                        "through the host (backend without device buffers)")}
+                del ls, A_, y0_, At_
+            except Exception as exc:
+                if rank == 0:
+                    out["lockstep"] = {"error": repr(exc)}
             adj = {}
             for mode, rows in (("strong", ADJ_BATCH // world), ("weak", ADJ_BATCH)):
                 try:
