@@ -322,3 +322,48 @@ def test_controller_kernel_many_segments(hip_kernels, oracle_kernels, dtype, n_s
     if not math.isnan(out_ctrl[1]):
         assert abs(dt_next - out_ctrl[1]) <= 4 * np.spacing(abs(out_ctrl[1]))
     assert torch.allclose(tn_d.cpu().double(), tn_o.double(), rtol=1e-6 if dtype == torch.float32 else 1e-14, equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n_seg", [1, 3, 20])
+def test_step_controller_on_device_sums_equals_fused_controller(hip_kernels, dtype, n_seg):
+    """tdeq_step_controller (ABI 15; the lock-step path: sums in device memory, all-reduced there, then the controller)
+    at world size 1 — a sum over one rank — must reproduce tdeq_error_norm_partial_ctrl word for word: sums, census,
+    accept, dt_next, ratio, t0', ctrl_dev and the next stage times."""
+    from torchdiffeq_amd import _native
+    chunk = 1024
+    g = torch.Generator().manual_seed(100 + n_seg)
+    numels = [int(v) for v in torch.randint(1, 4 * chunk, (n_seg,), generator=g)]
+    offs, off = [], 0
+    for m in numels:
+        offs.append(off)
+        off += (-(-m // chunk) * chunk) if n_seg > 1 else m
+    total = off
+    segs = [(o, m, 1e-6, 1e-8) for o, m in zip(offs, numels)]
+    dev = torch.device("cuda:0")
+    y0 = torch.randn(total, generator=g, dtype=torch.float64).to(dtype).cuda()
+    y1 = (y0.cpu().double() + 0.01 * torch.randn(total, generator=g, dtype=torch.float64)).to(dtype).cuda()
+    part = (torch.randn(total, generator=g, dtype=torch.float64) * 2e-7).to(dtype).cuda()
+    k6 = (torch.randn(total, generator=g, dtype=torch.float64) * 1e-7).to(dtype).cuda()
+    np_dtype = np.float32 if dtype == torch.float32 else np.float64
+    c = _ctrl(0.37, 0.0123, 5, DOPRI5, 1.0, 0.0, math.inf, np_dtype=np_dtype)
+    c.n_norm_seg = n_seg
+    dts = float(np_dtype(0.0123))
+    plan_a = hip_kernels.make_plan(segs, total, chunk, dev)
+    tn_a = torch.empty(c.n_times, dtype=dtype, device=dev)
+    hip_kernels.error_norm_partial_ctrl(plan_a, part, y0, y1, [k6], [0.025], dts, c, tn_a)
+    ref_words = hip_kernels._read_out(plan_a)
+    ref_dev = plan_a.ctrl_dev.cpu().tolist()
+    plan_b = hip_kernels.make_plan(segs, total, chunk, dev)                 # host-visible results
+    plan_sums = _native.NormPlan(segs, total, chunk, dev, pinned=False)     # sums in device memory
+    tn_b = torch.empty(c.n_times, dtype=dtype, device=dev)
+    hip_kernels.error_norm_partial(plan_sums, part, y0, y1, [k6], [0.025], dts)
+    hip_kernels.step_controller(plan_b, plan_sums, plan_b, c, tn_b, dtype)
+    words = hip_kernels._read_out(plan_b)
+    n = n_seg
+    assert np.array_equal(np.array(words[:n]), np.array(ref_words[:n]))                      # sums
+    assert words[2 * n:3 * n] == ref_words[2 * n:3 * n]                                      # census
+    assert np.array_equal(np.array(words[3 * n:3 * n + 4]), np.array(ref_words[3 * n:3 * n + 4]), equal_nan=True)
+    assert plan_b.ctrl_dev.cpu().tolist() == ref_dev
+    assert torch.equal(tn_a, tn_b)
