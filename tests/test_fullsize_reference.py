@@ -132,7 +132,7 @@ def test_cfg3_adjoint_vs_reference(case, rows, device):
         fp32 on the MI355X (hipBLASLt GEMMs, device tanh)                  ~3x    NFE 86 (74)
     and the reference alone moves its step sizes by up to 30 % when only its CPU thread count changes.  In fp64 every
     one of these steps grows by exactly ifactor = 10.  So: no rejected step, the first step equal (it comes from the
-    initial-step heuristic, before any noise), at most two accepted steps more or fewer than the reference, and the
+    initial-step heuristic, before any noise), at most three accepted steps more or fewer than the reference, and the
     fp64-evaluated field takes FEWER evaluations than the reference — the ordering above."""
     z, field, x, y_end, nfe_fwd, nfe_bwd, _ = _run_cfg3(case, rows, device, with_callbacks=False)
     idx = torch.from_numpy(z["rows"]).to(device)
@@ -142,14 +142,14 @@ def test_cfg3_adjoint_vs_reference(case, rows, device):
         ref = torch.from_numpy(z[f"grad_p{i}"])
         assert float((p.grad.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4, i
     assert nfe_fwd == int(z["nfe_fwd"])
-    assert abs(nfe_bwd - int(z["nfe_bwd"])) <= 12, (nfe_bwd, int(z["nfe_bwd"]))
+    assert abs(nfe_bwd - int(z["nfe_bwd"])) <= 18, (nfe_bwd, int(z["nfe_bwd"]))      # measured: +12 (full), +6 (shard)
     z, field, x, _, nfe_fwd2, nfe_bwd2, rec = _run_cfg3(case, rows, device, with_callbacks=True)
     assert (nfe_fwd2, nfe_bwd2) == (nfe_fwd, nfe_bwd)        # callbacks (host-driven loop) change nothing
     ok, msg = fs.steps_match(rec.acc, z["accepted"])
     assert ok, "forward: " + msg
     assert len(rec.rej) == 0 and len(rec.rej_adj) == 0
     ref_adj = z["accepted_adjoint"]
-    assert abs(len(rec.acc_adj) - len(ref_adj)) <= 2, (len(rec.acc_adj), len(ref_adj))
+    assert abs(len(rec.acc_adj) - len(ref_adj)) <= 3, (len(rec.acc_adj), len(ref_adj))      # measured: +2 / +1
     ok, msg = fs.steps_match(rec.acc_adj[:1], ref_adj[:1], rel=1e-4)
     assert ok, "backward, first step: " + msg
     ok, msg = fs.steps_match(rec.acc_adj[:2], ref_adj[:2], rel=0.2)
