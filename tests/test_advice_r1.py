@@ -80,3 +80,43 @@ def test_sharded_adjoint_keeps_option_validation(cpu_backend):
             assert torch.isfinite(y0.grad).all() and all(torch.isfinite(p.grad).all() for p in lin.parameters())
         finally:
             dist.destroy_process_group()
+
+
+def test_captured_step_cache_key_sees_every_tensor_a_func_holds():
+    """solvers._held_tensor_ptrs (part of the captured-step cache key): parameters, buffers and PLAIN tensor attributes
+    of a Module (all submodules), closure cells, defaults, module-level tensors named by a function body, the owner of
+    a bound method, functools.partial arguments — so re-binding any of them to new storage forces a new capture."""
+    import functools
+    from torchdiffeq_amd.solvers import _held_tensor_ptrs
+    A, B = torch.randn(3, 3), torch.randn(3, 3)
+
+    def make(M):
+        return lambda t, y: y @ M
+    assert _held_tensor_ptrs(make(A)) == (A.data_ptr(),)
+    assert _held_tensor_ptrs(make(A)) != _held_tensor_ptrs(make(B))
+    assert _held_tensor_ptrs(lambda t, y, M=A: y @ M) == (A.data_ptr(),)
+    assert _held_tensor_ptrs(functools.partial(lambda t, y, M: y @ M, M=B)) == (B.data_ptr(),)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(2, 2)
+            self.register_buffer("scale", torch.ones(2))
+            self.plain = torch.randn(2)
+            self.sub = torch.nn.Sequential(torch.nn.Linear(2, 2))
+            self.sub.extra = torch.randn(1)
+
+        def forward(self, t, y):
+            return self.sub(self.lin(y)) * self.scale * self.plain
+
+    m = M()
+    key = _held_tensor_ptrs(m)
+    for tensor in (m.lin.weight, m.lin.bias, m.scale, m.plain, m.sub[0].weight, m.sub.extra):
+        assert tensor.data_ptr() in key
+    assert set(_held_tensor_ptrs(m.forward)) == set(key)           # bound method -> its owner
+    m.plain = torch.randn(2)                                       # re-bound plain attribute: the key changes
+    assert _held_tensor_ptrs(m) != key
+    with torch.no_grad():
+        m.lin.weight.mul_(2.0)                                     # in-place update: same storage, same key
+    assert m.lin.weight.data_ptr() in _held_tensor_ptrs(m)
+    assert _held_tensor_ptrs(torch.tanh) == ()
