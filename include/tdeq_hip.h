@@ -222,7 +222,8 @@ int tdeq_step_controller(const double* sums, const double* nonfinite, const tdeq
  * state in static buffers.
  *   tdeq_stage_combine_dev  tdeq_stage_combine (err_out == NULL) or tdeq_stage_combine_err with
  *                           c_j = fl_T(fl_T(coef_j) * T(dt)), dt = ctrl_dev[1] read on the device; same operation
- *                           order, same results as the host-dt entry points.
+ *                           order, same results as the host-dt entry points (from 2^17 elements on with the same
+ *                           unrolled, 16-byte-per-lane streams; below, one run-time-term kernel: launch-bound anyway).
  *   tdeq_step_commit        if ctrl_dev[0] (accept): (y_prev, f_prev) <- (y_cur, f_cur); (y_cur, f_cur) <- (y1, f1)
  *                           — the accepted state becomes the next trial's base (rk_common.py:335-352) and the
  *                           previous pair stays available for the dense output of the step just taken.
