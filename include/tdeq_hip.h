@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 15
+#define TDEQ_ABI_VERSION 16
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
@@ -156,6 +156,37 @@ int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void*
                             const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
                             double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
                             void* stream);
+
+/*
+ * Carried partial sums (r03).  Every tableau row re-reads all earlier stages: row i of `_runge_kutta_step`
+ * (rk_common.py:69-81) is  y_i = y0 + ((c_i0 k_0 + c_i1 k_1) + ... + c_ii k_i), summed left to right, so the stages a
+ * LATER row r needs from k_0..k_i are in registers while row i is being formed.  This entry point makes ONE pass over
+ * `n_terms` stage streams and produces up to TDEQ_MAX_MULTI_OUT outputs from them:
+ *
+ *     s_o    = [acc_in +] sum over the set bits j of mask_o, ascending, of  fl_T(fl_T(coef_o[j]) * fl_T(dt)) * k_j
+ *     out_o  = add_y0_o ? y0 + s_o : s_o
+ *
+ * Output 0 is the row's own stage input; a further output with add_y0 = 0 is the left-to-right PREFIX of a later
+ * row's sum (a "carried" partial sum), which that row's launch continues through `acc_in` (output 0 only) over the
+ * stages computed since — it then reads acc_in, the new stages and y0 instead of every earlier stage; a further
+ * output with add_y0 = 1 is a later stage input that needs no newer stage at all (dopri8 row 12, whose weight on
+ * k_11 is zero: dopri8.py:5-70) and is finished here.  The partial embedded error of tdeq_stage_combine_err is the
+ * same thing (add_y0 = 0, continued by tdeq_error_norm_partial).  Rounding sequence = the one of tdeq_stage_combine
+ * (first product not added to a zero, structural zeros skipped — not multiplied —, products and sums rounded
+ * separately in T), so every output is BIT-IDENTICAL to the row-by-row kernels; only the bytes change:
+ * dopri8 98 -> 75 words per element and step (13 launches instead of 14), dopri5 37 -> 35 (tableaus.carry_plan).
+ * 1 <= n_terms <= TDEQ_MAX_TERMS, 1 <= n_out <= TDEQ_MAX_MULTI_OUT, every mask non-zero and within n_terms bits;
+ * `acc_in` may be NULL.  Outputs may alias nothing that is read.
+ */
+#define TDEQ_MAX_MULTI_OUT 4
+typedef struct tdeq_multi_out {
+    void* out;                      /* T[n]                                                                   */
+    double coef[TDEQ_MAX_TERMS];    /* fp64 tableau weights of this output's row over the n_terms streams       */
+    uint32_t mask;                  /* bit j set: stream j takes part in this output's sum                      */
+    int32_t add_y0;                 /* 1: out = y0 + sum (a finished stage input); 0: out = sum (a partial sum) */
+} tdeq_multi_out;
+int tdeq_stage_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                             const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream);
 
 /*
  * Device-resident step controller + look-ahead first stage.  The accept/reject LOOP stays on the host; what

@@ -25,6 +25,11 @@ _c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 
 
+class MultiOut(ctypes.Structure):
+    _fields_ = [("out", ctypes.c_void_p), ("coef", ctypes.c_double * 14), ("mask", ctypes.c_uint32),
+                ("add_y0", ctypes.c_int32)]
+
+
 class Segment(ctypes.Structure):
     _fields_ = [("chunk_start", ctypes.c_int64), ("numel", ctypes.c_int64),
                 ("rtol", ctypes.c_double), ("atol", ctypes.c_double)]
@@ -56,6 +61,7 @@ def load() -> ctypes.CDLL:
         "oracle_fixed_stage": [I, V, V, _c_void_pp, _c_double_p, I, D, I64, I],
         "oracle_weighted_sum": [V, _c_void_pp, _c_double_p, I, I64, I],
         "oracle_stage_combine_err": [V, V, V, _c_void_pp, _c_double_p, _c_double_p, I, D, I64, I],
+        "oracle_stage_combine_multi": [ctypes.POINTER(MultiOut), I, V, V, _c_void_pp, I, D, I64, I],
         "oracle_error_norm_partial": [V, V, V, _c_void_pp, _c_double_p, I, D, ctypes.POINTER(Segment), I, I64, I64,
                                       V, V, I],
         "oracle_error_norm_partial_ctrl": [V, V, V, _c_void_pp, _c_double_p, I, D, ctypes.POINTER(Segment), I, I64, I64,
@@ -142,6 +148,21 @@ class OracleKernels:
         ef = (ctypes.c_double * n)(*err_coefs)
         _ok(self.lib.oracle_stage_combine_err(out.data_ptr(), err_out.data_ptr(), y0.data_ptr(), ptrs, cf, ef, n, dt,
                                               y0.numel(), _code(y0.dtype)), "oracle_stage_combine_err")
+
+    def stage_combine_multi(self, outs, rows, y0, acc_in, ks, dt):
+        n = len(ks)
+        for k in ks:
+            assert k.device.type == "cpu" and k.is_contiguous()
+        ptrs = (ctypes.c_void_p * n)(*[k.data_ptr() for k in ks])
+        spec = (MultiOut * len(outs))()
+        for o, (t, (coefs, mask, add_y0)) in enumerate(zip(outs, rows)):
+            spec[o].out = t.data_ptr()
+            for j, c in enumerate(coefs):
+                spec[o].coef[j] = c
+            spec[o].mask, spec[o].add_y0 = mask, 1 if add_y0 else 0
+        _ok(self.lib.oracle_stage_combine_multi(spec, len(outs), y0.data_ptr(),
+                                                None if acc_in is None else acc_in.data_ptr(), ptrs, n, dt, y0.numel(),
+                                                _code(y0.dtype)), "oracle_stage_combine_multi")
 
     def error_norm_partial(self, plan, err_partial, y0, y1, ks, coefs, dt):
         n = len(ks)

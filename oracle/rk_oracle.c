@@ -433,6 +433,60 @@ int oracle_stage_combine_err(void* out, void* err_out, const void* y0, const voi
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * Carried partial sums (twin of tdeq_stage_combine_multi): one pass over the stages k_0..k_{nt-1}, n_out outputs,
+ *   s_o = [acc_in +] sum over the set bits j of mask_o (ascending) of fl_T(fl_T(coef_o[j])*fl_T(dt)) * k_j
+ *   out_o = add_y0_o ? y0 + s_o : s_o
+ * i.e. the SAME left-to-right sums as rk_common.py:79 / :89 — a prefix of a later row's sum is formed while an
+ * earlier row is, and that later row continues it (acc_in, output 0 only).  tests/test_carry.py checks that rows
+ * formed this way equal oracle_stage_combine / oracle_stage_combine_err bit for bit.
+ * ------------------------------------------------------------------------------------------------- */
+#define ORACLE_MAX_MULTI_OUT 4
+typedef struct oracle_multi_out {
+    void* out;
+    double coef[ORACLE_MAX_TERMS];
+    uint32_t mask;
+    int32_t add_y0;
+} oracle_multi_out;
+
+#define DEF_COMBINE_MULTI(NAME, T)                                                                    \
+    static void NAME(const oracle_multi_out* outs, int n_out, const T* y0, const T* acc_in,           \
+                     const T* const* k, int nt, double dt, int64_t n) {                               \
+        T c[ORACLE_MAX_MULTI_OUT][ORACLE_MAX_TERMS];                                                  \
+        const T dtT = (T)dt;                                                                          \
+        for (int o = 0; o < n_out; ++o)                                                               \
+            for (int j = 0; j < nt; ++j) c[o][j] = (T)outs[o].coef[j] * dtT;                          \
+        _Pragma("omp parallel for schedule(static)")                                                  \
+        for (int64_t i = 0; i < n; ++i) {                                                             \
+            for (int o = 0; o < n_out; ++o) {                                                         \
+                int started = (o == 0 && acc_in != NULL);                                             \
+                T s = started ? acc_in[i] : (T)0;                                                     \
+                for (int j = 0; j < nt; ++j) {                                                        \
+                    if (!((outs[o].mask >> j) & 1u)) continue;                                        \
+                    const T p = k[j][i] * c[o][j];                                                    \
+                    s = started ? s + p : p;                                                          \
+                    started = 1;                                                                      \
+                }                                                                                     \
+                ((T*)outs[o].out)[i] = outs[o].add_y0 ? y0[i] + s : s;                                \
+            }                                                                                         \
+        }                                                                                             \
+    }
+DEF_COMBINE_MULTI(combine_multi_f32, float)
+DEF_COMBINE_MULTI(combine_multi_f64, double)
+
+int oracle_stage_combine_multi(const oracle_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                               const void* const* k, int n_terms, double dt, int64_t n, int dtype) {
+    if (!outs || !y0 || !k || n_terms < 1 || n_terms > ORACLE_MAX_TERMS || n_out < 1 || n_out > ORACLE_MAX_MULTI_OUT)
+        return -1;
+    for (int o = 0; o < n_out; ++o) if (!outs[o].out || !outs[o].mask) return -1;
+    if (dtype == ORACLE_F32)
+        combine_multi_f32(outs, n_out, (const float*)y0, (const float*)acc_in, (const float* const*)k, n_terms, dt, n);
+    else if (dtype == ORACLE_F64)
+        combine_multi_f64(outs, n_out, (const double*)y0, (const double*)acc_in, (const double* const*)k, n_terms, dt, n);
+    else return -1;
+    return 0;
+}
+
 #define DEF_ERROR_PARTIAL(NAME, T, ABS, MAX)                                                          \
     static int NAME(const T* partial, const T* y0, const T* y1, const T* const* k, const double* coef,\
                     int nt, double dt, const oracle_segment* segs, int n_seg, int64_t chunk,          \

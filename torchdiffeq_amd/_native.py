@@ -17,13 +17,14 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 15
+TDEQ_ABI_VERSION = 16
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
 TDEQ_CHUNK_QUANTUM = 1024
 TDEQ_MAX_STAGE_TIMES = 16
 TDEQ_MAX_DENSE_OUTPUTS = 16
+TDEQ_MAX_MULTI_OUT = 4
 
 _LIB_NAME = "libtdeq_hip.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
@@ -47,6 +48,12 @@ class StepCtrl(ctypes.Structure):
                 ("n_times", ctypes.c_int32), ("n_norm_seg", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class MultiOut(ctypes.Structure):
+    """`tdeq_multi_out` of include/tdeq_hip.h: one output of tdeq_stage_combine_multi."""
+    _fields_ = [("out", ctypes.c_void_p), ("coef", ctypes.c_double * TDEQ_MAX_TERMS), ("mask", ctypes.c_uint32),
+                ("add_y0", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); the authoritative list of exported symbols (checked by the tests).
 ABI_SIGNATURES = {
     "tdeq_abi_version": (ctypes.c_int, []),
@@ -68,6 +75,9 @@ ABI_SIGNATURES = {
     "tdeq_stage_combine_err": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
                                               _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_double,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_stage_combine_multi": (ctypes.c_int, [ctypes.POINTER(MultiOut), ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_void_p, _c_void_pp, ctypes.c_int, ctypes.c_double,
+                                                ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_error_norm_partial": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
                                                _c_double_p, ctypes.c_int, ctypes.c_double, ctypes.POINTER(Segment),
                                                ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
@@ -358,6 +368,49 @@ class HipKernels:
         _check(self.lib.tdeq_stage_combine_err(out.data_ptr(), err_out.data_ptr(), y0.data_ptr(), ptrs, cf, ef, n, dt,
                                                y0.numel(), dtype_code(y0.dtype), self._stream()),
                "tdeq_stage_combine_err")
+
+    _MULTI_SPECS: dict = {}
+
+    @classmethod
+    def multi_spec(cls, rows):
+        """The constant part of a tdeq_stage_combine_multi call, built once per tableau row group: `rows` =
+        ((coefs over the call's stage streams, mask, add_y0), ...), one entry per output.  Returns a `tdeq_multi_out`
+        array whose `out` pointers are filled in per call (per thread: ctypes releases the GIL during a call)."""
+        per_thread = getattr(cls._TLS, "multi_specs", None)
+        if per_thread is None:
+            per_thread = cls._TLS.multi_specs = {}
+        arr = per_thread.get(rows)
+        if arr is None:
+            if len(per_thread) > 1024:
+                per_thread.clear()
+            arr = (MultiOut * len(rows))()
+            for o, (coefs, mask, add_y0) in enumerate(rows):
+                assert len(coefs) <= TDEQ_MAX_TERMS and mask
+                for j, c in enumerate(coefs):
+                    arr[o].coef[j] = c
+                arr[o].mask = mask
+                arr[o].add_y0 = 1 if add_y0 else 0
+            per_thread[rows] = arr
+        return arr
+
+    def stage_combine_multi(self, outs, rows, y0, acc_in, ks, dt: float) -> None:
+        """One pass over the stages `ks` producing len(outs) tensors (tdeq_stage_combine_multi): output o =
+        [y0 +] [acc_in +] sum over the set bits j of rows[o].mask of (rows[o].coefs[j] * dt) * ks[j] — a row's own
+        stage input plus carried left-to-right partial sums of later rows.  `rows` as for `multi_spec` (a tuple)."""
+        n = len(ks)
+        arrays = getattr(self._TLS, "ptr_arrays", None)
+        if arrays is None:
+            arrays = self._TLS.ptr_arrays = [(ctypes.c_void_p * m)() for m in range(TDEQ_MAX_TERMS + 1)]
+        ptrs = arrays[n]
+        for j in range(n):
+            ptrs[j] = ks[j].data_ptr()
+        spec = self.multi_spec(rows)
+        for o, t in enumerate(outs):
+            spec[o].out = t.data_ptr()
+        _check(self.lib.tdeq_stage_combine_multi(spec, len(outs), y0.data_ptr(),
+                                                 None if acc_in is None else acc_in.data_ptr(), ptrs, n, dt,
+                                                 y0.numel(), dtype_code(y0.dtype), self._stream()),
+               "tdeq_stage_combine_multi")
 
     def error_norm_partial(self, plan: NormPlan, err_partial, y0, y1, ks, coefs, dt: float) -> None:
         """Error norm continuing `err_partial` with the remaining stages `ks` (0..2 of them)."""

@@ -148,6 +148,48 @@ int dispatch_combine(void* out, const void* y0, const void* const* k, const doub
     return TDEQ_EINVAL;
 }
 
+// ---- stage_combine_multi (carried partial sums) ---------------------------------------------------------
+template <typename T, int NT>
+int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                         const void* const* k, double dt, int64_t n, hipStream_t s) {
+    MultiArgs<T, NT> a;
+    a.y0 = static_cast<const T*>(y0);
+    a.acc_in = static_cast<const T*>(acc_in);
+    bool vec = aligned16(y0) && aligned16(acc_in);
+    const T dtT = (T)dt;
+    for (int j = 0; j < NT; ++j) {
+        a.k[j] = static_cast<const T*>(k[j]);
+        vec = vec && aligned16(k[j]);
+    }
+    a.add_y0 = 0;
+    for (int o = 0; o < kMaxMultiOut; ++o) {
+        const bool live = o < n_out;
+        a.out[o] = live ? static_cast<T*>(outs[o].out) : nullptr;
+        a.mask[o] = live ? outs[o].mask : 0u;
+        if (live && outs[o].add_y0) a.add_y0 |= 1u << o;
+        for (int j = 0; j < NT; ++j) a.c[o][j] = live ? (T)outs[o].coef[j] * dtT : (T)0;   // rk_common.py:79,201-205
+        if (live) vec = vec && aligned16(outs[o].out);
+    }
+    a.n_out = n_out;
+    a.n = n;
+    constexpr int L = VecOf<T>::L;
+    if (vec) hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
+}
+
+template <typename T>
+int dispatch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                           const void* const* k, int nt, double dt, int64_t n, hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_combine_multi<T, N>(outs, n_out, y0, acc_in, k, dt, n, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
 // ---- segment table / workspace ---------------------------------------------------------------------
 int fill_segtable(SegTable& st, const tdeq_segment* segs, const void* segs_dev, int n_seg,
                   int64_t chunk, int64_t n_chunks) {
@@ -862,6 +904,21 @@ int tdeq_stage_combine_err(void* out, void* err_out, const void* y0, const void*
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == TDEQ_F32 ? dispatch_combine_err<float>(out, err_out, y0, k, coef, err_coef, n_terms, dt, n, s)
                              : dispatch_combine_err<double>(out, err_out, y0, k, coef, err_coef, n_terms, dt, n, s);
+}
+
+int tdeq_stage_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                             const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream) {
+    if (!outs || !y0 || !k || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS || n_out < 1 || n_out > TDEQ_MAX_MULTI_OUT) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    for (int o = 0; o < n_out; ++o) {
+        if (!outs[o].out || outs[o].mask == 0u) return TDEQ_EINVAL;
+        if (n_terms < 32 && (outs[o].mask >> n_terms) != 0u) return TDEQ_EINVAL;
+    }
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == TDEQ_F32 ? dispatch_combine_multi<float>(outs, n_out, y0, acc_in, k, n_terms, dt, n, s)
+                             : dispatch_combine_multi<double>(outs, n_out, y0, acc_in, k, n_terms, dt, n, s);
 }
 
 int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void* y1, const void* const* k,

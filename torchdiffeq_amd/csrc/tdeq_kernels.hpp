@@ -196,6 +196,70 @@ __global__ __launch_bounds__(kBlock) void stage_combine_kernel(const CombineArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// Carried partial sums (tdeq_stage_combine_multi): one pass over NT stage streams, up to kMaxMultiOut outputs.
+//   s_o = [acc_in +] sum_{j in mask_o, ascending} c_o[j] * k_j ;  out_o = add_y0_o ? y0 + s_o : s_o
+// Output 0 is the row's own stage input; the others are left-to-right prefixes of LATER rows' sums (continued by
+// those rows through acc_in) or later stage inputs that need no newer stage.  Same rounding sequence as
+// stage_combine_kernel: the first product starts the sum (no 0 + x, which would turn -0 into +0), structural zeros
+// are skipped by the wave-uniform mask — scalar branches on kernel arguments —, -ffp-contract=off.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxMultiOut = TDEQ_MAX_MULTI_OUT;
+
+template <typename T, int NT>
+struct MultiArgs {
+    const T* y0;
+    const T* acc_in;                  // nullable: prefix of output 0's sum
+    const T* k[NT];
+    T* out[kMaxMultiOut];
+    T c[kMaxMultiOut][NT];
+    uint32_t mask[kMaxMultiOut];
+    uint32_t add_y0;                  // bit o: out_o = y0 + s_o
+    int n_out;
+    int64_t n;
+};
+
+template <typename T, int NT, typename E>
+__device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, int64_t i) {
+    const E* __restrict__ y0 = reinterpret_cast<const E*>(a.y0);
+    E kk[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.k[j])[i];
+    const E y = y0[i];
+    E acc0 = y;                       // placeholder when there is no acc_in (never read then)
+    if (a.acc_in) acc0 = reinterpret_cast<const E*>(a.acc_in)[i];
+#pragma unroll
+    for (int o = 0; o < kMaxMultiOut; ++o) {
+        if (o < a.n_out) {
+            const uint32_t m = a.mask[o];
+            bool started = (o == 0) && a.acc_in;
+            E s = acc0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if ((m >> j) & 1u) {
+                    const E p = kk[j] * a.c[o][j];
+                    s = started ? s + p : p;
+                    started = true;
+                }
+            }
+            reinterpret_cast<E*>(a.out[o])[i] = ((a.add_y0 >> o) & 1u) ? y + s : s;
+        }
+    }
+}
+
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(kBlock) void stage_combine_multi_kernel(const MultiArgs<T, NT> a) {
+    using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
+    constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) multi_elem<T, NT, E>(a, i);
+    if (VEC) {   // scalar tail (n % L elements)
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) multi_elem<T, NT, T>(a, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Reductions.  One workgroup per chunk -> one fp64 partial per chunk (deterministic order), then a
 // finalize launch adds the partials of each segment in a fixed tree order.  wave64 shuffles first,
 // LDS only for the 4 per-wave values.

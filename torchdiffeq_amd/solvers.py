@@ -33,8 +33,8 @@ from . import _native
 from .autodiff import Ops, stitch
 from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, find_event, handle_unused_kwargs, rms_norm)
 from .misc import _null_callback as _null
-from .tableaus import (ADAPTIVE_HEUN, BOSH3, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau,
-                       adams_coefficients)
+from .tableaus import (ADAPTIVE_HEUN, ADAPTIVE_TABLEAUS, BOSH3, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau,
+                       adams_coefficients, carry_plan)
 
 
 def _nan_max(a: float, b: float) -> float:
@@ -486,6 +486,12 @@ class RKAdaptiveStepsizeODESolver:
         self._fuse = None
         if self._c_err.idx[:n_lead] == last.idx and len(self._c_err.idx) - n_lead <= 2:
             self._fuse = (self._c_err.coef[:n_lead], self._c_err.idx[n_lead:], self._c_err.coef[n_lead:])
+        # Carried partial sums (tableaus.carry_plan / tdeq_stage_combine_multi): fewer bytes per step for the same bits.
+        # TDEQ_CARRY=0 keeps the row-by-row launches.
+        self._carry = None
+        if self._fuse is not None and tab.fsal_solution and os.environ.get("TDEQ_CARRY", "1") != "0" \
+                and hasattr(self.kernels, "stage_combine_multi") and ADAPTIVE_TABLEAUS.get(tab.name) is tab:
+            self._carry = carry_plan(tab.name)
         self.n_accepted = 0
         self.n_rejected = 0
         # Device-resident controller + look-ahead first stage (tdeq_error_norm_partial_ctrl / tdeq_stage_combine_sel):
@@ -910,8 +916,36 @@ class RKAdaptiveStepsizeODESolver:
         fsal = self.tableau.fsal_solution
         builtin_norm = isinstance(self.norm, BuiltinNorm)
         err_partial = None
+        err_rem = self._fuse[1:] if self._fuse is not None else None     # (stages, weights) left to the norm kernel
         nograd = not torch.is_grad_enabled()      # no-grad solves (the adjoint's two solves, inference): no graph checks
-        for i in range(1, n_rows):
+        carry = self._carry if (builtin_norm and (nograd or (plain and not k1.requires_grad))) else None
+        if carry is not None:
+            # planned stage loop (tableaus.carry_plan): a launch may also emit the left-to-right prefixes of later
+            # rows' sums (continued by those rows: fewer bytes) or a later stage input that needs no newer stage;
+            # every stage input is bit-identical to the row-by-row launches below
+            held, S = {}, n_rows
+            for i in range(1, n_rows):
+                op = carry.ops[i]
+                if op is None:
+                    yi = held.pop(i)                      # finished by an earlier launch
+                elif len(op.targets) == 1 and not op.continues:
+                    row = self._beta[i]
+                    yi = torch.empty_like(y0)
+                    kern.stage_combine(yi, y0, [k[j] for j in row.idx], row.coef, dt_signed)
+                elif op.targets == (i, S) and i == S - 1 and not op.continues and op.idx == self._beta[i].idx:
+                    row = self._beta[i]                   # the end-of-step pair as before (tdeq_stage_combine_err)
+                    yi, held[S] = torch.empty_like(y0), torch.empty_like(y0)
+                    kern.stage_combine_err(yi, held[S], y0, [k[j] for j in row.idx], row.coef, self._fuse[0], dt_signed)
+                else:
+                    outs = [torch.empty_like(y0) for _ in op.targets]
+                    kern.stage_combine_multi(outs, op.spec, y0, held.pop(i) if op.continues else None,
+                                             [k[j] for j in op.idx], dt_signed)
+                    yi = outs[0]
+                    for tgt, buf in zip(op.targets[1:], outs[1:]):
+                        held[tgt] = buf
+                k.append(func.eval_at(stage_times[i], yi))
+            err_partial, err_rem = held.pop(S), (carry.err_idx, carry.err_coef)
+        for i in range(1, n_rows if carry is None else 0):
             row = self._beta[i]
             if i == n_rows - 1 and fsal and self._fuse is not None and builtin_norm and \
                     (nograd or not (y0.requires_grad or k[-1].requires_grad)):
@@ -941,13 +975,13 @@ class RKAdaptiveStepsizeODESolver:
             ctrl.t0, ctrl.dt = t0, dt
             tnext = torch.empty(ctrl.n_times, dtype=y0.dtype, device=y0.device)
             if self._sync is None:
-                kern.error_norm_partial_ctrl(self.plan, err_partial, y0, y1, [k[j] for j in self._fuse[1]],
-                                             self._fuse[2], dt_signed, ctrl, tnext)
+                kern.error_norm_partial_ctrl(self.plan, err_partial, y0, y1, [k[j] for j in err_rem[0]],
+                                             err_rem[1], dt_signed, ctrl, tnext)
             else:
                 # lock step: this rank's sums -> device buffer, all-reduce over the ranks on the device, the
                 # controller on the global sums (global element counts): every rank takes the whole-batch decision
-                kern.error_norm_partial(self._plan_dev, err_partial, y0, y1, [k[j] for j in self._fuse[1]],
-                                        self._fuse[2], dt_signed)
+                kern.error_norm_partial(self._plan_dev, err_partial, y0, y1, [k[j] for j in err_rem[0]],
+                                        err_rem[1], dt_signed)
                 self._sync.reduce_device(self._plan_dev.out, self.plan.n_seg)
                 kern.step_controller(self.plan, self._plan_dev, self._plan_glob, ctrl, tnext, y0.dtype)
             if t1 < self._t_end:
@@ -959,7 +993,7 @@ class RKAdaptiveStepsizeODESolver:
             accept_dev, dt_next_dev, error_ratio, bad = kern.read_ctrl(self.plan)
             y1_nonfinite = any(b != 0 for b in bad)
         elif err_partial is not None:
-            kern.error_norm_partial(self.plan, err_partial, y0, y1, [k[j] for j in self._fuse[1]], self._fuse[2],
+            kern.error_norm_partial(self.plan, err_partial, y0, y1, [k[j] for j in err_rem[0]], err_rem[1],
                                     dt_signed)
             sumsq, _, bad = self._read_norms()
             error_ratio = self._segment_norm(sumsq, bad)

@@ -258,6 +258,111 @@ ADAPTIVE_TABLEAUS = {t.name: t for t in (DOPRI8, DOPRI5, TSIT5, BOSH3, FEHLBERG2
 
 
 # ---------------------------------------------------------------------------------------------------
+# Carried partial sums (r03; include/tdeq_hip.h `tdeq_stage_combine_multi`).
+#
+# Row i of `_runge_kutta_step` (rk_common.py:69-81) is y_i = y0 + sum_{j<=i} (beta_ij dt) k_j: launched row by row,
+# every row re-reads all earlier stages — 32 words per element and dopri5 step, 94 per dopri8 step.
+# While a "host" row h is being formed its stages are in registers, so the same launch can also emit, for a later
+# "target" row t, the left-to-right prefix of t's sum over the stages <= h; row t then reads that one stream plus the
+# stages computed since (and y0).  The embedded error (rk_common.py:89) is one more target whose last consumer is the
+# norm kernel.  A target whose row has no weight on any stage after h needs no later launch at all: the host writes
+# the finished stage input (dopri8's row for stage 12 has a zero weight on k_11, dopri8.py:5-70).
+# The left-to-right order of every sum is unchanged, so all stage inputs are bit-identical to the row-by-row launches.
+#
+# The assignment target -> host below is the minimum of the word count over all assignments with at most
+# TDEQ_MAX_MULTI_OUT outputs per launch, hosts that are themselves read in full, and at most two error terms left to
+# the norm kernel (found by annealing over the assignment space, tools/carry_search.py; `CarryPlan.words` recomputes
+# the count, tests/test_carry.py pins it):  dopri5 37 -> 35 words per element and step, dopri8 98 -> 75 (13 launches
+# instead of 14).  Target S (= number of rows) is the embedded error.
+# ---------------------------------------------------------------------------------------------------
+_CARRY_HOSTS = {
+    "dopri5": {4: 3, 6: 5},
+    "dopri8": {5: 4, 7: 6, 8: 6, 9: 6, 11: 10, 12: 10, 13: 10},
+}
+MAX_MULTI_OUT = 4
+
+
+@dataclasses.dataclass(frozen=True)
+class CarryOp:
+    """One launch of the planned stage loop: forms the stage input of `row` (output 0) and the carried outputs."""
+    row: int
+    idx: Tuple[int, ...]                    # stage slots read, ascending
+    continues: bool                         # output 0 continues the partial sum carried for `row`
+    targets: Tuple[int, ...]                # tableau row of every output (targets[0] == row; n_rows = the error)
+    spec: Tuple[Tuple[Tuple[float, ...], int, bool], ...]   # per output: (weights over idx, mask, add_y0)
+
+
+@dataclasses.dataclass(frozen=True)
+class CarryPlan:
+    ops: Tuple[object, ...]                 # per tableau row: a CarryOp, or None (input finished by an earlier launch;
+                                            # row 0 keeps its own launch forms and is None as well)
+    err_idx: Tuple[int, ...]                # stages the norm kernel adds to the carried partial error
+    err_coef: Tuple[float, ...]
+    words: int                              # words per element and step moved by the planned launches + the norm
+    launches: int
+
+
+def _plan_from_hosts(tab: Tableau, hosts) -> CarryPlan:
+    rows = tab.beta_rows()
+    S = len(rows)
+    err = SparseRow.from_dense(tab.c_error)
+    nz = {i: dict(zip(r.idx, r.coef)) for i, r in enumerate(rows)}
+    nz[S] = dict(zip(err.idx, err.coef))
+    assert tab.fsal_solution and S not in () and hosts.get(S) is not None
+    for t, h in hosts.items():
+        assert 1 <= h < t <= S and h not in hosts, "hosts are rows that are formed in full"
+        assert any(j <= h for j in nz[t]), "nothing to carry"
+    ops, finished, words, launches = [None] * S, set(), 0, 0
+    for i in range(S):
+        if i in finished:
+            continue
+        h = hosts.get(i)
+        own = sorted(j for j in nz[i] if h is None or j > h)
+        if h is not None and not own:
+            raise AssertionError("a row without newer stages is finished by its host")
+        targets = [i] + sorted(t for t, hh in hosts.items() if hh == i)
+        assert len(targets) <= MAX_MULTI_OUT
+        idx = sorted(set(own) | {j for t in targets[1:] for j in nz[t] if j <= i})
+        spec = []
+        for t in targets:
+            take = own if t == i else [j for j in sorted(nz[t]) if j <= i]
+            mask = sum(1 << idx.index(j) for j in take)
+            coefs = tuple(nz[t].get(j, 0.0) if j in take else 0.0 for j in idx)
+            done = t == i or (t < S and all(j <= i for j in nz[t]))
+            if done and t != i:
+                finished.add(t)
+            spec.append((coefs, mask, done))
+        words += len(idx) + 1 + (1 if h is not None else 0) + len(targets)
+        launches += 1
+        if i > 0:
+            ops[i] = CarryOp(i, tuple(idx), h is not None, tuple(targets), tuple(spec))
+        else:
+            assert targets == [0]
+    rem = sorted(j for j in nz[S] if j > hosts[S])
+    assert len(rem) <= 2, "tdeq_error_norm_partial continues over at most two stages"
+    words += 1 + len(rem) + 2
+    launches += 1
+    return CarryPlan(tuple(ops), tuple(rem), tuple(nz[S][j] for j in rem), words, launches)
+
+
+@functools.lru_cache(maxsize=None)
+def carry_plan(name: str):
+    """The carried-partial-sum launch plan of the tableau `name`, or None when it has none (no saving, or a pair
+    whose solution is not its last stage input)."""
+    hosts = _CARRY_HOSTS.get(name)
+    return None if hosts is None else _plan_from_hosts(ADAPTIVE_TABLEAUS[name], dict(hosts))
+
+
+def row_by_row_words(tab: Tableau) -> int:
+    """Words per element and step of the row-by-row launches with the end-of-step fusion."""
+    rows = tab.beta_rows()
+    err = SparseRow.from_dense(tab.c_error)
+    last = rows[-1] if tab.fsal_solution else SparseRow.from_dense(tab.c_sol)
+    return sum(len(r.idx) + 2 for r in rows) + (0 if tab.fsal_solution else len(last.idx) + 2) + 1 + \
+        (1 + len(err.idx) - len(last.idx) + 2)
+
+
+# ---------------------------------------------------------------------------------------------------
 # Adams–Bashforth / Adams–Moulton weights (fixed_adams.py:10-152 holds them as integer tables over a common
 # divisor).  They are the integrals over one step of the Lagrange basis polynomials through the last k derivative
 # values (Bashforth: nodes t_n, t_{n-1}, ...; Moulton: t_{n+1}, t_n, ...), generated here in exact rational
