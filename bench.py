@@ -407,7 +407,7 @@ def shard_regime_linear(device, steps=100, warmup=20):
     return out
 
 
-def run_linear(args, rank, world, device):
+def run_linear(args, rank, world, device, parity=True):
     import torchdiffeq_amd as tda
     strong = args.scaling == "strong" and world > 1
     if strong:
@@ -428,17 +428,22 @@ def run_linear(args, rank, world, device):
         return y @ At
     with torch.no_grad():
         t_wall = time.perf_counter()
-        y_end = tda.odeint(counted, y0, torch.tensor([0.0, 1.0], device=device), rtol=RTOL, atol=ATOL, method="dopri5")[-1]
+        if not parity:          # (second regime of a multi-rank run: only the timed steps)
+            y_end = None
+        else:
+            y_end = tda.odeint(counted, y0, torch.tensor([0.0, 1.0], device=device), rtol=RTOL, atol=ATOL,
+                               method="dopri5")[-1]
         torch.cuda.synchronize()
-        odeint_wall = time.perf_counter() - t_wall
-        exact = y0.double() @ torch.linalg.matrix_exp(A.double()).T
-        rel_err = float((y_end.double() - exact).abs().max() / exact.abs().max())
-        if rank == 0 and not strong:
-            try:
-                rel_err_ref, ref_nfe = reference_rel_err(y_end)
-            except Exception as exc:
-                rel_err_ref = repr(exc)
-        del exact
+        if parity:
+            odeint_wall = time.perf_counter() - t_wall
+            exact = y0.double() @ torch.linalg.matrix_exp(A.double()).T
+            rel_err = float((y_end.double() - exact).abs().max() / exact.abs().max())
+            if rank == 0 and not strong:
+                try:
+                    rel_err_ref, ref_nfe = reference_rel_err(y_end)
+                except Exception as exc:
+                    rel_err_ref = repr(exc)
+            del exact
 
     # ---- timed region ----
     auto_graph = strong and n <= (1 << 21) and os.environ.get("TDEQ_BENCH_GRAPH", "1") != "0"
@@ -513,6 +518,215 @@ def run_linear(args, rank, world, device):
         torch.cuda.synchronize()
         solver._g.release()
     return out, field, y0
+
+
+# ---------------------------------------------------------------------------------------------------
+# the other BASELINE.json configurations, bounded (N = 1 line, `configs` object)
+# ---------------------------------------------------------------------------------------------------
+class MultiTimedKernels:
+    """Forwards to HipKernels; while armed, tdeq_stage_combine_multi launches with `n_terms` stage streams and
+    `n_out` outputs are stamped by the dispatch itself (tdeq_stage_combine_multi_timed)."""
+
+    def __init__(self, inner, n_terms, n_out, n_events):
+        self._inner, self._key = inner, (n_terms, n_out)
+        self.armed, self.events, self.words = False, [], None
+        self._pool = []
+        for _ in range(n_events):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            self._pool.append((e0, e1))
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+    def stage_combine_multi(self, outs, rows, y0, acc_in, ks, dt, events=None):
+        if self.armed and (len(ks), len(outs)) == self._key and self._pool:
+            ev = self._pool.pop()
+            self.events.append(ev)
+            self.words = len(ks) + 1 + (0 if acc_in is None else 1) + len(outs)
+            return self._inner.stage_combine_multi(outs, rows, y0, acc_in, ks, dt, events=ev)
+        return self._inner.stage_combine_multi(outs, rows, y0, acc_in, ks, dt)
+
+
+def cfg4_config(device):
+    """configs[3]: dopri8 fp64, 16384 x 512, rtol 1e-9 / atol 1e-11 — whole odeint vs the reference's own result
+    (tests/golden/fullsize_cfg4.npz) and the roofline of its dominant launch, in situ and HBM-cold."""
+    import _fullsize as fs
+    import torchdiffeq_amd as tda
+    from torchdiffeq_amd import tableaus as tb
+    from torchdiffeq_amd.misc import OdeFunc, StateLayout, rms_norm
+    from torchdiffeq_amd.solvers import Dopri8Solver
+    z = fs.load("cfg4")
+    A, y0 = fs.linear_problem(16384, 512, torch.float64)
+    At, y0 = A.T.contiguous().to(device), y0.to(device)
+    rtol, atol = [float(v) for v in z["tol"]]
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64, device=device)
+    nfe = [0]
+
+    def field(tt, y):
+        nfe[0] += 1
+        return y @ At
+    with torch.no_grad():
+        y_end = tda.odeint(field, y0, t, rtol=rtol, atol=atol, method="dopri8")[-1]
+        n_eval, nfe[0] = nfe[0], 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            tda.odeint(field, y0, t, rtol=rtol, atol=atol, method="dopri8")
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / 3
+    rows = torch.from_numpy(z["rows"]).to(device)
+    out = {"workload": "BASELINE.json configs[3]: dopri8 fp64, batch=16384 x dim=512, rtol=1e-9 atol=1e-11",
+           "odeint_t01_ms": ms, "nfe": n_eval, "reference_nfe": int(z["nfe"]),
+           "rk_stages_per_s": (n_eval - 2) / (ms * 1e-3),
+           "rel_err_vs_reference": fs.sample_rel_err(y_end[rows], z["y_end_rows"], z["y_end_absmax"]),
+           "words_per_element_and_step": {"row_by_row": tb.row_by_row_words(tb.DOPRI8),
+                                          "carried_partial_sums": tb.carry_plan("dopri8").words}}
+    # dominant launch of the planned step: row 10 of the tableau, 9 stage streams + y0 read, 4 streams written
+    layout = StateLayout([y0.shape], False)
+    solver = Dopri8Solver(func=OdeFunc(lambda tt, y: y @ At, layout, 1.0, y0.dtype, y0.device), y0=y0.reshape(-1),
+                          rtol=rtol, atol=atol, norm=rms_norm)
+    if solver._carry is not None:
+        solver._before_integrate([0.0])
+        solver._t_end = float("inf")
+        timed = MultiTimedKernels(solver.kernels, 9, 4, 16)
+        solver.kernels = timed
+        with torch.no_grad():
+            for _ in range(2):
+                solver._trial_step()
+            timed.armed = True
+            for _ in range(12):
+                solver._trial_step()
+            timed.armed = False
+        torch.cuda.synchronize()
+        msk = [a.elapsed_time(b) for a, b in timed.events]
+        n = y0.numel()
+        if msk:
+            avg = sum(msk) / len(msk)
+            nbytes = timed.words * n * 8
+            roof = {"bound": "hbm", "kernel": "stage_combine_multi_kernel<double, 9, true> (dopri8 row 10: 9 stages + "
+                                              "y0 read; y_10, y_11, the row-12 prefix and the error prefix written)",
+                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg, "launches_timed": len(msk),
+                    "achieved": nbytes / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "frac_is": "in situ; the launch moves 939 MB, 3.7x the 256 MiB Infinity Cache"}
+            # cold: the same launch on two rotating buffer sets (2 x 939 MB)
+            op = tb.carry_plan("dopri8").ops[10]
+            g = torch.Generator(device="cpu").manual_seed(2)
+            sets = []
+            for _ in range(2):
+                sets.append((torch.randn(n, generator=g, dtype=torch.float64).to(device),
+                             [torch.randn(n, generator=g, dtype=torch.float64).to(device) for _ in op.idx],
+                             [torch.empty(n, dtype=torch.float64, device=device) for _ in op.targets]))
+            kern = timed._inner
+            evs = []
+            for i in range(10):
+                yb, kb, ob = sets[i % 2]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                e1.record()
+                kern.stage_combine_multi(ob, op.spec, yb, None, kb, 0.1, events=(e0, e1))
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            cold = [a.elapsed_time(b) for a, b in evs[2:]]
+            cavg = sum(cold) / len(cold)
+            roof["cold"] = {"avg_launch_ms": cavg, "achieved": nbytes / (cavg * 1e-3) / 1e9,
+                            "frac": nbytes / (cavg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launches_timed": len(cold),
+                            "buffer_sets": 2}
+            out["roofline"] = roof
+    return out
+
+
+def cfg5_config(device):
+    """configs[4]: CNF 32768 x 2 (+ logp), dopri5 + adjoint, t 10 -> 0, rtol = atol = 1e-5 — forward / backward ms
+    eager and with captured trial steps, and the results vs the reference's (tests/golden/fullsize_cfg5.npz)."""
+    import _fullsize as fs
+    import torchdiffeq_amd as tda
+    z = fs.load("cfg5")
+    z0, logp0 = fs.cfg5_problem()
+    z0, logp0 = z0.to(device), logp0.to(device)
+    t = torch.tensor([10.0, 0.0], device=device)
+    idx = torch.from_numpy(z["rows"]).to(device)
+    out = {"workload": "BASELINE.json configs[4]: CNF (examples/cnf.py model, closed-form trace), dopri5 + adjoint, "
+                       "batch=32768 x dim=2, rtol=atol=1e-5"}
+    for name, opts in (("eager", None), ("captured_steps", {"hip_graph": "auto"})):
+        cnf = fs.ExampleCNF([z[f"p{i}"] for i in range(6)], trace="closed").to(device)
+        params = list(cnf.parameters())
+        best = None
+        for rep in range(4):
+            for p_ in params:
+                p_.grad = None
+            x = z0.clone().requires_grad_(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            zt, lp = tda.odeint_adjoint(cnf, (x, logp0), t, atol=1e-5, rtol=1e-5, method="dopri5", options=opts)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            loss = lp[-1].mean() - zt[-1].pow(2).sum() / 100
+            loss.backward()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if rep and (best is None or t2 - t0 < best[0] + best[1]):
+                best = (t1 - t0, t2 - t1)
+        gp = max(float((p_.grad.cpu() - torch.from_numpy(z[f"grad_p{i}"])).abs().max() /
+                       torch.from_numpy(z[f"grad_p{i}"]).abs().max()) for i, p_ in enumerate(params))
+        out[name] = {"fwd_ms": 1e3 * best[0], "bwd_ms": 1e3 * best[1],
+                     "rel_err_z": fs.sample_rel_err(zt[-1][idx], z["z_end_rows"], z["z_end_absmax"]),
+                     "rel_err_logp": fs.sample_rel_err(lp[-1][idx], z["logp_end_rows"], z["logp_end_absmax"]),
+                     "rel_err_loss": abs(float(loss.detach()) - float(z["loss"])) / abs(float(z["loss"])),
+                     "rel_err_grad_z0": fs.sample_rel_err(x.grad[idx], z["grad_z0_rows"], z["grad_z0_absmax"]),
+                     "max_rel_err_param_grads": gp}
+    out["reference_1thread_s"] = [float(v) for v in z["wall_s_1thread"]]
+    return out
+
+
+def cfg1_config(device):
+    """configs[0]: spiral, rk4, y0 in R^2, 999 steps, fp32 — on the GPU (eager and one captured step replayed) and,
+    as BASELINE.json writes it, on the CPU through the package's host path; the reference's trajectory is the
+    golden tests/golden/solves.npz."""
+    import numpy as np
+    import torchdiffeq_amd as tda
+    z = np.load(os.path.join(ROOT, "tests", "golden", "solves.npz"))
+    ref = torch.from_numpy(z["cfg1_y"])
+    out = {"workload": "BASELINE.json configs[0]: spiral ODE, rk4 fixed step, y0 in R^2, batch=1, fp32, 1000 output times"}
+    for name, dev_, opts in (("gpu_eager", device, None), ("gpu_captured_step", device, {"hip_graph": True}),
+                             ("cpu_host_path", torch.device("cpu"), None)):
+        try:
+            A = torch.from_numpy(z["cfg1_A"]).to(dev_)
+            y0 = torch.from_numpy(z["cfg1_y0"]).to(dev_)
+            t = torch.from_numpy(z["cfg1_t"]).to(dev_)
+            f = lambda t_, y_: (y_ ** 3) @ A
+            with torch.no_grad():
+                tda.odeint(f, y0, t, method="rk4", options=opts)
+                if dev_.type == "cuda":
+                    torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                y = tda.odeint(f, y0, t, method="rk4", options=opts)
+                if dev_.type == "cuda":
+                    torch.cuda.synchronize()
+                wall = time.perf_counter() - t0
+            yc = y.cpu()
+            out[name] = {"wall_s": wall, "bit_identical_to_reference": bool(torch.equal(yc, ref)),
+                         "rel_err_vs_reference": float((yc - ref).abs().max() / ref.abs().max()),
+                         "y_end": yc[-1, 0].tolist()}
+        except Exception as exc:
+            out[name] = {"error": repr(exc)}
+    out["reference_cpu_s"] = 0.134
+    return out
+
+
+def other_configs(device):
+    out = {}
+    for name, fn in (("cfg4", cfg4_config), ("cfg5", cfg5_config), ("cfg1", cfg1_config)):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn(device)
+        except Exception as exc:
+            out[name] = {"error": repr(exc)}
+        out[name]["measured_in_s"] = round(time.perf_counter() - t0, 2)
+        torch.cuda.empty_cache()
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -636,21 +850,26 @@ def run_adjoint(args, rank, world, device):
 # launch
 # ---------------------------------------------------------------------------------------------------
 class _Watchdog:
-    """Fires once after `seconds`: rank 0 prints the JSON line built so far (marked `extras_timed_out`), then the
-    process exits with status 0 without waiting for anything (os._exit: a hung collective cannot be joined)."""
+    """Fires once after `seconds`: rank 0 prints the JSON line built so far, marked `extras_timed_out` and naming the
+    extra measurement that was running (`extras_hung_in`), then the process exits WITHOUT waiting for anything
+    (os._exit: a hung collective cannot be joined).  The contract line's own measurement is complete by then, so the
+    exit status stays 0; the marker says the line is truncated."""
 
-    def __init__(self, seconds, rank, out):
+    def __init__(self, seconds, rank, out, progress):
         import threading
-        self._timer = threading.Timer(seconds, self._fire, args=(rank, out))
+        self._timer = threading.Timer(seconds, self._fire, args=(rank, out, progress, seconds))
         self._timer.daemon = True
         self._timer.start()
 
     @staticmethod
-    def _fire(rank, out):
+    def _fire(rank, out, progress, seconds):
         if rank == 0 and out is not None:
             try:
                 line = dict(out)
                 line["extras_timed_out"] = True
+                line["extras_hung_in"] = progress.get("current")
+                line["extras_done"] = list(progress.get("done", ()))
+                line["extras_timeout_s"] = seconds
                 print(json.dumps(line, default=repr), flush=True)
             except Exception:
                 pass
@@ -658,6 +877,67 @@ class _Watchdog:
 
     def cancel(self):
         self._timer.cancel()
+
+
+class _Extras:
+    """Names and times the measurements added to the contract line; the watchdog reads `progress`."""
+
+    def __init__(self, rank, out):
+        self.rank, self.out = rank, out
+        self.progress = {"current": None, "done": []}
+        self.seconds = {}
+
+    def run(self, name, fn):
+        """fn() -> value for out[name] (rank 0 keeps it); an exception becomes {"error": ...}, never a lost line."""
+        self.progress["current"] = name
+        t0 = time.perf_counter()
+        try:
+            val = fn()
+        except Exception as exc:
+            val = {"error": repr(exc)}
+        self.seconds[name] = round(time.perf_counter() - t0, 3)
+        self.progress["done"].append(name)
+        self.progress["current"] = None
+        if self.rank == 0 and self.out is not None and val is not None:
+            self.out[name] = val
+        return val
+
+
+def error_line(args, message, **extra):
+    """One JSON line saying why no measurement was made (printed by the process that found out)."""
+    line = {"metric": "dopri5 RK-stages/sec at batch=65536x dim=128", "value": None, "unit": "RK-stages/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": message}
+    line.update(extra)
+    print(json.dumps(line), flush=True)
+
+
+def comm_census(rank, world, device):
+    """What the collective backend really connects: under nccl (= RCCL) a ones tensor is all-reduced ON THE DEVICE —
+    `rccl_ranks` is the number of ranks RCCL summed over — and every rank reports the GPU it sits on.  Returns the
+    dict for the JSON line (identical on all ranks) and whether it is consistent with `world`."""
+    import torch.distributed as dist
+    props = torch.cuda.get_device_properties(device)
+    mine = {"rank": rank, "device_index": device.index, "device_name": props.name,
+            "device_uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
+            "visible_devices": torch.cuda.device_count()}
+    if world == 1:
+        return {"backend": None, "rccl_ranks": None, "comm_ranks": 1, "devices": [mine]}, True
+    backend = dist.get_backend()
+    ones = torch.ones(1, dtype=torch.float32, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(ones)
+    if ones.is_cuda:
+        torch.cuda.synchronize()
+    seen = int(round(float(ones.item())))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    census = {"backend": backend, "rccl_ranks": seen if backend == "nccl" else None, "comm_ranks": seen,
+              "devices": gathered}
+    ok = seen == world
+    if backend == "nccl":       # one rank per GPU: all device identities distinct
+        ids = {(d["device_uuid"] or d["device_index"]) for d in gathered}
+        idx = {d["device_index"] for d in gathered}
+        ok = ok and len(ids) == world and len(idx) == world
+    return census, ok
 
 
 def free_port():
@@ -669,13 +949,20 @@ def free_port():
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` as a plain command: start N ranks of this script under torch.distributed.run."""
+    """`python bench.py --gpus N` as a plain command: start N ranks of this script under torch.distributed.run
+    (backend nccl = RCCL, rank r owns GPU r).  More ranks than visible GPUs is REFUSED (one JSON error line, exit
+    status 2) unless TDEQ_DIST_BACKEND names a backend explicitly (gloo: ranks share devices — a smoke test of the
+    control flow, labelled as such in the line)."""
     env = dict(os.environ)
     visible = torch.cuda.device_count()
-    if args.gpus > visible and not env.get("TDEQ_DIST_BACKEND"):
-        # RCCL refuses two ranks on one GPU; say so in the line instead of dying without one
-        env["TDEQ_DIST_BACKEND"] = "gloo"
-        env["TDEQ_BENCH_NOTE"] = f"{args.gpus} ranks on {visible} visible GPU(s): ranks share devices, backend gloo"
+    forced = env.get("TDEQ_DIST_BACKEND")
+    if args.gpus > visible and not forced:
+        error_line(args, f"--gpus {args.gpus} but only {visible} GPU(s) are visible: RCCL needs one GPU per rank. "
+                         "Not falling back to another backend silently; set TDEQ_DIST_BACKEND=gloo to smoke-test the "
+                         "multi-rank control flow with ranks sharing devices.", visible_devices=visible)
+        return 2
+    if args.gpus > visible:
+        env["TDEQ_BENCH_NOTE"] = f"{args.gpus} ranks on {visible} visible GPU(s): ranks share devices, backend {forced}"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -701,100 +988,123 @@ def main():
         sys.exit(self_launch(args))
 
     from torchdiffeq_amd import dist as tdist
-    # TDEQ_DIST_BACKEND=gloo lets the N>1 control flow be smoke-tested on a 1-GPU box (ranks share the device;
-    # RCCL itself refuses two ranks on one GPU).  Unset, the backend is nccl (= RCCL) and rank r owns GPU r.
-    rank, world, local_rank = tdist.init_from_env(backend=os.environ.get("TDEQ_DIST_BACKEND") or None)
+    # Backend: nccl (= RCCL), rank r owns GPU r.  TDEQ_DIST_BACKEND=gloo lets the N>1 control flow be smoke-tested on
+    # a 1-GPU box (ranks share the device; RCCL itself refuses two ranks on one GPU) — only when asked for by name.
+    forced = os.environ.get("TDEQ_DIST_BACKEND") or None
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    visible = torch.cuda.device_count()
+    if world_env > 1 and world_env > visible and not forced:
+        if int(os.environ.get("RANK", "0")) == 0:
+            error_line(args, f"WORLD_SIZE={world_env} but only {visible} GPU(s) are visible: RCCL needs one GPU per "
+                             "rank; refusing instead of falling back to another backend (TDEQ_DIST_BACKEND=gloo runs "
+                             "the control flow with ranks sharing devices).", visible_devices=visible)
+        sys.exit(2)
+    rank, world, local_rank = tdist.init_from_env(backend=forced)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    local_rank = local_rank % max(visible, 1)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    # what the collective backend really connects — BEFORE anything is timed; an N-rank run whose RCCL communicator
+    # does not span N distinct GPUs does not produce a line that looks like a measurement
+    census, census_ok = comm_census(rank, world, device)
+    if not census_ok:
+        if rank == 0:
+            error_line(args, f"communicator check failed: all-reduce of ones over backend {census['backend']} gave "
+                             f"{census['comm_ranks']} for world size {world}, or ranks share a GPU", comm=census)
+        sys.exit(3)
+
     if args.workload == "adjoint":
         out = run_adjoint(args, rank, world, device)
+        if rank == 0:
+            out["comm"] = census
+            out["rccl_ranks"], out["backend"] = census["rccl_ranks"], census["backend"]
     else:
         out, field, y0 = run_linear(args, rank, world, device)
+        if rank == 0:
+            out["comm"] = census
+            out["rccl_ranks"], out["backend"] = census["rccl_ranks"], census["backend"]
         extras = not args.no_extras
         # The contract line is measured; everything below only adds objects to it.  If an extra hangs (a collective
         # that never completes on some node), every rank's watchdog fires after the same delay: rank 0 prints the
-        # line as far as it got and all ranks leave — the scaling run keeps its number.
-        watchdog = _Watchdog(float(os.environ.get("TDEQ_BENCH_EXTRAS_TIMEOUT", "300")), rank, out)
+        # line as far as it got — marked, with the name of the measurement that hung — and all ranks leave.
+        ex = _Extras(rank, out)
+        watchdog = _Watchdog(float(os.environ.get("TDEQ_BENCH_EXTRAS_TIMEOUT", "240")), rank, out, ex.progress)
         if extras and world > 1:
             # the same ranks on the other regime and on the workload that communicates (short runs)
             other = argparse.Namespace(**vars(args))
             other.scaling = "strong" if args.scaling == "weak" else "weak"
             other.steps, other.warmup = min(args.steps, 100), min(args.warmup, 20)
-            try:
-                o2, _, _ = run_linear(other, rank, world, device)
-                if rank == 0:
-                    out[other.scaling] = {k: o2[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "blocks")}
-            except Exception as exc:
-                if rank == 0:
-                    out[other.scaling] = {"error": repr(exc)}
-            try:
+
+            def other_regime():
+                o2, _, _ = run_linear(other, rank, world, device, parity=False)
+                return None if o2 is None else {k: o2[k] for k in ("value", "unit", "ms_per_step", "scaling", "config",
+                                                                      "blocks")}
+            ex.run(other.scaling, other_regime)
+            if rank == 0:       # the contract line's own regime under its name too, so both are always there
+                out[args.scaling] = {k: out[k] for k in ("value", "unit", "ms_per_step", "scaling", "blocks")}
+
+            def lockstep():
                 # lock-step mode (every shard takes the whole-batch step sequence): one all-reduce of 3 doubles per
                 # trial step, on the device with RCCL (finalize -> all-reduce -> tdeq_step_controller)
                 A_, y0_ = make_problem(device, seed_offset=rank)
                 At_ = A_.T.contiguous()
                 ls = make_stepper(lambda t, y: y @ At_, y0_, dist_sync=torch.distributed.group.WORLD)
-                stl = block_stats(time_steps(ls, min(args.steps, 100), min(args.warmup, 20), world, device, n_blocks=3),
-                                  min(args.steps, 100))
-                if rank == 0:
-                    out["lockstep"] = {"ms_per_step": stl["median"], "blocks": stl, "scaling": "weak",
-                                       "value": 6e3 / stl["median"] * world, "unit": "RK-stages/s",
-                                       "lookahead": bool(ls._lookahead),
-                                       "collective": "all_reduce of the 3 norm words per trial step, "
-                                                     + ("on the device (RCCL)" if ls._plan_dev is not None else
-                                                        "through the host (backend without device buffers)")}
-                del ls, A_, y0_, At_
-            except Exception as exc:
-                if rank == 0:
-                    out["lockstep"] = {"error": repr(exc)}
+                n_ls = min(args.steps, 100)
+                stl = block_stats(time_steps(ls, n_ls, min(args.warmup, 20), world, device, n_blocks=3), n_ls)
+                return {"ms_per_step": stl["median"], "blocks": stl, "scaling": "weak",
+                        "value": 6e3 / stl["median"] * world, "unit": "RK-stages/s",
+                        "lookahead": bool(ls._lookahead),
+                        "collective": "all_reduce of the 3 norm words per trial step, "
+                                      + ("on the device (RCCL)" if ls._plan_dev is not None else
+                                         "through the host (backend without device buffers)")}
+            ex.run("lockstep", lockstep)
+
             adj = {}
-            for mode, rows in (("strong", ADJ_BATCH // world), ("weak", ADJ_BATCH)):
-                try:
-                    r = adjoint_pass(world, rank, device, rows, 3, 1)
-                    if rank == 0:
+
+            def adjoint_modes():
+                for mode, rows in (("strong", ADJ_BATCH // world), ("weak", ADJ_BATCH)):
+                    ex.progress["current"] = "adjoint." + mode
+                    try:
+                        r = adjoint_pass(world, rank, device, rows, 3, 1)
                         r["rk_stages_per_s"] = r["rk_stages_per_pass"] / (r["ms_per_pass"] * 1e-3) * \
                             (1 if mode == "strong" else world)
                         adj[mode] = r
+                    except Exception as exc:
+                        adj[mode] = {"error": repr(exc)}
+                ex.progress["current"] = "adjoint.strong_hip_graph_auto"
+                try:        # the strong split once more with captured trial steps (forward and backward solve)
+                    adj["strong_hip_graph_auto"] = adjoint_pass(world, rank, device, ADJ_BATCH // world, 3, 2, graph=True)
                 except Exception as exc:
-                    adj[mode] = {"error": repr(exc)}
-            try:        # the strong split once more with captured trial steps (forward and backward solve)
-                r = adjoint_pass(world, rank, device, ADJ_BATCH // world, 3, 2, graph=True)
-                if rank == 0:
-                    adj["strong_hip_graph_auto"] = r
-            except Exception as exc:
-                adj["strong_hip_graph_auto"] = {"error": repr(exc)}
-            if rank == 0:
-                out["adjoint"] = adj
+                    adj["strong_hip_graph_auto"] = {"error": repr(exc)}
+                return adj
+            ex.run("adjoint", adjoint_modes)
         if extras and world == 1 and rank == 0:
-            try:
-                out["shard_regime"] = {"linear": shard_regime_linear(device),
-                                       "adjoint": adjoint_pass(1, 0, device, ADJ_BATCH // 8, 3, 1),
-                                       "adjoint_hip_graph_auto": adjoint_pass(1, 0, device, ADJ_BATCH // 8, 3, 2,
-                                                                              graph=True)}
+            def shard_regime():
+                r = {"linear": shard_regime_linear(device),
+                     "adjoint": adjoint_pass(1, 0, device, ADJ_BATCH // 8, 3, 1),
+                     "adjoint_hip_graph_auto": adjoint_pass(1, 0, device, ADJ_BATCH // 8, 3, 2, graph=True)}
                 full = out["ms_per_step"]
-                la = out["shard_regime"]["linear"]
+                la = r["linear"]
                 best = min(v["ms_per_step"] for v in la.values() if isinstance(v, dict) and "ms_per_step" in v)
                 la["full_size_ms_per_step"] = full
                 la["speedup_of_best_over_full_size"] = full / best
                 la["note"] = "per-rank work of an 8-GPU strong-scaling run of cfg2; >= 6 would mean the north star's " \
                              "6x at 8 GPUs holds for a fixed global batch"
-            except Exception as exc:
-                out["shard_regime"] = {"error": repr(exc)}
-            try:
-                out["adjoint_full"] = adjoint_pass(1, 0, device, ADJ_BATCH, 3, 1)
-            except Exception as exc:
-                out["adjoint_full"] = {"error": repr(exc)}
+                return r
+            ex.run("shard_regime", shard_regime)
+            ex.run("adjoint_full", lambda: adjoint_pass(1, 0, device, ADJ_BATCH, 3, 1))
+            ex.run("configs", lambda: other_configs(device))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            try:
+            def eager():
                 with torch.no_grad():
-                    out["reference_style_eager_gpu"] = eager_gpu_baseline(field, y0, 0.05)
-            except Exception as exc:      # an extra figure, never allowed to break the contract line
-                out["reference_style_eager_gpu"] = {"error": repr(exc)}
+                    return eager_gpu_baseline(field, y0, 0.05)
+            ex.run("reference_style_eager_gpu", eager)
+            watchdog.cancel()           # the CPU leg is bounded by its own clock
             out["cpu_baseline"] = cpu_baseline()
-    if args.workload != "adjoint":
         watchdog.cancel()
+        if rank == 0:
+            out["extras_s"] = ex.seconds
     if rank == 0:
         if os.environ.get("TDEQ_BENCH_NOTE"):
             out["note"] = os.environ["TDEQ_BENCH_NOTE"]

@@ -187,6 +187,10 @@ typedef struct tdeq_multi_out {
 } tdeq_multi_out;
 int tdeq_stage_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
                              const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream);
+/* Measurement hook, as tdeq_stage_combine_timed: the dispatch stamps the two events with its own begin / end. */
+int tdeq_stage_combine_multi_timed(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                                   const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream,
+                                   void* start_event, void* stop_event);
 
 /*
  * Device-resident step controller + look-ahead first stage.  The accept/reject LOOP stays on the host; what

@@ -19,8 +19,8 @@ def T(a, device="cpu"):
 
 
 def rel_err(a, b):
-    a = torch.as_tensor(a).double().cpu()
-    b = torch.as_tensor(b).double().cpu()
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max())
 
 

@@ -63,9 +63,10 @@ def main():
 
     base = grads(tda.odeint_adjoint)
     assert calls["n"] == 0
-    # (1) one all-reduce of the parameter-adjoint tail (+ one for the time gradients), on device buffers, via RCCL
+    # (1) ONE all-reduce for everything `backward` sums over the batch — the parameter-adjoint tail and, in the same
+    # buffer, the len(t) time gradients (reference adjoint.py:121-153) — on a device buffer, via RCCL
     sharded = grads(tdist.odeint_adjoint_sharded, group=dist.group.WORLD)
-    assert calls["n"] == 2 and calls["cuda"] == 2, calls
+    assert calls["n"] == 1 and calls["cuda"] == 1, calls
     n_params = sum(p.numel() for p in f.parameters())
     assert calls["bytes"] >= 4 * n_params, calls
     for a, b in zip(base, sharded):

@@ -26,7 +26,7 @@ def cpu_backend(monkeypatch, oracle_kernels):
     The product has no CPU path (get_kernels raises for non-ROCm devices); this patch exists only so
     the solver / adjoint / sharding control flow can be tested in the GPU-less container."""
     from torchdiffeq_amd import _native
-    monkeypatch.setattr(_native, "get_kernels", lambda device: oracle_kernels)
+    monkeypatch.setattr(_native, "get_kernels", lambda device, dtype=None: oracle_kernels)
     return oracle_kernels
 
 
@@ -37,7 +37,7 @@ def dev(request, monkeypatch, oracle_kernels):
     import torch
     if request.param == "cpu":
         from torchdiffeq_amd import _native
-        monkeypatch.setattr(_native, "get_kernels", lambda device: oracle_kernels)
+        monkeypatch.setattr(_native, "get_kernels", lambda device, dtype=None: oracle_kernels)
     else:
         assert torch.cuda.is_available(), "gpu test on a box without a GPU"
     prev = torch.get_default_device()

@@ -825,10 +825,64 @@ def gen_detest():
     save("detest.npz", **arrays)
 
 
+# ---------------------------------------------------------------------------------------------------
+def complex_problem(D, dtype, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    G = torch.randn(D, D, generator=g, dtype=torch.float64) / D ** 0.5
+    H = torch.randn(D, D, generator=g, dtype=torch.float64) / D ** 0.5
+    A = (0.5 * (G - G.T) - 0.1 * torch.eye(D, dtype=torch.float64)) + 1j * 0.5 * (H + H.T)
+    y0 = torch.randn(5, D, generator=g, dtype=torch.float64) + 1j * torch.randn(5, D, generator=g, dtype=torch.float64)
+    return A.to(dtype), y0.to(dtype)
+
+
+def gen_hostpath():
+    """States the HIP kernels do not take (r03, torchdiffeq_amd/_fallback.py): complex states (misc.py:185,
+    rk_common.py:61) and second-order gradients through plain odeint (rk_common.py:31-40 is a differentiable op)."""
+    arrays = {}
+    for tag, dtype, tdtype in (("c64", torch.complex64, torch.float32), ("c128", torch.complex128, torch.float64)):
+        A, y0 = complex_problem(6, dtype)
+        arrays[f"{tag}_A"], arrays[f"{tag}_y0"] = A, y0
+        for method, kw in (("dopri5", dict(rtol=1e-5, atol=1e-7)), ("dopri8", dict(rtol=1e-6, atol=1e-8)),
+                           ("rk4", dict(options=dict(step_size=0.05))), ("bosh3", dict(rtol=1e-4, atol=1e-6))):
+            for dname, t in (("fwd", torch.tensor([0.0, 0.4, 1.0], dtype=tdtype)),
+                             ("rev", torch.tensor([1.0, 0.3, 0.0], dtype=tdtype))):
+                y, nfe, c = solve(lambda t_, y_: y_ @ A.T, y0, t, method=method, **kw)
+                arrays[f"{tag}_{method}_{dname}_t"] = t
+                arrays[f"{tag}_{method}_{dname}_y"] = y
+                arrays[f"{tag}_{method}_{dname}_nfe"] = nfe
+                arrays[f"{tag}_{method}_{dname}_accept_dt"] = np.array(c.accept)
+                arrays[f"{tag}_{method}_{dname}_reject_dt"] = np.array(c.reject)
+    # gradient of a real loss through a complex solve (plain odeint, autograd through the solver)
+    A, y0 = complex_problem(6, torch.complex128)
+    y0g = y0.clone().requires_grad_(True)
+    y = torchdiffeq.odeint(lambda t_, y_: y_ @ A.T, y0g, torch.tensor([0.0, 1.0], dtype=torch.float64), method="dopri5",
+                           rtol=1e-7, atol=1e-9)
+    (y[-1].abs() ** 2).sum().backward()
+    arrays["c128_grad_y0"] = y0g.grad
+    # second-order gradients, real fp64
+    g = torch.Generator().manual_seed(9)
+    W0 = torch.randn(4, 4, generator=g, dtype=torch.float64) * 0.5
+    x0 = torch.randn(3, 4, generator=g, dtype=torch.float64)
+    arrays["hess_W"], arrays["hess_y0"] = W0, x0
+    for method, kw in (("rk4", dict(options=dict(step_size=0.1))), ("dopri5", dict(rtol=1e-8, atol=1e-10)),
+                       ("midpoint", dict(options=dict(step_size=0.1)))):
+        W = W0.clone().requires_grad_(True)
+        x = x0.clone().requires_grad_(True)
+        y = torchdiffeq.odeint(lambda t_, y_: torch.tanh(y_ @ W.T), x, torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64),
+                               method=method, **kw)
+        loss = (y[-1] ** 2).sum() + (y[1] ** 3).sum()
+        gx, gW = torch.autograd.grad(loss, (x, W), create_graph=True)
+        second = (gx ** 2).sum() + (gW ** 2).sum()
+        hx, hW = torch.autograd.grad(second, (x, W))
+        arrays[f"hess_{method}_gx"], arrays[f"hess_{method}_gW"] = gx.detach(), gW.detach()
+        arrays[f"hess_{method}_hx"], arrays[f"hess_{method}_hW"] = hx, hW
+    save("hostpath.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
                      ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
-                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest)]:
+                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath)]:
         if not only or name in only:
             fn()

@@ -1,4 +1,5 @@
 """The C-ABI library builds for gfx950, loads without a GPU and exports what include/tdeq_hip.h declares."""
+import contextlib
 import os
 import re
 
@@ -70,12 +71,17 @@ def test_argument_errors_without_gpu():
                                   None) == -1                                                         # chunk not a multiple of 1024
 
 
-def test_cpu_state_is_rejected_loudly():
+def test_gpu_state_without_the_library_is_rejected_loudly(monkeypatch, tmp_path):
+    """A real state on a ROCm device has exactly one backend: libtdeq_hip.so.  Missing library -> NativeLibraryError,
+    never a substitute (the torch-op host path serves CPU / complex states only: tests/test_hostpath.py)."""
     import torch
-    import torchdiffeq_amd as tda
-    from torchdiffeq_amd._native import NativeLibraryError
-    with pytest.raises(NativeLibraryError):
-        tda.odeint(lambda t, y: -y, torch.ones(3), torch.tensor([0.0, 1.0]))
+    from torchdiffeq_amd import _fallback, _native
+    monkeypatch.setattr(_native, "_KERNELS", None)
+    monkeypatch.setattr(_native, "_LIB_PATH", str(tmp_path / "no_such_lib.so"))
+    with pytest.raises(_native.NativeLibraryError):
+        _native.get_kernels(torch.device("cuda", 0), torch.float32)
+    with pytest.warns(_fallback.HostPathWarning) if not _fallback._warned else contextlib.nullcontext():
+        assert _native.get_kernels(torch.device("cpu"), torch.float32).name == "host"
 
 
 def test_product_never_imports_oracle():

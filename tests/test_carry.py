@@ -157,7 +157,7 @@ def test_multi_rejects_bad_arguments():
 
 def _solve(method, dtype, device, carry, monkeypatch, rtol, atol, reverse=False):
     import torchdiffeq_amd as tda
-    monkeypatch.setenv("TDEQ_CARRY", "1" if carry else "0")
+    monkeypatch.setenv("TDEQ_CARRY", "1" if carry else "0")      # "1": every tableau with a plan (dopri5 too)
     g = torch.Generator(device="cpu").manual_seed(5)
     D = 24
     G = torch.randn(D, D, generator=g, dtype=torch.float64, device="cpu") / D ** 0.5

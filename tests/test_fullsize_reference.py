@@ -28,7 +28,7 @@ _CPU_TOO = os.environ.get("TDEQ_FULLSIZE_CPU") == "1"
 def device(request, monkeypatch, oracle_kernels):
     if request.param == "cpu":
         from torchdiffeq_amd import _native
-        monkeypatch.setattr(_native, "get_kernels", lambda device: oracle_kernels)
+        monkeypatch.setattr(_native, "get_kernels", lambda device, dtype=None: oracle_kernels)
     return torch.device(request.param)
 
 

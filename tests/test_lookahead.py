@@ -264,7 +264,7 @@ def test_lookahead_under_every_readback_mode(hip_kernels, monkeypatch):
     for mode in ("poll", "pinned", "copy"):
         monkeypatch.setenv("TDEQ_READBACK", mode)
         kern = _native.HipKernels(hip_kernels.lib)
-        monkeypatch.setattr(_native, "get_kernels", lambda device, _k=kern: _k)
+        monkeypatch.setattr(_native, "get_kernels", lambda device, dtype=None, _k=kern: _k)
         f = _Counting(fn)
         with torch.no_grad():
             y = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(first_step=0.7))

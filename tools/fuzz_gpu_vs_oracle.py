@@ -25,7 +25,7 @@ oracle = OracleKernels()
 _orig_get = _native.get_kernels
 
 
-def backend(device):
+def backend(device, dtype=None):
     return hip if torch.device(device).type == "cuda" else oracle
 
 

@@ -24,7 +24,7 @@ from torchdiffeq_amd import _native  # noqa: E402
 from oracle.kernels import OracleKernels  # noqa: E402
 
 ok = OracleKernels()
-_native.get_kernels = lambda d: ok
+_native.get_kernels = lambda d, dtype=None: ok
 torch.set_num_threads(1)
 mode = sys.argv[1] if len(sys.argv) > 1 else "fixed"
 sys.argv = [sys.argv[0]] + sys.argv[2:]

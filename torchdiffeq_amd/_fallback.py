@@ -1,0 +1,324 @@
+"""Host path for states the HIP kernels do not take: tensors that are NOT on a ROCm device, and complex states.
+
+The reference runs wherever its tensors live (torchdiffeq/_impl/odeint.py:49-108 — BASELINE.json's configs[0] is
+"rk4 ... fp32 on CPU (plumbing, no GPU)" — and misc.py:185 / rk_common.py:61 use `abs().dtype` so that complex states
+work).  `HostKernels` gives the solver drivers the same kernel interface as `_native.HipKernels`, written with plain
+torch ops on the state's own device, so that such a call is a drop-in too instead of an error.
+
+Selection is by the STATE alone (`_native.get_kernels`): a real fp32 / fp64 state on a ROCm device always takes the
+HIP kernels and fails loudly if libtdeq_hip.so is missing — it never lands here.  This module never imports `oracle/`
+(tests/test_abi.py::test_product_never_imports_oracle); the first use warns once (`HostPathWarning`).
+
+Arithmetic: the same rounding sequence as the kernels (include/tdeq_hip.h) — coefficients
+fl_T(fl_T(coef) * fl_T(dt)), products and sums rounded separately, left to right over the non-zero tableau entries
+(rk_common.py:79,89,201-205), the operation order of interp.py:17-21,42-47 and rk_common.py:110-157 — so the fixed-grid
+methods equal the reference bit for bit here as they do on the GPU; the norm sums are accumulated in fp64 like the
+kernels' (DESIGN.md §8).  T = the REAL dtype of the state (`y0.abs().dtype`), also for complex states.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+class HostPathWarning(UserWarning):
+    """torchdiffeq_amd is integrating a state with torch ops instead of the MI355X HIP kernels."""
+
+
+_warned = False
+
+
+def warn_once(reason: str) -> None:
+    global _warned
+    if not _warned:
+        _warned = True
+        warnings.warn(f"torchdiffeq_amd: {reason}; this solve runs on the package's torch-op host path, not on the "
+                      "MI355X HIP kernels (move a real fp32 / fp64 state to a ROCm device for those)", HostPathWarning,
+                      stacklevel=3)
+
+
+def real_np_dtype(dtype: torch.dtype):
+    """numpy scalar type of `y0.abs().dtype` (misc.py:185, rk_common.py:61)."""
+    return np.float32 if dtype in (torch.float32, torch.complex64) else np.float64
+
+
+class HostPlan:
+    """Segment table and result words of the norm operations for one state layout (`_native.NormPlan`'s role)."""
+
+    def __init__(self, segments: Sequence[Tuple[int, int, float, float]], total: int, chunk: int):
+        self.chunk = chunk
+        self.n_seg = len(segments)
+        self.numels = [int(s[1]) for s in segments]
+        self.n_chunks = max(1, -(-total // chunk))
+        self.segs = [(int(off), int(n), float(rt), float(at)) for off, n, rt, at in segments]
+        self.segs_dev = None
+        self.pinned = False
+        self.expect = ()
+        self.sums0 = [0.0] * self.n_seg
+        self.sums1 = [0.0] * self.n_seg
+        self.bad = [0.0] * self.n_seg
+
+
+def _sumsq(r: torch.Tensor) -> float:
+    a = r.abs() if r.is_complex() else r
+    return float(a.double().pow(2).sum())
+
+
+def _nonfinite(*xs: torch.Tensor) -> float:
+    ok = torch.isfinite(xs[0])
+    for x in xs[1:]:
+        ok = ok & torch.isfinite(x)
+    return float((~ok).sum())
+
+
+def real_dot(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Re sum conj(g) x, accumulated in double precision (differentiable torch ops)."""
+    if g.is_complex() or x.is_complex():
+        return (g.to(torch.complex128).conj() * x.to(torch.complex128)).real.sum()
+    return (g.double() * x.double()).sum()
+
+
+def _no_grad_methods(cls):
+    """The kernel interface computes VALUES (autograd is autodiff._LinearOp's business): no graph is recorded here."""
+    for name, fn in list(vars(cls).items()):
+        if callable(fn) and not name.startswith("_") and not isinstance(fn, (staticmethod, classmethod)):
+            setattr(cls, name, torch.no_grad()(fn))
+    return cls
+
+
+@_no_grad_methods
+class HostKernels:
+    """`_native.HipKernels`' tensor-level interface in torch ops (elementwise in the state dtype, fp64 norm sums).
+    The device-resident controller, the look-ahead stage and hipGraph capture are properties of the HIP path and do
+    not exist here (`device_controller = False`): the host loop of solvers.py drives every step."""
+
+    name = "host"
+    device_controller = False
+
+    # -- helpers -----------------------------------------------------------------------------------------
+    @staticmethod
+    def _T(x: torch.Tensor):
+        return real_np_dtype(x.dtype)
+
+    @classmethod
+    def _coefs(cls, like: torch.Tensor, coefs: Sequence[float], dt: float) -> List[float]:
+        T = cls._T(like)
+        dtT = T(dt)
+        return [float(T(T(c) * dtT)) for c in coefs]
+
+    @staticmethod
+    def _lsum(ks: Sequence[torch.Tensor], cs: Sequence[float], start: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(start + c0 k0) + c1 k1 ... left to right; without `start` the first product starts the sum."""
+        acc = start
+        for k, c in zip(ks, cs):
+            p = k * c
+            acc = p if acc is None else acc + p
+        return acc
+
+    def make_plan(self, segments, total, chunk, device) -> HostPlan:
+        return HostPlan(segments, total, chunk)
+
+    # -- stage combines ------------------------------------------------------------------------------------
+    def stage_combine(self, out, y0, ks, coefs, dt: float) -> None:
+        torch.add(y0, self._lsum(ks, self._coefs(y0, coefs, dt)), out=out)
+
+    def stage_combine_fill(self, out, y0, ks, coefs, dt: float, fill_dst, fill_vals) -> None:
+        self.stage_combine(out, y0, ks, coefs, dt)
+        self.fill_scalars(fill_dst, fill_vals)
+
+    def stage_combine_err(self, out, err_out, y0, ks, coefs, err_coefs, dt: float) -> None:
+        self.stage_combine(out, y0, ks, coefs, dt)
+        err_out.copy_(self._lsum(ks, self._coefs(y0, err_coefs, dt)))
+
+    def stage_combine_multi(self, outs, rows, y0, acc_in, ks, dt: float, events=None) -> None:
+        for o, (out, (coefs, mask, add_y0)) in enumerate(zip(outs, rows)):
+            cs = self._coefs(y0, coefs, dt)
+            take = [j for j in range(len(ks)) if (mask >> j) & 1]
+            s = self._lsum([ks[j] for j in take], [cs[j] for j in take], acc_in if o == 0 else None)
+            if add_y0:
+                torch.add(y0, s, out=out)
+            else:
+                out.copy_(s)
+
+    # -- norms -----------------------------------------------------------------------------------------------
+    def _error_sums(self, plan: HostPlan, e, y0, y1, scaled_out) -> None:
+        T = self._T(y0)
+        for s, (off, n, rtol, atol) in enumerate(plan.segs):
+            sl = slice(off, off + n)
+            tol = torch.fmax(y0[sl].abs(), y1[sl].abs()) * float(T(rtol)) + float(T(atol))
+            r = e[sl] / tol
+            plan.sums0[s] = _sumsq(r)
+            plan.bad[s] = _nonfinite(y0[sl], y1[sl])
+            if scaled_out is not None:
+                scaled_out[sl] = r
+        if scaled_out is not None and plan.n_seg > 1:          # padding of a segmented layout: zeros
+            hi = 0
+            for off, n, _, _ in plan.segs:
+                if off > hi:
+                    scaled_out[hi:off].zero_()
+                hi = off + n
+            scaled_out[hi:].zero_()
+
+    def error_norm(self, plan, y0, y1, ks, coefs, dt: float, scaled_out=None) -> None:
+        self._error_sums(plan, self._lsum(ks, self._coefs(y0, coefs, dt)), y0, y1, scaled_out)
+
+    def error_norm_partial(self, plan, err_partial, y0, y1, ks, coefs, dt: float) -> None:
+        e = self._lsum(ks, self._coefs(y0, coefs, dt), err_partial) if len(ks) else err_partial
+        self._error_sums(plan, e, y0, y1, None)
+
+    def error_scaled(self, plan, out, y0, y1, ks, coefs, dt: float) -> None:
+        self.error_norm(plan, y0, y1, ks, coefs, dt, scaled_out=out)
+
+    def _init_quotients(self, plan, mode, a, b, yscale):
+        T = self._T(yscale)
+        for s, (off, n, rtol, atol) in enumerate(plan.segs):
+            sl = slice(off, off + n)
+            scale = yscale[sl].abs() * float(T(rtol)) + float(T(atol))
+            if mode == 0:
+                yield s, sl, a[sl] / scale, b[sl] / scale
+            else:
+                yield s, sl, (a[sl] - b[sl]) / scale, None
+
+    def init_norms(self, plan, mode: int, a, b, yscale) -> None:
+        for s, sl, q0, q1 in self._init_quotients(plan, mode, a, b, yscale):
+            plan.sums0[s] = _sumsq(q0)
+            if q1 is not None:
+                plan.sums1[s] = _sumsq(q1)
+            plan.bad[s] = _nonfinite(yscale[sl])
+
+    def init_scaled(self, plan, mode: int, a, b, yscale, out0, out1=None) -> None:
+        if plan.n_seg > 1:
+            out0.zero_()
+            if out1 is not None:
+                out1.zero_()
+        for s, sl, q0, q1 in self._init_quotients(plan, mode, a, b, yscale):
+            out0[sl] = q0
+            if q1 is not None:
+                out1[sl] = q1
+
+    def read_norms(self, plan):
+        return list(plan.sums0), list(plan.sums1), list(plan.bad)
+
+    # -- dense output (rk_common.py:363-369, interp.py:1-48) -----------------------------------------------------
+    def _quartic(self, y0, y1, f0, f1, ks, coefs, dt: float):
+        T = self._T(y0)
+        dtT = float(T(dt))
+        ymid = y0 + self._lsum(ks, self._coefs(y0, coefs, dt))
+        two_dt = float(T(T(2) * T(dt)))
+        qa = (two_dt * (f1 - f0) - 8 * (y1 + y0)) + 16 * ymid
+        qb = ((dtT * (5 * f0 - 3 * f1) + 18 * y0) + 14 * y1) - 32 * ymid
+        qc = ((dtT * (f1 - 4 * f0) - 11 * y0) - 5 * y1) + 16 * ymid
+        qd = dtT * f0
+        return y0, qd, qc, qb, qa
+
+    def _poly(self, q, x: float, like):
+        T = self._T(like)
+        xT = T(x)
+        qe, qd, qc, qb, qa = q
+        total = qe + float(xT) * qd
+        xp = T(xT * xT)
+        total = total + float(xp) * qc
+        xp = T(xp * xT)
+        total = total + float(xp) * qb
+        xp = T(xp * xT)
+        return total + float(xp) * qa
+
+    def dense_eval(self, out, y0, y1, f0, f1, ks, coefs, dt: float, x: float) -> None:
+        out.copy_(self._poly(self._quartic(y0, y1, f0, f1, ks, coefs, dt), x, y0))
+
+    def dense_eval_multi(self, out_rows, y0, y1, f0, f1, ks, coefs, dt: float, xs: Sequence[float]) -> None:
+        q = self._quartic(y0, y1, f0, f1, ks, coefs, dt)
+        for row, x in zip(out_rows, xs):
+            row.copy_(self._poly(q, x, y0))
+
+    def interp_fit(self, coeffs, y0, y1, f0, f1, ks, coefs, dt: float) -> None:
+        for plane, q in zip(coeffs, self._quartic(y0, y1, f0, f1, ks, coefs, dt)):
+            plane.copy_(q)
+
+    # -- fixed-grid steps (rk_common.py:110-157, solvers.py:166-181) ------------------------------------------------
+    def rk4_stage(self, stage: int, out, y0, k1, k2, k3, k4, dt: float) -> None:
+        T = self._T(y0)
+        dtT, third = float(T(dt)), float(T(1.0 / 3.0))
+        if stage == 1:
+            r = y0 + (dtT * k1) * third
+        elif stage == 2:
+            r = y0 + dtT * (k2 - k1 * third)
+        elif stage == 3:
+            r = y0 + dtT * ((k1 - k2) + k3)
+        else:
+            r = y0 + (((k1 + 3 * (k2 + k3)) + k4) * dtT) * 0.125
+        out.copy_(r)
+
+    def lerp(self, out, y0, y1, slope: float) -> None:
+        out.copy_(y0 + float(self._T(y0)(slope)) * (y1 - y0))
+
+    def fixed_stage(self, mode: int, out, y0, ks, ws, dt: float) -> None:
+        T = self._T(y0)
+        dtT = float(T(dt))
+        if mode == 1:
+            out.copy_(y0 + (ks[0] * dtT) * float(T(ws[0])))
+            return
+        out.copy_(y0 + self._lsum(ks, [float(T(w)) for w in ws]) * dtT)
+
+    def weighted_sum(self, out, xs, ws) -> None:
+        T = self._T(out)
+        out.copy_(self._lsum(xs, [float(T(w)) for w in ws]))
+
+    def scale_many(self, outs, g, ws) -> None:
+        T = self._T(g)
+        for o, w in zip(outs, ws):
+            torch.mul(g, float(T(w)), out=o)
+
+    def multi_dot(self, g, xs) -> torch.Tensor:
+        """fp64 [len(xs)] of Re <g, x_m> (= sum g x_m for real states): the derivative of a real loss wrt a real
+        scalar s of out = sum_m w_m(s) x_m, given g = dL/d conj(out) as autograd hands it over."""
+        return torch.stack([real_dot(g, x) for x in xs])
+
+    # -- Adams–Bashforth(–Moulton) (fixed_adams.py:160-223) ------------------------------------------------------
+    def adams_predict(self, y_out, y0, hist, cb, cm=None, dt: float = 0.0, dy_out=None, delta_out=None) -> None:
+        T = self._T(y0)
+        dy = None
+        for f, c in zip(hist, cb):
+            p = float(T(c)) * f
+            dy = p if dy is None else dy + p
+        torch.add(y0, dy, out=y_out)
+        if dy_out is not None:
+            sm = None
+            for f, c in zip(hist, cm):
+                p = float(T(c)) * f
+                sm = p if sm is None else sm + p
+            dy_out.copy_(dy)
+            delta_out.copy_(float(T(dt)) * sm)
+
+    def adams_correct(self, plan, dy_out, dy_old, y_out=None, f=None, delta=None, y0=None, c: float = 0.0,
+                      compute: bool = True) -> None:
+        T = self._T(dy_out)
+        if compute:
+            d = float(T(c)) * f + delta
+            dy_out.copy_(d)
+            torch.add(y0, d, out=y_out)
+        for s, (off, n, rtol, atol) in enumerate(plan.segs):
+            sl = slice(off, off + n)
+            d0, d1 = dy_old[sl], dy_out[sl]
+            tol = torch.fmax(d0.abs(), d1.abs()) * float(T(rtol)) + float(T(atol))
+            r = (d0 - d1).abs() / tol
+            plan.sums0[s] = float((~(r < 1)).sum())
+            plan.bad[s] = _nonfinite(d1)
+
+    # -- packing / scalars -------------------------------------------------------------------------------------
+    def pack_segments(self, out, srcs, chunk_starts, numels, scales, chunk: int) -> None:
+        out.zero_()
+        for t, cs, n, sc in zip(srcs, chunk_starts, numels, scales):
+            if t is None or n == 0:
+                continue
+            dst = out[cs * chunk:cs * chunk + n]
+            dst.copy_(t.reshape(-1) if sc == 1.0 else t.reshape(-1) * sc)
+
+    def fill_scalars(self, dst, vals: Sequence[float]) -> None:
+        dst.copy_(torch.tensor(list(vals), dtype=torch.float64).to(dst.dtype))
+
+    # `arm_readback` / `read_ctrl` / `stage_combine_sel` / `stage_combine_dev` / `step_commit` / `step_controller`:
+    # deliberately absent (see the class docstring); solvers.py checks `device_controller`.

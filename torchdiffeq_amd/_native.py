@@ -1,8 +1,9 @@
 """ctypes binding of libtdeq_hip.so (include/tdeq_hip.h) and the tensor-level kernel interface.
 
-`HipKernels` is the only compute backend of the package: every state-sized arithmetic operation of
-the solvers goes through it.  There is no CPU or eager-PyTorch fallback — `get_kernels()` raises if
-the library is missing or the state does not live on a ROCm device.
+`HipKernels` is the compute backend of the package: every state-sized arithmetic operation of the solvers on a
+real fp32 / fp64 state on a ROCm device goes through it — `get_kernels()` raises if the library is missing, there is
+no substitute on the GPU.  States the kernels do not take (not on a ROCm device, or complex) are served by the
+torch-op `_fallback.HostKernels` behind the same interface.
 """
 from __future__ import annotations
 
@@ -78,6 +79,10 @@ ABI_SIGNATURES = {
     "tdeq_stage_combine_multi": (ctypes.c_int, [ctypes.POINTER(MultiOut), ctypes.c_int, ctypes.c_void_p,
                                                 ctypes.c_void_p, _c_void_pp, ctypes.c_int, ctypes.c_double,
                                                 ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_stage_combine_multi_timed": (ctypes.c_int, [ctypes.POINTER(MultiOut), ctypes.c_int, ctypes.c_void_p,
+                                                      ctypes.c_void_p, _c_void_pp, ctypes.c_int, ctypes.c_double,
+                                                      ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_void_p]),
     "tdeq_error_norm_partial": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
                                                _c_double_p, ctypes.c_int, ctypes.c_double, ctypes.POINTER(Segment),
                                                ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
@@ -192,7 +197,7 @@ def dtype_code(dtype: torch.dtype) -> int:
         return TDEQ_F32
     if dtype == torch.float64:
         return TDEQ_F64
-    raise TypeError(f"torchdiffeq_amd supports float32 / float64 states, got {dtype}")
+    raise TypeError(f"torchdiffeq_amd supports float32 / float64 (and complex64 / complex128) states, got {dtype}")
 
 
 def _check(code: int, what: str) -> None:
@@ -393,7 +398,7 @@ class HipKernels:
             per_thread[rows] = arr
         return arr
 
-    def stage_combine_multi(self, outs, rows, y0, acc_in, ks, dt: float) -> None:
+    def stage_combine_multi(self, outs, rows, y0, acc_in, ks, dt: float, events=None) -> None:
         """One pass over the stages `ks` producing len(outs) tensors (tdeq_stage_combine_multi): output o =
         [y0 +] [acc_in +] sum over the set bits j of rows[o].mask of (rows[o].coefs[j] * dt) * ks[j] — a row's own
         stage input plus carried left-to-right partial sums of later rows.  `rows` as for `multi_spec` (a tuple)."""
@@ -407,6 +412,12 @@ class HipKernels:
         spec = self.multi_spec(rows)
         for o, t in enumerate(outs):
             spec[o].out = t.data_ptr()
+        if events is not None:      # measurement hook: (start, stop) torch events stamped by the dispatch itself
+            _check(self.lib.tdeq_stage_combine_multi_timed(
+                spec, len(outs), y0.data_ptr(), None if acc_in is None else acc_in.data_ptr(), ptrs, n, dt, y0.numel(),
+                dtype_code(y0.dtype), self._stream(), events[0].cuda_event, events[1].cuda_event),
+                "tdeq_stage_combine_multi_timed")
+            return
         _check(self.lib.tdeq_stage_combine_multi(spec, len(outs), y0.data_ptr(),
                                                  None if acc_in is None else acc_in.data_ptr(), ptrs, n, dt,
                                                  y0.numel(), dtype_code(y0.dtype), self._stream()),
@@ -680,16 +691,27 @@ def on_state_device(method):
 
 
 _KERNELS: Optional[HipKernels] = None
+_HOST_KERNELS = None
 
 
-def get_kernels(device: torch.device) -> HipKernels:
-    """The compute backend for a state on `device`.  Fails loudly: no GPU / no library => error."""
-    global _KERNELS
+def get_kernels(device: torch.device, dtype: Optional[torch.dtype] = None):
+    """The compute backend for a state of `dtype` on `device`.
+
+    A real fp32 / fp64 state on a ROCm device -> the HIP kernels, and ONLY those: a missing or stale libtdeq_hip.so
+    raises `NativeLibraryError` here (no silent substitute on the GPU).  A state that the kernels do not take — not
+    on a ROCm device (BASELINE.json configs[0] is a CPU case; the reference runs wherever its tensors live,
+    odeint.py:49-108) or complex (misc.py:185) — -> `_fallback.HostKernels`, the same interface in torch ops, with
+    one `HostPathWarning` per process."""
+    global _KERNELS, _HOST_KERNELS
     device = torch.device(device)
-    if device.type != "cuda":
-        raise NativeLibraryError(
-            f"torchdiffeq_amd runs the RK hot path in HIP kernels on an MI355X; the state is on "
-            f"'{device}'.  Move y0 to a ROCm device (there is no CPU / eager fallback).")
+    is_complex = dtype is not None and dtype.is_complex
+    if device.type != "cuda" or is_complex:
+        from . import _fallback
+        _fallback.warn_once(f"the state is complex ({dtype})" if (is_complex and device.type == "cuda")
+                            else f"the state lives on '{device}'")
+        if _HOST_KERNELS is None:
+            _HOST_KERNELS = _fallback.HostKernels()
+        return _HOST_KERNELS
     if _KERNELS is None:
         _KERNELS = HipKernels(load_library())
     return _KERNELS

@@ -28,6 +28,11 @@ from .misc import (ALL_ADJOINT_CALLBACK_NAMES, ALL_CALLBACK_NAMES, BuiltinNorm, 
 from .odeint import SOLVERS
 
 
+import weakref
+
+_PROXY_CHECKED = weakref.WeakKeyDictionary()      # func -> (parameter storages, functional_call VJPs verified)
+
+
 class _AugmentedDynamics(OdeFunc):
     """d/ds [vjp_t, y, adj_y, adj_θ] = [-(∂f/∂t)·a, f, -(∂f/∂y)ᵀa, -(∂f/∂θ)ᵀa]   (adjoint.py:72-105).
 
@@ -65,7 +70,8 @@ class _AugmentedDynamics(OdeFunc):
         return ("adjoint", self.fwd.sign, tuple(p.data_ptr() for p in self.params),
                 tuple(tuple(sh) for sh in self.fwd.layout.shapes))
 
-    def call_base(self, t_user: torch.Tensor, aug: torch.Tensor) -> torch.Tensor:
+    def _vjps(self, t_user: torch.Tensor, aug: torch.Tensor, use_proxy: bool):
+        """(f components, grads wrt (t, *y components, *params)) of one evaluation: f(t, y) and a^T df/d(t, y, θ)."""
         fwd, lay, n_y = self.fwd, self.layout, self.n_y
         views = lay.unpack(aug, lo=1, hi=1 + 2 * n_y)       # only y and adj_y are read: [vjp_t | y | adj_y | θ-adjoints]
         y_views, adj_views = views[:n_y], views[n_y:]
@@ -78,7 +84,7 @@ class _AugmentedDynamics(OdeFunc):
             t_ = (t_user * sign_f if sign_f != 1.0 else t_user).detach().requires_grad_(True)
             y_in = tuple(v.detach().requires_grad_(True) for v in y_views)
             y_arg = y_in if fwd.layout.is_tuple else y_in[0]
-            if self.use_proxy:
+            if use_proxy:
                 leaves = tuple(p.detach().requires_grad_(True) for p in self.params)
                 f = torch.func.functional_call(fwd.base_func, dict(zip(self.proxy_names, leaves)), (t_, y_arg))
             else:
@@ -93,6 +99,40 @@ class _AugmentedDynamics(OdeFunc):
                                             allow_unused=True)
             else:
                 grads = (None,) * len(wrt)
+        return f_list, grads
+
+    def proxy_is_faithful(self, t_user: torch.Tensor, aug: torch.Tensor) -> bool:
+        """Captured evaluations differentiate func through `functional_call` on leaf aliases of the parameters.  A
+        forward that reaches a registered parameter some other way than by attribute lookup on the module (a Python
+        list or an alias holding the same Parameter objects, a pre-bound closure) is not re-routed by functional_call:
+        its VJP would come back None and be packed as zeros — silently.  One evaluation both ways, once per func and
+        parameter storage: the proxied VJPs must exist exactly where the direct ones do, and agree."""
+        key = tuple(p.data_ptr() for p in self.params)
+        try:
+            hit = _PROXY_CHECKED.get(self.fwd.base_func)
+        except TypeError:
+            hit = None
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        n_y = self.n_y
+        _, direct = self._vjps(t_user, aug, False)
+        _, proxied = self._vjps(t_user, aug, True)
+        ok = True
+        for a, b in zip(direct[1 + n_y:], proxied[1 + n_y:]):
+            if (a is None) != (b is None):
+                ok = False
+            elif a is not None and not torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(a.abs().max()) + 1e-30):
+                ok = False
+        try:
+            _PROXY_CHECKED[self.fwd.base_func] = (key, ok)
+        except TypeError:
+            pass
+        return ok
+
+    def call_base(self, t_user: torch.Tensor, aug: torch.Tensor) -> torch.Tensor:
+        fwd, lay, n_y = self.fwd, self.layout, self.n_y
+        sign_f = fwd.sign
+        f_list, grads = self._vjps(t_user, aug, self.use_proxy)
         g_t, grads = grads[0], grads[1:]
         g_y, g_p = grads[:n_y], grads[n_y:]
 
@@ -217,7 +257,17 @@ class OdeintAdjointMethod(torch.autograd.Function):
                                   "nn.Module and every adjoint parameter is one of its parameters; running it eagerly")
                 options["hip_graph"] = False
             elif wanted:
-                aug_func.use_proxy = True
+                # parameter VJPs through leaf aliases (functional_call) only if they are the real ones: checked by one
+                # evaluation both ways, once per func (see proxy_is_faithful)
+                t_end_user = torch.full((), fwd.user_time(float(t[-1])) if hasattr(fwd, "user_time") else float(t[-1]),
+                                        dtype=fwd.time_dtype, device=device)
+                if aug_func.proxy_is_faithful(t_end_user, aug):
+                    aug_func.use_proxy = True
+                else:
+                    warnings.warn("hip_graph: func reaches some of its parameters other than by attribute lookup on the "
+                                  "module (torch.func.functional_call cannot re-route them), so the backward solve "
+                                  "cannot be captured with correct parameter gradients; running it eagerly")
+                    options["hip_graph"] = False
             if sync is not None:
                 # lock-step backward solve: [vjp_t | θ-adjoints] replicated (all-reduced per evaluation), y / adj_y
                 # sharded; the norm sums are added over ranks (solvers._LockStep)
@@ -268,9 +318,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
             # ---- one collective for the batch-summed quantities ----
             if group is not None:
                 pg = None if group is True else group     # True = the default process group
-                _allreduce_tail(aug, aug_layout, 1 + 2 * n_y, pg)
-                if t_requires_grad:
-                    torch.distributed.all_reduce(time_vjps, group=pg)
+                time_vjps = _allreduce_tail(aug, aug_layout, 1 + 2 * n_y, pg, extra=time_vjps)
 
             adj_y = torch.zeros(fwd_layout.total, dtype=dtype, device=device) if fwd_layout.n_seg > 1 \
                 else torch.empty(fwd_layout.total, dtype=dtype, device=device)
@@ -280,33 +328,50 @@ class OdeintAdjointMethod(torch.autograd.Function):
         return (None, adj_y, time_vjps, *adj_params)
 
 
-def _allreduce_tail(aug: torch.Tensor, layout: StateLayout, first_seg: int, group) -> None:
-    """Sum the parameter adjoints over ranks: one all-reduce on the contiguous tail of the flat state."""
+def _allreduce_tail(aug: torch.Tensor, layout: StateLayout, first_seg: int, group, extra=None):
+    """Sum the batch-summed results of `backward` over the ranks with ONE collective: the parameter
+    adjoints — the contiguous tail of the flat state, reduced in place — and, when `t` requires grad, the `len(t)`
+    time gradients `extra` (adjoint.py:121-148), which travel in the same buffer (state dtype: that is the precision
+    they were formed in, adjoint.py:127-131).  Returns `extra` summed (or None)."""
     import torch.distributed as dist
-    if first_seg >= layout.n_seg:
-        return
-    lo = layout.offsets[first_seg]
-    tail = aug[lo:]
-    # padding holds unspecified values; zero it so no NaN garbage travels through the collective
-    mask_lo = lo
-    for off, n in zip(layout.offsets[first_seg:], layout.numels[first_seg:]):
-        if off > mask_lo:
-            aug[mask_lo:off].zero_()
-        mask_lo = off + n
-    if mask_lo < layout.total:
-        aug[mask_lo:].zero_()
-    dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group)
+    has_tail = first_seg < layout.n_seg
+    if not has_tail and extra is None:
+        return extra
+    tail = None
+    if has_tail:
+        lo = layout.offsets[first_seg]
+        tail = aug[lo:]
+        # padding holds unspecified values; zero it so no NaN garbage travels through the collective
+        mask_lo = lo
+        for off, n in zip(layout.offsets[first_seg:], layout.numels[first_seg:]):
+            if off > mask_lo:
+                aug[mask_lo:off].zero_()
+            mask_lo = off + n
+        if mask_lo < layout.total:
+            aug[mask_lo:].zero_()
+    if extra is None:
+        dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group)
+        return None
+    n_tail = 0 if tail is None else tail.numel()
+    buf = torch.empty(n_tail + extra.numel(), dtype=aug.dtype, device=aug.device)
+    if tail is not None:
+        buf[:n_tail].copy_(tail)
+    buf[n_tail:].copy_(extra)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if tail is not None:
+        tail.copy_(buf[:n_tail])
+    return buf[n_tail:].to(extra.dtype)
 
 
 def find_parameters(module):
-    """Parameters of `module`, also inside nn.DataParallel replicas (adjoint.py:226-240)."""
+    """The tensors `module` is differentiated with respect to (adjoint.py:226-240): its parameters — or, for an
+    nn.DataParallel replica (whose parameters are plain tensor attributes, not registered Parameters), every tensor
+    attribute that requires grad, collected over its submodules."""
     assert isinstance(module, nn.Module)
-    if getattr(module, "_is_replica", False):
-        def find_tensor_attributes(module):
-            return [(k, v) for k, v in module.__dict__.items() if torch.is_tensor(v) and v.requires_grad]
-        gen = module._named_members(get_members_fn=find_tensor_attributes)
-        return [param for _, param in gen]
-    return list(module.parameters())
+    if not getattr(module, "_is_replica", False):
+        return list(module.parameters())
+    grad_attrs = lambda m: [(name, v) for name, v in vars(m).items() if torch.is_tensor(v) and v.requires_grad]
+    return [tensor for _, tensor in module._named_members(get_members_fn=grad_attrs)]
 
 
 def handle_adjoint_norm_(adjoint_options, n_params: int, state_norm=None, layout: Optional[StateLayout] = None) -> None:
@@ -339,66 +404,74 @@ def handle_adjoint_norm_(adjoint_options, n_params: int, state_norm=None, layout
     adjoint_options["norm"] = _adjoint_norm
 
 
+_NEED_PARAMS = ("func must be an instance of nn.Module to specify the adjoint parameters; alternatively they can be "
+                "specified explicitly via the `adjoint_params` argument. If there are no parameters then it is allowable "
+                "to set `adjoint_params=()`.")
+_NEED_ADJOINT_OPTIONS = ("If `adjoint_method != method` then we cannot infer `adjoint_options` from `options`. So as "
+                         "`options` has been passed then `adjoint_options` must be passed as well.")
+_FROZEN_PARAM = ("An adjoint parameter was passed without requiring gradient. For efficiency this will be excluded from "
+                 "the adjoint pass, and will not appear as a tensor in the adjoint norm.")
+
+
+def _backward_solve_settings(rtol, atol, method, options, adjoint_rtol, adjoint_atol, adjoint_method, adjoint_options,
+                             extra):
+    """What the backward solve runs with: every `adjoint_*` argument left at None follows its forward counterpart
+    (adjoint.py:166-181); options are inherited without the forward norm — the adjoint norm is chosen by
+    `handle_adjoint_norm_` — and only when both solves use the same method."""
+    inherited = adjoint_options is None
+    method_b = method if adjoint_method is None else adjoint_method
+    if inherited and options is not None and method_b != method:
+        raise ValueError(_NEED_ADJOINT_OPTIONS)
+    if inherited:
+        opts = {} if options is None else {key: val for key, val in options.items() if key != "norm"}
+    else:
+        opts = dict(adjoint_options)
+    if extra:
+        opts.update(extra)
+    return (rtol if adjoint_rtol is None else adjoint_rtol, atol if adjoint_atol is None else adjoint_atol,
+            method_b, opts)
+
+
+def _trainable(func, adjoint_params, adjoint_options):
+    """The tensors the backward solve carries an adjoint for: the given ones (default: func's own parameters) that
+    require grad (adjoint.py:183-197).  Dropping a frozen one changes what a user-supplied adjoint norm is handed, so
+    that case warns."""
+    given = tuple(find_parameters(func)) if adjoint_params is None else tuple(adjoint_params)
+    kept = tuple(p for p in given if p.requires_grad)
+    if len(kept) < len(given) and callable(adjoint_options.get("norm")):
+        warnings.warn(_FROZEN_PARAM)
+    return kept
+
+
 def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None,
                    adjoint_rtol=None, adjoint_atol=None, adjoint_method=None, adjoint_options=None,
                    adjoint_params=None, _adjoint_extra=None):
     """Same signature, defaults and errors as the reference `odeint_adjoint` (adjoint.py:156-223).
     (`_adjoint_extra`: private — keys torchdiffeq_amd.dist merges into the inferred adjoint options.)"""
     if adjoint_params is None and not isinstance(func, nn.Module):
-        raise ValueError("func must be an instance of nn.Module to specify the adjoint parameters; alternatively they "
-                         "can be specified explicitly via the `adjoint_params` argument. If there are no parameters "
-                         "then it is allowable to set `adjoint_params=()`.")
-    if adjoint_rtol is None:
-        adjoint_rtol = rtol
-    if adjoint_atol is None:
-        adjoint_atol = atol
-    if adjoint_method is None:
-        adjoint_method = method
-    if adjoint_method != method and options is not None and adjoint_options is None:
-        raise ValueError("If `adjoint_method != method` then we cannot infer `adjoint_options` from `options`. So as "
-                         "`options` has been passed then `adjoint_options` must be passed as well.")
-    if adjoint_options is None:
-        adjoint_options = {k: v for k, v in options.items() if k != "norm"} if options is not None else {}
-    else:
-        adjoint_options = adjoint_options.copy()
-    if _adjoint_extra:
-        adjoint_options.update(_adjoint_extra)
-
-    if adjoint_params is None:
-        adjoint_params = tuple(find_parameters(func))
-    else:
-        adjoint_params = tuple(adjoint_params)
-    oldlen_ = len(adjoint_params)
-    adjoint_params = tuple(p for p in adjoint_params if p.requires_grad)
-    if len(adjoint_params) != oldlen_:
-        if "norm" in adjoint_options and callable(adjoint_options["norm"]):
-            warnings.warn("An adjoint parameter was passed without requiring gradient. For efficiency this will be "
-                          "excluded from the adjoint pass, and will not appear as a tensor in the adjoint norm.")
+        raise ValueError(_NEED_PARAMS)
+    adjoint_rtol, adjoint_atol, adjoint_method, adjoint_options = _backward_solve_settings(
+        rtol, atol, method, options, adjoint_rtol, adjoint_atol, adjoint_method, adjoint_options, _adjoint_extra)
+    adjoint_params = _trainable(func, adjoint_params, adjoint_options)
 
     ci = check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS)
     if adjoint_method is None:
-        adjoint_method = ci.method
+        adjoint_method = ci.method          # both left at None: the default method, resolved by check_inputs
     if adjoint_method not in SOLVERS:
         raise ValueError('Invalid method "{}". Must be one of {}'.format(
             adjoint_method, '{"' + '", "'.join(SOLVERS.keys()) + '"}.'))
-    handle_adjoint_norm_(adjoint_options, len(adjoint_params), ci.options["norm"], ci.layout)
-
     layout = ci.layout
-    y0_tensors = y0 if layout.is_tuple else (y0,)
-    y0_flat = pack_differentiable(layout, y0_tensors)
+    handle_adjoint_norm_(adjoint_options, len(adjoint_params), ci.options["norm"], layout)
+
     cfg = dict(func=ci.func, rtol=ci.rtol, atol=ci.atol, method=ci.method, options=ci.options,
                adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol, adjoint_method=adjoint_method,
                adjoint_options=adjoint_options, t_requires_grad=ci.t.requires_grad, event_fn=ci.event_fn)
-    ans = OdeintAdjointMethod.apply(cfg, y0_flat, ci.t, *adjoint_params)
-    if ci.event_fn is None:
-        solution = ans
-    else:
-        event_t, solution = ans
-        event_t = event_t.to(ci.t)
-        if ci.t_is_reversed:
-            event_t = -event_t
+    y0_flat = pack_differentiable(layout, y0 if layout.is_tuple else (y0,))
+    result = OdeintAdjointMethod.apply(cfg, y0_flat, ci.t, *adjoint_params)
+    event_t, solution = (None, result) if ci.event_fn is None else result
     if layout.is_tuple:
         solution = layout.unpack(solution, (len(ci.t),))
-    if ci.event_fn is None:
+    if event_t is None:
         return solution
-    return event_t, solution
+    event_t = event_t.to(ci.t)
+    return (-event_t if ci.t_is_reversed else event_t), solution

@@ -31,7 +31,6 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
-from torch.autograd.function import once_differentiable
 
 Scalar = Optional[torch.Tensor]          # shadow of a time-like scalar (0-dim, requires grad) or None
 
@@ -57,14 +56,16 @@ def stitch(value: torch.Tensor, shadow: Scalar) -> torch.Tensor:
 
 class _Spec:
     """Everything `_LinearOp` needs about one kernel call."""
-    __slots__ = ("kernels", "launch", "w", "dw", "like")
+    __slots__ = ("kernels", "launch", "w", "dw", "like", "w_fn")
 
-    def __init__(self, kernels, launch, w, dw, like):
+    def __init__(self, kernels, launch, w, dw, like, w_fn=None):
         self.kernels = kernels      # HipKernels
         self.launch = launch        # launch(out) -> None: runs the forward kernel on detached inputs
         self.w = w                  # [M] weights of the state-sized inputs, as rounded by the kernel
         self.dw = dw                # [S][M] derivatives of the weights wrt each time-like scalar
         self.like = like            # tensor giving shape / dtype / device of the output
+        self.w_fn = w_fn            # w_fn(scalars) -> [M] weights as differentiable 0-dim tensors (needed only when the
+                                    # weights are not linear in the scalars: second-order gradients, see _backward_with_graph)
 
 
 class _LinearOp(torch.autograd.Function):
@@ -75,13 +76,15 @@ class _LinearOp(torch.autograd.Function):
         spec.launch(out)
         ctx.spec, ctx.n_scalars = spec, n_scalars
         ctx.scalar_dtypes = [None if s is None else s.dtype for s in args[:n_scalars]]
-        if any(ctx.needs_input_grad[2:2 + n_scalars]):
-            ctx.save_for_backward(*xs)
+        ctx.scalars_saved = any(ctx.needs_input_grad[2:2 + n_scalars])
+        if ctx.scalars_saved:
+            ctx.save_for_backward(*[s if s is not None else xs[0].new_zeros(()) for s in args[:n_scalars]], *xs)
         return out
 
     @staticmethod
-    @once_differentiable      # the backward runs raw HIP kernels: double backward raises instead of being silently wrong
     def backward(ctx, g):
+        if torch.is_grad_enabled() and g.requires_grad:
+            return _LinearOp._backward_with_graph(ctx, g)
         spec, ns = ctx.spec, ctx.n_scalars
         kern = spec.kernels
         g = g.contiguous()
@@ -102,13 +105,66 @@ class _LinearOp(torch.autograd.Function):
             kern.scale_many(outs[lo:lo + 14], g, ws[lo:lo + 14])
         grads_s: List[Optional[torch.Tensor]] = [None] * ns
         if any(ctx.needs_input_grad[2:2 + ns]):
-            xs = ctx.saved_tensors
+            xs = ctx.saved_tensors[ns:]
             dots = torch.cat([kern.multi_dot(g, [x.detach() for x in xs[lo:lo + 14]])
                               for lo in range(0, len(xs), 14)])
             for i in range(ns):
                 if ctx.needs_input_grad[2 + i]:
                     dw = torch.tensor(spec.dw[i], dtype=torch.float64, device=g.device)
                     grads_s[i] = (dw * dots).sum().to(ctx.scalar_dtypes[i])
+        return (None, None, *grads_s, *grads_x)
+
+    @staticmethod
+    def _backward_with_graph(ctx, g):
+        """The same vector-Jacobian product written with differentiable torch ops: taken when the backward pass is
+        itself being recorded (`create_graph=True` — second-order gradients through the solver, which the reference's
+        eager op graph supports, rk_common.py:31-40).  out = sum_m w_m(s) X_m, so grad X_m = w_m g and
+        grad s_i = d/ds_i sum_m w_m(s) Re<g, X_m>.  A weight whose scalar carries a graph keeps the kernel's VALUE and
+        takes its derivatives from `spec.w_fn` (the weight as a torch expression of the scalars) or, for weights
+        linear in their scalar — every stage combine —, from the constant dw/ds."""
+        spec, ns = ctx.spec, ctx.n_scalars
+        need_x = ctx.needs_input_grad[2 + ns:]
+        need_s = [ctx.scalars_saved and ctx.needs_input_grad[2 + i] for i in range(ns)]
+        scalars = list(ctx.saved_tensors[:ns]) if ctx.scalars_saved else []
+        xs = ctx.saved_tensors[ns:] if ctx.scalars_saved else ()
+        wts: List[object] = list(spec.w)
+        dwts: List[List[object]] = [list(row) for row in spec.dw]
+        if any(need_s):
+            if spec.w_fn is not None:
+                # value from the kernel's own (T-rounded) weight, derivatives of every order from the torch expression
+                live_w, live_dw = spec.w_fn([s if need else None for s, need in zip(scalars, need_s)])
+                relink = lambda v, f: v if not isinstance(f, torch.Tensor) else v + (f - f.detach())
+                wts = [relink(w, f) for w, f in zip(spec.w, live_w)]
+                dwts = [[relink(v, f) for v, f in zip(row, frow)] for row, frow in zip(spec.dw, live_dw)]
+            else:
+                for m in range(len(wts)):
+                    for i in range(ns):
+                        if need_s[i] and spec.dw[i][m] != 0.0:
+                            wts[m] = wts[m] + spec.dw[i][m] * (scalars[i] - scalars[i].detach())
+        grads_x: List[Optional[torch.Tensor]] = [None] * len(spec.w)
+        for m, (wt, need) in enumerate(zip(wts, need_x)):
+            if not need or (isinstance(wt, float) and wt == 0.0):
+                continue
+            if isinstance(wt, float):
+                grads_x[m] = g if wt == 1.0 else g * wt
+            else:
+                grads_x[m] = g * wt.to(g.real.dtype if g.is_complex() else g.dtype)
+        grads_s: List[Optional[torch.Tensor]] = [None] * ns
+        if any(need_s):
+            from ._fallback import real_dot
+            dots = [real_dot(g, x) for x in xs]
+            for i in range(ns):
+                if not need_s[i]:
+                    continue
+                total = None
+                for m, d in enumerate(dots):
+                    c = dwts[i][m]
+                    if isinstance(c, float) and c == 0.0:
+                        continue
+                    term = d * c
+                    total = term if total is None else total + term
+                if total is not None:
+                    grads_s[i] = total.to(ctx.scalar_dtypes[i])
         return (None, None, *grads_s, *grads_x)
 
 
@@ -290,5 +346,38 @@ class Ops:
         for j, c in zip(mid_idx, mid_coef):
             cT = float(T(c))
             add(k[j], cT * dtv * p_m, cT * dtv * dp_m, cT * p_m)
-        spec = _Spec(self.k, launch, w, [dwdt, dwx], y0)
+        order = list(xs)
+
+        def w_fn(scalars):
+            """(weights, [d/d dt, d/d x] of the weights) as torch expressions of (dt, x): polynomial in x, bilinear in
+            (dt, x) — same formulas as the floats above."""
+            dts, xsd = scalars
+            # a shadow carries the GRADIENT of its scalar, not its value (e.g. x's shadow is -anchor / width): the value
+            # is the host's, the shadow is attached with zero value
+            dt_t = torch.full((), dtv, dtype=torch.float64, device=y0.device)
+            x_t = torch.full((), xv, dtype=torch.float64, device=y0.device)
+            if dts is not None:
+                dt_t = dt_t + (dts - dts.detach()).double()
+            if xsd is not None:
+                x_t = x_t + (xsd - xsd.detach()).double()
+            x2_, x3_, x4_ = x_t * x_t, x_t ** 3, x_t ** 4
+            pf0, dpf0 = x_t - 4 * x2_ + 5 * x3_ - 2 * x4_, 1 - 8 * x_t + 15 * x2_ - 8 * x3_
+            pf1, dpf1 = x2_ - 3 * x3_ + 2 * x4_, 2 * x_t - 9 * x2_ + 8 * x3_
+            pm, dpm = 16 * x2_ - 32 * x3_ + 16 * x4_, 32 * x_t - 96 * x2_ + 64 * x3_
+            n_x = len(order)
+            zero = torch.zeros((), dtype=torch.float64, device=y0.device)
+            ww = [1 + 5 * x2_ - 14 * x3_ + 8 * x4_, -5 * x2_ + 14 * x3_ - 8 * x4_] + [zero] * (n_x - 2)
+            wx = [10 * x_t - 42 * x2_ + 32 * x3_, -10 * x_t + 42 * x2_ - 32 * x3_] + [zero] * (n_x - 2)
+            wd = [zero, zero] + [zero] * (n_x - 2)
+
+            def put(tensor, val, dx, ddt):
+                i = slot[id(tensor)]
+                ww[i], wx[i], wd[i] = ww[i] + val, wx[i] + dx, wd[i] + ddt
+            put(f0, dt_t * pf0, dt_t * dpf0, pf0)
+            put(f1, dt_t * pf1, dt_t * dpf1, pf1)
+            for j, c in zip(mid_idx, mid_coef):
+                cT_ = float(T(c))
+                put(k[j], cT_ * dt_t * pm, cT_ * dt_t * dpm, cT_ * pm)
+            return ww, [wd, wx]
+        spec = _Spec(self.k, launch, w, [dwdt, dwx], y0, w_fn=w_fn)
         return _LinearOp.apply(spec, 2, dt_shadow, x_shadow, *xs)

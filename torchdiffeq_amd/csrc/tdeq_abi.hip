@@ -151,7 +151,8 @@ int dispatch_combine(void* out, const void* y0, const void* const* k, const doub
 // ---- stage_combine_multi (carried partial sums) ---------------------------------------------------------
 template <typename T, int NT>
 int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
-                         const void* const* k, double dt, int64_t n, hipStream_t s) {
+                         const void* const* k, double dt, int64_t n, hipStream_t s, hipEvent_t ev_start = nullptr,
+                         hipEvent_t ev_stop = nullptr) {
     MultiArgs<T, NT> a;
     a.y0 = static_cast<const T*>(y0);
     a.acc_in = static_cast<const T*>(acc_in);
@@ -173,16 +174,20 @@ int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, 
     a.n_out = n_out;
     a.n = n;
     constexpr int L = VecOf<T>::L;
-    if (vec) hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
+    if (vec && ev_start && ev_stop)      // measurement hook (tdeq_stage_combine_multi_timed)
+        hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s,
+                              ev_start, ev_stop, 0, a);
+    else if (vec) hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
     return check_launch();
 }
 
 template <typename T>
 int dispatch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
-                           const void* const* k, int nt, double dt, int64_t n, hipStream_t s) {
+                           const void* const* k, int nt, double dt, int64_t n, hipStream_t s, hipEvent_t e0 = nullptr,
+                           hipEvent_t e1 = nullptr) {
     switch (nt) {
-#define TDEQ_CASE(N) case N: return launch_combine_multi<T, N>(outs, n_out, y0, acc_in, k, dt, n, s);
+#define TDEQ_CASE(N) case N: return launch_combine_multi<T, N>(outs, n_out, y0, acc_in, k, dt, n, s, e0, e1);
         TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
         TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
 #undef TDEQ_CASE
@@ -906,8 +911,9 @@ int tdeq_stage_combine_err(void* out, void* err_out, const void* y0, const void*
                              : dispatch_combine_err<double>(out, err_out, y0, k, coef, err_coef, n_terms, dt, n, s);
 }
 
-int tdeq_stage_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
-                             const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream) {
+static int combine_multi_checked(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                                 const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream,
+                                 void* e0, void* e1) {
     if (!outs || !y0 || !k || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS || n_out < 1 || n_out > TDEQ_MAX_MULTI_OUT) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
@@ -917,8 +923,20 @@ int tdeq_stage_combine_multi(const tdeq_multi_out* outs, int n_out, const void* 
     }
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return dtype == TDEQ_F32 ? dispatch_combine_multi<float>(outs, n_out, y0, acc_in, k, n_terms, dt, n, s)
-                             : dispatch_combine_multi<double>(outs, n_out, y0, acc_in, k, n_terms, dt, n, s);
+    return dtype == TDEQ_F32 ? dispatch_combine_multi<float>(outs, n_out, y0, acc_in, k, n_terms, dt, n, s, static_cast<hipEvent_t>(e0), static_cast<hipEvent_t>(e1))
+                             : dispatch_combine_multi<double>(outs, n_out, y0, acc_in, k, n_terms, dt, n, s, static_cast<hipEvent_t>(e0), static_cast<hipEvent_t>(e1));
+}
+
+int tdeq_stage_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                             const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream) {
+    return combine_multi_checked(outs, n_out, y0, acc_in, k, n_terms, dt, n, dtype, stream, nullptr, nullptr);
+}
+
+int tdeq_stage_combine_multi_timed(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                                   const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream,
+                                   void* start_event, void* stop_event) {
+    if (!start_event || !stop_event) return TDEQ_EINVAL;
+    return combine_multi_checked(outs, n_out, y0, acc_in, k, n_terms, dt, n, dtype, stream, start_event, stop_event);
 }
 
 int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void* y1, const void* const* k,

@@ -224,7 +224,9 @@ class OdeFunc:
         self.sign = float(sign)
         self.dtype = dtype
         self.device = device
-        self.np_dtype = np.float32 if dtype == torch.float32 else np.float64
+        # T = y0.abs().dtype: the precision of every time-like scalar func sees (misc.py:185; real for complex states)
+        self.np_dtype = np.float32 if dtype in (torch.float32, torch.complex64) else np.float64
+        self.time_dtype = torch.float32 if self.np_dtype is np.float32 else torch.float64
         self.nfe = 0
         self._kernels = None
         self._anchor_user = None     # user-time t[0] when `t` requires grad (adaptive solvers)
@@ -234,7 +236,7 @@ class OdeFunc:
     def kernels(self):
         """The HIP kernel interface of the state's device (created on first use)."""
         if self._kernels is None:
-            self._kernels = _native.get_kernels(self.device)
+            self._kernels = _native.get_kernels(self.device, self.dtype)
         return self._kernels
 
     def graph_key(self):
@@ -260,14 +262,14 @@ class OdeFunc:
 
     def time_tensor(self, value: float, shadow=None) -> torch.Tensor:
         """0-dim tensor with the host value; its gradient goes to `shadow` (user time) or the anchor."""
-        v = torch.full((), value, dtype=self.dtype, device=self.device)
+        v = torch.full((), value, dtype=self.time_dtype, device=self.device)
         return stitch(v, shadow if shadow is not None else self._anchor_user)
 
     def time_tensors(self, kernels, times_and_perturbs, shadows=None) -> Tuple[torch.Tensor, ...]:
         """0-dim device tensors for several evaluation times with ONE launch (instead of one fill kernel
         per stage): the values are computed on the host and travel in the kernel arguments."""
         vals = [self.user_time(t, p) for t, p in times_and_perturbs]
-        buf = torch.empty(len(vals), dtype=self.dtype, device=self.device)
+        buf = torch.empty(len(vals), dtype=self.time_dtype, device=self.device)
         kernels.fill_scalars(buf, vals)
         out = buf.unbind(0)
         if shadows is None and self._anchor_user is None:
@@ -294,6 +296,8 @@ class OdeFunc:
         reference (rk_common.py:79); anything else raises here instead of being read out of bounds by a kernel."""
         if not isinstance(f, torch.Tensor):
             raise TypeError("func must return a Tensor{}; got {}".format(what, type(f).__name__))
+        if f.device != self.device and f.dim() == 0:
+            f = f.to(self.device)       # `y0 + dt * f` accepts a 0-dim tensor from another device (rk_common.py:79)
         if f.device != self.device:
             raise RuntimeError("func returned a tensor on '{}'{} but the state lives on '{}'".format(
                 f.device, what, self.device))
@@ -424,9 +428,10 @@ def check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS) ->
         first = y0
     dtype = first.dtype
     device = first.device
-    if torch.is_complex(first):
-        raise NotImplementedError("complex states are outside the scope of the MI355X RK hot path")
-    _native.dtype_code(dtype)   # float32 / float64 only
+    if not torch.is_complex(first):
+        _native.dtype_code(dtype)   # float32 / float64 (HIP kernels); complex64 / complex128 take the host path
+    elif dtype not in (torch.complex64, torch.complex128):
+        raise TypeError(f"torchdiffeq_amd supports complex64 / complex128 complex states, got {dtype}")
 
     if options is None:
         options = {}

@@ -178,14 +178,25 @@ def odeint_event(func, y0, t0, *, event_fn, reverse_time=False, odeint_interface
     time_sign = -1.0 if reverse_time else 1.0
     ts_value = (event_t.detach() * time_sign) if reverse_time else event_t.detach()      # t* in solver time
 
+    if not (torch.is_grad_enabled() and y_event.requires_grad):
+        # nothing to differentiate (forward-only call, no_grad, detached state): the solve's own (event_t, solution) is
+        # the answer — no extra evaluation of func, no backward through event_fn (the reference does both only in its
+        # autograd Function's backward, odeint.py:195-231)
+        return event_t, solution
+
     # first-order data at the event: f(t*, y*), dc/dt, dc/dy (all constants of the correction below)
     y_const = y_event.detach()
     with torch.no_grad(), device_guard(y_const.device):
+        nfe_before = flat_func.nfe
         f_event = flat_func(ts_value, y_const)
+        flat_func.nfe = nfe_before
     with torch.enable_grad():
         ts_leaf, y_leaf = ts_value.clone().requires_grad_(True), y_const.clone().requires_grad_(True)
         c = flat_event(ts_leaf, y_leaf)
-        c_t, c_y = torch.autograd.grad(c, (ts_leaf, y_leaf), torch.ones_like(c), allow_unused=True)
+        if c.requires_grad:
+            c_t, c_y = torch.autograd.grad(c, (ts_leaf, y_leaf), torch.ones_like(c), allow_unused=True)
+        else:               # an event function without a graph (detached, integer / boolean based, a constant)
+            c_t = c_y = None
     c_t = torch.zeros_like(ts_value) if c_t is None else c_t
     c_y = torch.zeros_like(y_const) if c_y is None else c_y
     # rate of change of c along the trajectory; the tiny offset keeps a grazing event (rate 0) finite, as the

@@ -19,6 +19,7 @@ from __future__ import annotations
 import bisect
 import collections
 import contextlib
+import functools
 import gc
 import math
 import weakref
@@ -33,7 +34,7 @@ from . import _native
 from .autodiff import Ops, stitch
 from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, find_event, handle_unused_kwargs, rms_norm)
 from .misc import _null_callback as _null
-from .tableaus import (ADAPTIVE_HEUN, ADAPTIVE_TABLEAUS, BOSH3, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau,
+from .tableaus import (ADAPTIVE_HEUN, ADAPTIVE_TABLEAUS, BOSH3, CARRY_DEFAULT_ON, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau,
                        adams_coefficients, carry_plan)
 
 
@@ -149,23 +150,48 @@ def _graph_request(hip_graph):
     return bool(hip_graph), False
 
 
+def _tensors_in(value, _level=0):
+    """Tensors directly in `value` or one container level down (list / tuple / dict / set attribute values)."""
+    if isinstance(value, torch.Tensor):
+        return [value]
+    if _level == 0 and isinstance(value, (list, tuple, set, frozenset)):
+        return [t for v in value for t in _tensors_in(v, 1)]
+    if _level == 0 and isinstance(value, dict):
+        return [t for v in value.values() for t in _tensors_in(v, 1)]
+    return []
+
+
+def _object_tensor_ptrs(obj):
+    """Storage addresses of the tensors an object's attributes hold (directly or inside a list / tuple / dict)."""
+    return [t.data_ptr() for v in getattr(obj, "__dict__", {}).values() for t in _tensors_in(v)]
+
+
 def _held_tensor_ptrs(fn, _depth=0):
     """Storage addresses of the tensors a func object visibly holds: an nn.Module's parameters, buffers and plain
-    tensor attributes (all submodules); a function's closure cells, defaults and the module-level tensors its body
-    names; a bound method's owner; a
-    functools.partial's arguments.  Part of the captured-step cache key (see _GraphStep._key)."""
+    tensor attributes (all submodules, also inside list / tuple / dict attributes); a function's closure cells,
+    defaults and the module-level tensors its body names; a bound method's owner; an instance with `__call__` (its
+    attributes and what its `__call__` closes over); a functools.partial's arguments.  Part of the captured-step cache
+    key (see _GraphStep._key)."""
     ptrs = []
     if isinstance(fn, torch.nn.Module):
         ptrs += [p.data_ptr() for p in fn.parameters()] + [b.data_ptr() for b in fn.buffers()]
         for m in fn.modules():
-            ptrs += [v.data_ptr() for v in m.__dict__.values() if isinstance(v, torch.Tensor)]
+            ptrs += _object_tensor_ptrs(m)
         return tuple(ptrs)
     if _depth > 2:
         return ()
     owner = getattr(fn, "__self__", None)
     if owner is not None and not isinstance(owner, type):
         ptrs += _held_tensor_ptrs(owner, _depth + 1) if isinstance(owner, torch.nn.Module) else \
-            [v.data_ptr() for v in getattr(owner, "__dict__", {}).values() if isinstance(v, torch.Tensor)]
+            _object_tensor_ptrs(owner)
+    is_function = hasattr(fn, "__code__") or hasattr(getattr(fn, "__func__", None), "__code__")
+    if not is_function and not isinstance(fn, type) and hasattr(type(fn), "__call__") \
+            and not isinstance(fn, functools.partial) and getattr(fn, "__dict__", None) is not None:
+        # a callable INSTANCE (class with __call__): what it stores, and what its __call__ is written over
+        ptrs += _object_tensor_ptrs(fn)
+        call = getattr(type(fn), "__call__", None)
+        if call is not None and hasattr(call, "__code__"):
+            ptrs += _held_tensor_ptrs(call, _depth + 1)
     inner = getattr(fn, "__func__", fn)
     held = [c.cell_contents for c in (getattr(inner, "__closure__", None) or ()) if _cell_is_set(c)]
     held += list(getattr(inner, "__defaults__", None) or ())
@@ -176,11 +202,26 @@ def _held_tensor_ptrs(fn, _depth=0):
     if getattr(fn, "func", None) is not None and callable(fn.func):
         held.append(fn.func)
     for v in held:
-        if isinstance(v, torch.Tensor):
-            ptrs.append(v.data_ptr())
-        elif isinstance(v, torch.nn.Module) or callable(v):
+        if isinstance(v, torch.nn.Module) or (callable(v) and not isinstance(v, torch.Tensor)):
             ptrs += _held_tensor_ptrs(v, _depth + 1)
+        else:
+            ptrs += [t.data_ptr() for t in _tensors_in(v)]
     return tuple(ptrs)
+
+
+def _reusable_across_solves(fn) -> bool:
+    """Whether a captured step of `fn` may be kept for the NEXT solve.  The cache key must change when fn is re-bound
+    to new storage; for a plain function / lambda / partial / Module the discovery above sees what it holds.  An
+    arbitrary callable object in which NO tensor could be found (state hidden behind properties, __slots__, nested
+    objects ...) gives an empty key that cannot notice a re-binding — such a func is captured per solve, unless it
+    carries a `hip_graph_token`."""
+    if isinstance(fn, torch.nn.Module) or getattr(fn, "hip_graph_token", None) is not None:
+        return True
+    if hasattr(fn, "__code__") or hasattr(getattr(fn, "__func__", None), "__code__") or isinstance(fn, functools.partial):
+        return True
+    if type(fn).__module__ in ("builtins", "torch") or isinstance(fn, type(torch.tanh)):
+        return True         # a builtin / torch op: holds nothing
+    return len(_held_tensor_ptrs(fn)) > 0
 
 
 def _cell_is_set(cell) -> bool:
@@ -276,6 +317,8 @@ class _GraphStep:
 
     @classmethod
     def acquire(cls, s, t0: float, dt: float) -> "_GraphStep":
+        if not _reusable_across_solves(s.func.base_func):
+            return cls(s, t0, dt)   # nothing in the key would notice a re-bound tensor: capture per solve
         try:
             per_func = cls._cache.get(s.func.base_func)
         except TypeError:           # func object cannot be weakly referenced: no reuse
@@ -380,9 +423,9 @@ class _InitialStepShadow:
         self.d0 = self._norm(y0)
         self.d1 = self._norm(f0)
         if h0_is_const:
-            self.h0 = torch.full((), h0_value, dtype=y0.dtype, device=y0.device)
+            self.h0 = torch.full((), h0_value, dtype=s.func.time_dtype, device=y0.device)
         else:
-            self.h0 = stitch(torch.full((), h0_value, dtype=y0.dtype, device=y0.device),
+            self.h0 = stitch(torch.full((), h0_value, dtype=s.func.time_dtype, device=y0.device),
                              (0.01 * self.d0 / self.d1).abs())
         # y1 = y0 + h0 * f0 in solver time (f0 is the raw func output: the time sign rides on h0)
         self.y1 = y0 + (self.h0 * s.func.sign) * f0
@@ -445,8 +488,8 @@ class RKAdaptiveStepsizeODESolver:
         self._sync = _LockStep(dist_sync, dist_replicated) if dist_sync is not None else None
         self.layout: StateLayout = func.layout
         self.state_dtype = y0.dtype
-        self.np_dtype = np.float32 if y0.dtype == torch.float32 else np.float64
-        self.dtype = torch.promote_types(dtype, y0.dtype)   # accepted for API parity; host math is fp64
+        self.np_dtype = func.np_dtype        # T = y0.abs().dtype (real also for complex states: rk_common.py:61)
+        self.dtype = torch.promote_types(dtype, func.time_dtype)   # accepted for API parity; host math is fp64
         self.norm = rms_norm if norm is None else norm
         self.rtol, self.atol = rtol, atol
         self.min_step = _as_float(min_step)
@@ -459,7 +502,7 @@ class RKAdaptiveStepsizeODESolver:
         self.step_t = None if step_t is None else torch.as_tensor(step_t, dtype=torch.float64).reshape(-1).tolist()
         self.jump_t = None if jump_t is None else torch.as_tensor(jump_t, dtype=torch.float64).reshape(-1).tolist()
 
-        self.kernels = _native.get_kernels(y0.device)
+        self.kernels = _native.get_kernels(y0.device, y0.dtype)
         self.ops = Ops(self.kernels, self.np_dtype)      # elementwise kernels, differentiable when grad is needed
         self.plan = self.kernels.make_plan(self.layout.segments(rtol, atol), self.layout.total,
                                            self.layout.chunk, y0.device)
@@ -487,9 +530,12 @@ class RKAdaptiveStepsizeODESolver:
         if self._c_err.idx[:n_lead] == last.idx and len(self._c_err.idx) - n_lead <= 2:
             self._fuse = (self._c_err.coef[:n_lead], self._c_err.idx[n_lead:], self._c_err.coef[n_lead:])
         # Carried partial sums (tableaus.carry_plan / tdeq_stage_combine_multi): fewer bytes per step for the same bits.
-        # TDEQ_CARRY=0 keeps the row-by-row launches.
+        # TDEQ_CARRY: unset / "auto" = the tableaus where it is a measured gain (CARRY_DEFAULT_ON); "1" = every
+        # tableau that has a plan; "0" = row-by-row launches.
         self._carry = None
-        if self._fuse is not None and tab.fsal_solution and os.environ.get("TDEQ_CARRY", "1") != "0" \
+        carry_env = os.environ.get("TDEQ_CARRY", "auto").lower()
+        if self._fuse is not None and tab.fsal_solution and carry_env != "0" \
+                and (carry_env == "1" or tab.name in CARRY_DEFAULT_ON) \
                 and hasattr(self.kernels, "stage_combine_multi") and ADAPTIVE_TABLEAUS.get(tab.name) is tab:
             self._carry = carry_plan(tab.name)
         self.n_accepted = 0
@@ -502,7 +548,8 @@ class RKAdaptiveStepsizeODESolver:
         # are all-reduced between the norm's finalize and the controller kernel without leaving the GPU)
         sync_dev = self._sync is not None and self._sync.on_device and y0.device.type == "cuda" \
             and hasattr(self.kernels, "step_controller")
-        device_ctrl = (self._fuse is not None and isinstance(self.norm, BuiltinNorm)
+        device_ctrl = (getattr(self.kernels, "device_controller", True)
+                       and self._fuse is not None and isinstance(self.norm, BuiltinNorm)
                        and len(self._beta) <= _native.TDEQ_MAX_STAGE_TIMES and n_norm_seg >= 0
                        and self.step_t is None and self.jump_t is None and (self._sync is None or sync_dev))
         self._plan_dev = self._plan_glob = None
@@ -521,9 +568,11 @@ class RKAdaptiveStepsizeODESolver:
         self.hip_graph = wanted and device_ctrl and self._sync is None and y0.device.type == "cuda" \
             and hasattr(self.kernels, "stage_combine_dev") \
             and self.layout.total <= (_GRAPH_AUTO_MAX_ELEMENTS if auto else _GRAPH_MODE_MAX_ELEMENTS)
-        if wanted and not auto and not self.hip_graph:
+        if wanted and not auto and not self.hip_graph and hip_graph is not None:
+            # (asked for by option; a process-wide TDEQ_HIP_GRAPH=1 default applies where it can and stays silent)
             warnings.warn("{}: hip_graph=True needs a builtin norm, no step_t / jump_t, a tableau with a fused error "
-                          "combine, a ROCm device and a state of at most {} elements (larger states are "
+                          "combine, a ROCm device, no lock-step sharding (dist_sync: a per-step collective does not "
+                          "belong in a captured graph) and a state of at most {} elements (larger states are "
                           "bandwidth-bound: the eager path with its unrolled kernels is the fast one); running the "
                           "eager path".format(self.__class__.__name__, _GRAPH_MODE_MAX_ELEMENTS))
         self._g = None
@@ -895,7 +944,7 @@ class RKAdaptiveStepsizeODESolver:
             if len(times) <= 16 and plain:
                 # one launch: first stage input + the step's stage times (tdeq_stage_combine_fill)
                 yi = torch.empty_like(y0)
-                tbuf = torch.empty(len(times), dtype=y0.dtype, device=y0.device)
+                tbuf = torch.empty(len(times), dtype=func.time_dtype, device=y0.device)
                 kern.stage_combine_fill(yi, y0, [f0], row0.coef, dt_signed, tbuf,
                                         [func.user_time(t, p) for t, p in times])
                 stage_times = tbuf.unbind(0)
@@ -1168,7 +1217,7 @@ class FixedGridODESolver(object):
         self.step_size = step_size
         self.interp = interp
         self.perturb = perturb
-        self.kernels = _native.get_kernels(y0.device)
+        self.kernels = _native.get_kernels(y0.device, y0.dtype)
         self.ops = Ops(self.kernels, func.np_dtype)
         if step_size is None:
             if grid_constructor is None:
