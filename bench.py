@@ -121,8 +121,12 @@ def timed_blocks(step_fn, steps, warmup, world, device, n_blocks=N_BLOCKS):
 
 
 class EventTimedKernels:
-    """Forwards to HipKernels; while `armed`, the dominant kernel's launches go through tdeq_stage_combine_timed,
-    whose dispatch stamps a pair of HIP events with its own begin / end timestamps (hipExtLaunchKernelGGL)."""
+    """Forwards to HipKernels; while `armed`, the step's dominant stage-combine launch — the one that moves 7 words per
+    element (234.9 MB at cfg2) — goes through the `_timed` entry point, whose dispatch stamps a pair of HIP events with
+    its own begin / end timestamps (hipExtLaunchKernelGGL).  Row by row that launch is tableau row 5 (5 stages + y0
+    read, y_5 written: stage_combine_kernel<float, 5>); with carried partial sums (tableaus.carry_plan, on for dopri5 at
+    this size) it is row 4's launch (4 stages + y0 read; y_4 and the prefix of row 5's sum written:
+    stage_combine_multi_kernel<float, 4>) — same bytes."""
 
     def __init__(self, inner, dominant_terms, n_events, every):
         self._seen = 0
@@ -131,6 +135,7 @@ class EventTimedKernels:
         self.every = every         # an event-stamped dispatch costs a few microseconds of pipeline
         self.armed = False
         self.events = []
+        self.kernel = None
         # events are created (and recorded once: torch creates the hipEvent_t lazily) before the timed region
         self._pool = []
         for _ in range(n_events):
@@ -142,15 +147,30 @@ class EventTimedKernels:
     def __getattr__(self, name):
         return getattr(self._inner, name)
 
+    def _take(self):
+        self._seen += 1
+        if self._seen % self.every == 0 and self._pool:
+            ev = self._pool.pop()
+            self.events.append(ev)
+            return ev
+        return None
+
     def stage_combine(self, out, y0, ks, coefs, dt):
         if self.armed and len(ks) == self._nt:
-            self._seen += 1
-            if self._seen % self.every == 0 and self._pool:
-                e0, e1 = self._pool.pop()
-                self._inner.stage_combine_timed(out, y0, ks, coefs, dt, e0, e1)
-                self.events.append((e0, e1))
+            ev = self._take()
+            if ev is not None:
+                self.kernel = f"stage_combine_kernel<float, {self._nt}, 1, true>"
+                self._inner.stage_combine_timed(out, y0, ks, coefs, dt, ev[0], ev[1])
                 return
         self._inner.stage_combine(out, y0, ks, coefs, dt)
+
+    def stage_combine_multi(self, outs, rows, y0, acc_in, ks, dt, events=None):
+        if self.armed and acc_in is None and len(ks) + 1 + len(outs) == self._nt + 2:
+            ev = self._take()
+            if ev is not None:
+                self.kernel = f"stage_combine_multi_kernel<float, {len(ks)}, true> ({len(outs)} outputs)"
+                return self._inner.stage_combine_multi(outs, rows, y0, acc_in, ks, dt, events=ev)
+        return self._inner.stage_combine_multi(outs, rows, y0, acc_in, ks, dt)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -285,13 +305,27 @@ def solver_only_rate(solver, device):
     last = len(solver._beta) - 1
     la = bool(solver._lookahead and fuse is not None)
     tnext = torch.empty(len(solver._beta), dtype=y0s.dtype, device=device)
+    carry = solver._carry
+    carry_bufs = {t: torch.empty_like(y0s) for op in (carry.ops if carry is not None else ()) if op is not None
+                  for t in op.targets[1:]}
 
     def one_pass():
         # exactly the solver's launch sequence for one trial step, minus func (and, without look-ahead, the
         # stage-time fill)
+        held = {}
         for i, row in enumerate(solver._beta):
+            op = carry.ops[i] if (carry is not None and i > 0) else None
             if i == 0 and la:
                 kern.stage_combine_sel(outs[0], rec.y1, ks[-1], y0s, ks[0], row.coef[0], solver.plan)
+            elif carry is not None and i > 0 and op is None:
+                held.pop(i)                           # finished by an earlier launch of the plan
+            elif op is not None and not (len(op.targets) == 1 and not op.continues) and \
+                    not (op.targets == (i, last + 1) and i == last and not op.continues):
+                bufs = [outs[i & 1]] + [carry_bufs[t] for t in op.targets[1:]]
+                kern.stage_combine_multi(bufs, op.spec, y0s, held.pop(i) if op.continues else None,
+                                         [ks[j] for j in op.idx], rec.dt_signed)
+                for t, b in zip(op.targets[1:], bufs[1:]):
+                    held[t] = b
             elif i == last and fuse is not None:
                 kern.stage_combine_err(outs[i & 1], epart, y0s, [ks[j] for j in row.idx], row.coef, fuse[0],
                                        rec.dt_signed)
@@ -320,7 +354,7 @@ def solver_only_rate(solver, device):
     n = y0s.numel()
     # SURVEY.md §8(d) counts 32 + 8 = 40 words per element for a dopri5 step; the end-of-step fusion moves
     # 37 (3+4+5+6+7+8 for the six combines, 4 for the norm) — both rates are reported.
-    moved = (37 if fuse is not None else 40) * n * 4
+    moved = (carry.words if carry is not None else (37 if fuse is not None else 40)) * n * 4
     survey = 40 * n * 4
     return {"stages_per_s": 6 / t_step, "us_per_step": 1e6 * t_step,
             "bytes_moved_per_step": moved, "GBps_moved": moved / t_step / 1e9,
@@ -332,27 +366,38 @@ def solver_only_rate(solver, device):
                     "only partly"}
 
 
-def cold_dominant_kernel(kern, n, device, sets=4, launches=24):
-    """The dominant kernel (5 stage terms, 7 words per element) on `sets` rotating buffer sets whose total size
-    exceeds the 256 MiB Infinity Cache several times: every read comes from HBM.  Timed per launch by the dispatch's
-    own start/stop events."""
+def cold_dominant_kernel(kern, n, device, sets=4, launches=24, carried=False):
+    """The dominant launch (7 words per element) on `sets` rotating buffer sets whose total size exceeds the 256 MiB
+    Infinity Cache several times: every read comes from HBM.  Timed per launch by the dispatch's own start/stop
+    events.  carried=False: stage_combine_kernel<float, 5> (5 stages + y0 -> y); carried=True: the two-output launch of
+    the carried-partial-sum plan (4 stages + y0 -> y, prefix)."""
     g = torch.Generator(device="cpu").manual_seed(1)
+    nk = 4 if carried else 5
     bufs = []
     for _ in range(sets):
         y0 = torch.randn(n, generator=g).to(device)
-        ks = [torch.randn(n, generator=g).to(device) for _ in range(5)]
-        bufs.append((y0, ks, torch.empty(n, device=device)))
-    coefs = [0.1, -0.2, 0.3, 0.25, -0.15]
-    for y0, ks, out in bufs:                    # first touch
-        kern.stage_combine(out, y0, ks, coefs, 0.1)
+        ks = [torch.randn(n, generator=g).to(device) for _ in range(nk)]
+        bufs.append((y0, ks, [torch.empty(n, device=device) for _ in range(2 if carried else 1)]))
+    coefs = (0.1, -0.2, 0.3, 0.25, -0.15)[:nk]
+    spec = ((coefs, (1 << nk) - 1, True), (tuple(-c for c in coefs), (1 << nk) - 1, False))
+
+    def launch(b, ev=None):
+        y0, ks, outs = b
+        if carried:
+            kern.stage_combine_multi(outs, spec, y0, None, ks, 0.1, events=ev)
+        elif ev is None:
+            kern.stage_combine(outs[0], y0, ks, coefs, 0.1)
+        else:
+            kern.stage_combine_timed(outs[0], y0, ks, coefs, 0.1, ev[0], ev[1])
+    for b in bufs:                              # first touch
+        launch(b)
     torch.cuda.synchronize()
     evs = []
     for i in range(launches):
-        y0, ks, out = bufs[i % sets]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         e1.record()
-        kern.stage_combine_timed(out, y0, ks, coefs, 0.1, e0, e1)
+        launch(bufs[i % sets], (e0, e1))
         evs.append((e0, e1))
     torch.cuda.synchronize()
     ms = [a.elapsed_time(b) for a, b in evs]
@@ -361,18 +406,22 @@ def cold_dominant_kernel(kern, n, device, sets=4, launches=24):
     ach = bytes_per_launch / (avg * 1e-3) / 1e9
     return {"achieved": ach, "frac": ach / HBM_PEAK_GBPS, "avg_launch_ms": avg, "launches_timed": len(ms),
             "buffer_sets": sets, "working_set_bytes": sets * 7 * n * 4,
+            "kernel": "stage_combine_multi_kernel<float, 4, true> (2 outputs)" if carried
+                      else "stage_combine_kernel<float, 5, 1, true>",
             "note": "same kernel, rotating buffer sets larger than the 256 MiB Infinity Cache: all reads from HBM"}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (tools/profile_gpu.sh)."""
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary that has it
+    (tools/profile_gpu.sh; counters cannot be read from inside this process)."""
     import re
+    prefix = "tdeq::" + (kernel_name or "").split(" (")[0].rsplit(", true>", 1)[0]
     paths = [q for q in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json"))
              if re.fullmatch(r"r\d+[a-z]?_pmc_hbm\.json", os.path.basename(q))]      # profiles of THIS command only
     for pmc_path in sorted(paths, reverse=True):
         try:
             kernels = json.load(open(pmc_path))["kernels"]
-            hit = [v for k, v in kernels.items() if k.startswith("tdeq::stage_combine_kernel<float, 5,")]
+            hit = [v for k, v in kernels.items() if k.startswith(prefix)]
             if hit:
                 return hit[0]["hbm_bytes_per_launch"], os.path.relpath(pmc_path, ROOT)
         except Exception:
@@ -469,7 +518,7 @@ def run_linear(args, rank, world, device, parity=True):
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         bytes_per_launch = 7 * n * 4
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kernel_ms else None
-        traffic, traffic_src = pmc_traffic() if n == BATCH * DIM else (None, None)
+        traffic, traffic_src = pmc_traffic(timed.kernel) if n == BATCH * DIM else (None, None)
         out = {
             "metric": "dopri5 RK-stages/sec at batch=65536x dim=128 (end-to-end adaptive trial steps incl. func, "
                       "error norm, read-back and host controller)",
@@ -497,7 +546,11 @@ def run_linear(args, rank, world, device, parity=True):
         }
         if n == BATCH * DIM:
             out["roofline"] = {
-                "bound": "hbm", "kernel": "stage_combine_kernel<float, 5, 1, true>", "achieved": achieved,
+                "bound": "hbm", "kernel": timed.kernel, "achieved": achieved,
+                "kernel_is": "the step's 7-words-per-element stage-combine launch (234.9 MB): row 5 launched row by row "
+                             "(stage_combine_kernel<float, 5>), or row 4 + the carried prefix of row 5 under "
+                             "tableaus.carry_plan (stage_combine_multi_kernel<float, 4>, 2 outputs) — `carry_plan` says which",
+                "carry_plan": solver._carry is not None,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "frac_is": "in situ (stage tensors freshly written by func; partly Infinity-Cache resident) — see `cold`",
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
@@ -507,7 +560,9 @@ def run_linear(args, rank, world, device, parity=True):
                 "traffic_source": (traffic_src + " (rocprofv3 --pmc passes of this same command, replayed — not "
                                    "measured in this run)") if traffic_src else None}
             try:
-                out["roofline"]["cold"] = cold_dominant_kernel(timed._inner, n, device)
+                out["roofline"]["cold"] = cold_dominant_kernel(timed._inner, n, device, carried=solver._carry is not None)
+                if solver._carry is not None:       # continuity with r01 / r02: the row-by-row kernel, cold
+                    out["roofline"]["cold_row_by_row_kernel"] = cold_dominant_kernel(timed._inner, n, device)
             except Exception as exc:
                 out["roofline"]["cold"] = {"error": repr(exc)}
             try:

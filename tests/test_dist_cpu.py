@@ -62,14 +62,13 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_adjoint_world2(tmp_path):
+def test_sharded_adjoint_world2(tmp_path, cpu_backend):
     import torchdiffeq_amd as tda
     world = 2
     port = 29600 + (os.getpid() % 300)
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(world)]
 
-    _patch_backend()
     f, y0 = _make(torch.float64)
     y0 = y0.clone().requires_grad_(True)
     t = torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64, requires_grad=True)
@@ -135,14 +134,13 @@ def _lockstep_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_lockstep_world2_equals_single_process(tmp_path):
+def test_lockstep_world2_equals_single_process(tmp_path, cpu_backend):
     import torchdiffeq_amd as tda
     world = 2
     port = 29950 + (os.getpid() % 300)
     mp.spawn(_lockstep_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, f"ls{r}.pt"), weights_only=False) for r in range(world)]
 
-    _patch_backend()
     f, y0 = _make(torch.float64)
     f = _CountingModule(f)
     y0 = y0.clone().requires_grad_(True)
@@ -182,7 +180,7 @@ def _adams_lockstep_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_implicit_adams_lockstep_world2_equals_single_process(tmp_path):
+def test_implicit_adams_lockstep_world2_equals_single_process(tmp_path, cpu_backend):
     """The corrector's convergence census is all-reduced in lock-step mode: every shard runs the whole-batch number
     of iterations per step, so rows and evaluation counts equal the single-process solve EXACTLY (the census is an
     integer count — no rounding in the cross-rank sum)."""
@@ -191,7 +189,6 @@ def test_implicit_adams_lockstep_world2_equals_single_process(tmp_path):
     port = 30300 + (os.getpid() % 300)
     mp.spawn(_adams_lockstep_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, f"ad{r}.pt"), weights_only=False) for r in range(world)]
-    _patch_backend()
     f, y0 = _make(torch.float64)
     f = _CountingModule(f)
     with torch.no_grad():

@@ -125,7 +125,7 @@ def test_adaptive_graph_mode_equals_eager(case, dtype, monkeypatch):
     with torch.no_grad():
         solver.integrate(ci.t)
     assert ci.func.nfe == f_e.n
-    assert solver._g is not None and (solver._g.graph is not None or solver._g.calls == 1)
+    assert solver._g is not None and (solver._g.graphs[0] is not None or solver._g.calls == 1)
 
 
 def test_adaptive_graph_mode_many_outputs_and_tuple_state():
@@ -203,7 +203,7 @@ def test_adjoint_backward_solve_captured_equals_eager(kind, reverse):
             assert torch.equal(a, b), (rep, float((a - b).abs().max()))
     per_func = _GraphStep._cache.get(f)
     assert per_func is not None and len(per_func) == 2      # one captured step for the forward, one for the backward
-    assert all(g.graph is not None for g in per_func.values())
+    assert all(g.graphs[0] is not None for g in per_func.values())
     explicit = run(None, dict(hip_graph=True))              # backward only
     for a, b in zip(explicit, eager):
         assert torch.equal(a, b)
@@ -270,7 +270,7 @@ def test_graph_is_reused_across_solves_of_the_same_func():
         per_func = _GraphStep._cache.get(f)
         assert per_func is not None and len(per_func) == 1
         g = next(iter(per_func.values()))
-        graphs.append((g, g.graph, g.calls))
+        graphs.append((g, g.graphs[0], g.calls))
         assert not g.in_use
     assert all(a[0] is graphs[0][0] and a[1] is graphs[0][1] for a in graphs)      # one capture, reused
     assert graphs[-1][2] > graphs[0][2]

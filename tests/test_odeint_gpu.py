@@ -73,10 +73,18 @@ def test_tuple_state_and_mixed_norm():
     assert float((got - exact).abs().max() / exact.abs().max()) < 1e-5
 
 
-def test_cpu_state_fails_loudly():
-    from torchdiffeq_amd._native import NativeLibraryError
-    with pytest.raises(NativeLibraryError):
-        tda.odeint(lambda t_, y_: -y_, torch.ones(3), torch.tensor([0.0, 1.0]))
+def test_cpu_state_takes_the_host_path_and_gpu_state_the_kernels():
+    """r03: a CPU state is integrated by the torch-op host path (with a HostPathWarning, tests/test_hostpath.py); the
+    same call with the state on the GPU runs the HIP kernels and gives the same answer to rounding."""
+    import warnings
+    from torchdiffeq_amd import _fallback
+    y0, t = torch.linspace(-1.0, 1.0, 12).reshape(4, 3), torch.tensor([0.0, 1.0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", _fallback.HostPathWarning)
+        y_cpu = tda.odeint(lambda t_, y_: -y_, y0, t)
+    y_gpu = tda.odeint(lambda t_, y_: -y_, y0.cuda(), t.cuda())
+    assert y_cpu.device.type == "cpu" and y_gpu.is_cuda
+    assert torch.allclose(y_cpu, y_gpu.cpu(), rtol=1e-6, atol=1e-7)
 
 
 def test_solves_on_a_user_stream_match_the_default_stream():

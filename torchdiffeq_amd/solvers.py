@@ -261,32 +261,48 @@ def _capture(graph):
 
 
 class _GraphStep:
-    """Static buffers + the captured hipGraph of one adaptive trial step (RKAdaptiveStepsizeODESolver._graph_trial_step).
+    """Static buffers + the captured hipGraphs of one adaptive trial step (RKAdaptiveStepsizeODESolver._graph_trial_step).
+
+    r03: TWO graphs over ping-pong state buffers instead of one graph + a commit kernel.  The host reads the
+    controller's decision after every replay anyway, so it — not a device-side select — knows which state pair the
+    next trial step starts from:
+        side 0   reads (y[0], f0),            writes y1 into y[1]; its last evaluation k0[-1] = f(t1, y[1]) IS side 1's f
+        side 1   reads (y[1], k0[-1]),        writes y1 into y[0]; its last evaluation is copied into f0 (one N-word
+                                              copy inside the graph: func's output buffer cannot be chosen)
+    An accepted step flips the side, a rejected one replays the same graph (its input pair is untouched).  The r02
+    `tdeq_step_commit` (4 reads + 4 writes per element and step, one dispatch) is gone: per accepted step 0 or 2 words
+    move instead of 8.  The pair a step started from stays intact until the next replay, which is what the lazy dense
+    output of the last accepted step reads.
     The first trial step runs the body eagerly on a side stream (library / allocator warm-up), the second call
-    captures it, every later call is a replay.  Holds no reference to the solver (no reference cycle: the graph and
-    its memory pool are released by reference counting, deterministically, when the solver goes away)."""
+    captures side 0, side 1 is captured when first needed; every later call is a replay.  Holds no reference to the
+    solver (no reference cycle: the graphs and their memory pool are released by reference counting)."""
 
     def __init__(self, s, t0: float, dt: float):
         dev = s.y0.device
-        self.y_cur, self.f_cur = torch.empty_like(s.y1), torch.empty_like(s.y1)
-        self.y_prev, self.f_prev = torch.empty_like(self.y_cur), torch.empty_like(self.y_cur)
-        self.y1 = torch.empty_like(self.y_cur)
-        self.epart = torch.empty_like(self.y_cur)
+        self.y = [torch.empty_like(s.y1), torch.empty_like(s.y1)]
+        self.f0 = torch.empty_like(s.y1)
+        self.epart = [torch.empty_like(s.y1), torch.empty_like(s.y1)]
         self.tbuf = torch.empty(len(s._beta), dtype=s.y0.dtype, device=dev)
         self.ts = self.tbuf.unbind(0)
-        self.k: List[torch.Tensor] = []
-        self.graph = None
+        self.k: List[Optional[List[torch.Tensor]]] = [None, None]
+        self.graphs = [None, None]
+        self.side = 0
         self.calls = 0
-        self.plan = s.plan          # the graph's norm kernels write into THIS plan's buffers
+        self.plan = s.plan          # the graphs' norm kernels write into THIS plan's buffers
         self.in_use = True
         self.reset(s, t0, dt)
 
+    # -- the current pair ----------------------------------------------------------------------------------
+    def f_in(self, side: int) -> torch.Tensor:
+        return self.f0 if side == 0 else self.k[0][-1]
+
     def reset(self, s, t0: float, dt: float) -> None:
-        """Load a solve's current state into the static buffers: y, f(t0, y), the device-resident step state
+        """Load a solve's current state into side 0's input pair: y, f(t0, y), the device-resident step state
         {accept, sign*T(dt), t0, dt} and the first trial's stage times."""
         func, kern, T = s.func, s.kernels, s.np_dtype
-        self.y_cur.copy_(s.y1.detach())
-        self.f_cur.copy_(s.f1.detach())
+        self.side = 0
+        self.y[0].copy_(s.y1.detach())
+        self.f0.copy_(s.f1.detach())
         t0_T, dt_T, t1_T = T(t0), T(dt), T(t0 + dt)
         self.plan.ctrl_dev.copy_(torch.tensor([0.0, float(dt_T) * func.sign, t0, dt], dtype=torch.float64))
         times = [(t1_T, Perturb.PREV) if s._alpha_is_one[i] else (t0_T + s._alpha[i] * dt_T, Perturb.NONE)
@@ -349,57 +365,72 @@ class _GraphStep:
     def release(self) -> None:
         self.in_use = False
 
-    def body(self, s) -> None:
+    def body(self, s, side: int) -> None:
         func, kern, plan = s.func, s.kernels, s.plan
         beta, fuse, fsal = s._beta, s._fuse, s.tableau.fsal_solution
-        k = [self.f_cur]
-        yi = torch.empty_like(self.y_cur)
-        kern.stage_combine_dev(yi, None, self.y_cur, [self.f_cur], beta[0].coef, None, plan)
+        y_cur, f_cur, y1, epart = self.y[side], self.f_in(side), self.y[1 - side], self.epart[side]
+        k = [f_cur]
+        yi = torch.empty_like(y_cur)
+        kern.stage_combine_dev(yi, None, y_cur, [f_cur], beta[0].coef, None, plan)
         k.append(func.eval_at(self.ts[0], yi))
         n_rows = len(beta)
         for i in range(1, n_rows):
             row = beta[i]
             ks = [k[j] for j in row.idx]
             if i == n_rows - 1 and fsal:
-                yi = self.y1
-                kern.stage_combine_dev(yi, self.epart, self.y_cur, ks, row.coef, fuse[0], plan)
+                yi = y1
+                kern.stage_combine_dev(yi, epart, y_cur, ks, row.coef, fuse[0], plan)
             else:
-                yi = torch.empty_like(self.y_cur)
-                kern.stage_combine_dev(yi, None, self.y_cur, ks, row.coef, None, plan)
+                yi = torch.empty_like(y_cur)
+                kern.stage_combine_dev(yi, None, y_cur, ks, row.coef, None, plan)
             k.append(func.eval_at(self.ts[i], yi))
         if not fsal:
             sol = s._c_sol
-            kern.stage_combine_dev(self.y1, self.epart, self.y_cur, [k[j] for j in sol.idx], sol.coef, fuse[0], plan)
-        kern.error_norm_partial_ctrl(plan, self.epart, self.y_cur, self.y1, [k[j] for j in fuse[1]], fuse[2], 0.0,
+            kern.stage_combine_dev(y1, epart, y_cur, [k[j] for j in sol.idx], sol.coef, fuse[0], plan)
+        kern.error_norm_partial_ctrl(plan, epart, y_cur, y1, [k[j] for j in fuse[1]], fuse[2], 0.0,
                                      s._ctrl, self.tbuf, state_in_dev=True)
-        kern.step_commit(self.y_prev, self.f_prev, self.y_cur, self.f_cur, self.y1, k[-1], plan)
-        self.k = k
+        if side == 1:
+            self.f0.copy_(k[-1])          # side 0 reads its derivative from a buffer of its own (see the class text)
+        self.k[side] = k
 
     def run(self, s) -> None:
+        """One trial step from the current side's pair.  The caller flips `side` when the step was accepted."""
         kern, func = s.kernels, s.func
         self.calls += 1
+        side = self.side
         if self.calls == 1:
             current = torch.cuda.current_stream(s.y0.device)
-            side = torch.cuda.Stream(s.y0.device)
-            side.wait_stream(current)
-            with torch.cuda.stream(side):
-                self.body(s)
-            current.wait_stream(side)
+            stream = torch.cuda.Stream(s.y0.device)
+            stream.wait_stream(current)
+            with torch.cuda.stream(stream):
+                self.body(s, 0)
+            current.wait_stream(stream)
+            self.eager = True
             return
-        if self.graph is None:
+        self.eager = False
+        if self.graphs[side] is None:
             graph = torch.cuda.CUDAGraph()
             nfe = func.nfe
             try:
                 with _capture(graph):
-                    self.body(s)
+                    self.body(s, side)
             except Exception as exc:       # func is not capturable (host sync, unsupported op ...): nothing has run
                 func.nfe = nfe
                 raise _CaptureFailed(repr(exc)) from exc
             func.nfe = nfe
-            self.graph = graph
+            self.graphs[side] = graph
         kern.arm_readback(s.plan)
-        self.graph.replay()
+        self.graphs[side].replay()
         func.nfe += len(s._beta)
+
+    def accepted(self, s) -> None:
+        """The step just run was accepted: its end state becomes the next trial step's input pair."""
+        if self.eager:
+            # the warm-up step ran on transient buffers: move its end state into side 0's pair (once per capture)
+            self.y[0].copy_(self.y[1])
+            self.f0.copy_(self.k[0][-1])
+            return
+        self.side = 1 - self.side
 
 
 def clear_graph_cache() -> None:
@@ -535,7 +566,7 @@ class RKAdaptiveStepsizeODESolver:
         self._carry = None
         carry_env = os.environ.get("TDEQ_CARRY", "auto").lower()
         if self._fuse is not None and tab.fsal_solution and carry_env != "0" \
-                and (carry_env == "1" or tab.name in CARRY_DEFAULT_ON) \
+                and (carry_env == "1" or self.layout.total >= CARRY_DEFAULT_ON.get(tab.name, float("inf"))) \
                 and hasattr(self.kernels, "stage_combine_multi") and ADAPTIVE_TABLEAUS.get(tab.name) is tab:
             self._carry = carry_plan(tab.name)
         self.n_accepted = 0
@@ -1120,14 +1151,26 @@ class RKAdaptiveStepsizeODESolver:
         g = self._g
         if g is None:
             g = self._g = _GraphStep.acquire(self, t0, dt)
+        side = g.side
         g.run(self)
         accept_step, dt_next, _ratio, bad = kern.read_ctrl(self.plan)
         dt_signed = float(T(dt)) * func.sign
         if accept_step:
+            k = g.k[side]
             rec = _DenseRecord()
-            rec.y0, rec.y1, rec.k, rec.dt_signed, rec.t0, rec.t1 = g.y_prev, g.y1, [g.f_prev] + g.k[1:], dt_signed, t0, t1
+            if g.eager:
+                # warm-up step on transient buffers: keep private copies of the pair it started from (the static pair
+                # is about to receive its end state)
+                rec.y0, rec.k = g.y[0].clone(), [g.f0.clone()] + k[1:]
+                rec.y1 = g.y[1].clone()
+                self.y1, self.f1 = g.y[0], g.f0
+            else:
+                rec.y0, rec.y1, rec.k = g.y[side], g.y[1 - side], k
+                self.y1, self.f1 = g.y[1 - side], (k[-1] if side == 0 else g.f0)
+            rec.dt_signed, rec.t0, rec.t1 = dt_signed, t0, t1
             self._dense = rec
-            self.y1, self.f1, self.t0, self.t1 = g.y_cur, g.f_cur, t0, t1
+            g.accepted(self)
+            self.t0, self.t1 = t0, t1
             self._y_nonfinite = any(b != 0 for b in bad)
             self.n_accepted += 1
         else:

@@ -280,11 +280,13 @@ _CARRY_HOSTS = {
     "dopri8": {5: 4, 7: 6, 8: 6, 9: 6, 11: 10, 12: 10, 13: 10},
 }
 MAX_MULTI_OUT = 4
-# Where the plan is switched on without being asked for (TDEQ_CARRY unset): measured on the MI355X
-# (profiles/r03_carry_bench.json) — dopri8: solver kernels -25 % (fp64 16384x512) / -22 % (fp32 65536x128), trial step
-# -12 % / -16 %; dopri5: 2 of 37 words, solver kernels +-0 % at 65536x128 and -4 % on the 1/8 shard (the two-output
-# launch costs what the two saved words gain), so dopri5 keeps its row-by-row launches.
-CARRY_DEFAULT_ON = frozenset({"dopri8"})
+# Where the plan is switched on without being asked for (TDEQ_CARRY unset): tableau -> smallest state (elements) it
+# applies to.  Measured on the MI355X (profiles/r03_carry_bench.json, r03_cfg2_carry1_kernel_stats.csv) — dopri8:
+# solver kernels -25 % (fp64 16384x512) / -22 % (fp32 65536x128), trial step -12 % / -16 %, also on the 1/8 shards (one
+# launch fewer); dopri5: 2 of 37 words — rows 4 + 5 take 33.8 + 21.5 us instead of 29.6 + 36.1 at 65536x128 (trial step
+# -1.5 %), but the two-output launch costs more than it saves where a launch is latency, not bytes (1/8 shard: +0.8 %),
+# so dopri5 takes the plan from 4 M elements on.
+CARRY_DEFAULT_ON = {"dopri8": 0, "dopri5": 1 << 22}
 
 
 @dataclasses.dataclass(frozen=True)
