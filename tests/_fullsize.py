@@ -37,6 +37,28 @@ class MLPField(torch.nn.Module):
         return self.net(y)
 
 
+class F64MLPField(torch.nn.Module):
+    """cfg3's MLP with fp32 parameters and fp32 states EVALUATED IN fp64 (inputs and weights cast up, the result
+    rounded once): a field whose rounding noise is ~1e-9 of the fp32 one's.  Both the reference and this package are
+    run on THIS module for the `*_f64field` fixtures, so the fp32 error estimate of the adjoint's backward solve is
+    no longer the field's own noise and the two step sequences can be compared step for step."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        self.nfe = 0
+
+    def forward(self, t, y):
+        self.nfe += 1
+        h = y.double()
+        for layer in self.net:
+            if isinstance(layer, torch.nn.Linear):
+                h = torch.nn.functional.linear(h, layer.weight.double(), layer.bias.double())
+            else:
+                h = layer(h)
+        return h.to(y.dtype)
+
+
 def cfg3_problem(rows=None):
     """manual_seed(0), default-initialised layers, then y0 = randn(65536, 64) from the same
     global CPU generator.  Returns (field, y0) on the CPU; `rows` selects a shard of the batch."""
@@ -67,8 +89,9 @@ class ExampleCNF(torch.nn.Module):
     "closed" = the same quantity in closed form, "hutchinson" = the one-probe stochastic estimator e^T (df/dz) e
     with a fixed Rademacher probe (a benchmark-side variant; not in the reference's tree)."""
 
-    def __init__(self, params, trace="autograd", width=64, dim=2, hidden=32, probe_seed=0):
+    def __init__(self, params, trace="autograd", width=64, dim=2, hidden=32, probe_seed=0, f64=False):
         super().__init__()
+        self.f64 = f64          # closed-form trace only: evaluate in fp64, round the two outputs once (see F64MLPField)
         self.fc1 = torch.nn.Linear(1, hidden)
         self.fc2 = torch.nn.Linear(hidden, hidden)
         self.fc3 = torch.nn.Linear(hidden, 3 * width * dim + width)
@@ -81,8 +104,13 @@ class ExampleCNF(torch.nn.Module):
 
     def _hyper(self, t):
         width, dim, block = self.width, self.dim, self.width * self.dim
-        p = torch.tanh(self.fc1(t.reshape(1, 1)))
-        p = self.fc3(torch.tanh(self.fc2(p))).reshape(-1)
+        if self.f64:
+            lin = lambda layer, x: torch.nn.functional.linear(x, layer.weight.double(), layer.bias.double())
+            p = torch.tanh(lin(self.fc1, t.double().reshape(1, 1)))
+            p = lin(self.fc3, torch.tanh(lin(self.fc2, p))).reshape(-1)
+        else:
+            p = torch.tanh(self.fc1(t.reshape(1, 1)))
+            p = self.fc3(torch.tanh(self.fc2(p))).reshape(-1)
         W = p[:block].reshape(width, dim)
         U = p[block:2 * block].reshape(width, dim) * torch.sigmoid(p[2 * block:3 * block].reshape(width, dim))
         return W, U, p[3 * block:]
@@ -92,10 +120,13 @@ class ExampleCNF(torch.nn.Module):
         z = states[0]
         W, U, b = self._hyper(t)
         if self.trace == "closed":
+            out_dtype = z.dtype
+            if self.f64:
+                z = z.double()
             h = torch.tanh(z @ W.T + b)
             dz = (h @ U) / self.width
             tr = ((1 - h * h) * (W * U).sum(-1)).sum(-1, keepdim=True) / self.width
-            return dz, -tr
+            return dz.to(out_dtype), (-tr).to(out_dtype)
         with torch.enable_grad():
             if not z.requires_grad:          # forward solve (no-grad mode): a leaf sharing z's storage
                 z = z.detach().requires_grad_(True)

@@ -87,14 +87,14 @@ def linear_problem(B, D, dtype):
     return A, y0
 
 
-def gen_linear(tag, B, D, dtype, method, rtol, atol):
+def gen_linear(tag, B, D, dtype, method, rtol, atol, options=None):
     A, y0 = linear_problem(B, D, dtype)
     At = A.T.contiguous()
     f = Recorded(lambda t, y: y @ At)
     t = torch.tensor([0.0, 1.0], dtype=torch.float64 if dtype == torch.float64 else torch.float32)
     w = time.perf_counter()
     with torch.no_grad():
-        y = torchdiffeq.odeint(f, y0, t, rtol=rtol, atol=atol, method=method)
+        y = torchdiffeq.odeint(f, y0, t, rtol=rtol, atol=atol, method=method, options=options)
     w = time.perf_counter() - w
     idx = sample_rows(B)
     exact = y0.double() @ torch.linalg.matrix_exp(A.double()).T
@@ -104,17 +104,27 @@ def gen_linear(tag, B, D, dtype, method, rtol, atol):
          rel_err_vs_expm=float((y[-1].double() - exact).abs().max() / exact.abs().max()))
 
 
-def gen_cfg3(tag="cfg3", rows=None):
+def gen_cfg3(tag="cfg3", rows=None, f64field=False, f64state=False):
     """SURVEY.md §8(d) cfg3: manual_seed(0); Sequential(Linear(64,256),Tanh,Linear(256,256),Tanh,Linear(256,64));
     y0 = randn(65536, 64) from the global generator right after the layers; rtol 1e-5, atol 1e-7; loss y[-1]^2 sum."""
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(),
                               torch.nn.Linear(256, 64))
     y0_all = torch.randn(65536, 64)
-    y0 = (y0_all if rows is None else y0_all[rows].clone()).requires_grad_(True)
-    f = Recorded(lambda t, y: net(y))
+    y0 = (y0_all if rows is None else y0_all[rows].clone())
+    if f64state:        # the same numbers carried in fp64 (state, parameters, times): no fp32 rounding anywhere
+        net, y0 = net.double(), y0.double()
+    y0 = y0.requires_grad_(True)
+    if f64field:
+        # the `*_f64field` companions: the SAME module on both sides (tests/_fullsize.F64MLPField — fp32 parameters and
+        # states, evaluated in fp64), so that the backward solve's fp32 error estimate is not the field's own noise
+        sys.path.insert(0, os.path.dirname(HERE))
+        import _fullsize as fs
+        f = Recorded(fs.F64MLPField(net))
+    else:
+        f = Recorded(lambda t, y: net(y))
     f.net = net          # parameters visible to odeint_adjoint
-    t = torch.tensor([0.0, 1.0])
+    t = torch.tensor([0.0, 1.0], dtype=y0.dtype)
     w0 = time.perf_counter()
     y = torchdiffeq.odeint_adjoint(f, y0, t, rtol=1e-5, atol=1e-7, method="dopri5")
     w1 = time.perf_counter()
@@ -131,6 +141,36 @@ def gen_cfg3(tag="cfg3", rows=None):
         arrays[f"p{i}"] = p
         arrays[f"grad_p{i}"] = p.grad
     save(f"fullsize_{tag}.npz", **arrays)
+
+
+def gen_cfg5_f64field():
+    """Companion of cfg5 with a noise-free field: tests/_fullsize.ExampleCNF(trace="closed", f64=True) — cfg5's flow
+    with the same parameters, evaluated in fp64 — through the reference's odeint_adjoint; same state, times,
+    tolerances and loss as cfg5."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import _fullsize as fs
+    z = fs.load("cfg5")
+    func = fs.ExampleCNF([z[f"p{i}"] for i in range(6)], trace="closed", f64=True)
+    stats = {"acc": [], "rej": [], "acc_adj": [], "rej_adj": []}
+    func.callback_accept_step = lambda t0, y0, dt: stats["acc"].append((float(t0), float(dt)))
+    func.callback_reject_step = lambda t0, y0, dt: stats["rej"].append((float(t0), float(dt)))
+    func.callback_accept_step_adjoint = lambda t0, y0, dt: stats["acc_adj"].append((float(t0), float(dt)))
+    func.callback_reject_step_adjoint = lambda t0, y0, dt: stats["rej_adj"].append((float(t0), float(dt)))
+    z0, logp0 = fs.cfg5_problem()
+    z0 = z0.requires_grad_(True)
+    t = torch.tensor([10.0, 0.0])
+    z_t, logp_t = torchdiffeq.odeint_adjoint(func, (z0, logp0), t, atol=1e-5, rtol=1e-5, method="dopri5")
+    nfe_fwd, func.nfe = func.nfe, 0
+    loss = logp_t[-1].mean() - z_t[-1].pow(2).sum() / 100
+    loss.backward()
+    idx = sample_rows(z0.shape[0])
+    arrays = dict(rows=idx, z_end_rows=z_t[-1][idx], logp_end_rows=logp_t[-1][idx], z_end_absmax=z_t[-1].abs().max(),
+                  logp_end_absmax=logp_t[-1].abs().max(), grad_z0_rows=z0.grad[idx], grad_z0_absmax=z0.grad.abs().max(),
+                  loss=loss, nfe_fwd=nfe_fwd, nfe_bwd=func.nfe, accepted=steps(stats["acc"]), rejected=steps(stats["rej"]),
+                  accepted_adjoint=steps(stats["acc_adj"]), rejected_adjoint=steps(stats["rej_adj"]))
+    for i, p in enumerate(func.parameters()):
+        arrays[f"grad_p{i}"] = p.grad
+    save("fullsize_cfg5_f64field.npz", **arrays)
 
 
 def gen_cfg5():
@@ -190,6 +230,13 @@ CASES = {
     "cfg3": lambda: gen_cfg3(),
     "cfg3_shard": lambda: gen_cfg3("cfg3_shard", slice(0, 8192)),
     "cfg5": gen_cfg5,
+    # exact companions of the noise-limited comparisons (r03): same solver, same inputs, noise removed at its source
+    "cfg3_f64field": lambda: gen_cfg3("cfg3_f64field", f64field=True),
+    "cfg3_shard_f64field": lambda: gen_cfg3("cfg3_shard_f64field", slice(0, 8192), f64field=True),
+    "cfg3_shard_f64state": lambda: gen_cfg3("cfg3_shard_f64state", slice(0, 8192), f64state=True),
+    "cfg4_first_step": lambda: gen_linear("cfg4_first_step", 16384, 512, torch.float64, "dopri8", 1e-9, 1e-11,
+                                          options=dict(first_step=0.1)),
+    "cfg5_f64field": gen_cfg5_f64field,
 }
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@ def device(request, monkeypatch, oracle_kernels):
     return torch.device(request.param)
 
 
-def _solve_linear(case, B, D, dtype, method, device, with_callbacks):
+def _solve_linear(case, B, D, dtype, method, device, with_callbacks, options=None):
     z = fs.load(case)
     A, y0 = fs.linear_problem(B, D, dtype)
     assert np.array_equal(y0[:4].numpy(), z["y0_rows"]) and np.array_equal(A[:2].numpy(), z["A_rows"]), \
@@ -47,7 +47,7 @@ def _solve_linear(case, B, D, dtype, method, device, with_callbacks):
     t = torch.tensor([0.0, 1.0], dtype=torch.float64 if dtype == torch.float64 else torch.float32, device=device)
     rtol, atol = [float(v) for v in z["tol"]]
     with torch.no_grad():
-        y = tda.odeint(field, y0.to(device), t, rtol=rtol, atol=atol, method=method)
+        y = tda.odeint(field, y0.to(device), t, rtol=rtol, atol=atol, method=method, options=options)
     return z, y[-1], nfe[0], rec
 
 
@@ -86,13 +86,17 @@ def test_cfg4_vs_reference(device):
     assert abs(nfe - int(z["nfe"])) <= 13, (nfe, int(z["nfe"]))
 
 
-def _run_cfg3(case, rows, device, with_callbacks, fp64_field=False):
+def _run_cfg3(case, rows, device, with_callbacks, fp64_field=False, shared_f64_module=False, f64_state=False):
     z = fs.load(case)
     field, y0 = fs.cfg3_problem(rows)
+    if f64_state:
+        field, y0 = field.double(), y0.double()
     assert np.array_equal(y0[:4].numpy(), z["y0_rows"])
     for i, p in enumerate(field.net.parameters()):
         assert np.array_equal(p.detach().numpy(), z[f"p{i}"]), "layer initialisation differs from the reference run"
     field = field.to(device)
+    if shared_f64_module:
+        field = fs.F64MLPField(field.net)       # the module the `*_f64field` fixtures were made with
     if fp64_field:
         net64 = field.net.double()
 
@@ -109,7 +113,7 @@ def _run_cfg3(case, rows, device, with_callbacks, fp64_field=False):
         field = F64()
     rec = fs.Recorder(field) if with_callbacks else None
     x = y0.to(device).requires_grad_(True)
-    t = torch.tensor([0.0, 1.0], device=device)
+    t = torch.tensor([0.0, 1.0], device=device, dtype=y0.dtype)
     y = tda.odeint_adjoint(field, x, t, rtol=1e-5, atol=1e-7, method="dopri5")
     nfe_fwd, field.nfe = field.nfe, 0
     y[-1].pow(2).sum().backward()
@@ -216,3 +220,108 @@ def test_cfg5_hutchinson_trace_variant(device):
     assert torch.isfinite(lp[-1]).all() and torch.isfinite(x.grad).all()
     assert all(torch.isfinite(p.grad).all() for p in cnf.parameters())
     assert abs(float(lp[-1].mean()) - float(torch.from_numpy(z["logp_end_rows"]).mean())) < 0.5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Exact companions of the three noise-limited comparisons above (r03).  Each of the wide tolerances above — cfg3's
+# backward evaluation count (+-18), cfg4's count (+-13) and solution bound (1e-7), cfg5's backward step sizes (35 %) —
+# is explained by rounding noise that the two libraries do not share (the field's own fp32 arithmetic; dopri8's first,
+# heuristic step).  Here the noise is removed AT ITS SOURCE, identically on both sides, and the comparison becomes
+# exact: the reference was run on the very same noise-free module / with the same fixed first step
+# (make_golden_fullsize.py: cfg3_f64field, cfg3_shard_f64field, cfg4_first_step, cfg5_f64field).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case,rows", [("cfg3_f64field", None), ("cfg3_shard_f64field", slice(0, 8192))])
+def test_cfg3_backward_solve_under_equal_field_noise(case, rows, device):
+    """cfg3 with the MLP evaluated in fp64 on BOTH sides (tests/_fullsize.F64MLPField): evaluation counts EQUAL forward
+    and backward (the +-18 of the fp32-field test is the field's noise, as claimed there), the same number of accepted
+    steps, none rejected, the first backward step — which comes from the initial-step heuristic, before any noise — to
+    1e-6.  What is left in the later step sizes is the fp32 rounding of the SOLVER's own stage sums, which the two
+    libraries order differently (ATen's blocked sum vs left to right): the backward error estimate is ~2e-4 of the
+    tolerance (each step grows ~5x), i.e. rounding residue, and a 12 % spread of dt is a 50 % spread of that residue
+    (measured: <= 12.2 % on the shard, within 15 % asserted).  The companion below removes that too."""
+    z, field, x, y_end, nfe_fwd, nfe_bwd, rec = _run_cfg3(case, rows, device, with_callbacks=True, shared_f64_module=True)
+    assert (nfe_fwd, nfe_bwd) == (int(z["nfe_fwd"]), int(z["nfe_bwd"])), (nfe_fwd, nfe_bwd)
+    ok, msg = fs.steps_match(rec.acc, z["accepted"], rel=3e-2)
+    assert ok, "forward: " + msg
+    ok, msg = fs.steps_match(rec.acc_adj[:1], z["accepted_adjoint"][:1], rel=1e-6)
+    assert ok, "backward, first step: " + msg
+    ok, msg = fs.steps_match(rec.acc_adj, z["accepted_adjoint"], rel=0.15)
+    assert ok, "backward: " + msg
+    assert len(rec.rej) == len(z["rejected"]) and len(rec.rej_adj) == len(z["rejected_adjoint"])
+    idx = torch.from_numpy(z["rows"]).to(device)
+    assert fs.sample_rel_err(y_end[idx], z["y_end_rows"], z["y_end_absmax"]) < 1e-5
+    assert fs.sample_rel_err(x.grad[idx], z["grad_y0_rows"], z["grad_y0_absmax"]) < 1e-5
+    for i, p in enumerate(field.net.parameters()):
+        ref = torch.from_numpy(z[f"grad_p{i}"])
+        assert float((p.grad.cpu() - ref).abs().max() / ref.abs().max()) < 2e-5, i
+    # and the look-ahead path (no callbacks) takes the same number of evaluations
+    *_, nfe_fwd2, nfe_bwd2, _ = _run_cfg3(case, rows, device, with_callbacks=False, shared_f64_module=True)
+    assert (nfe_fwd2, nfe_bwd2) == (nfe_fwd, nfe_bwd)
+
+
+def test_cfg3_shard_in_fp64_is_step_for_step_the_reference(device):
+    """The same shard, same numbers, carried in fp64 (state, parameters, times; rtol 1e-5 / atol 1e-7 as cfg3): no fp32
+    rounding anywhere, and the adjoint's backward solve matches the reference STEP FOR STEP — every accepted step size,
+    forward and backward, to 1e-6, equal evaluation counts, gradients to 1e-9."""
+    z, field, x, y_end, nfe_fwd, nfe_bwd, rec = _run_cfg3("cfg3_shard_f64state", slice(0, 8192), device,
+                                                          with_callbacks=True, f64_state=True)
+    assert (nfe_fwd, nfe_bwd) == (int(z["nfe_fwd"]), int(z["nfe_bwd"])), (nfe_fwd, nfe_bwd)
+    for mine, ref, what in ((rec.acc, z["accepted"], "forward"), (rec.acc_adj, z["accepted_adjoint"], "backward")):
+        ok, msg = fs.steps_match(mine, ref, rel=1e-6)
+        assert ok, what + ": " + msg
+    assert len(rec.rej) == len(z["rejected"]) and len(rec.rej_adj) == len(z["rejected_adjoint"])
+    idx = torch.from_numpy(z["rows"]).to(device)
+    assert fs.sample_rel_err(y_end[idx], z["y_end_rows"], z["y_end_absmax"]) < 1e-9
+    assert fs.sample_rel_err(x.grad[idx], z["grad_y0_rows"], z["grad_y0_absmax"]) < 1e-9
+    for i, p in enumerate(field.net.parameters()):
+        ref = torch.from_numpy(z[f"grad_p{i}"])
+        assert float((p.grad.cpu() - ref).abs().max() / ref.abs().max()) < 1e-9, i
+
+
+def test_cfg4_with_a_fixed_first_step_equals_the_reference(device):
+    """cfg4 with options={'first_step': 0.1}: no heuristic first step, hence no step whose error estimate is pure
+    rounding noise — evaluation count EQUAL (1 + 13 per trial step), every step size to 1 %, solution to 1e-9."""
+    z, y_end, nfe, rec = _solve_linear("cfg4_first_step", 16384, 512, torch.float64, "dopri8", device, with_callbacks=True,
+                                       options=dict(first_step=0.1))
+    assert nfe == int(z["nfe"]), (nfe, int(z["nfe"]))
+    ok, msg = fs.steps_match(rec.acc, z["accepted"], rel=1e-2)
+    assert ok, msg
+    assert len(rec.rej) == len(z["rejected"])
+    err = fs.sample_rel_err(y_end[torch.from_numpy(z["rows"]).to(device)], z["y_end_rows"], z["y_end_absmax"])
+    assert err < 1e-9, err
+    z, y_end2, nfe2, _ = _solve_linear("cfg4_first_step", 16384, 512, torch.float64, "dopri8", device, with_callbacks=False,
+                                       options=dict(first_step=0.1))
+    assert nfe2 == nfe and fs.sample_rel_err(y_end2, y_end, z["y_end_absmax"]) < 1e-12
+
+
+def test_cfg5_backward_solve_under_equal_field_noise(device):
+    """cfg5's flow evaluated in fp64 on both sides (ExampleCNF(trace='closed', f64=True) with cfg5's parameters):
+    equal evaluation counts and rejections, forward steps to 1 %, backward steps to 5 %, gradients to 1e-5."""
+    z, p = fs.load("cfg5_f64field"), fs.load("cfg5")
+    z0, logp0 = fs.cfg5_problem()
+    cnf = fs.ExampleCNF([p[f"p{i}"] for i in range(6)], trace="closed", f64=True).to(device)
+    rec = fs.Recorder(cnf)
+    x = z0.to(device).requires_grad_(True)
+    t = torch.tensor([10.0, 0.0], device=device)
+    zt, lp = tda.odeint_adjoint(cnf, (x, logp0.to(device)), t, atol=1e-5, rtol=1e-5, method="dopri5")
+    nfe_fwd, cnf.nfe = cnf.nfe, 0
+    loss = lp[-1].mean() - zt[-1].pow(2).sum() / 100
+    loss.backward()
+    assert (nfe_fwd, cnf.nfe) == (int(z["nfe_fwd"]), int(z["nfe_bwd"])), (nfe_fwd, cnf.nfe)
+    # forward to 1 %; backward to 5 % (measured 2.4 %: what is left is the solver's own fp32 stage-sum rounding, see
+    # test_cfg3_backward_solve_under_equal_field_noise) — against 35 % with the fp32 field
+    for mine, ref, what, rel in ((rec.acc, z["accepted"], "forward", 1e-2),
+                                 (rec.acc_adj, z["accepted_adjoint"], "backward", 5e-2)):
+        ok, msg = fs.steps_match(mine, ref, rel=rel)
+        assert ok, what + ": " + msg
+    assert len(rec.rej) == len(z["rejected"]) and len(rec.rej_adj) == len(z["rejected_adjoint"])
+    idx = torch.from_numpy(z["rows"]).to(device)
+    errs = {"z": fs.sample_rel_err(zt[-1][idx], z["z_end_rows"], z["z_end_absmax"]),
+            "logp": fs.sample_rel_err(lp[-1][idx], z["logp_end_rows"], z["logp_end_absmax"]),
+            "grad_z0": fs.sample_rel_err(x.grad[idx], z["grad_z0_rows"], z["grad_z0_absmax"])}
+    for i, q in enumerate(cnf.parameters()):
+        ref = torch.from_numpy(z[f"grad_p{i}"])
+        errs[f"grad_p{i}"] = float((q.grad.cpu() - ref).abs().max() / ref.abs().max())
+    # (fp32 state at rtol = atol = 1e-5: the two solutions differ by the step-size spread above; measured on the CPU
+    # host logic: z 3e-6, logp 2.1e-5, gradients <= 4e-5)
+    assert errs["z"] < 2e-5 and errs["logp"] < 1e-4 and all(v < 2e-4 for k, v in errs.items() if k.startswith("grad")), errs

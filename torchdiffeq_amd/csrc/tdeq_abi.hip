@@ -307,7 +307,11 @@ int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, doub
         if (e) return e;
         a.presummed = 1;
     }
-    hipLaunchKernelGGL(norm_finalize_ctrl_kernel, dim3(1), dim3(kBlock), 0, s, a);
+    // one instantiation per segment-count bucket (the per-lane accumulators are a static array of 2·NS doubles)
+    if (a.presummed || st.n_seg == 1) hipLaunchKernelGGL(norm_finalize_ctrl_kernel<1>, dim3(1), dim3(kBlock), 0, s, a);
+    else if (st.n_seg <= 4) hipLaunchKernelGGL(norm_finalize_ctrl_kernel<4>, dim3(1), dim3(kBlock), 0, s, a);
+    else if (st.n_seg <= 8) hipLaunchKernelGGL(norm_finalize_ctrl_kernel<8>, dim3(1), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(norm_finalize_ctrl_kernel<TDEQ_INLINE_SEGMENTS>, dim3(1), dim3(kBlock), 0, s, a);
     return check_launch();
 }
 
@@ -1011,7 +1015,7 @@ int tdeq_step_controller(const double* sums, const double* nonfinite, const tdeq
     a.presummed = 1;
     a.in_sumsq = sums;
     a.in_bad = nonfinite;
-    hipLaunchKernelGGL(norm_finalize_ctrl_kernel, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(norm_finalize_ctrl_kernel<1>, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
     return check_launch();
 }
 

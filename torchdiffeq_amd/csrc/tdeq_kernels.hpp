@@ -687,9 +687,16 @@ __device__ __forceinline__ T ctl_stage_time(const tdeq_step_ctrl& c, double t0n,
     return (T)c.time_sign * tt;
 }
 
+// NS = upper bound of the segment count this instantiation serves (1, 4, 8 or TDEQ_INLINE_SEGMENTS).  r03: every
+// lane first accumulates ITS partials of ALL segments (independent loads: the memory round trips overlap), then ONE
+// block_sum reduces the 2·n_seg values together — one barrier instead of two per segment.  Per segment the per-lane
+// stride, the batch order and the wave / LDS reduction order are those of norm_finalize_kernel, so every sum has the
+// same bits as before; the 9-segment state of an adjoint backward solve: 16.4 -> 7 us on the serial path of every
+// trial step (profiles/r03_ctrl_bench.json).
+template <int NS>
 __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlArgs a) {
-    __shared__ double red[2 * (kBlock / kWave)];
-    __shared__ double seg_val[2][TDEQ_INLINE_SEGMENTS];
+    __shared__ double red[2 * NS * (kBlock / kWave)];
+    __shared__ double seg_val[2][NS];
     __shared__ double next_step[2];     // {t0', dt'} broadcast to the lanes that form the stage times
     const int n_seg = a.st.n_seg;
     if (a.presummed) {
@@ -727,35 +734,47 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
             seg_val[0][0] = flag[0] != 0.0 ? __builtin_nan("") : mm;
         }
         __syncthreads();
-    }
-    for (int s = 0; s < n_seg && !a.presummed; ++s) {
-        const int64_t c0 = a.st.inl[s].chunk_start;
-        const int64_t c1 = (s + 1 < n_seg) ? a.st.inl[s + 1].chunk_start : a.st.n_chunks;
-        double acc[2] = {0.0, 0.0};
+    } else {
+        double acc[2 * NS];
+#pragma unroll
+        for (int q = 0; q < 2 * NS; ++q) acc[q] = 0.0;
         const double* __restrict__ ps = a.part_sumsq;
         const double* __restrict__ pb = a.part_bad;
-        int64_t i = c0 + threadIdx.x;
-        for (; i + (kFinBatch - 1) * kBlock < c1; i += kFinBatch * kBlock) {     // batched loads, same sum order
-            double v[kFinBatch], w[kFinBatch];
 #pragma unroll
-            for (int u = 0; u < kFinBatch; ++u) {
-                v[u] = ps[i + u * kBlock];
-                w[u] = pb[i + u * kBlock];
-            }
+        for (int s = 0; s < NS; ++s) {
+            if (s < n_seg) {
+                const int64_t c0 = a.st.inl[s].chunk_start;
+                const int64_t c1 = (s + 1 < n_seg) ? a.st.inl[s + 1].chunk_start : a.st.n_chunks;
+                double a0 = 0.0, a1 = 0.0;
+                int64_t i = c0 + threadIdx.x;
+                for (; i + (kFinBatch - 1) * kBlock < c1; i += kFinBatch * kBlock) {     // batched loads, same sum order
+                    double v[kFinBatch], w[kFinBatch];
 #pragma unroll
-            for (int u = 0; u < kFinBatch; ++u) {
-                acc[0] += v[u];
-                acc[1] += w[u];
+                    for (int u = 0; u < kFinBatch; ++u) {
+                        v[u] = ps[i + u * kBlock];
+                        w[u] = pb[i + u * kBlock];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kFinBatch; ++u) {
+                        a0 += v[u];
+                        a1 += w[u];
+                    }
+                }
+                for (; i < c1; i += kBlock) {
+                    a0 += ps[i];
+                    a1 += pb[i];
+                }
+                acc[2 * s] = a0;
+                acc[2 * s + 1] = a1;
             }
         }
-        for (; i < c1; i += kBlock) {
-            acc[0] += ps[i];
-            acc[1] += pb[i];
-        }
-        block_sum<2>(acc, red);
+        block_sum<2 * NS>(acc, red);
         if (threadIdx.x == 0) {
-            seg_val[0][s] = acc[0];
-            seg_val[1][s] = acc[1];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                seg_val[0][s] = acc[2 * s];
+                seg_val[1][s] = acc[2 * s + 1];
+            }
         }
         __syncthreads();
     }
