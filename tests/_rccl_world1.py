@@ -24,8 +24,10 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29631")
     torch.cuda.set_device(0)
-    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    # the same call torchdiffeq_amd.dist.init_from_env makes for backend nccl: communicator bound to this rank's GPU
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     assert dist.get_backend() == "nccl"
+    dist.barrier()
     dev = torch.device("cuda:0")
     calls = {"n": 0, "cuda": 0, "bytes": 0}
     orig = dist.all_reduce

@@ -35,9 +35,38 @@ def test_bench_self_launches_two_ranks_gloo():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["strong"]["value"] > 0
-    ar = out["adjoint"]["strong"]["allreduce"]
-    assert ar["calls"] == 1 and ar["bytes"] >= 4 * 98880
+    assert out["strong"]["value"] > 0 and out["weak"]["value"] > 0 and out["lockstep"]["value"] > 0
+    for mode in ("strong", "weak"):
+        ar = out["adjoint"][mode]["allreduce"]
+        assert ar["calls"] == 1 and ar["bytes"] >= 4 * 98880 and ar["ms"] > 0
+    # what the collective backend connected, in the line itself (r03)
+    two_gpus = torch.cuda.device_count() >= 2
+    assert out["backend"] == ("nccl" if two_gpus else "gloo")
+    assert out["rccl_ranks"] == (2 if two_gpus else None) and out["comm"]["comm_ranks"] == 2
+    assert [d["rank"] for d in out["comm"]["devices"]] == [0, 1]
+    assert "extras_timed_out" not in out and set(out["extras_s"]) >= {"strong", "lockstep", "adjoint"}
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs FEWER visible GPUs than ranks")
+def test_bench_refuses_more_ranks_than_gpus_without_an_explicit_backend():
+    """`--gpus 2` on a 1-GPU box with TDEQ_DIST_BACKEND unset: no silent gloo run — one JSON error line, status 2;
+    the same under torch.distributed.run (the way the driver launches N > 1)."""
+    import json
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("TDEQ_DIST_BACKEND", None)
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "5", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stdout[-1000:], r.stderr[-1000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["value"] is None and "RCCL needs one GPU per rank" in line["error"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29717", bench, "--gpus", "2", "--steps", "5",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["value"] is None
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")

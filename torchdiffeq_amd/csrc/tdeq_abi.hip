@@ -300,18 +300,17 @@ int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, doub
     a.presummed = 0;
     a.in_sumsq = nullptr;
     a.in_bad = nullptr;
-    if (st.n_seg > TDEQ_INLINE_SEGMENTS) {
-        // more segments than the inline table holds: the per-segment sums by the parallel finalize (one workgroup per
-        // segment, segment table from device memory), then the one-workgroup controller on those sums
+    if (st.n_seg > kCtrlInlineSegments) {
+        // more segments than the one-workgroup form handles well: the per-segment sums by the parallel finalize (one
+        // workgroup per segment; segment table inline, or from device memory beyond TDEQ_INLINE_SEGMENTS), then the
+        // one-workgroup controller on those sums
         const int e = launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
         if (e) return e;
         a.presummed = 1;
     }
     // one instantiation per segment-count bucket (the per-lane accumulators are a static array of 2·NS doubles)
     if (a.presummed || st.n_seg == 1) hipLaunchKernelGGL(norm_finalize_ctrl_kernel<1>, dim3(1), dim3(kBlock), 0, s, a);
-    else if (st.n_seg <= 4) hipLaunchKernelGGL(norm_finalize_ctrl_kernel<4>, dim3(1), dim3(kBlock), 0, s, a);
-    else if (st.n_seg <= 8) hipLaunchKernelGGL(norm_finalize_ctrl_kernel<8>, dim3(1), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL(norm_finalize_ctrl_kernel<TDEQ_INLINE_SEGMENTS>, dim3(1), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(norm_finalize_ctrl_kernel<kCtrlInlineSegments>, dim3(1), dim3(kBlock), 0, s, a);
     return check_launch();
 }
 

@@ -687,12 +687,15 @@ __device__ __forceinline__ T ctl_stage_time(const tdeq_step_ctrl& c, double t0n,
     return (T)c.time_sign * tt;
 }
 
-// NS = upper bound of the segment count this instantiation serves (1, 4, 8 or TDEQ_INLINE_SEGMENTS).  r03: every
-// lane first accumulates ITS partials of ALL segments (independent loads: the memory round trips overlap), then ONE
-// block_sum reduces the 2·n_seg values together — one barrier instead of two per segment.  Per segment the per-lane
-// stride, the batch order and the wave / LDS reduction order are those of norm_finalize_kernel, so every sum has the
-// same bits as before; the 9-segment state of an adjoint backward solve: 16.4 -> 7 us on the serial path of every
-// trial step (profiles/r03_ctrl_bench.json).
+// NS = upper bound of the segment count this instantiation serves (1 or kCtrlInlineSegments).  r03: every lane
+// accumulates ITS partials of all segments, then ONE block_sum reduces the 2·n_seg values together — one barrier
+// instead of two per segment; per segment the per-lane stride, the batch order and the wave / LDS reduction order are
+// those of norm_finalize_kernel, so every sum has the same bits as before.  States with more segments than
+// kCtrlInlineSegments (an adjoint's augmented state: 9 at cfg3) take the parallel finalize — one workgroup per
+// segment — and this kernel's `presummed` form: 16.4 us (r02, serial per-segment loop) -> 13.4 (one barrier) ->
+// parallel finalize + controller (profiles/r03_ctrl_seg_bench.json); a grouped-prefetch variant of the serial form
+// measured slower (17.7 us at 9 segments: 194 VGPRs, guarded loads) and was dropped.
+constexpr int kCtrlInlineSegments = 4;
 template <int NS>
 __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlArgs a) {
     __shared__ double red[2 * NS * (kBlock / kWave)];
