@@ -879,10 +879,42 @@ def gen_hostpath():
     save("hostpath.npz", **arrays)
 
 
+def gen_eager_pin():
+    """Pins oracle/eager_torch_port.py (bench.py's `reference_style_eager_gpu` comparator) to the
+    reference AS AN OP SEQUENCE: the reference's accepted / rejected (t0, dt) pairs with a given first step, on one CPU
+    thread.  A port that issues the same ATen ops in the same order reproduces these fp64 values bit for bit."""
+    arrays = {}
+    for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        for method, rtol, atol, first in (("dopri5", 1e-5, 1e-7, 0.35), ("dopri8", 1e-7, 1e-9, 0.5), ("bosh3", 1e-4, 1e-6, 0.2)):
+            A, y0 = linear_problem(20, 8, dtype, seed=5)
+            A = A * 3.0
+            steps = {"acc": [], "rej": []}
+
+            class F(torch.nn.Module):
+                def forward(self, t, y):
+                    return y @ A.T
+
+                def callback_accept_step(self, t0, y_, dt):
+                    steps["acc"].append((float(t0), float(dt)))
+
+                def callback_reject_step(self, t0, y_, dt):
+                    steps["rej"].append((float(t0), float(dt)))
+            with torch.no_grad():
+                y = torchdiffeq.odeint(F(), y0, torch.tensor([0.0, 2.0], dtype=dtype), rtol=rtol, atol=atol, method=method,
+                                       options=dict(first_step=first))
+            key = f"{tag}_{method}"
+            arrays[f"{key}_A"], arrays[f"{key}_y0"] = A, y0
+            arrays[f"{key}_tol"] = np.array([rtol, atol, first])
+            arrays[f"{key}_acc"] = np.array(steps["acc"]).reshape(-1, 2)
+            arrays[f"{key}_rej"] = np.array(steps["rej"]).reshape(-1, 2)
+            arrays[f"{key}_y"] = y
+    save("eager_pin.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
                      ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
-                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath)]:
+                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin)]:
         if not only or name in only:
             fn()

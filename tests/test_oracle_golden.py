@@ -433,3 +433,33 @@ def test_oracle_adams_kernels_pinned_to_the_reference_expressions(oracle_kernels
     assert converged() == bool(z[f"kv_{tag}_converged_close"])
     oracle_kernels.adams_correct(plan, dy_new, dy_new, compute=False)
     assert converged() == bool(z[f"kv_{tag}_converged_same"]) is True
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("method", ["dopri5", "dopri8", "bosh3"])
+def test_eager_torch_port_is_the_reference_op_for_op(tag, method):
+    """r03: oracle/eager_torch_port.py stands in for "the unmodified reference on cuda"  in bench.py.  Its
+    fidelity AS AN OP SEQUENCE is pinned here to the reference itself: on one CPU thread the port must reproduce the
+    reference's accepted AND rejected (t0, dt) pairs — fp64 values that have gone through every stage sum, the fp32 /
+    fp64 error norm and the controller — BIT FOR BIT (tests/golden/eager_pin.npz <- make_golden.py eager_pin: the
+    reference's own callbacks, `first_step` given).  In fp32 the error estimate is rounding-level, so any difference in
+    operation order would show."""
+    from oracle import eager_torch_port as ep
+    z = load("eager_pin.npz")
+    key = f"{tag}_{method}"
+    A, y0 = T(z[key + "_A"]), T(z[key + "_y0"])
+    rtol, atol, first = [float(v) for v in z[key + "_tol"]]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        e = ep.EagerAdaptiveRK(lambda t, y: y @ A.T, y0, 0.0, first, rtol, atol, method)
+        acc, rej = [], []
+        with torch.no_grad():
+            while float(e.t) < 2.0 and len(acc) + len(rej) < 1000:
+                t0, dt = float(e.t), float(e.dt)
+                (acc if e.adaptive_step() else rej).append((t0, dt))
+    finally:
+        torch.set_num_threads(threads)
+    assert np.array_equal(np.array(acc).reshape(-1, 2), z[key + "_acc"])
+    assert np.array_equal(np.array(rej).reshape(-1, 2), z[key + "_rej"])
+    assert len(rej) > 0

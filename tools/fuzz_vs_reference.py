@@ -1,6 +1,7 @@
 """Differential fuzzing against the reference (build container only: imports /root/reference).
 
   PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event} [seed] [cases]
+  (TDEQ_FUZZ_BACKEND=host: the product's torch-op host path for CPU states instead of the oracle test backend)
 
 Random states (0-dim .. 3-dim, tuples), dtypes, time grids (both directions), options and methods are solved by the
 reference and by torchdiffeq_amd (host logic over the CPU oracle kernels — the same code path the `dev="cpu"` tests
@@ -24,7 +25,11 @@ from torchdiffeq_amd import _native  # noqa: E402
 from oracle.kernels import OracleKernels  # noqa: E402
 
 ok = OracleKernels()
-_native.get_kernels = lambda d, dtype=None: ok
+if os.environ.get("TDEQ_FUZZ_BACKEND", "oracle") == "host":
+    # r03: the package's own torch-op host path (torchdiffeq_amd/_fallback.py) instead of the test backend
+    warnings.simplefilter("ignore")
+else:
+    _native.get_kernels = lambda d, dtype=None: ok
 torch.set_num_threads(1)
 mode = sys.argv[1] if len(sys.argv) > 1 else "fixed"
 sys.argv = [sys.argv[0]] + sys.argv[2:]

@@ -692,9 +692,10 @@ __device__ __forceinline__ T ctl_stage_time(const tdeq_step_ctrl& c, double t0n,
 // instead of two per segment; per segment the per-lane stride, the batch order and the wave / LDS reduction order are
 // those of norm_finalize_kernel, so every sum has the same bits as before.  States with more segments than
 // kCtrlInlineSegments (an adjoint's augmented state: 9 at cfg3) take the parallel finalize — one workgroup per
-// segment — and this kernel's `presummed` form: 16.4 us (r02, serial per-segment loop) -> 13.4 (one barrier) ->
-// parallel finalize + controller (profiles/r03_ctrl_seg_bench.json); a grouped-prefetch variant of the serial form
-// measured slower (17.7 us at 9 segments: 194 VGPRs, guarded loads) and was dropped.
+// segment — and this kernel's `presummed` form.  Cost of finalize + controller on the 9-segment state of cfg3's backward
+// solve, on top of the partial-norm launch (profiles/r03_ctrl_seg_bench.json): 16.4 us (r02, serial per-segment loop) ->
+// 13.4 (one barrier) -> 5.6 (parallel finalize + presummed controller); a grouped-prefetch variant of the serial form
+// measured slower (17.7 us: 194 VGPRs, guarded loads) and was dropped.
 constexpr int kCtrlInlineSegments = 4;
 template <int NS>
 __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlArgs a) {
