@@ -6,7 +6,11 @@
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself as N ranks (one process per GPU,
 `python -m torch.distributed.run ... bench.py`, rendezvous on 127.0.0.1, backend nccl = RCCL); under
 `torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* itself.  Rank r owns GPU r.
-`TDEQ_DIST_BACKEND=gloo` runs the N > 1 control flow on a box with fewer GPUs than ranks (ranks share devices).
+More ranks than visible GPUs is REFUSED (one JSON error line, exit status 2) — never a silent fallback to another
+backend; `TDEQ_DIST_BACKEND=gloo` asks for the multi-rank control flow with ranks sharing devices by name.  Before
+anything is timed every N > 1 run all-reduces a ones tensor through the backend ON THE DEVICE and gathers each rank's GPU
+identity: the line carries `backend`, `rccl_ranks` (what RCCL summed over; must equal N) and `comm.devices`; a census
+that does not match ends the run with an error line and status 3.
 
 Workloads
   linear   (default) BASELINE.json configs[1] / SURVEY.md §8d cfg2 — the configuration the metric is quoted on:
@@ -26,21 +30,35 @@ torch.cuda.synchronize(); per block the MAX over ranks; `value` / `ms_per_step` 
 `blocks`).
 
 Extra objects in the JSON line (linear workload):
-  roofline      dominant kernel = stage_combine with 5 stage terms (tableau row 5: read 5 k_j + y0, write y_i =
-                7 words/element = 234.9 MB per launch; row 6 is the same kernel plus the fused partial-error store);
+  roofline      dominant launch = the step's 7-words-per-element stage combine (234.9 MB): tableau row 5 launched row by
+                row (5 k_j + y0 read, y_i written: stage_combine_kernel<float, 5>) or, with carried partial sums
+                (tableaus.carry_plan — on for dopri5 at this size), row 4 + the prefix of row 5's sum
+                (stage_combine_multi_kernel<float, 4>, 2 outputs) — `kernel` / `carry_plan` say which;
                 `achieved`/`frac` = IN SITU: its launches inside the timed region, each stamped by the dispatch itself
-                (tdeq_stage_combine_timed -> hipExtLaunchKernelGGL start/stop events) — every launch when K <= 50,
-                every 4th otherwise; the stage tensors were written by `func` just before, so part of the reads is
-                served by the 256 MiB Infinity Cache.  `cold` = the same kernel on 4 rotating buffer sets (940 MB
-                > 256 MiB), i.e. every byte from HBM.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes
-                committed under profiles/ (`traffic_source`; counters cannot be read from inside this process).
+                (tdeq_stage_combine[_multi]_timed -> hipExtLaunchKernelGGL start/stop events) — every launch when
+                K <= 50, every 4th otherwise; the stage tensors were written by `func` just before, so part of the
+                reads is served by the 256 MiB Infinity Cache.  `cold` = the same kernel on 4 rotating buffer sets
+                (940 MB > 256 MiB), i.e. every byte from HBM (`cold_row_by_row_kernel`: r02's kernel, for continuity).
+                `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
+                (`traffic_source`; counters cannot be read from inside this process).
   solver_only   the step's solver kernels alone, back to back on the last step's stage tensors.
   shard_regime  (N = 1) what one GPU does on a 1/8 shard of the batch — the per-rank work of an 8-GPU strong-scaling
                 run: 8192 x 128 linear trial steps (host-driven, look-ahead, hip_graph) and the 8192 x 64 adjoint pass.
-  strong, adjoint  (N > 1) the same ranks on the strong-scaling split of cfg2 and on cfg3 with its all-reduce.
+  configs       (N = 1) the other BASELINE.json configurations, bounded (<= 15 s): cfg4 (dopri8 fp64 16384 x 512: odeint
+                ms, NFE vs the reference's, rel-err vs tests/golden/fullsize_cfg4.npz, roofline of its dominant launch in
+                situ + cold), cfg5 (CNF + adjoint: forward / backward ms eager and with captured steps, rel-errs vs
+                fullsize_cfg5.npz), cfg1 (rk4 spiral: GPU eager / captured, and on the CPU as BASELINE writes it,
+                with the bit-equality flag vs the reference's trajectory).
+  weak, strong, lockstep, adjoint   (N > 1) the same ranks on both scaling regimes of cfg2, in lock-step mode, and on
+                cfg3 (strong and weak; forward / backward ms, evaluation counts, `allreduce.{calls, bytes, ms}`);
+                `extras_s` = seconds each took; a watchdog (TDEQ_BENCH_EXTRAS_TIMEOUT, 240 s) prints the line marked
+                `extras_timed_out` + `extras_hung_in` if one of them hangs.
+  comm, backend, rccl_ranks   what the collective backend connected (see above).
   rel_err_vs_reference  full odeint(t=[0,1]) of cfg2 vs the REFERENCE's own result on these inputs
                 (tests/golden/fullsize_cfg2.npz, sample rows; rank 0), next to rel_err vs the closed form.
-  reference_style_eager_gpu   the reference's eager op sequence restated in stock PyTorch on the same GPU.
+  reference_style_eager_gpu   the reference's eager op sequence restated in stock PyTorch on the same GPU
+                (oracle/eager_torch_port.py — pinned op for op to the reference's step sequences,
+                tests/test_oracle_golden.py::test_eager_torch_port_is_the_reference_op_for_op).
   cpu_baseline  the CPU oracle (a port: the reference itself cannot travel to the GPU box) on a bounded sample, on
                 rank 0 at N = 1, with BASELINE.md's figure for the real reference on 8 cores beside it.
 """

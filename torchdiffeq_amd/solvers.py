@@ -237,7 +237,7 @@ class _CaptureFailed(RuntimeError):
 
 
 @contextlib.contextmanager
-def _capture(graph):
+def _capture(graph, pool=None):
     """Stream capture of a step body into `graph`.  Unlike the `torch.cuda.graph` context this neither synchronises
     the device nor empties the caching allocator (both cost milliseconds — more than a short solve), and it pauses
     the cyclic garbage collector: a collection in the middle of a capture may finalize unrelated objects that own HIP
@@ -249,7 +249,10 @@ def _capture(graph):
     gc.disable()
     try:
         with torch.cuda.stream(side):
-            graph.capture_begin()
+            if pool is None:
+                graph.capture_begin()
+            else:
+                graph.capture_begin(pool=pool)      # same private memory pool as a graph that never runs concurrently
             try:
                 yield
             finally:
@@ -411,8 +414,12 @@ class _GraphStep:
         if self.graphs[side] is None:
             graph = torch.cuda.CUDAGraph()
             nfe = func.nfe
+            # the two sides never run concurrently and keep their own results alive (self.k): one memory pool serves
+            # both captures — the second one reuses the blocks the first one's freed intermediates left behind instead
+            # of paying for fresh device allocations
+            other = self.graphs[1 - side]
             try:
-                with _capture(graph):
+                with _capture(graph, pool=None if other is None else other.pool()):
                     self.body(s, side)
             except Exception as exc:       # func is not capturable (host sync, unsupported op ...): nothing has run
                 func.nfe = nfe
