@@ -43,7 +43,11 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     torch.set_num_threads(1)
-    _patch_backend()
+    if os.environ.get("TDEQ_TEST_HOST_PATH") == "1":
+        import warnings
+        warnings.simplefilter("ignore")      # the package's own torch-op host path for CPU states (HostPathWarning)
+    else:
+        _patch_backend()
     from torchdiffeq_amd import dist as tdist
     r, w, _ = tdist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
@@ -89,6 +93,32 @@ def test_sharded_adjoint_world2(tmp_path, cpu_backend):
     n_tail = sum(-(-p.numel() // 1024) * 1024 for p in f.parameters())
     assert len(res[0]["calls"]) == 1 and res[0]["calls"][0] == n_tail + 3, res[0]["calls"]
     assert res[0]["rows"] == slice(0, 6) and res[1]["rows"] == slice(6, 11)
+
+
+def test_sharded_adjoint_world2_on_the_host_path(tmp_path, monkeypatch):
+    """The same two-rank sharded adjoint with NO test backend substituted: CPU shards are integrated by the package's
+    torch-op host path (r03, _fallback.HostKernels) and the parameter adjoints are summed by the one gloo all-reduce.
+    Must equal the single-process solve on the same path."""
+    import warnings
+    import torchdiffeq_amd as tda
+    monkeypatch.setenv("TDEQ_TEST_HOST_PATH", "1")
+    world = 2
+    port = 29900 + (os.getpid() % 90)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(world)]
+    f, y0 = _make(torch.float64)
+    y0 = y0.clone().requires_grad_(True)
+    t = torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64, requires_grad=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = tda.odeint_adjoint(f, y0, t, rtol=1e-9, atol=1e-11)
+        (y[-1].pow(2).sum() + y[1].sum()).backward()
+    for r in range(world):
+        assert torch.allclose(res[r]["gy"], y0.grad[res[r]["rows"]], rtol=1e-6, atol=1e-8)
+        for g_shard, p in zip(res[r]["gp"], f.parameters()):
+            assert torch.allclose(g_shard, p.grad, rtol=1e-6, atol=1e-8)
+        assert torch.allclose(res[r]["gt"], t.grad, rtol=1e-6, atol=1e-8)
+    assert len(res[0]["calls"]) == 1
 
 
 class _CountingModule(torch.nn.Module):
