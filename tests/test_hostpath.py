@@ -63,12 +63,12 @@ def test_a_real_state_on_the_gpu_never_takes_the_host_path(monkeypatch):
         monkeypatch.setattr(_fallback.HostKernels, name, lambda *a, **k: calls.__setitem__("host", calls["host"] + 1))
     hip = _native.get_kernels(torch.device("cuda:0"), torch.float32)
     assert isinstance(hip, _native.HipKernels)
-    orig = hip.lib.tdeq_stage_combine
+    orig = hip.stage_combine
 
-    def counted(*a):
+    def counted(*a, **k):
         calls["hip"] += 1
-        return orig(*a)
-    monkeypatch.setattr(hip.lib, "tdeq_stage_combine", counted)
+        return orig(*a, **k)
+    monkeypatch.setattr(hip, "stage_combine", counted)
     y0 = torch.randn(64, 8, device="cuda")
     lin = torch.nn.Linear(8, 8).cuda()
     with torch.no_grad():
