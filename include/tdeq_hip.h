@@ -262,6 +262,9 @@ int tdeq_step_controller(const double* sums, const double* nonfinite, const tdeq
  *   tdeq_step_commit        if ctrl_dev[0] (accept): (y_prev, f_prev) <- (y_cur, f_cur); (y_cur, f_cur) <- (y1, f1)
  *                           — the accepted state becomes the next trial's base (rk_common.py:335-352) and the
  *                           previous pair stays available for the dense output of the step just taken.
+ *                           For callers that keep ONE captured graph and let the device select the pair.  The package's
+ *                           own host (solvers._GraphStep, r03) no longer needs it: it reads the decision after every
+ *                           replay anyway and alternates between two graphs over ping-pong buffers instead (no copy).
  */
 int tdeq_stage_combine_dev(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
                            const double* err_coef, int n_terms, const double* ctrl_dev, int64_t n, int dtype,
