@@ -18,14 +18,14 @@ def _rand(n, dtype, seed, special=True):
     return x
 
 
-@pytest.mark.parametrize("name,words,launches,before", [("dopri5", 35, 7, 37), ("dopri8", 75, 13, 98)])
+@pytest.mark.parametrize("name,words,launches,before", [("dopri5", 35, 7, 37), ("dopri8", 75, 13, 98), ("tsit5", 41, 8, 46)])
 def test_plan_word_counts(name, words, launches, before):
     plan = tb.carry_plan(name)
     tab = tb.ADAPTIVE_TABLEAUS[name]
     assert (plan.words, plan.launches) == (words, launches)
     assert tb.row_by_row_words(tab) == before
     rows = tab.beta_rows()
-    S = len(rows)
+    S = len(rows) if tab.fsal_solution else len(rows) + 1          # launch rows (tsit5: + the c_sol combine)
     # structure: every row's stage input is produced exactly once; the error partial exactly once
     produced = [0]
     for op in plan.ops:
@@ -38,13 +38,16 @@ def test_plan_word_counts(name, words, launches, before):
                 produced.append(t)
     assert sorted(produced) == list(range(S))
     assert sum(1 for op in plan.ops if op is not None and S in op.targets) == 1
-    assert tb.carry_plan("tsit5") is None and tb.carry_plan("bosh3") is None
+    assert tb.carry_plan("bosh3") is None and tb.carry_plan("fehlberg2") is None
 
 
 def _run_rows(kern, tab, y0, ks, dt, planned):
-    """Stage inputs y_1..y_{S-1} (given ALL stages up front — the combines are linear in them, so parity of the
-    launch forms does not need a func) + the partial error and what is left to the norm kernel."""
+    """Stage inputs y_1..y_{S-1} [+ the solution y1 of a non-FSAL pair] (given ALL stages up front — the combines are
+    linear in them, so parity of the launch forms does not need a func) + the partial error and what is left to the
+    norm kernel."""
     rows = tab.beta_rows()
+    if not tab.fsal_solution:
+        rows = rows + [tb.SparseRow.from_dense(tab.c_sol)]
     S = len(rows)
     err = tb.SparseRow.from_dense(tab.c_error)
     ys = {}
@@ -79,7 +82,7 @@ def _bits(x):
     return x.cpu().contiguous().view(torch.int32 if x.dtype == torch.float32 else torch.int64)
 
 
-@pytest.mark.parametrize("name", ["dopri5", "dopri8"])
+@pytest.mark.parametrize("name", ["dopri5", "dopri8", "tsit5"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("n", [1, 7, 1024, 4099])
 @pytest.mark.parametrize("dt", [0.37, -0.011])
@@ -106,7 +109,7 @@ def test_planned_rows_equal_row_by_row_oracle(oracle_kernels, name, dtype, n, dt
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["dopri5", "dopri8"])
+@pytest.mark.parametrize("name", ["dopri5", "dopri8", "tsit5"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("n", [1, 5, 1023, 65536 + 3, 1 << 20])
 @pytest.mark.parametrize("dt", [0.37, -0.011])
@@ -181,7 +184,8 @@ def _solve(method, dtype, device, carry, monkeypatch, rtol, atol, reverse=False)
 
 
 @pytest.mark.parametrize("method,dtype,rtol,atol", [("dopri5", torch.float32, 1e-6, 1e-8), ("dopri5", torch.float64, 1e-9, 1e-11),
-                                                    ("dopri8", torch.float64, 1e-10, 1e-12), ("dopri8", torch.float32, 1e-6, 1e-8)])
+                                                    ("dopri8", torch.float64, 1e-10, 1e-12), ("dopri8", torch.float32, 1e-6, 1e-8),
+                                                    ("tsit5", torch.float32, 1e-6, 1e-8), ("tsit5", torch.float64, 1e-9, 1e-11)])
 @pytest.mark.parametrize("reverse", [False, True])
 def test_solve_with_plan_is_bit_identical(dev, monkeypatch, method, dtype, rtol, atol, reverse):
     a, sa = _solve(method, dtype, dev, False, monkeypatch, rtol, atol, reverse)

@@ -15,7 +15,7 @@ import torchdiffeq_amd as tda  # noqa: E402
 import _fullsize as fs  # noqa: E402
 from torchdiffeq_amd import tableaus as tb  # noqa: E402
 from torchdiffeq_amd.misc import OdeFunc, StateLayout, rms_norm  # noqa: E402
-from torchdiffeq_amd.solvers import Dopri5Solver, Dopri8Solver  # noqa: E402
+from torchdiffeq_amd.solvers import Dopri5Solver, Dopri8Solver, Tsit5Solver  # noqa: E402
 
 dev = torch.device("cuda:0")
 
@@ -101,7 +101,8 @@ def case(name, cls, B, D, dtype, method, rtol, atol, steps):
         os.environ["TDEQ_CARRY"] = carry
         s = stepper(cls, field, y0, rtol, atol)
         r = {"ms_per_trial_step": ms_per_step(s, steps, max(steps // 5, 3))}
-        r["solver_kernels_only_ms_per_step"] = solver_kernels_only(s)
+        if s.tableau.fsal_solution:
+            r["solver_kernels_only_ms_per_step"] = solver_kernels_only(s)
         with torch.no_grad():
             tda.odeint(field, y0, t, rtol=rtol, atol=atol, method=method)
             torch.cuda.synchronize()
@@ -116,16 +117,23 @@ def case(name, cls, B, D, dtype, method, rtol, atol, steps):
         del s
     out["solutions_bit_identical"] = bool(torch.equal(sols["0"], sols["1"]))
     for key in ("ms_per_trial_step", "solver_kernels_only_ms_per_step", "odeint_t01_ms"):
-        out["gain_" + key] = 1.0 - out["carry_on"][key] / out["carry_off"][key]
+        if key in out["carry_on"]:
+            out["gain_" + key] = 1.0 - out["carry_on"][key] / out["carry_off"][key]
     print(name, json.dumps(out), flush=True)
     return out
 
 
-res = {}
-res["cfg2"] = case("cfg2", Dopri5Solver, 65536, 128, torch.float32, "dopri5", 1e-7, 1e-9, 100)
-res["cfg4"] = case("cfg4", Dopri8Solver, 16384, 512, torch.float64, "dopri8", 1e-9, 1e-11, 30)
-res["cfg2_shard"] = case("cfg2_shard", Dopri5Solver, 8192, 128, torch.float32, "dopri5", 1e-7, 1e-9, 100)
-res["cfg4_shard"] = case("cfg4_shard", Dopri8Solver, 2048, 512, torch.float64, "dopri8", 1e-9, 1e-11, 30)
-res["dopri8_f32_cfg2_state"] = case("dopri8_f32", Dopri8Solver, 65536, 128, torch.float32, "dopri8", 1e-7, 1e-9, 30)
+CASES = {
+    "cfg2": lambda: case("cfg2", Dopri5Solver, 65536, 128, torch.float32, "dopri5", 1e-7, 1e-9, 100),
+    "cfg4": lambda: case("cfg4", Dopri8Solver, 16384, 512, torch.float64, "dopri8", 1e-9, 1e-11, 30),
+    "cfg2_shard": lambda: case("cfg2_shard", Dopri5Solver, 8192, 128, torch.float32, "dopri5", 1e-7, 1e-9, 100),
+    "cfg4_shard": lambda: case("cfg4_shard", Dopri8Solver, 2048, 512, torch.float64, "dopri8", 1e-9, 1e-11, 30),
+    "dopri8_f32_cfg2_state": lambda: case("dopri8_f32", Dopri8Solver, 65536, 128, torch.float32, "dopri8", 1e-7, 1e-9, 30),
+    "tsit5_cfg2_state": lambda: case("tsit5_f32", Tsit5Solver, 65536, 128, torch.float32, "tsit5", 1e-7, 1e-9, 60),
+    "tsit5_f64_cfg4_state": lambda: case("tsit5_f64", Tsit5Solver, 16384, 512, torch.float64, "tsit5", 1e-9, 1e-11, 30),
+}
+names = sys.argv[1:] or list(CASES)
+res = {name: CASES[name]() for name in names}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "carry_bench.json"), "w"), indent=1)
+tag = "" if not sys.argv[1:] else "_" + "_".join(names)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"carry_bench{tag}.json"), "w"), indent=1)

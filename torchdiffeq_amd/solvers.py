@@ -572,7 +572,7 @@ class RKAdaptiveStepsizeODESolver:
         # tableau that has a plan; "0" = row-by-row launches.
         self._carry = None
         carry_env = os.environ.get("TDEQ_CARRY", "auto").lower()
-        if self._fuse is not None and tab.fsal_solution and carry_env != "0" \
+        if self._fuse is not None and carry_env != "0" \
                 and (carry_env == "1" or self.layout.total >= CARRY_DEFAULT_ON.get(tab.name, float("inf"))) \
                 and hasattr(self.kernels, "stage_combine_multi") and ADAPTIVE_TABLEAUS.get(tab.name) is tab:
             self._carry = carry_plan(tab.name)
@@ -1006,23 +1006,24 @@ class RKAdaptiveStepsizeODESolver:
         err_rem = self._fuse[1:] if self._fuse is not None else None     # (stages, weights) left to the norm kernel
         nograd = not torch.is_grad_enabled()      # no-grad solves (the adjoint's two solves, inference): no graph checks
         carry = self._carry if (builtin_norm and (nograd or (plain and not k1.requires_grad))) else None
+        y1_planned = None
         if carry is not None:
-            # planned stage loop (tableaus.carry_plan): a launch may also emit the left-to-right prefixes of later
-            # rows' sums (continued by those rows: fewer bytes) or a later stage input that needs no newer stage;
-            # every stage input is bit-identical to the row-by-row launches below
-            held, S = {}, n_rows
-            for i in range(1, n_rows):
+            # planned launches (tableaus.carry_plan): a launch may also emit the left-to-right prefixes of later rows'
+            # sums (continued by those rows: fewer bytes) or a later stage input that needs no newer stage; launch row
+            # n_rows of a pair whose solution is not its last stage input is the c_sol combine (no evaluation follows).
+            # Every stage input is bit-identical to the row-by-row launches below.
+            held, R = {}, len(carry.ops)
+            for i in range(1, R):
                 op = carry.ops[i]
+                row = self._beta[i] if i < n_rows else self._c_sol
                 if op is None:
                     yi = held.pop(i)                      # finished by an earlier launch
                 elif len(op.targets) == 1 and not op.continues:
-                    row = self._beta[i]
                     yi = torch.empty_like(y0)
                     kern.stage_combine(yi, y0, [k[j] for j in row.idx], row.coef, dt_signed)
-                elif op.targets == (i, S) and i == S - 1 and not op.continues and op.idx == self._beta[i].idx:
-                    row = self._beta[i]                   # the end-of-step pair as before (tdeq_stage_combine_err)
-                    yi, held[S] = torch.empty_like(y0), torch.empty_like(y0)
-                    kern.stage_combine_err(yi, held[S], y0, [k[j] for j in row.idx], row.coef, self._fuse[0], dt_signed)
+                elif op.targets == (i, R) and i == R - 1 and not op.continues and op.idx == row.idx:
+                    yi, held[R] = torch.empty_like(y0), torch.empty_like(y0)      # the end-of-step pair as before
+                    kern.stage_combine_err(yi, held[R], y0, [k[j] for j in row.idx], row.coef, self._fuse[0], dt_signed)
                 else:
                     outs = [torch.empty_like(y0) for _ in op.targets]
                     kern.stage_combine_multi(outs, op.spec, y0, held.pop(i) if op.continues else None,
@@ -1030,8 +1031,11 @@ class RKAdaptiveStepsizeODESolver:
                     yi = outs[0]
                     for tgt, buf in zip(op.targets[1:], outs[1:]):
                         held[tgt] = buf
-                k.append(func.eval_at(stage_times[i], yi))
-            err_partial, err_rem = held.pop(S), (carry.err_idx, carry.err_coef)
+                if i < n_rows:
+                    k.append(func.eval_at(stage_times[i], yi))
+                else:
+                    y1_planned = yi
+            err_partial, err_rem = held.pop(R), (carry.err_idx, carry.err_coef)
         for i in range(1, n_rows if carry is None else 0):
             row = self._beta[i]
             if i == n_rows - 1 and fsal and self._fuse is not None and builtin_norm and \
@@ -1046,6 +1050,8 @@ class RKAdaptiveStepsizeODESolver:
             k.append(func.eval_at(stage_times[i], yi))
         if fsal:
             y1 = yi
+        elif y1_planned is not None:
+            y1 = y1_planned
         elif self._fuse is not None and builtin_norm and \
                 not (torch.is_grad_enabled() and (y0.requires_grad or k[-1].requires_grad)):
             sol = self._c_sol

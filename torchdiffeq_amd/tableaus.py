@@ -278,6 +278,9 @@ ADAPTIVE_TABLEAUS = {t.name: t for t in (DOPRI8, DOPRI5, TSIT5, BOSH3, FEHLBERG2
 _CARRY_HOSTS = {
     "dopri5": {4: 3, 6: 5},
     "dopri8": {5: 4, 7: 6, 8: 6, 9: 6, 11: 10, 12: 10, 13: 10},
+    # tsit5's solution is not its last stage input (c_sol ends in 1/66): launch row 6 is the c_sol combine, target 7 the
+    # error.  Row 2 hosts row 3; row 4 hosts row 5, the solution and the error: 46 -> 41 words.
+    "tsit5": {3: 2, 5: 4, 6: 4, 7: 4},
 }
 MAX_MULTI_OUT = 4
 # Where the plan is switched on without being asked for (TDEQ_CARRY unset): tableau -> smallest state (elements) it
@@ -285,8 +288,9 @@ MAX_MULTI_OUT = 4
 # solver kernels -25 % (fp64 16384x512) / -22 % (fp32 65536x128), trial step -12 % / -16 %, also on the 1/8 shards (one
 # launch fewer); dopri5: 2 of 37 words — rows 4 + 5 take 33.8 + 21.5 us instead of 29.6 + 36.1 at 65536x128 (trial step
 # -1.5 %), but the two-output launch costs more than it saves where a launch is latency, not bytes (1/8 shard: +0.8 %),
-# so dopri5 takes the plan from 4 M elements on.
-CARRY_DEFAULT_ON = {"dopri8": 0, "dopri5": 1 << 22}
+# so dopri5 takes the plan from 4 M elements on; tsit5 likewise (trial step -3.6 % fp32 at 65536x128, -6.9 % fp64 at
+# 16384x512, profiles/r03_carry_bench_tsit5.json).
+CARRY_DEFAULT_ON = {"dopri8": 0, "dopri5": 1 << 22, "tsit5": 1 << 22}
 
 
 @dataclasses.dataclass(frozen=True)
@@ -310,17 +314,24 @@ class CarryPlan:
 
 
 def _plan_from_hosts(tab: Tableau, hosts) -> CarryPlan:
+    """Launch rows 0..S-1 form the stage inputs; a pair whose solution is not its last stage input (tsit5) has one more
+    launch row S, the solution combine over c_sol (no evaluation follows it).  The embedded error is target R = the
+    number of launch rows."""
     rows = tab.beta_rows()
     S = len(rows)
+    R = S if tab.fsal_solution else S + 1
     err = SparseRow.from_dense(tab.c_error)
     nz = {i: dict(zip(r.idx, r.coef)) for i, r in enumerate(rows)}
-    nz[S] = dict(zip(err.idx, err.coef))
-    assert tab.fsal_solution and S not in () and hosts.get(S) is not None
+    if not tab.fsal_solution:
+        sol = SparseRow.from_dense(tab.c_sol)
+        nz[S] = dict(zip(sol.idx, sol.coef))
+    nz[R] = dict(zip(err.idx, err.coef))
+    assert hosts.get(R) is not None
     for t, h in hosts.items():
-        assert 1 <= h < t <= S and h not in hosts, "hosts are rows that are formed in full"
+        assert 1 <= h < t <= R and h not in hosts, "hosts are rows that are formed in full"
         assert any(j <= h for j in nz[t]), "nothing to carry"
-    ops, finished, words, launches = [None] * S, set(), 0, 0
-    for i in range(S):
+    ops, finished, words, launches = [None] * R, set(), 0, 0
+    for i in range(R):
         if i in finished:
             continue
         h = hosts.get(i)
@@ -345,17 +356,17 @@ def _plan_from_hosts(tab: Tableau, hosts) -> CarryPlan:
             ops[i] = CarryOp(i, tuple(idx), h is not None, tuple(targets), tuple(spec))
         else:
             assert targets == [0]
-    rem = sorted(j for j in nz[S] if j > hosts[S])
+    rem = sorted(j for j in nz[R] if j > hosts[R])
     assert len(rem) <= 2, "tdeq_error_norm_partial continues over at most two stages"
     words += 1 + len(rem) + 2
     launches += 1
-    return CarryPlan(tuple(ops), tuple(rem), tuple(nz[S][j] for j in rem), words, launches)
+    return CarryPlan(tuple(ops), tuple(rem), tuple(nz[R][j] for j in rem), words, launches)
 
 
 @functools.lru_cache(maxsize=None)
 def carry_plan(name: str):
-    """The carried-partial-sum launch plan of the tableau `name`, or None when it has none (no saving, or a pair
-    whose solution is not its last stage input)."""
+    """The carried-partial-sum launch plan of the tableau `name`, or None when it has none (no saving: bosh3,
+    fehlberg2, adaptive_heun)."""
     hosts = _CARRY_HOSTS.get(name)
     return None if hosts is None else _plan_from_hosts(ADAPTIVE_TABLEAUS[name], dict(hosts))
 
