@@ -303,6 +303,9 @@ class OdeintAdjointMethod(torch.autograd.Function):
                     time_vjps[i] = dLd_cur_t
                 solver = SOLVERS[ctx.adjoint_method](func=aug_func, y0=aug, rtol=ctx.adjoint_rtol,
                                                      atol=ctx.adjoint_atol, **options)
+                if aug_func.use_proxy and not getattr(solver, "hip_graph", False):
+                    aug_func.use_proxy = False      # the solver runs eagerly after all (state too large, user norm ...):
+                                                    # differentiate func directly, as without the option
                 t_pair = -t[i - 1:i + 1].detach().flip(0)
                 aug = solver.integrate(t_pair)[1]
                 aug_views = aug_layout.unpack(aug)
