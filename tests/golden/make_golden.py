@@ -876,6 +876,18 @@ def gen_hostpath():
         hx, hW = torch.autograd.grad(second, (x, W))
         arrays[f"hess_{method}_gx"], arrays[f"hess_{method}_gW"] = gx.detach(), gW.detach()
         arrays[f"hess_{method}_hx"], arrays[f"hess_{method}_hW"] = hx, hW
+    # second order with the output TIMES in the graph (dense-output weights are polynomial in the interpolation point)
+    for method, kw in (("rk4", dict(options=dict(step_size=0.1))), ("dopri5", dict(rtol=1e-8, atol=1e-10))):
+        W = W0.clone().requires_grad_(True)
+        x = x0.clone().requires_grad_(True)
+        tt = torch.tensor([0.0, 0.43, 1.0], dtype=torch.float64, requires_grad=True)
+        y = torchdiffeq.odeint(lambda t_, y_: torch.tanh(y_ @ W.T) * torch.cos(t_), x, tt, method=method, **kw)
+        loss = (y[-1] ** 2).sum() + (y[1] ** 3).sum()
+        gx, gt = torch.autograd.grad(loss, (x, tt), create_graph=True)
+        second = (gx ** 2).sum() + (gt ** 2).sum()
+        hx, ht, hW = torch.autograd.grad(second, (x, tt, W))
+        arrays[f"hesst_{method}_gt"], arrays[f"hesst_{method}_hx"] = gt.detach(), hx
+        arrays[f"hesst_{method}_ht"], arrays[f"hesst_{method}_hW"] = ht, hW
     save("hostpath.npz", **arrays)
 
 

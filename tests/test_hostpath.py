@@ -209,3 +209,22 @@ def test_host_path_adjoint_and_tuple_state(quiet):
         (ya[-1].sum() + yb[-1].pow(2).sum()).backward()
         grads.append((x.grad.clone(), lin.weight.grad.clone()))
     assert rel_err(grads[0][0], grads[1][0]) < 1e-6 and rel_err(grads[0][1], grads[1][1]) < 1e-6
+
+
+@pytest.mark.parametrize("method,kw", [("rk4", dict(options=dict(step_size=0.1))), ("dopri5", dict(rtol=1e-8, atol=1e-10))])
+def test_second_order_gradients_with_times_in_the_graph(dev, method, kw):
+    """Second-order quantities when `t` requires grad too: the fixed-grid interpolation / the dense output's weights
+    are functions of the output times (polynomial in the interpolation point for the adaptive methods), so their
+    higher derivatives matter (autodiff._Spec.w_fn)."""
+    z = load("hostpath.npz")
+    W = T(z["hess_W"], dev).requires_grad_(True)
+    x = T(z["hess_y0"], dev).requires_grad_(True)
+    tt = torch.tensor([0.0, 0.43, 1.0], dtype=torch.float64, device=dev, requires_grad=True)
+    y = tda.odeint(lambda t_, y_: torch.tanh(y_ @ W.T) * torch.cos(t_), x, tt, method=method, **kw)
+    loss = (y[-1] ** 2).sum() + (y[1] ** 3).sum()
+    gx, gt = torch.autograd.grad(loss, (x, tt), create_graph=True)
+    assert rel_err(gt, z[f"hesst_{method}_gt"]) < 1e-8
+    hx, ht, hW = torch.autograd.grad((gx ** 2).sum() + (gt ** 2).sum(), (x, tt, W))
+    tol = 1e-8 if method == "rk4" else 1e-5
+    for got, key in ((hx, "hx"), (ht, "ht"), (hW, "hW")):
+        assert rel_err(got, z[f"hesst_{method}_{key}"]) < tol, (key, rel_err(got, z[f"hesst_{method}_{key}"]))
