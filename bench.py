@@ -993,7 +993,7 @@ def comm_census(rank, world, device):
     mine = {"rank": rank, "device_index": device.index, "device_name": props.name,
             "device_uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
             "visible_devices": torch.cuda.device_count()}
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return {"backend": None, "rccl_ranks": None, "comm_ranks": 1, "devices": [mine]}, True
     backend = dist.get_backend()
     ones = torch.ones(1, dtype=torch.float32, device=device if backend == "nccl" else "cpu")
@@ -1182,7 +1182,7 @@ def main():
         if os.environ.get("TDEQ_BENCH_NOTE"):
             out["note"] = os.environ["TDEQ_BENCH_NOTE"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -47,6 +47,25 @@ def test_bench_self_launches_two_ranks_gloo():
     assert "extras_timed_out" not in out and set(out["extras_s"]) >= {"strong", "lockstep", "adjoint"}
 
 
+def test_bench_census_through_rccl_at_world_size_one():
+    """bench.py's communicator census — the all-reduce of ones ON THE DEVICE and the gather of the ranks' GPU identities
+    that every N > 1 run performs before timing anything — executed through RCCL itself: TDEQ_DIST_FORCE_INIT=1 creates
+    the nccl process group (bound to the rank's GPU, as dist.init_from_env does for N ranks) at world size 1."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TDEQ_DIST_FORCE_INIT="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29723")
+    env.pop("TDEQ_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "1", "--steps", "5",
+                        "--warmup", "2", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["backend"] == "nccl" and out["rccl_ranks"] == 1 and out["comm"]["comm_ranks"] == 1
+    dev = out["comm"]["devices"][0]
+    assert dev["rank"] == 0 and dev["device_index"] == 0 and dev["device_name"]
+    assert out["value"] > 0 and out["n_gpus"] == 1
+
+
 @pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs FEWER visible GPUs than ranks")
 def test_bench_refuses_more_ranks_than_gpus_without_an_explicit_backend():
     """`--gpus 2` on a 1-GPU box with TDEQ_DIST_BACKEND unset: no silent gloo run — one JSON error line, status 2;

@@ -31,7 +31,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # (TDEQ_DIST_FORCE_INIT=1: create the process group at world size 1 too — how bench.py's communicator census is
+    # exercised through RCCL on a one-GPU box)
+    if (world > 1 or os.environ.get("TDEQ_DIST_FORCE_INIT") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
