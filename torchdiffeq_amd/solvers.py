@@ -1150,9 +1150,10 @@ class RKAdaptiveStepsizeODESolver:
     def _graph_trial_step(self) -> None:
         """One trial step as ONE hipGraph replay (`options={'hip_graph': True}`; small states, where a step costs
         launch latency).  The graph holds the S evaluations of `func`, the stage combines reading the step size
-        from device memory (tdeq_stage_combine_dev), the error norm + device controller (state_in_dev) and
-        tdeq_step_commit; the host replays it, reads the controller's words and keeps its own mirror of (t0, dt) —
-        identical doubles — for the output loop.  Same kernels' arithmetic and decisions as the eager path."""
+        from device memory (tdeq_stage_combine_dev) and the error norm + device controller (state_in_dev); the host
+        replays the graph of the current side (see _GraphStep: two graphs over ping-pong state buffers), reads the
+        controller's words, flips the side when the step was accepted and keeps its own mirror of (t0, dt) — identical
+        doubles — for the output loop.  Same kernels' arithmetic and decisions as the eager path."""
         func, kern, T = self.func, self.kernels, self.np_dtype
         t0, dt = self.t1, self.dt
         if not math.isfinite(dt):
