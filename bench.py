@@ -126,12 +126,14 @@ def timed_blocks(step_fn, steps, warmup, world, device, n_blocks=N_BLOCKS):
     for _ in range(warmup):
         step_fn()
     blocks = []
+    timed_blocks.local = []          # this rank's own block times, before the barrier (skew diagnosis at N > 1)
     for _ in range(n_blocks):
         dist_sync(world)
         t0 = time.perf_counter()
         for _ in range(steps):
             step_fn()
         torch.cuda.synchronize()
+        timed_blocks.local.append(time.perf_counter() - t0)
         if world > 1:
             torch.distributed.barrier()
         blocks.append(max_over_ranks(time.perf_counter() - t0, world, device))
@@ -527,6 +529,10 @@ def run_linear(args, rank, world, device, parity=True):
         timed.armed = False
     st = block_stats(blocks, args.steps)
     ms_per_step = st["median"]
+    per_rank = None
+    if world > 1:       # every rank's own median block (no barrier inside): shows a straggler GPU, if any
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, 1e3 * statistics.median(timed_blocks.local) / args.steps)
     # weak: every rank did its own stages; strong: a stage of the global batch is done when every shard's is
     value = 6e3 / ms_per_step * (1 if strong else world)
 
@@ -551,7 +557,7 @@ def run_linear(args, rank, world, device, parity=True):
                        "rejected": solver.n_rejected, "lookahead": bool(solver._lookahead),
                        "hip_graph": bool(solver.hip_graph),
                        "backend": torch.distributed.get_backend() if world > 1 else None},
-            "blocks": {"ms_per_step": st, "value_is": "median block"},
+            "blocks": {"ms_per_step": st, "value_is": "median block", "per_rank_ms_per_step": per_rank},
             "rel_err_vs_reference": rel_err_ref,
             "rel_err_vs_reference_definition": "max|y - y_ref| over the sample rows / max|y_ref| of odeint(t=[0,1]) at "
                                                "full size, y_ref = rtqichen/torchdiffeq v0.2.5 on the same inputs "
