@@ -354,6 +354,22 @@ int tdeq_grid_advance(const void* grid, int grid_dtype, int64_t n_grid, int64_t*
                       void* times_out, double* dt_out, int state_dtype, void* stream);
 int tdeq_grid_commit(void* solution, int64_t row_stride, void* y_cur, const void* y_new, const int64_t* counter,
                      int64_t n, int dtype, void* stream);
+/*
+ * hipGraph mode of the OTHER explicit fixed-grid methods (r03: euler, midpoint, heun2, heun3; fixed_grid.py:6-60,
+ * rk_common.py:121-157) — the same scheme as tdeq_grid_advance / tdeq_rk4_38_stage_dev with the method described by data:
+ *   tdeq_grid_advance_stages  counter += 1; t0 = grid[c], t1 = grid[c+1], dt = t1 - t0 in the grid's dtype; stage time i
+ *                             = t1 if (mode_i & 1) else t0 + dt * fl_G(frac_i)  (t0 itself for frac_i = 0), cast to the
+ *                             state dtype, perturbed to the NEXT (mode_i & 2) / PREVIOUS (mode_i & 4) representable value
+ *                             when `perturb`, times `sign`; dt_out = sign * dt.  1 <= n_times <= 4.
+ *   tdeq_fixed_stage_dev      tdeq_fixed_stage with the step size read from device memory (*dt_dev, rounded to T).
+ * Euler's and midpoint's stages are tdeq_stage_combine_dev (whose ctrl_dev[1] is this dt_out).  Same operation order as the
+ * host-dt entry points, so a captured step replays the eager step bit for bit.
+ */
+int tdeq_grid_advance_stages(const void* grid, int grid_dtype, int64_t n_grid, int64_t* counter, int perturb, double sign,
+                             const double* frac, const int* mode, int n_times, void* times_out, double* dt_out,
+                             int state_dtype, void* stream);
+int tdeq_fixed_stage_dev(int mode, void* out, const void* y0, const void* const* k, const double* w, int n_terms,
+                         const double* dt_dev, int64_t n, int dtype, void* stream);
 
 /* Fixed-grid output interpolation  out = y0 + slope*(y1 - y0)  (solvers.py:175-181). */
 int tdeq_lerp(void* out, const void* y0, const void* y1, double slope, int64_t n, int dtype,

@@ -29,11 +29,12 @@ def test_cfg1_graph_equals_eager_and_reference_bits():
     assert y_graph[-1, 0].tolist() == [-0.4436032772064209, 0.27951884269714355]
 
 
+@pytest.mark.parametrize("method", ["rk4", "euler", "midpoint", "heun2", "heun3"])
 @pytest.mark.parametrize("state_dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("grid_dtype", [torch.float32, torch.float64], ids=["t32", "t64"])
 @pytest.mark.parametrize("perturb", [False, True])
 @pytest.mark.parametrize("reverse", [False, True])
-def test_graph_mode_time_dependent_field(state_dtype, grid_dtype, perturb, reverse):
+def test_graph_mode_time_dependent_field(method, state_dtype, grid_dtype, perturb, reverse):
     g = torch.Generator().manual_seed(4)
     y0 = torch.randn(257, 3, generator=g, dtype=torch.float64).to(state_dtype).cuda()
     w = torch.randn(3, 3, generator=g, dtype=torch.float64).to(state_dtype).cuda() * 0.3
@@ -42,10 +43,35 @@ def test_graph_mode_time_dependent_field(state_dtype, grid_dtype, perturb, rever
     if reverse:
         t = t.flip(0)
     opts = dict(perturb=perturb)
-    with torch.no_grad():
-        y_eager = tda.odeint(f, y0, t, method="rk4", options=dict(opts))
-        y_graph = tda.odeint(f, y0, t, method="rk4", options=dict(opts, hip_graph=True))
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")            # in particular: no "running the eager path" fallback warning
+        y_eager = tda.odeint(f, y0, t, method=method, options=dict(opts))
+        y_graph = tda.odeint(f, y0, t, method=method, options=dict(opts, hip_graph=True))
     assert torch.equal(y_graph, y_eager)
+
+
+@pytest.mark.parametrize("method,n_eval", [("euler", 1), ("midpoint", 2), ("heun2", 2), ("heun3", 3), ("rk4", 4)])
+def test_graph_mode_of_every_explicit_fixed_grid_method_replays(method, n_eval):
+    """r03: the captured step exists for every explicit Runge-Kutta fixed-grid method, not only rk4: same bits as the
+    eager path, func runs in Python for the first step and the capture only, the evaluation count is the eager one."""
+    A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], device="cuda")
+    calls = [0]
+
+    def f(t, y):
+        calls[0] += 1
+        return torch.tanh(y @ A) * torch.cos(t)
+    y0 = torch.tensor([[2.0, 0.0]], device="cuda")
+    t = torch.linspace(0.0, 5.0, 400, device="cuda")
+    with torch.no_grad():
+        y_eager = tda.odeint(f, y0, t, method=method)
+        assert calls[0] == n_eval * 399
+        calls[0] = 0
+        ci = check_inputs(f, y0, t, 1e-7, 1e-9, method, dict(hip_graph=True), None, SOLVERS)
+        solver = SOLVERS[method](func=ci.func, y0=ci.y0_flat, rtol=ci.rtol, atol=ci.atol, **ci.options)
+        y_graph = solver.integrate(ci.t)
+    assert torch.isfinite(y_eager).all() and torch.equal(y_graph.view_as(y_eager), y_eager)
+    assert calls[0] == 2 * n_eval              # the eager first step + the captured one
+    assert ci.func.nfe == n_eval * 399         # ... while the solver's count is the eager path's
 
 
 def test_graph_mode_counts_evaluations_and_handles_short_grids():

@@ -138,6 +138,12 @@ ABI_SIGNATURES = {
                                          ctypes.c_void_p]),
     "tdeq_grid_commit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_grid_advance_stages": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                                                ctypes.c_int, ctypes.c_double, _c_double_p, ctypes.POINTER(ctypes.c_int),
+                                                ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_void_p]),
+    "tdeq_fixed_stage_dev": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_lerp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                  ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_fixed_stage": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p,
@@ -583,6 +589,23 @@ class HipKernels:
         _check(self.lib.tdeq_grid_advance(grid.data_ptr(), dtype_code(grid.dtype), grid.numel(), counter.data_ptr(),
                                           1 if perturb else 0, sign, times_out.data_ptr(), dt_out.data_ptr(),
                                           dtype_code(times_out.dtype), self._stream()), "tdeq_grid_advance")
+
+    def grid_advance_stages(self, grid, counter, perturb: bool, sign: float, fracs, modes, times_out, dt_out) -> None:
+        """tdeq_grid_advance_stages: the next step's dt and stage times t0 + dt*frac_i / t1 (mode bits: 1 = t1,
+        2 = Perturb.NEXT, 4 = Perturb.PREV), formed on the device."""
+        n = len(fracs)
+        fr = (ctypes.c_double * n)(*fracs)
+        md = (ctypes.c_int * n)(*modes)
+        _check(self.lib.tdeq_grid_advance_stages(grid.data_ptr(), dtype_code(grid.dtype), grid.numel(),
+                                                 counter.data_ptr(), 1 if perturb else 0, sign, fr, md, n,
+                                                 times_out.data_ptr(), dt_out.data_ptr(), dtype_code(times_out.dtype),
+                                                 self._stream()), "tdeq_grid_advance_stages")
+
+    def fixed_stage_dev(self, mode: int, out, y0, ks, ws, dt_dev) -> None:
+        """fixed_stage with the step size read from device memory (hipGraph mode)."""
+        ptrs, cf, n = self._terms(ks, ws)
+        _check(self.lib.tdeq_fixed_stage_dev(mode, out.data_ptr(), y0.data_ptr(), ptrs, cf, n, dt_dev.data_ptr(),
+                                             y0.numel(), dtype_code(y0.dtype), self._stream()), "tdeq_fixed_stage_dev")
 
     def grid_commit(self, solution, y_cur, y_new, counter) -> None:
         _check(self.lib.tdeq_grid_commit(solution.data_ptr(), solution.stride(0), y_cur.data_ptr(), y_new.data_ptr(),

@@ -643,8 +643,9 @@ int launch_lerp(void* out, const void* y0, const void* y1, double slope, int64_t
 // ---- low-order fixed-grid stages / weighted sums -----------------------------------------------------
 template <typename T, int NT, int MODE>
 int launch_fixed(void* out, const void* y0, const void* const* k, const double* w, double dt, int64_t n,
-                 hipStream_t s) {
+                 hipStream_t s, const double* dt_dev = nullptr) {
     FixedArgs<T, NT> a;
+    a.dt_dev = dt_dev;
     a.out = static_cast<T*>(out);
     a.y0 = static_cast<const T*>(y0);
     bool vec = aligned16(out) && (MODE == 2 || aligned16(y0));
@@ -663,9 +664,9 @@ int launch_fixed(void* out, const void* y0, const void* const* k, const double* 
 
 template <typename T, int MODE>
 int dispatch_fixed(void* out, const void* y0, const void* const* k, const double* w, int nt, double dt,
-                   int64_t n, hipStream_t s) {
+                   int64_t n, hipStream_t s, const double* dt_dev = nullptr) {
     switch (nt) {
-#define TDEQ_CASE(N) case N: return launch_fixed<T, N, MODE>(out, y0, k, w, dt, n, s);
+#define TDEQ_CASE(N) case N: return launch_fixed<T, N, MODE>(out, y0, k, w, dt, n, s, dt_dev);
         TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4)
         case 5: if (MODE == 2) return launch_fixed<T, 5, MODE>(out, y0, k, w, dt, n, s); break;
         case 6: if (MODE == 2) return launch_fixed<T, 6, MODE>(out, y0, k, w, dt, n, s); break;
@@ -1169,6 +1170,31 @@ int tdeq_grid_advance(const void* grid, int grid_dtype, int64_t n_grid, int64_t*
     return check_launch();
 }
 
+int tdeq_grid_advance_stages(const void* grid, int grid_dtype, int64_t n_grid, int64_t* counter, int perturb, double sign,
+                             const double* frac, const int* mode, int n_times, void* times_out, double* dt_out,
+                             int state_dtype, void* stream) {
+    if (!grid || !counter || !times_out || !dt_out || !frac || !mode || n_grid < 2 || bad_dtype(grid_dtype) ||
+        bad_dtype(state_dtype) || n_times < 1 || n_times > kMaxGridStages)
+        return TDEQ_EINVAL;
+    GridStagesArgs a;
+    a.base.grid = grid;
+    a.base.grid_is_f32 = grid_dtype == TDEQ_F32;
+    a.base.n_grid = n_grid;
+    a.base.counter = counter;
+    a.base.perturb = perturb ? 1 : 0;
+    a.base.sign = sign;
+    a.base.times_out = times_out;
+    a.base.state_is_f32 = state_dtype == TDEQ_F32;
+    a.base.dt_out = dt_out;
+    a.n_times = n_times;
+    for (int i = 0; i < kMaxGridStages; ++i) {
+        a.frac[i] = i < n_times ? frac[i] : 0.0;
+        a.mode[i] = i < n_times ? mode[i] : 0;
+    }
+    hipLaunchKernelGGL(grid_advance_stages_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch();
+}
+
 int tdeq_grid_commit(void* solution, int64_t row_stride, void* y_cur, const void* y_new, const int64_t* counter,
                      int64_t n, int dtype, void* stream) {
     if (!solution || !y_cur || !y_new || !counter || n < 0 || row_stride < n || bad_dtype(dtype)) return TDEQ_EINVAL;
@@ -1198,6 +1224,20 @@ int tdeq_fixed_stage(int mode, void* out, const void* y0, const void* const* k, 
                          : dispatch_fixed<float, 1>(out, y0, k, w, n_terms, dt, n, s);
     return mode == 0 ? dispatch_fixed<double, 0>(out, y0, k, w, n_terms, dt, n, s)
                      : dispatch_fixed<double, 1>(out, y0, k, w, n_terms, dt, n, s);
+}
+
+int tdeq_fixed_stage_dev(int mode, void* out, const void* y0, const void* const* k, const double* w, int n_terms,
+                         const double* dt_dev, int64_t n, int dtype, void* stream) {
+    if (!out || !y0 || !k || !w || !dt_dev || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if ((mode != 0 && mode != 1) || n_terms < 1 || n_terms > 4 || (mode == 1 && n_terms != 1)) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_F32)
+        return mode == 0 ? dispatch_fixed<float, 0>(out, y0, k, w, n_terms, 0.0, n, s, dt_dev)
+                         : dispatch_fixed<float, 1>(out, y0, k, w, n_terms, 0.0, n, s, dt_dev);
+    return mode == 0 ? dispatch_fixed<double, 0>(out, y0, k, w, n_terms, 0.0, n, s, dt_dev)
+                     : dispatch_fixed<double, 1>(out, y0, k, w, n_terms, 0.0, n, s, dt_dev);
 }
 
 int tdeq_weighted_sum(void* out, const void* const* x, const double* w, int n_terms, int64_t n, int dtype,

@@ -1268,6 +1268,45 @@ __global__ void grid_advance_kernel(const GridAdvanceArgs a) {
     }
 }
 
+// The same for ANY explicit fixed-grid method (r03: euler, midpoint, heun2, heun3 in hipGraph mode): the stage times of
+// a step are t0 + dt * fl_G(frac_i) (`dt * c` with the Python float c rounded to the grid dtype, solvers._tmul) or t1
+// itself, optionally perturbed (NEXT / PREV when the solver's `perturb` option is on: fixed_grid.py, rk_common.py:110-157).
+constexpr int kMaxGridStages = 4;
+struct GridStagesArgs {
+    GridAdvanceArgs base;
+    int n_times;
+    double frac[kMaxGridStages];
+    int mode[kMaxGridStages];   // bit 0: the time is t1 (not t0 + dt*frac); bit 1: Perturb.NEXT; bit 2: Perturb.PREV
+};
+
+template <typename G, typename T>
+__device__ __forceinline__ void grid_stage_times(const GridStagesArgs& a, int64_t c) {
+    const G* grid = static_cast<const G*>(a.base.grid);
+    const G t0 = grid[c], t1 = grid[c + 1];
+    const G dt = t1 - t0;
+    T* out = static_cast<T*>(a.base.times_out);
+    for (int i = 0; i < a.n_times; ++i) {
+        const G tg = (a.mode[i] & 1) ? t1 : (a.frac[i] == 0.0 ? t0 : t0 + dt * (G)a.frac[i]);
+        T tt = (T)tg;
+        if (a.base.perturb && (a.mode[i] & 2)) tt = ctl_next(tt);
+        if (a.base.perturb && (a.mode[i] & 4)) tt = ctl_prev(tt);
+        out[i] = (T)a.base.sign * tt;
+    }
+    *a.base.dt_out = (double)dt * a.base.sign;
+}
+
+__global__ void grid_advance_stages_kernel(const GridStagesArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t c = *a.base.counter + 1;
+    *a.base.counter = c;
+    if (c + 1 >= a.base.n_grid) return;       // past the last interval: nothing to prepare
+    if (a.base.grid_is_f32) {
+        if (a.base.state_is_f32) grid_stage_times<float, float>(a, c); else grid_stage_times<float, double>(a, c);
+    } else {
+        if (a.base.state_is_f32) grid_stage_times<double, float>(a, c); else grid_stage_times<double, double>(a, c);
+    }
+}
+
 template <typename T>
 struct GridCommitArgs {
     T* solution;           // [n_grid, row_stride]
@@ -1303,19 +1342,20 @@ struct FixedArgs {
     T w[NT];
     T dt;
     int64_t n;
+    const double* dt_dev;   // non-null (hipGraph mode of the fixed-grid methods): the step size is read on the device
 };
 
 template <typename T, int NT, int MODE, typename E>
-__device__ __forceinline__ E fixed_one(const FixedArgs<T, NT>& a, int64_t i) {
+__device__ __forceinline__ E fixed_one(const FixedArgs<T, NT>& a, T dt, int64_t i) {
     E kk[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.k[j])[i];
-    if (MODE == 1) return reinterpret_cast<const E*>(a.y0)[i] + (kk[0] * a.dt) * a.w[0];
+    if (MODE == 1) return reinterpret_cast<const E*>(a.y0)[i] + (kk[0] * dt) * a.w[0];
     E acc = kk[0] * a.w[0];
 #pragma unroll
     for (int j = 1; j < NT; ++j) acc = acc + kk[j] * a.w[j];
     if (MODE == 2) return acc;
-    return reinterpret_cast<const E*>(a.y0)[i] + acc * a.dt;
+    return reinterpret_cast<const E*>(a.y0)[i] + acc * dt;
 }
 
 template <typename T, int NT, int MODE, bool VEC>
@@ -1324,11 +1364,12 @@ __global__ __launch_bounds__(kBlock) void fixed_stage_kernel(const FixedArgs<T, 
     constexpr int L = VEC ? VecOf<T>::L : 1;
     const int64_t ne = a.n / L;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const T dt = a.dt_dev ? (T)*a.dt_dev : a.dt;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
-        reinterpret_cast<E*>(a.out)[i] = fixed_one<T, NT, MODE, E>(a, i);
+        reinterpret_cast<E*>(a.out)[i] = fixed_one<T, NT, MODE, E>(a, dt, i);
     if (VEC) {
         const int64_t t = ne * L + threadIdx.x;
-        if (blockIdx.x == 0 && t < a.n) a.out[t] = fixed_one<T, NT, MODE, T>(a, t);
+        if (blockIdx.x == 0 && t < a.n) a.out[t] = fixed_one<T, NT, MODE, T>(a, dt, t);
     }
 }
 

@@ -232,6 +232,15 @@ def _cell_is_set(cell) -> bool:
         return False
 
 
+class _DtCell:
+    """A two-double device buffer shaped like a norm plan's `ctrl_dev` ({accept, sign*dt, ...}): lets the fixed-grid
+    graph mode reuse tdeq_stage_combine_dev, which reads its step size from word 1."""
+    __slots__ = ("ctrl_dev",)
+
+    def __init__(self, buf):
+        self.ctrl_dev = buf
+
+
 class _CaptureFailed(RuntimeError):
     """The step body could not be captured into a hipGraph; no kernel of it has run."""
 
@@ -1338,9 +1347,9 @@ class FixedGridODESolver(object):
                                                           self.layout.total > _GRAPH_AUTO_MAX_ELEMENTS):
                 return self._integrate_graph(t)
             if not self._graph_auto:
-                warnings.warn("{}: hip_graph=True needs the rk4 method, the output times as the grid, linear "
-                              "interpolation, no callback, no autograd graph and a ROCm device; running the eager "
-                              "path".format(self.__class__.__name__))
+                warnings.warn("{}: hip_graph=True needs an explicit Runge-Kutta fixed-grid method (euler, midpoint, "
+                              "heun2, heun3, rk4), the output times as the grid, linear interpolation, no callback, no "
+                              "autograd graph and a ROCm device; running the eager path".format(self.__class__.__name__))
         # host copies, in the grid's own dtype (dt = t1 - t0 is formed in t.dtype: solvers.py:112)
         grid = time_grid.detach().cpu().numpy()
         tt = t.detach().cpu().numpy()
@@ -1400,8 +1409,80 @@ class FixedGridODESolver(object):
                 solution[i].copy_(r)
         return solution
 
+    # -- hipGraph mode ----------------------------------------------------------------------------------------
+    _graph_times = None          # per method: ((fraction of dt, mode bits), ...) of its stage times — see _integrate_graph
+
+    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
+        """The method's step on device-resident step data: evaluations at the 0-dim tensors `ts`, stage kernels that
+        read the step size from `dt_dev` (`ctrl.ctrl_dev[1]`); returns y(t1)."""
+        raise NotImplementedError
+
     def _graph_capable(self, t: torch.Tensor, time_grid: torch.Tensor) -> bool:
-        return False
+        return (self._graph_times is not None and time_grid is t and self.interp == "linear"
+                and self.func.callback_step is _null and self.device.type == "cuda"
+                and hasattr(self.kernels, "grid_advance_stages")
+                and not (torch.is_grad_enabled() and (t.requires_grad or self.y0.requires_grad)))
+
+    def _integrate_graph(self, t: torch.Tensor) -> torch.Tensor:
+        """`integrate` for small states, where a step costs launch latency, not bandwidth: ONE hipGraph — the method's
+        evaluations of `func`, its stage kernels with the step size read from device memory, tdeq_grid_commit (y1 ->
+        output row and next state) and tdeq_grid_advance_stages (next step's dt and stage times, formed on the device
+        with the host's rounding sequence) — is captured once and replayed per grid interval.  Same kernels and
+        operation order as the eager path, so the solution is bit-identical.  euler, midpoint, heun2, heun3, rk4 (r03:
+        the method is data — `_graph_times` — plus its `_graph_step`).  `func` must be capturable (static shapes, no
+        host synchronisation, no Python side effects it relies on: it runs only for the first step and once more
+        during capture)."""
+        func, kern = self.func, self.kernels
+        n_t = len(t)
+        solution = torch.empty(n_t, self.layout.total, dtype=self.dtype, device=self.device)
+        solution[0].copy_(self.y0)
+        if n_t == 1:
+            return solution
+        grid = t.detach().contiguous()
+        y_cur = self.y0.clone()
+        counter = torch.full((), -1, dtype=torch.int64, device=self.device)
+        fracs, modes = [f for f, _ in self._graph_times], [m for _, m in self._graph_times]
+        n_eval = len(fracs)
+        times = torch.empty(n_eval, dtype=self.dtype, device=self.device)
+        # {unused, sign * dt}: the layout tdeq_stage_combine_dev reads its step size from (a norm plan's ctrl_dev)
+        ctrl = _DtCell(torch.zeros(2, dtype=torch.float64, device=self.device))
+        dt_dev = ctrl.ctrl_dev[1:]
+        kern.grid_advance_stages(grid, counter, self.perturb, func.sign, fracs, modes, times, dt_dev)      # step 0
+        ts = times.unbind(0)
+
+        def step():
+            y1 = self._graph_step(ts, y_cur, dt_dev, ctrl)
+            kern.grid_commit(solution, y_cur, y1, counter)
+            kern.grid_advance_stages(grid, counter, self.perturb, func.sign, fracs, modes, times, dt_dev)
+
+        # the first step runs eagerly on a side stream (library / allocator warm-up before capture) ...
+        current = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(current)
+        with torch.cuda.stream(side):
+            step()
+        current.wait_stream(side)
+        if n_t > 2:
+            # ... the others are replays of one captured step
+            graph = torch.cuda.CUDAGraph()
+            nfe_before = func.nfe
+            try:
+                with _capture(graph):
+                    step()
+            except Exception as exc:      # func is not capturable: nothing has run, the same body works eagerly
+                func.nfe = nfe_before
+                warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({!r}); continuing with "
+                              "the eager path".format(exc))
+                for _ in range(n_t - 2):
+                    step()
+                return solution
+            func.nfe = nfe_before
+            for _ in range(n_t - 2):
+                graph.replay()
+            func.nfe += n_eval * (n_t - 2)
+            # the graph and its private memory pool go away with this frame: let the replays finish first
+            current.synchronize()
+        return solution
 
     @_native.on_state_device
     def integrate_until_event(self, t0: torch.Tensor, event_fn):
@@ -1525,6 +1606,14 @@ class Euler(FixedGridODESolver):
         y1 = self.ops.combine(y0, [f0], [1.0], float(dt) * func.sign, sh.dt_signed(), out=y1_out)
         return y1, f0
 
+    _graph_times = ((0.0, 2),)                                           # t0 (NEXT under `perturb`)
+
+    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
+        f0 = self.func.eval_at(ts[0], y_cur)
+        y1 = torch.empty_like(y_cur)
+        self.kernels.stage_combine_dev(y1, None, y_cur, [f0], (1.0,), None, ctrl)
+        return y1
+
 
 class Midpoint(FixedGridODESolver):
     """Explicit midpoint (fixed_grid.py:14-21): y_mid = y0 + f0*(dt/2); dy = dt * f(t0 + dt/2, y_mid)."""
@@ -1541,6 +1630,18 @@ class Midpoint(FixedGridODESolver):
         y1 = ops.combine(y0, [k2], [1.0], dts, sh.dt_signed(), out=y1_out)
         return y1, f0
 
+    _graph_times = ((0.0, 2), (0.5, 0))                                  # t0 (NEXT), t0 + dt/2
+
+    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
+        func, kern = self.func, self.kernels
+        f0 = func.eval_at(ts[0], y_cur)
+        y_mid = torch.empty_like(y_cur)
+        kern.stage_combine_dev(y_mid, None, y_cur, [f0], (0.5,), None, ctrl)
+        k2 = func.eval_at(ts[1], y_mid)
+        y1 = torch.empty_like(y_cur)
+        kern.stage_combine_dev(y1, None, y_cur, [k2], (1.0,), None, ctrl)
+        return y1
+
 
 class Heun2(FixedGridODESolver):
     """Heun's 2nd-order method through the reference's rk2 step (fixed_grid.py:49-60, rk_common.py:142-157)."""
@@ -1555,6 +1656,18 @@ class Heun2(FixedGridODESolver):
         k2 = func.eval(scalar(t0 + self._tmul(scalar, dt, 1.0)), ya, self._last_perturb(), shadow=sh.time(1.0))
         y1 = ops.fixed_stage(0, y0, [k1, k2], [0.5, 0.5], dts, sh.dt_signed(), out=y1_out)
         return y1, k1
+
+    _graph_times = ((0.0, 2), (1.0, 4))                                  # t0 (NEXT), t0 + dt*1.0 (PREV) — not t1 itself
+
+    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
+        func, kern = self.func, self.kernels
+        k1 = func.eval_at(ts[0], y_cur)
+        ya = torch.empty_like(y_cur)
+        kern.fixed_stage_dev(1, ya, y_cur, [k1], (1.0,), dt_dev)
+        k2 = func.eval_at(ts[1], ya)
+        y1 = torch.empty_like(y_cur)
+        kern.fixed_stage_dev(0, y1, y_cur, [k1, k2], (0.5, 0.5), dt_dev)
+        return y1
 
 
 class Heun3(FixedGridODESolver):
@@ -1573,6 +1686,22 @@ class Heun3(FixedGridODESolver):
         k3 = func.eval(scalar(t0 + self._tmul(scalar, dt, two_thirds)), yb, shadow=sh.time(two_thirds))
         y1 = ops.fixed_stage(0, y0, [k1, k3], [1 / 4, 3 / 4], dts, sh.dt_signed(), out=y1_out)   # k2: structural zero
         return y1, k1
+
+    _graph_times = ((0.0, 2), (1 / 3, 0), (2 / 3, 0))                    # t0 (NEXT), t0 + dt/3, t0 + 2dt/3
+
+    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
+        func, kern = self.func, self.kernels
+        third, two_thirds = 1 / 3, 2 / 3
+        k1 = func.eval_at(ts[0], y_cur)
+        ya = torch.empty_like(y_cur)
+        kern.fixed_stage_dev(1, ya, y_cur, [k1], (third,), dt_dev)
+        k2 = func.eval_at(ts[1], ya)
+        yb = torch.empty_like(y_cur)
+        kern.fixed_stage_dev(0, yb, y_cur, [k2], (two_thirds,), dt_dev)
+        k3 = func.eval_at(ts[2], yb)
+        y1 = torch.empty_like(y_cur)
+        kern.fixed_stage_dev(0, y1, y_cur, [k1, k3], (1 / 4, 3 / 4), dt_dev)
+        return y1
 
 
 def _rk4_38_step(solver, t0, dt, t1, y0, k1, y1_out, sh):
@@ -1611,77 +1740,24 @@ class RK4(FixedGridODESolver):
     def _step(self, t0, dt, t1, y0, y1_out, sh):
         return _rk4_38_step(self, t0, dt, t1, y0, None, y1_out, sh)
 
-    # -- hipGraph mode --------------------------------------------------------------------------------
-    def _graph_capable(self, t: torch.Tensor, time_grid: torch.Tensor) -> bool:
-        return (time_grid is t and self.interp == "linear" and self.func.callback_step is _null
-                and self.device.type == "cuda" and hasattr(self.kernels, "grid_advance")
-                and not (torch.is_grad_enabled() and (t.requires_grad or self.y0.requires_grad)))
+    # -- hipGraph mode (FixedGridODESolver._integrate_graph) ------------------------------------------------
+    _graph_times = ((0.0, 2), (1 / 3, 0), (2 / 3, 0), (0.0, 1 | 4))     # t0 (NEXT), t0 + dt/3, t0 + 2dt/3, t1 (PREV)
 
-    def _integrate_graph(self, t: torch.Tensor) -> torch.Tensor:
-        """`integrate` for small states, where a step costs launch latency, not bandwidth: ONE hipGraph — the four
-        evaluations of `func`, the four 3/8-rule stage kernels, tdeq_grid_commit (y1 -> output row and next state) and
-        tdeq_grid_advance (next step's dt and stage times, on the device) — is captured once and replayed per grid
-        interval.  Same kernels and operation order as the eager path, so the solution is bit-identical.  `func`
-        must be capturable (static shapes, no host synchronisation, no Python side effects it relies on: it runs
-        only for the first step and once more during capture)."""
+    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
         func, kern = self.func, self.kernels
-        n_t = len(t)
-        solution = torch.empty(n_t, self.layout.total, dtype=self.dtype, device=self.device)
-        solution[0].copy_(self.y0)
-        if n_t == 1:
-            return solution
-        grid = t.detach().contiguous()
-        y_cur = self.y0.clone()
-        counter = torch.full((), -1, dtype=torch.int64, device=self.device)
-        times = torch.empty(4, dtype=self.dtype, device=self.device)
-        dt_dev = torch.empty((), dtype=torch.float64, device=self.device)
-        kern.grid_advance(grid, counter, self.perturb, func.sign, times, dt_dev)      # step 0
-        ts = times.unbind(0)
-
-        def step():
-            k1 = func.eval_at(ts[0], y_cur)
-            ya = torch.empty_like(y_cur)
-            kern.rk4_stage_dev(1, ya, y_cur, k1, None, None, None, dt_dev)
-            k2 = func.eval_at(ts[1], ya)
-            yb = torch.empty_like(y_cur)
-            kern.rk4_stage_dev(2, yb, y_cur, k1, k2, None, None, dt_dev)
-            k3 = func.eval_at(ts[2], yb)
-            yc = torch.empty_like(y_cur)
-            kern.rk4_stage_dev(3, yc, y_cur, k1, k2, k3, None, dt_dev)
-            k4 = func.eval_at(ts[3], yc)
-            y1 = torch.empty_like(y_cur)
-            kern.rk4_stage_dev(4, y1, y_cur, k1, k2, k3, k4, dt_dev)
-            kern.grid_commit(solution, y_cur, y1, counter)
-            kern.grid_advance(grid, counter, self.perturb, func.sign, times, dt_dev)
-
-        # the first step runs eagerly on a side stream (library / allocator warm-up before capture) ...
-        current = torch.cuda.current_stream(self.device)
-        side = torch.cuda.Stream(self.device)
-        side.wait_stream(current)
-        with torch.cuda.stream(side):
-            step()
-        current.wait_stream(side)
-        if n_t > 2:
-            # ... the others are replays of one captured step
-            graph = torch.cuda.CUDAGraph()
-            nfe_before = func.nfe
-            try:
-                with _capture(graph):
-                    step()
-            except Exception as exc:      # func is not capturable: nothing has run, the same body works eagerly
-                func.nfe = nfe_before
-                warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({!r}); continuing with "
-                              "the eager path".format(exc))
-                for _ in range(n_t - 2):
-                    step()
-                return solution
-            func.nfe = nfe_before
-            for _ in range(n_t - 2):
-                graph.replay()
-            func.nfe += 4 * (n_t - 2)
-            # the graph and its private memory pool go away with this frame: let the replays finish first
-            current.synchronize()
-        return solution
+        k1 = func.eval_at(ts[0], y_cur)
+        ya = torch.empty_like(y_cur)
+        kern.rk4_stage_dev(1, ya, y_cur, k1, None, None, None, dt_dev)
+        k2 = func.eval_at(ts[1], ya)
+        yb = torch.empty_like(y_cur)
+        kern.rk4_stage_dev(2, yb, y_cur, k1, k2, None, None, dt_dev)
+        k3 = func.eval_at(ts[2], yb)
+        yc = torch.empty_like(y_cur)
+        kern.rk4_stage_dev(3, yc, y_cur, k1, k2, k3, None, dt_dev)
+        k4 = func.eval_at(ts[3], yc)
+        y1 = torch.empty_like(y_cur)
+        kern.rk4_stage_dev(4, y1, y_cur, k1, k2, k3, k4, dt_dev)
+        return y1
 
 
 # ---------------------------------------------------------------------------------------------------
