@@ -187,6 +187,11 @@ typedef struct tdeq_multi_out {
 } tdeq_multi_out;
 int tdeq_stage_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
                              const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream);
+/* hipGraph mode: the step size is ctrl_dev[1] (sign * T(dt), maintained by tdeq_error_norm_partial_ctrl with
+ * state_in_dev = 1), read on the device; c = fl_T(fl_T(coef) * T(dt)) as above, same bits as the host-dt entry point. */
+int tdeq_stage_combine_multi_dev(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                                 const void* const* k, int n_terms, const double* ctrl_dev, int64_t n, int dtype,
+                                 void* stream);
 /* Measurement hook, as tdeq_stage_combine_timed: the dispatch stamps the two events with its own begin / end. */
 int tdeq_stage_combine_multi_timed(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
                                    const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream,

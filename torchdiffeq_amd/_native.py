@@ -79,6 +79,9 @@ ABI_SIGNATURES = {
     "tdeq_stage_combine_multi": (ctypes.c_int, [ctypes.POINTER(MultiOut), ctypes.c_int, ctypes.c_void_p,
                                                 ctypes.c_void_p, _c_void_pp, ctypes.c_int, ctypes.c_double,
                                                 ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_stage_combine_multi_dev": (ctypes.c_int, [ctypes.POINTER(MultiOut), ctypes.c_int, ctypes.c_void_p,
+                                                    ctypes.c_void_p, _c_void_pp, ctypes.c_int, ctypes.c_void_p,
+                                                    ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_stage_combine_multi_timed": (ctypes.c_int, [ctypes.POINTER(MultiOut), ctypes.c_int, ctypes.c_void_p,
                                                       ctypes.c_void_p, _c_void_pp, ctypes.c_int, ctypes.c_double,
                                                       ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -403,6 +406,18 @@ class HipKernels:
                 arr[o].add_y0 = 1 if add_y0 else 0
             per_thread[rows] = arr
         return arr
+
+    def stage_combine_multi_dev(self, outs, rows, y0, acc_in, ks, plan: "NormPlan") -> None:
+        """`stage_combine_multi` with the step size read on the device from the plan's controller words (hipGraph mode)."""
+        n = len(ks)
+        ptrs = (ctypes.c_void_p * n)(*[k.data_ptr() for k in ks])
+        spec = self.multi_spec(rows)
+        for o, t in enumerate(outs):
+            spec[o].out = t.data_ptr()
+        _check(self.lib.tdeq_stage_combine_multi_dev(spec, len(outs), y0.data_ptr(),
+                                                     None if acc_in is None else acc_in.data_ptr(), ptrs, n,
+                                                     plan.ctrl_dev.data_ptr(), y0.numel(), dtype_code(y0.dtype),
+                                                     self._stream()), "tdeq_stage_combine_multi_dev")
 
     def stage_combine_multi(self, outs, rows, y0, acc_in, ks, dt: float, events=None) -> None:
         """One pass over the stages `ks` producing len(outs) tensors (tdeq_stage_combine_multi): output o =

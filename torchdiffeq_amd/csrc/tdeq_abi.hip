@@ -152,8 +152,9 @@ int dispatch_combine(void* out, const void* y0, const void* const* k, const doub
 template <typename T, int NT>
 int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
                          const void* const* k, double dt, int64_t n, hipStream_t s, hipEvent_t ev_start = nullptr,
-                         hipEvent_t ev_stop = nullptr) {
+                         hipEvent_t ev_stop = nullptr, const double* dt_dev = nullptr) {
     MultiArgs<T, NT> a;
+    a.dt_dev = dt_dev;
     a.y0 = static_cast<const T*>(y0);
     a.acc_in = static_cast<const T*>(acc_in);
     bool vec = aligned16(y0) && aligned16(acc_in);
@@ -168,7 +169,8 @@ int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, 
         a.out[o] = live ? static_cast<T*>(outs[o].out) : nullptr;
         a.mask[o] = live ? outs[o].mask : 0u;
         if (live && outs[o].add_y0) a.add_y0 |= 1u << o;
-        for (int j = 0; j < NT; ++j) a.c[o][j] = live ? (T)outs[o].coef[j] * dtT : (T)0;   // rk_common.py:79,201-205
+        for (int j = 0; j < NT; ++j)      // rk_common.py:79,201-205 (dt from device memory: the kernel multiplies)
+            a.c[o][j] = !live ? (T)0 : (dt_dev ? (T)outs[o].coef[j] : (T)outs[o].coef[j] * dtT);
         if (live) vec = vec && aligned16(outs[o].out);
     }
     a.n_out = n_out;
@@ -185,9 +187,9 @@ int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, 
 template <typename T>
 int dispatch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
                            const void* const* k, int nt, double dt, int64_t n, hipStream_t s, hipEvent_t e0 = nullptr,
-                           hipEvent_t e1 = nullptr) {
+                           hipEvent_t e1 = nullptr, const double* dt_dev = nullptr) {
     switch (nt) {
-#define TDEQ_CASE(N) case N: return launch_combine_multi<T, N>(outs, n_out, y0, acc_in, k, dt, n, s, e0, e1);
+#define TDEQ_CASE(N) case N: return launch_combine_multi<T, N>(outs, n_out, y0, acc_in, k, dt, n, s, e0, e1, dt_dev);
         TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
         TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
 #undef TDEQ_CASE
@@ -917,7 +919,7 @@ int tdeq_stage_combine_err(void* out, void* err_out, const void* y0, const void*
 
 static int combine_multi_checked(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
                                  const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream,
-                                 void* e0, void* e1) {
+                                 void* e0, void* e1, const double* dt_dev = nullptr) {
     if (!outs || !y0 || !k || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS || n_out < 1 || n_out > TDEQ_MAX_MULTI_OUT) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
@@ -927,13 +929,20 @@ static int combine_multi_checked(const tdeq_multi_out* outs, int n_out, const vo
     }
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return dtype == TDEQ_F32 ? dispatch_combine_multi<float>(outs, n_out, y0, acc_in, k, n_terms, dt, n, s, static_cast<hipEvent_t>(e0), static_cast<hipEvent_t>(e1))
-                             : dispatch_combine_multi<double>(outs, n_out, y0, acc_in, k, n_terms, dt, n, s, static_cast<hipEvent_t>(e0), static_cast<hipEvent_t>(e1));
+    return dtype == TDEQ_F32 ? dispatch_combine_multi<float>(outs, n_out, y0, acc_in, k, n_terms, dt, n, s, static_cast<hipEvent_t>(e0), static_cast<hipEvent_t>(e1), dt_dev)
+                             : dispatch_combine_multi<double>(outs, n_out, y0, acc_in, k, n_terms, dt, n, s, static_cast<hipEvent_t>(e0), static_cast<hipEvent_t>(e1), dt_dev);
 }
 
 int tdeq_stage_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
                              const void* const* k, int n_terms, double dt, int64_t n, int dtype, void* stream) {
     return combine_multi_checked(outs, n_out, y0, acc_in, k, n_terms, dt, n, dtype, stream, nullptr, nullptr);
+}
+
+int tdeq_stage_combine_multi_dev(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,
+                                 const void* const* k, int n_terms, const double* ctrl_dev, int64_t n, int dtype,
+                                 void* stream) {
+    if (!ctrl_dev) return TDEQ_EINVAL;
+    return combine_multi_checked(outs, n_out, y0, acc_in, k, n_terms, 0.0, n, dtype, stream, nullptr, nullptr, ctrl_dev);
 }
 
 int tdeq_stage_combine_multi_timed(const tdeq_multi_out* outs, int n_out, const void* y0, const void* acc_in,

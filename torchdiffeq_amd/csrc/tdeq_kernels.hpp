@@ -216,10 +216,11 @@ struct MultiArgs {
     uint32_t add_y0;                  // bit o: out_o = y0 + s_o
     int n_out;
     int64_t n;
+    const double* dt_dev;             // non-null (hipGraph mode): c[][] holds fl_T(coef) and is multiplied by T(dt_dev[1]) here
 };
 
 template <typename T, int NT, typename E>
-__device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, int64_t i) {
+__device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int64_t i) {
     const E* __restrict__ y0 = reinterpret_cast<const E*>(a.y0);
     E kk[NT];
 #pragma unroll
@@ -236,7 +237,8 @@ __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, int64_t i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if ((m >> j) & 1u) {
-                    const E p = kk[j] * a.c[o][j];
+                    const T cj = a.dt_dev ? a.c[o][j] * dtT : a.c[o][j];     // fl_T(fl_T(coef) * T(dt)) either way
+                    const E p = kk[j] * cj;
                     s = started ? s + p : p;
                     started = true;
                 }
@@ -252,10 +254,11 @@ __global__ __launch_bounds__(kBlock) void stage_combine_multi_kernel(const Multi
     constexpr int L = VEC ? VecOf<T>::L : 1;
     const int64_t ne = a.n / L;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) multi_elem<T, NT, E>(a, i);
+    const T dtT = a.dt_dev ? (T)a.dt_dev[1] : (T)1;          // ctrl_dev[1] = sign * T(dt) of the device-resident controller
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) multi_elem<T, NT, E>(a, dtT, i);
     if (VEC) {   // scalar tail (n % L elements)
         const int64_t t = ne * L + threadIdx.x;
-        if (blockIdx.x == 0 && t < a.n) multi_elem<T, NT, T>(a, t);
+        if (blockIdx.x == 0 && t < a.n) multi_elem<T, NT, T>(a, dtT, t);
     }
 }
 

@@ -386,6 +386,39 @@ class _GraphStep:
         kern.stage_combine_dev(yi, None, y_cur, [f_cur], beta[0].coef, None, plan)
         k.append(func.eval_at(self.ts[0], yi))
         n_rows = len(beta)
+        carry = s._carry if hasattr(kern, "stage_combine_multi_dev") else None
+        if carry is not None:
+            # planned launches (tableaus.carry_plan) with the step size read on the device: same stage inputs, fewer
+            # bytes and — dopri8 — one node fewer per captured step
+            held, R = {}, len(carry.ops)
+            for i in range(1, R):
+                op = carry.ops[i]
+                row = beta[i] if i < n_rows else s._c_sol
+                if op is None:
+                    yi = held.pop(i)
+                elif len(op.targets) == 1 and not op.continues:
+                    yi = y1 if i == R - 1 else torch.empty_like(y_cur)
+                    kern.stage_combine_dev(yi, None, y_cur, [k[j] for j in row.idx], row.coef, None, plan)
+                elif op.targets == (i, R) and i == R - 1 and not op.continues and op.idx == row.idx:
+                    yi, held[R] = y1, epart
+                    kern.stage_combine_dev(yi, epart, y_cur, [k[j] for j in row.idx], row.coef, fuse[0], plan)
+                else:
+                    # the step's solution (launch row R - 1) and the partial error go to the static buffers
+                    outs = [y1 if t == R - 1 else (epart if t == R else torch.empty_like(y_cur)) for t in op.targets]
+                    kern.stage_combine_multi_dev(outs, op.spec, y_cur, held.pop(i) if op.continues else None,
+                                                 [k[j] for j in op.idx], plan)
+                    yi = outs[0]
+                    for tgt, buf in zip(op.targets[1:], outs[1:]):
+                        held[tgt] = buf
+                if i < n_rows:
+                    k.append(func.eval_at(self.ts[i], yi))
+            assert held.pop(R) is epart and not held
+            kern.error_norm_partial_ctrl(plan, epart, y_cur, y1, [k[j] for j in carry.err_idx], carry.err_coef, 0.0,
+                                         s._ctrl, self.tbuf, state_in_dev=True)
+            if side == 1:
+                self.f0.copy_(k[-1])
+            self.k[side] = k
+            return
         for i in range(1, n_rows):
             row = beta[i]
             ks = [k[j] for j in row.idx]
