@@ -203,3 +203,34 @@ def test_plan_is_used_by_the_no_grad_solve(cpu_backend, monkeypatch):
     n = len(calls)
     _solve("dopri8", torch.float64, "cpu", False, monkeypatch, 1e-8, 1e-10)
     assert len(calls) == n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dopri5", "dopri8", "tsit5"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [7, 1023, (1 << 17) + 5])
+def test_multi_with_the_step_size_on_the_device_equals_host_dt(hip_kernels, name, dtype, n):
+    """tdeq_stage_combine_multi_dev (captured steps: dt = ctrl_dev[1], read by the kernel) against the host-dt entry
+    point on every planned launch of the tableau: bit-identical outputs."""
+    tab = tb.ADAPTIVE_TABLEAUS[name]
+    plan = tb.carry_plan(name)
+    dev = torch.device("cuda:0")
+    T_ = np.float32 if dtype == torch.float32 else np.float64
+    dt = -0.0371
+    y0 = _rand(n, dtype, 1).to(dev)
+    ks = [_rand(n, dtype, 10 + j).to(dev) for j in range(len(tab.beta) + 1)]
+    nplan = hip_kernels.make_plan([(0, n, 1e-3, 1e-6)], n, 1024, dev)
+    nplan.ctrl_dev.copy_(torch.tensor([1.0, float(T_(dt)), 0.0, abs(dt)], dtype=torch.float64))
+    acc = _rand(n, dtype, 99).to(dev)
+    checked = 0
+    for op in plan.ops:
+        if op is None:
+            continue
+        a = [torch.empty_like(y0) for _ in op.targets]
+        b = [torch.empty_like(y0) for _ in op.targets]
+        hip_kernels.stage_combine_multi(a, op.spec, y0, acc if op.continues else None, [ks[j] for j in op.idx], dt)
+        hip_kernels.stage_combine_multi_dev(b, op.spec, y0, acc if op.continues else None, [ks[j] for j in op.idx], nplan)
+        for x, y in zip(a, b):
+            assert torch.equal(_bits(x), _bits(y)), (name, op.row)
+        checked += 1
+    assert checked >= 5
