@@ -94,6 +94,19 @@ def main():
         y_lock = tdist.odeint_sharded(f, y0, t, group=dist.group.WORLD, sync_steps=True, rtol=1e-6, atol=1e-8)
     assert calls["n"] > n0
     assert torch.allclose(y_plain, y_lock, rtol=1e-5, atol=1e-6)
+    # (4) captured trial steps in a process that HAS a live RCCL communicator: its watchdog thread issues HIP calls of
+    #     its own, which a "global" capture would be invalidated by (solvers._capture uses thread_local); a failed
+    #     capture would fall back to the eager path with a warning — turned into an error here
+    import warnings
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        y_eager = tda.odeint(f, y0, t, rtol=1e-6, atol=1e-8)
+        for _ in range(3):
+            y_graph = tda.odeint(f, y0, t, rtol=1e-6, atol=1e-8, options=dict(hip_graph=True))
+            assert torch.equal(y_eager, y_graph)
+    x = torch.ones(8, device=dev)
+    dist.all_reduce(x)              # ... and the communicator still works after the captures
+    assert float(x.sum()) == 8.0
     torch.cuda.synchronize()
     dist.destroy_process_group()
     print("RCCL_WORLD1_OK", calls)

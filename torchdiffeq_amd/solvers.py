@@ -258,10 +258,14 @@ def _capture(graph, pool=None):
     gc.disable()
     try:
         with torch.cuda.stream(side):
-            if pool is None:
-                graph.capture_begin()
-            else:
-                graph.capture_begin(pool=pool)      # same private memory pool as a graph that never runs concurrently
+            # capture_error_mode "thread_local": only THIS thread's calls are held to the capture rules.  Under the
+            # default ("global") a HIP call from any other thread during the capture is an error that invalidates it —
+            # and a process with an RCCL process group has such a thread (the communicator's watchdog polls events):
+            # every rank of a multi-GPU run would lose its capture at random.
+            kw = {"capture_error_mode": "thread_local"}
+            if pool is not None:
+                kw["pool"] = pool                   # same private memory pool as a graph that never runs concurrently
+            graph.capture_begin(**kw)
             try:
                 yield
             finally:
