@@ -391,7 +391,7 @@ def test_stage_combine_timed_same_result_and_plausible_time(hip_kernels):
     # lower bound: the algorithmic bytes at 3x the 8 TB/s HBM peak — at this size (7 x 16 MB) the streams were just
     # written and sit in the 256 MiB Infinity Cache, so the launch may beat the HBM rate (seen: 0.97x the HBM-peak time)
     floor_ms = (len(sel) + 2) * n * 4 / (3 * 8.0e12) * 1e3
-    assert floor_ms < ms <= bracket * 1.05, (floor_ms, ms, bracket)
+    assert floor_ms < ms <= bracket * 1.25, (floor_ms, ms, bracket)      # slack: clocks ramp between the two
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
