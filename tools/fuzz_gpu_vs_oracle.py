@@ -81,6 +81,8 @@ for case in range(n_cases):
                 return (ya * (tt * 0.5 - 1.0) * self.a - ya * ya * ya * 0.1 + yb.sum() * 0.01, yb * (-0.5) * (1.0 + tt))
             return y * (tt * 0.5 - 1.0) * self.a - y * y * y * 0.1
 
+    if case % 10 == 0:
+        print("case", case, flush=True)        # progress: a timeout then shows where (blow-up cases take minutes)
     results = []
     for dev, hg, look in (("cpu", None, "1"), ("cuda", None, "1"), ("cuda", None, "0"), ("cuda", graph, "1")):
         if dev == "cuda" and hg is None and look == "1" and False:
