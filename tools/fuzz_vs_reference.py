@@ -1,6 +1,6 @@
 """Differential fuzzing against the reference (build container only: imports /root/reference).
 
-  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event} [seed] [cases]
+  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex} [seed] [cases]
   (TDEQ_FUZZ_BACKEND=host: the product's torch-op host path for CPU states instead of the oracle test backend)
 
 Random states (0-dim .. 3-dim, tuples), dtypes, time grids (both directions), options and methods are solved by the
@@ -303,5 +303,68 @@ elif mode == "event":
         dt=abs(float(a[1])-float(b[1])); dy=float((a[2]-b[2]).abs().max())
         if dt>tol or dy>tol or a[2].dtype!=b[2].dtype or a[1].dtype!=b[1].dtype: bad+=1; print('VALUE',desc,dt,dy,a[1].dtype,b[1].dtype)
     print('done',n,'bad',bad)
+elif mode == "complex":
+    # r03: complex states (host path; the reference supports them on the CPU): every explicit method + both Adams,
+    # tuples, reverse time, adjoint gradients.  Fixed-grid results bit for bit, adaptive 1e-9 (complex128) / 2e-5.
+    rng = random.Random(int(sys.argv[1]))
+    n = int(sys.argv[2])
+    M=['euler','midpoint','heun2','heun3','rk4','explicit_adams','implicit_adams','dopri5','dopri8','tsit5','bosh3','fehlberg2','adaptive_heun']
+    bad=0
+    for case in range(n):
+        method=rng.choice(M); cd=rng.choice([torch.complex64,torch.complex128])
+        rd=torch.float32 if cd==torch.complex64 else torch.float64
+        shape=rng.choice([(),(1,),(3,),(2,3)]); is_tuple=rng.random()<0.25; rev=rng.random()<0.4
+        npts=rng.choice([2,3,6]); adj=rng.random()<0.3 and method in('dopri5','rk4','bosh3','euler')
+        g=torch.Generator().manual_seed(rng.randrange(10**6))
+        y0=torch.randn(shape,generator=g,dtype=torch.complex128).to(cd)
+        y0b=torch.randn(2,generator=g,dtype=torch.float64).to(rd)
+        t=torch.sort(torch.rand(npts,generator=g,dtype=torch.float64)).values.to(rd)
+        if float((t[1:]-t[:-1]).min())<1e-3: continue
+        if rev: t=t.flip(0)
+        w=complex(rng.choice([-0.5,0.2]),rng.choice([1.0,3.0]))
+        opts={}
+        if method in M[:7]:
+            if rng.random()<0.5: opts['step_size']=rng.choice([0.05,0.013])
+            if rng.random()<0.2: opts['perturb']=True
+            if rng.random()<0.3: opts['interp']='cubic'
+        else:
+            if rng.random()<0.2: opts['first_step']=0.05
+            if rng.random()<0.2: opts['max_step']=0.1
+        class F(torch.nn.Module):
+            def __init__(s):
+                super().__init__(); s.w=torch.nn.Parameter(torch.tensor(w,dtype=cd))
+            def forward(s,tt,y):
+                if is_tuple:
+                    a,b=y; return (a*s.w*(1+0.3*tt)-0.1*a*a.abs()**2 + b.sum()*0.05, -b*0.5)
+                return y*s.w*(1+0.3*tt)-0.1*y*y.abs()**2
+        res=[]
+        for lib in (ref,tda):
+            f=F(); x=y0.clone().requires_grad_(adj)
+            st=(x,y0b) if is_tuple else x
+            try:
+                if adj:
+                    out=lib.odeint_adjoint(f,st,t,method=method,options=dict(opts) or None,rtol=1e-7,atol=1e-9)
+                    o=out[0] if is_tuple else out
+                    o[-1].abs().pow(2).sum().backward()
+                    res.append(('ok',[o.detach(),x.grad,f.w.grad]))
+                else:
+                    with torch.no_grad(): out=lib.odeint(f,st,t,method=method,options=dict(opts) or None,rtol=1e-7,atol=1e-9)
+                    res.append(('ok',list(out) if is_tuple else [out]))
+            except Exception as e:
+                res.append(('err',type(e).__name__+': '+str(e)[:90]))
+        a,b=res; desc=(case,method,str(cd)[6:],shape,is_tuple,rev,npts,adj,opts)
+        if a[0]!=b[0]: bad+=1; print('STATUS',desc,a[1] if a[0]=='err' else 'ok',b[1] if b[0]=='err' else 'ok'); continue
+        if a[0]=='err':
+            if a[1].split(':')[0]!=b[1].split(':')[0]: bad+=1; print('ERRTYPE',desc,a[1],b[1])
+            continue
+        fixed=method in M[:7]
+        tol=(0.0 if fixed and not adj else (2e-5 if cd==torch.complex64 else 1e-9))
+        for i,(p,q) in enumerate(zip(a[1],b[1])):
+            if p.dtype!=q.dtype or p.shape!=q.shape: bad+=1; print('TYPE',desc,i,p.dtype,q.dtype); break
+            fin=torch.isfinite(p.abs())&torch.isfinite(q.abs())
+            if bool((torch.isfinite(p.abs())!=torch.isfinite(q.abs())).any()): bad+=1; print('NONFINITE',desc,i); break
+            d=float((p-q)[fin].abs().max()/(p[fin].abs().max()+1e-30)) if fin.any() else 0.0
+            if not d<=tol: bad+=1; print('VALUE',desc,i,d); break
+    print('done',n,'bad',bad)
 else:
-    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event")
+    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex")
