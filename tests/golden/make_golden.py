@@ -9,6 +9,7 @@ Every array stored here is an output of rtqichen/torchdiffeq v0.2.5 functions on
 to them), so the CPU oracle (oracle/) and the HIP path can be pinned to the reference without the
 reference being present.  Nothing from the reference's source is copied — only its numerical outputs.
 """
+import math
 import os
 import sys
 
@@ -923,10 +924,72 @@ def gen_eager_pin():
     save("eager_pin.npz", **arrays)
 
 
+def gen_dropin():
+    """Found by running the reference's own test suite against the package (tools/run_reference_tests.py, r03):
+    (1) a 0-dim fp32 state under the Adams methods while something requires grad (fixed_adams.py:205-216: the 0-dim x
+    0-dim products promote to fp64 whether or not autograd records) — solution, gradients and the event time of the
+    unstable explicit-Adams run of event_tests.py:14-49; (2) what a norm placed in `grad_fn.adjoint_options['norm']`
+    is called with when the forward state is a tuple (norm_tests.py:155-191): (t, y, adj_y, *adj_params) with y and
+    adj_y FLAT."""
+    arrays = {}
+    for method in ("explicit_adams", "implicit_adams"):
+        for tag, tdtype in (("t32", torch.float32), ("t64", torch.float64)):
+            w = torch.tensor(0.7, requires_grad=True)
+            x = torch.tensor(1.3, requires_grad=True)
+            t = torch.linspace(0.0, 0.5, 26, dtype=tdtype).requires_grad_(True)
+            y = torchdiffeq.odeint(lambda t_, y_: -y_ * w * (1 + t_) + torch.sin(3 * t_), x, t, method=method)
+            y[-1].backward()
+            key = f"adams0_{method}_{tag}"
+            arrays[f"{key}_y"], arrays[f"{key}_gx"], arrays[f"{key}_gt"], arrays[f"{key}_gw"] = y.detach(), x.grad, t.grad, w.grad
+    # event_tests.py: the sine problem (problems.py:27-37), fp32, 0-dim, explicit Adams at step 0.01 (diverging run: the
+    # event time is decided by rounding — 2.3979 in the reference)
+    class Sine(torch.nn.Module):
+        def forward(self, t_, y_):
+            return 2 * y_ / t_ + t_ ** 4 * torch.sin(2 * t_) - t_ ** 2 + 4 * t_ ** 3
+
+        def y_exact(self, t_):
+            return -0.5 * t_ ** 4 * torch.cos(2 * t_) + 0.5 * t_ ** 3 * torch.sin(2 * t_) + 0.25 * t_ ** 2 * torch.cos(
+                2 * t_) - t_ ** 3 + 2 * t_ ** 4 + (math.pi - 0.25) * t_ ** 2
+    f = Sine()
+    t_points = torch.linspace(1, 8, 10, dtype=torch.float64)
+    sol = f.y_exact(t_points).to(torch.float32)
+    y0 = sol[0]
+    event_fn = lambda t_, y_: torch.sum(y_ - sol[2]).real
+    et, ys = torchdiffeq.odeint(f, y0, t_points[0:2], event_fn=event_fn, method="explicit_adams",
+                                options={"step_size": 0.01, "interp": "cubic"})
+    arrays["sine_t_points"], arrays["sine_sol"] = t_points, sol
+    arrays["sine_event_t"], arrays["sine_event_y"] = et.detach(), ys.detach()
+
+    # (2) tuple forward state: the tuples a replaced adjoint norm receives in the backward solve
+    g = torch.Generator().manual_seed(3)
+    p1 = torch.rand(7, generator=g).requires_grad_(True)
+    p2 = torch.rand((), generator=g).requires_grad_(True)
+    x0 = (torch.tensor(1.0), torch.tensor([[0.5, 0.5], [0.1, 0.1]]))
+    for tag, kw in (("default", {}), ("seminorm", dict(adjoint_options=dict(norm="seminorm")))):
+        xs = torchdiffeq.odeint_adjoint(lambda t_, x_: (x_[0] * p2, x_[1] * p1[:4].reshape(2, 2)), x0,
+                                        torch.tensor([0.0, 1.0]), adjoint_params=(p1, p2), **kw)
+        opts = xs[0].grad_fn.next_functions[0][0].next_functions[0][0].adjoint_options
+        auto = opts["norm"]
+        seen = []
+
+        def spy(tensors):
+            seen.append(([tuple(v.shape) for v in tensors], float(auto(tensors))))
+            return auto(tensors)
+        opts["norm"] = spy
+        (xs[0].sum() + xs[1].sum()).backward()
+        arrays[f"adjnorm_{tag}_n_entries"] = np.array([len(sh) for sh, _ in seen])
+        arrays[f"adjnorm_{tag}_y_numel"] = np.array([int(np.prod(sh[1])) for sh, _ in seen])
+        arrays[f"adjnorm_{tag}_first_values"] = np.array([v for _, v in seen[:3]])
+        arrays[f"adjnorm_{tag}_gp1"], arrays[f"adjnorm_{tag}_gp2"] = p1.grad.clone(), p2.grad.clone()
+        p1.grad = p2.grad = None
+    arrays["adjnorm_p1"], arrays["adjnorm_p2"] = p1.detach(), p2.detach()
+    save("dropin.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
                      ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
-                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin)]:
+                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin), ("dropin", gen_dropin)]:
         if not only or name in only:
             fn()

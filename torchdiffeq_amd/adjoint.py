@@ -232,8 +232,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
             for name, adj_name in zip(ALL_CALLBACK_NAMES, ALL_ADJOINT_CALLBACK_NAMES):
                 cb = getattr(fwd, adj_name, None)
                 if cb is not None:
-                    def wrapped(t0, y0, dt, _cb=cb, _lay=aug_layout):
-                        return _cb(-t0, _lay.unpack(y0), dt)
+                    def wrapped(t0, y0, dt, _cb=cb, _lay=aug_layout, _fwd=fwd_layout):
+                        return _cb(-t0, _reference_state(_lay, _fwd, y0), dt)
                     setattr(aug_func, name, wrapped)
 
             # ---- options of the nested solve (time is reversed: misc.py:273-293) ----
@@ -277,8 +277,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
                 group = None          # nothing left to reduce at the end
             norm = options.get("norm")
             if not isinstance(norm, BuiltinNorm):
-                def _user_norm(flat, _norm=norm, _lay=aug_layout):
-                    return _norm(_lay.unpack(flat))
+                def _user_norm(flat, _norm=norm, _lay=aug_layout, _fwd=fwd_layout):
+                    return _norm(_reference_state(_lay, _fwd, flat))
                 options["norm"] = _user_norm
             for key in ("step_t", "jump_t"):
                 if isinstance(options.get(key), torch.Tensor):
@@ -377,31 +377,86 @@ def find_parameters(module):
     return [tensor for _, tensor in module._named_members(get_members_fn=grad_attrs)]
 
 
+def _reference_state(aug_layout: StateLayout, fwd_layout: StateLayout, flat: torch.Tensor):
+    """The backward solve's state the way the reference shows it to norms and callbacks: `(t, y, adj_y, *θ-adjoints)`
+    (adjoint.py:64-65).  `odeint_adjoint` flattens a TUPLE forward state before its autograd Function sees it
+    (adjoint.py:200-201), so y and adj_y are then ONE 1-D tensor each — a tensor state keeps its shape."""
+    parts = aug_layout.unpack(flat)
+    if not fwd_layout.is_tuple:
+        return parts
+    n_y = fwd_layout.n_seg
+    joined = lambda comps: torch.cat([c.reshape(-1) for c in comps])
+    return (parts[0], joined(parts[1:1 + n_y]), joined(parts[1 + n_y:1 + 2 * n_y])) + tuple(parts[1 + 2 * n_y:])
+
+
+def _components(y: torch.Tensor, fwd_layout: StateLayout):
+    """Inverse of the flattening above: the components of a forward state given as `_reference_state` gives it."""
+    if not fwd_layout.is_tuple:
+        return (y,)
+    out, off = [], 0
+    for n, shape in zip(fwd_layout.numels, fwd_layout.shapes):
+        out.append(y[off:off + n].view(shape))
+        off += n
+    return tuple(out)
+
+
+def _rms(x: torch.Tensor) -> torch.Tensor:
+    return x.abs().pow(2).mean().sqrt()
+
+
+class AdjointBuiltinNorm(BuiltinNorm):
+    """The default adjoint norm / the seminorm (adjoint.py:246-270).  The solvers recognise it as built in and evaluate
+    it in the segmented norm kernel; CALLED — e.g. by a user who wraps `grad_fn.adjoint_options['norm']`
+    (norm_tests.py:97-111) — it takes the reference's `(t, y, adj_y, *θ-adjoints)` and applies the mixed norm to the
+    components of a tuple forward state, as the reference's `state_norm(y)` does."""
+
+    def __init__(self, fwd_layout: Optional[StateLayout], n_params: int, seminorm: bool):
+        super().__init__(n_skip_tail=n_params if seminorm else 0, name="adjoint-seminorm" if seminorm else "adjoint-mixed")
+        self.fwd_layout = fwd_layout
+        self.seminorm = seminorm
+
+    def __call__(self, tensors):
+        if isinstance(tensors, torch.Tensor) or self.fwd_layout is None:
+            return super().__call__(tensors)
+        t, y, adj_y, *adj_params = tensors
+        vals = [t.abs()] + [_rms(c) for c in _components(y, self.fwd_layout) + _components(adj_y, self.fwd_layout)
+                            if c.numel() > 0]
+        if not self.seminorm:
+            vals += [_rms(p) for p in adj_params if p.numel() > 0]
+        return max(vals)
+
+
 def handle_adjoint_norm_(adjoint_options, n_params: int, state_norm=None, layout: Optional[StateLayout] = None) -> None:
     """Choose the adjoint norm in place (adjoint.py:243-288): default = mixed norm over
     (vjp_t, y, adj_y, every θ-adjoint); 'seminorm' drops the θ-adjoints; a callable is the user's.
     `state_norm` = the forward solve's norm when that is a USER callable (wrapped by check_inputs: flat forward
-    state -> scalar): the default and the seminorm then apply it to y and adj_y, as the reference does."""
+    state -> scalar): the default and the seminorm then apply it to y and adj_y, as the reference does.
+    Whatever ends up in `adjoint_options['norm']` is called with the reference's `(t, y, adj_y, *θ-adjoints)`
+    (`_reference_state`); the USER's own norm sees the components of a tuple state instead (adjoint.py:271-288)."""
     norm = adjoint_options.get("norm")
     user_state_norm = state_norm is not None and not isinstance(state_norm, BuiltinNorm)
+    is_tuple = layout is not None and layout.is_tuple
     if norm is not None and not isinstance(norm, str):
+        if is_tuple and not isinstance(norm, BuiltinNorm):
+            def _on_components(tensors, _norm=norm, _lay=layout):
+                t, y, adj_y, *adj_params = tensors
+                return _norm((t, *_components(y, _lay), *_components(adj_y, _lay), *adj_params))
+            adjoint_options["norm"] = _on_components
         return                                              # the user's own adjoint norm
     if isinstance(norm, str) and norm != "seminorm":
         raise ValueError(f"Unknown adjoint norm '{norm}'")
     seminorm = norm == "seminorm"
     if not user_state_norm:
-        adjoint_options["norm"] = BuiltinNorm(n_skip_tail=n_params, name="adjoint-seminorm") if seminorm \
-            else BuiltinNorm(name="adjoint-mixed")
+        adjoint_options["norm"] = AdjointBuiltinNorm(layout, n_params, seminorm)
         return
-    n_y = layout.n_seg
 
     def _adjoint_norm(tensors, _state_norm=state_norm, _lay=layout, _seminorm=seminorm):
-        # (t, *y components, *adj_y components, *θ-adjoints): the user's state norm sees y and adj_y the way the
-        # forward solve hands them to it
-        t, ys, adj = tensors[0], tensors[1:1 + n_y], tensors[1 + n_y:1 + 2 * n_y]
-        vals = [t.abs(), _state_norm(_lay.pack(list(ys))), _state_norm(_lay.pack(list(adj)))]
+        # the user's state norm sees y and adj_y the way the forward solve hands them to it
+        t, y, adj_y, *adj_params = tensors
+        vals = [t.abs(), _state_norm(_lay.pack(list(_components(y, _lay)))),
+                _state_norm(_lay.pack(list(_components(adj_y, _lay))))]
         if not _seminorm:
-            vals += [p.abs().pow(2).mean().sqrt() for p in tensors[1 + 2 * n_y:] if p.numel() > 0]
+            vals += [_rms(p) for p in adj_params if p.numel() > 0]
         return max(vals)
 
     adjoint_options["norm"] = _adjoint_norm

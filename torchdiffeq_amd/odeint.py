@@ -106,7 +106,9 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
     if ci.layout.is_tuple:
         solution = ci.layout.unpack(solution, (len(ci.t),))
     else:
-        solution = solution.view(len(ci.t), *ci.layout.shapes[0])
+        # rows as the solver returned them (len(t) for every solver of this package; the SciPy wrapper hands back fewer
+        # when solve_ivp gives up early — the reference passes that through, odeint.py:98-101)
+        solution = solution.view(solution.shape[0], *ci.layout.shapes[0])
     if ci.event_fn is None:
         return solution
     return event_t, solution

@@ -1842,47 +1842,34 @@ class AdamsBashforthMoulton(FixedGridODESolver):
     def _step_zero_dim(self, t1, y0, f0, hist, order, dt64, sh):
         """The step for a 0-dim fp32 state with the reference's type promotion (fixed_adams.py:205-216): the history
         dot products and `dt * m0 * f` are formed in fp64 (0-dim fp64 coefficient x 0-dim fp32 derivative promotes) and
-        rounded to fp32 once.  Same kernels, on fp64 copies of the one-element tensors."""
-        func, kern = self.func, self.kernels
+        rounded to fp32 once.  Same kernels, on fp64 copies of the one-element tensors; through `ops`, so the step is
+        recorded for autograd when something requires grad (func's parameters, y0, t)."""
+        func, ops = self.func, self.ops
         sign = func.sign
+        dsh = sh.dt_signed()
+        wrt_dt = lambda dw: [(dsh, list(dw))] if dsh is not None else []
         bash, _ = adams_coefficients(order)
         h64 = [h.double() for h in hist]
+        dot64 = lambda coefs, sc=(): ops._long_sum(h64, list(coefs), list(sc)).float()     # left to right in fp64, one rounding
+        add = lambda a, b: ops.weighted_sum([a, b], [1.0, 1.0])
 
-        def dot64(coefs):            # left to right in fp64, then one rounding to fp32
-            acc = None
-            for lo in range(0, order, 7):
-                xs = ([acc] if acc is not None else []) + h64[lo:lo + 7]
-                ws = ([1.0] if acc is not None else []) + list(coefs[lo:lo + 7])
-                out = torch.empty_like(h64[0])
-                kern.weighted_sum(out, xs, ws)
-                acc = out
-            return acc.float()
-
-        def add(a, b):
-            out = torch.empty_like(a)
-            kern.weighted_sum(out, [a, b], [1.0, 1.0])
-            return out
-
-        dy = dot64([dt64 * b * sign for b in bash])
+        dy = dot64([dt64 * b * sign for b in bash], wrt_dt(bash))
         y = add(y0, dy)
         if not self.implicit:
             return y, f0
         _, moulton = adams_coefficients(order + 1)
-        sm = dot64(list(moulton[1:]))
-        delta = torch.empty_like(sm)
-        kern.weighted_sum(delta, [sm], [dt64 * sign])
+        delta = ops.weighted_sum([dot64(moulton[1:])], [dt64 * sign], wrt_dt([1.0]))
         if self._plan is None:
-            self._plan = kern.make_plan(self.layout.segments(self.rtol, self.atol), self.layout.total,
-                                        self.layout.chunk, self.device)
+            self._plan = self.kernels.make_plan(self.layout.segments(self.rtol, self.atol), self.layout.total,
+                                                self.layout.chunk, self.device)
         c = dt64 * moulton[0] * sign
+        last = self._last_perturb()
         converged = False
         for _ in range(self.max_iters):
-            f = func.eval(t1, y, self._last_perturb())
-            p64 = torch.empty_like(h64[0])
-            kern.weighted_sum(p64, [f.double()], [c])
-            dy_new = add(p64.float(), delta)
+            f = func.eval(t1, y, last, shadow=sh.time(1.0))
+            dy_new = add(ops.weighted_sum([f.double()], [c], wrt_dt([moulton[0]])).float(), delta)
             y = add(y0, dy_new)
-            kern.adams_correct(self._plan, dy_new, dy, compute=False)
+            self.kernels.adams_correct(self._plan, dy_new.detach(), dy.detach(), compute=False)
             dy = dy_new
             converged = self._converged()
             if converged:
@@ -1916,8 +1903,7 @@ class AdamsBashforthMoulton(FixedGridODESolver):
         dt64 = float(dt)
         bash, _ = adams_coefficients(order)
         hist = [self.prev_f[j] for j in range(order)]
-        if self._zero_dim_f32 and not (torch.is_grad_enabled() and (y0.requires_grad or hist[0].requires_grad
-                                                                     or sh is not _NO_SHADOW)):
+        if self._zero_dim_f32:
             return self._step_zero_dim(t1, y0, f0, hist, order, dt64, sh)
         cb = [dt64 * b * sign for b in bash]            # `dt * bashforth_coeffs` in fp64 (:205); the sign is exact
         dsh = sh.dt_signed()
