@@ -146,3 +146,32 @@ def test_scipy_wrapper_passes_a_short_solution_through():
                            method="scipy_solver", options=dict(solver="LSODA", min_step=2.0, max_step=5.0))
     assert full.shape == (10, 2)
     assert short.shape[1:] == (2,) and 1 <= short.shape[0] <= 10
+
+
+def test_flat_state_padding_is_zero_so_step_size_gradients_stay_finite(where, monkeypatch):
+    """examples/cnf.py without --adjoint (found by tools/run_reference_examples.py): tuple state, y0 without grad, func
+    parameters with grad.  The flat state pads every component to a chunk boundary; the kernels stream over the padding
+    and the gradient of the first step size is a dot product over the WHOLE flat vector (tdeq_multi_dot) — padding left
+    uninitialised by StateLayout.pack turned into NaN parameter gradients whenever the allocator handed back memory
+    holding NaNs.  Here every fresh `torch.empty` is poisoned to provoke exactly that."""
+    real_empty = torch.empty
+
+    def poisoned_empty(*args, **kw):
+        out = real_empty(*args, **kw)
+        if out.is_floating_point():
+            out.fill_(float("nan"))
+        return out
+    lin = torch.nn.Linear(3, 3).to(where)
+    x = torch.randn(5, 3)
+    logp = torch.zeros(5, 1)
+
+    def func(t_, state):
+        z, _ = state
+        dz = torch.tanh(lin(z)) * torch.cos(t_)
+        return dz, dz.sum(1, keepdim=True)
+    monkeypatch.setattr(torch, "empty", poisoned_empty)
+    z_t, l_t = tda.odeint(func, (x, logp), torch.tensor([1.0, 0.0]), rtol=1e-5, atol=1e-5, method="dopri5")
+    monkeypatch.setattr(torch, "empty", real_empty)
+    (z_t[-1].pow(2).sum() + l_t[-1].sum()).backward()
+    for p in lin.parameters():
+        assert torch.isfinite(p.grad).all()

@@ -21,8 +21,7 @@ assert "torchdiffeq" not in sys.modules
 sys.modules["torchdiffeq"] = torchdiffeq_amd
 sys.path.insert(0, REF_TESTS)
 sys.dont_write_bytecode = True          # /root/reference is read-only
-warnings.filterwarnings("ignore", category=torchdiffeq_amd.HostPathWarning if hasattr(torchdiffeq_amd, "HostPathWarning")
-                        else UserWarning)
+warnings.filterwarnings("ignore", category=torchdiffeq_amd.HostPathWarning)
 
 if __name__ == "__main__":
     import api_tests, event_tests, gradient_tests, norm_tests, odeint_tests  # noqa: E401,E402

@@ -9,6 +9,8 @@ include/tdeq_hip.h).
 from .odeint import SOLVERS, odeint, odeint_dense, odeint_event
 from .adjoint import odeint_adjoint
 from .solvers import clear_graph_cache
+from ._fallback import HostPathWarning
 
 __version__ = "0.1.0"
-__all__ = ["odeint", "odeint_adjoint", "odeint_event", "odeint_dense", "SOLVERS", "clear_graph_cache"]
+__all__ = ["odeint", "odeint_adjoint", "odeint_event", "odeint_dense", "SOLVERS", "clear_graph_cache",
+           "HostPathWarning"]

@@ -107,7 +107,9 @@ class StateLayout:
                 t = t.to(dtype)
             return t.reshape(-1).contiguous()
         first = tensors[0]
-        flat = torch.empty(self.total, dtype=dtype or first.dtype, device=first.device)
+        # padding zero-filled: every kernel streams over the padding as well, and the time-gradient dot products
+        # (tdeq_multi_dot: sum g x over the WHOLE flat vector) would turn a stray NaN there into a NaN gradient
+        flat = torch.zeros(self.total, dtype=dtype or first.dtype, device=first.device)
         for i, (t, off, n) in enumerate(zip(tensors, self.offsets, self.numels)):
             dst = flat[off:off + n]
             src = t.reshape(-1)
