@@ -134,18 +134,32 @@ def test_user_adjoint_norm_still_sees_the_components_of_a_tuple_state(where):
 
 def test_scipy_wrapper_passes_a_short_solution_through():
     """odeint_tests.py:251-268 with LSODA and min_step = 2: solve_ivp gives up after the first output; the reference
-    returns the rows it got (scipy_wrapper.py:43-51, odeint.py:98-101) instead of failing on the reshape."""
+    returns the rows it got (scipy_wrapper.py:43-51, odeint.py:98-101) instead of failing on the reshape.  In a
+    subprocess: ODEPACK reports the failure through Fortran's buffered stdout, which would otherwise land after pytest's
+    summary line."""
     pytest.importorskip("scipy")
-    A = torch.tensor([[-0.5, 2.0], [-2.0, -0.5]], dtype=torch.float64) * 4
-    t = torch.linspace(1.0, 8.0, 10, dtype=torch.float64)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        full = tda.odeint(lambda t_, y_: y_ @ A.T, torch.ones(2, dtype=torch.float64), t, method="scipy_solver",
-                          options=dict(solver="LSODA"))
-        short = tda.odeint(lambda t_, y_: y_ @ A.T * math.exp(3.0), torch.ones(2, dtype=torch.float64), t,
-                           method="scipy_solver", options=dict(solver="LSODA", min_step=2.0, max_step=5.0))
-    assert full.shape == (10, 2)
-    assert short.shape[1:] == (2,) and 1 <= short.shape[0] <= 10
+    import os
+    import subprocess
+    import sys
+    code = """
+import math, sys, warnings, torch
+sys.path.insert(0, %r)
+import torchdiffeq_amd as tda
+warnings.simplefilter("ignore")
+A = torch.tensor([[-0.5, 2.0], [-2.0, -0.5]], dtype=torch.float64) * 4
+t = torch.linspace(1.0, 8.0, 10, dtype=torch.float64)
+y0 = torch.ones(2, dtype=torch.float64)
+full = tda.odeint(lambda t_, y_: y_ @ A.T, y0, t, method="scipy_solver", options=dict(solver="LSODA"))
+short = tda.odeint(lambda t_, y_: y_ @ A.T * math.exp(3.0), y0, t, method="scipy_solver",
+                   options=dict(solver="LSODA", min_step=2.0, max_step=5.0))
+print("SHAPES", tuple(full.shape), tuple(short.shape))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("SHAPES")][0]
+    full_shape, short_shape = eval(line[len("SHAPES"):].replace(") (", "), ("))
+    assert full_shape == (10, 2)
+    assert short_shape[1:] == (2,) and 1 <= short_shape[0] <= 10
 
 
 def test_flat_state_padding_is_zero_so_step_size_gradients_stay_finite(where, monkeypatch):

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from ._native import device_guard
 from .misc import (ALL_ADJOINT_CALLBACK_NAMES, ALL_CALLBACK_NAMES, BuiltinNorm, OdeFunc, Perturb, StateLayout,
-                   check_inputs, pack_differentiable)
+                   check_inputs, pack_differentiable, plugin_solver_inputs)
 from .odeint import SOLVERS
 
 
@@ -176,8 +176,10 @@ class OdeintAdjointMethod(torch.autograd.Function):
         event_fn = cfg.get("event_fn")
         ctx.event_mode = event_fn is not None
         with torch.no_grad(), device_guard(y0_flat.device):
-            solver = SOLVERS[cfg["method"]](func=cfg["func"], y0=y0_flat.detach(), rtol=cfg["rtol"],
-                                            atol=cfg["atol"], **cfg["options"])
+            fwd_cls = SOLVERS[cfg["method"]]
+            fwd_options, fwd_rtol, fwd_atol = plugin_solver_inputs(fwd_cls, cfg["func"].layout, cfg["options"], cfg["rtol"],
+                                                                   cfg["atol"], y0_flat.device)
+            solver = fwd_cls(func=cfg["func"], y0=y0_flat.detach(), rtol=fwd_rtol, atol=fwd_atol, **fwd_options)
             if event_fn is None:
                 solution = solver.integrate(t)
                 ctx.save_for_backward(t, solution, *adjoint_params)
@@ -301,8 +303,10 @@ class OdeintAdjointMethod(torch.autograd.Function):
                         torch.distributed.all_reduce(dLd_cur_t, group=aug_func.sync_group)   # a sum over the batch
                     aug_views[0].sub_(dLd_cur_t)
                     time_vjps[i] = dLd_cur_t
-                solver = SOLVERS[ctx.adjoint_method](func=aug_func, y0=aug, rtol=ctx.adjoint_rtol,
-                                                     atol=ctx.adjoint_atol, **options)
+                bwd_cls = SOLVERS[ctx.adjoint_method]
+                bwd_options, bwd_rtol, bwd_atol = plugin_solver_inputs(bwd_cls, aug_layout, options, ctx.adjoint_rtol,
+                                                                       ctx.adjoint_atol, device)
+                solver = bwd_cls(func=aug_func, y0=aug, rtol=bwd_rtol, atol=bwd_atol, **bwd_options)
                 if aug_func.use_proxy and not getattr(solver, "hip_graph", False):
                     aug_func.use_proxy = False      # the solver runs eagerly after all (state too large, user norm ...):
                                                     # differentiate func directly, as without the option

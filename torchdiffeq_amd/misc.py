@@ -206,6 +206,37 @@ def _per_segment(tol, n_seg: int, name: str) -> List[float]:
     return vals
 
 
+def plugin_solver_inputs(solver_cls, layout: "StateLayout", options: dict, rtol, atol, device):
+    """`(options, rtol, atol)` for constructing `solver_cls`.  This package's own classes take them as they are.  Anything
+    else registered in `SOLVERS` that follows the reference's protocol `cls(func=, y0=, rtol=, atol=, **options)
+    .integrate(t)` (odeint.py:92, solvers.py:28) — the reference's own classes, a third party's — does its arithmetic with
+    torch ops on the flat state and calls `func(t, y, perturb=...)` / `norm(y)` / `func.callback_*` itself (OdeFunc
+    answers those calls).  What such a class cannot know is the flat layout of a TUPLE state here — components padded to
+    chunk boundaries, tolerances per component — so the built-in norm becomes a callable over the components and
+    per-component tolerances are expanded per element, as the reference's `_check_inputs` does (misc.py:237-254)."""
+    if getattr(solver_cls, "flat_state_native", False) or not layout.is_tuple:
+        return options, rtol, atol
+    options = dict(options)
+    norm = options.get("norm")
+    if isinstance(norm, BuiltinNorm):
+        def _component_norm(flat, _lay=layout, _skip=norm.n_skip_tail):
+            parts = [c for c in _lay.unpack(flat) if c.numel() > 0]
+            if _skip:
+                parts = parts[:len(parts) - _skip]
+            return max(c.abs().pow(2).mean().sqrt() for c in parts)
+        options["norm"] = _component_norm
+
+    def per_element(tol, name):
+        vals = _per_segment(tol, layout.n_seg, name)
+        if len(set(vals)) == 1:
+            return vals[0] if isinstance(tol, (list, tuple)) else tol
+        out = torch.full((layout.total,), vals[-1], dtype=torch.float64, device=device)
+        for off, n, v in zip(layout.offsets, layout.numels, vals):
+            out[off:off + n] = v
+        return out
+    return options, per_element(rtol, "rtol"), per_element(atol, "atol")
+
+
 # ---------------------------------------------------------------------------------------------------
 # func wrapper
 # ---------------------------------------------------------------------------------------------------
@@ -337,6 +368,10 @@ class OdeFunc:
 
     def __call__(self, t, y_flat, *, perturb: Perturb = Perturb.NONE):
         # Reference-style call: `t` is a 0-dim tensor in (negated) solver time.
+        if not isinstance(perturb, Perturb):
+            # a solver class written against ANOTHER copy of the enum (the reference's own classes work as plug-ins in
+            # SOLVERS): members are matched by name
+            perturb = Perturb.__members__.get(getattr(perturb, "name", None), perturb)
         return self.eval(float(t), y_flat, perturb) * self.sign if self.sign != 1.0 else \
             self.eval(float(t), y_flat, perturb)
 

@@ -5,7 +5,7 @@ from __future__ import annotations
 import torch
 
 from ._native import device_guard
-from .misc import check_inputs, pack_differentiable
+from .misc import check_inputs, pack_differentiable, plugin_solver_inputs
 from .implicit import (SDIRK2, TRBDF2, GaussLegendre4, GaussLegendre6, ImplicitEuler, ImplicitMidpoint, RadauIIA3,
                        RadauIIA5, Trapezoid)
 from .scipy_wrapper import ScipyWrapperODESolver
@@ -95,7 +95,10 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
         if any(y_.requires_grad for y_ in y0_list):
             y0_flat = pack_differentiable(ci.layout, y0_list)        # backprop through the solver (autodiff.py)
     with device_guard(y0_flat.device):       # kernels go to the state's device, whatever the caller's current one is
-        solver = SOLVERS[ci.method](func=ci.func, y0=y0_flat, rtol=ci.rtol, atol=ci.atol, **ci.options)
+        solver_cls = SOLVERS[ci.method]
+        # (a class someone registered in SOLVERS — plugin protocol, odeint.py:19-46 — gets inputs it can read)
+        options, rtol, atol = plugin_solver_inputs(solver_cls, ci.layout, ci.options, ci.rtol, ci.atol, y0_flat.device)
+        solver = solver_cls(func=ci.func, y0=y0_flat, rtol=rtol, atol=atol, **options)
         if ci.event_fn is None:
             solution = solver.integrate(ci.t)
         else:

@@ -16,6 +16,8 @@ from .misc import OdeFunc, handle_unused_kwargs
 
 
 class ScipyWrapperODESolver:
+    flat_state_native = True
+
     def __init__(self, func: OdeFunc, y0: torch.Tensor, rtol, atol, min_step=0, max_step=float("inf"),
                  solver="LSODA", **unused_kwargs):
         unused_kwargs.pop("norm", None)

@@ -555,6 +555,7 @@ class RKAdaptiveStepsizeODESolver:
     """Adaptive embedded RK pair driven from the host; subclasses set `order` and `tableau`."""
     order: int
     tableau: Tableau
+    flat_state_native = True         # takes the package's padded flat state / BuiltinNorm / per-segment tolerances (odeint.py)
 
     def __init__(self, func: OdeFunc, y0: torch.Tensor, rtol, atol, min_step=0, max_step=float("inf"),
                  first_step=None, step_t=None, jump_t=None, safety=0.9, ifactor=10.0, dfactor=0.2,
@@ -1296,6 +1297,7 @@ class FixedGridODESolver(object):
     outputs by linear (default) or cubic Hermite interpolation between grid points.  Time-like scalars
     keep `t.dtype` (no fp64 promotion in the fixed-grid path).  Subclasses implement `_step`."""
     order: int
+    flat_state_native = True
 
     def __init__(self, func: OdeFunc, y0: torch.Tensor, step_size=None, grid_constructor=None,
                  interp="linear", perturb=False, hip_graph=None, **unused_kwargs):
