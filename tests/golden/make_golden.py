@@ -983,6 +983,45 @@ def gen_dropin():
         arrays[f"adjnorm_{tag}_gp1"], arrays[f"adjnorm_{tag}_gp2"] = p1.grad.clone(), p2.grad.clone()
         p1.grad = p2.grad = None
     arrays["adjnorm_p1"], arrays["adjnorm_p2"] = p1.detach(), p2.detach()
+
+    # (3) a USER-DEFINED tableau on the reference's adaptive machinery (rk_common.py:15, :153-211): Cash–Karp 5(4), which
+    # is in neither library's table, written the way the reference's tableaus are (a closing stage at t1 whose row is the
+    # solution weights); the package's native solver takes the same table (tests/test_plugin_protocol.py)
+    from fractions import Fraction as Fr
+    alpha = [Fr(1, 5), Fr(3, 10), Fr(3, 5), Fr(1), Fr(7, 8)]
+    a = [[Fr(1, 5)], [Fr(3, 40), Fr(9, 40)], [Fr(3, 10), Fr(-9, 10), Fr(6, 5)],
+         [Fr(-11, 54), Fr(5, 2), Fr(-70, 27), Fr(35, 27)],
+         [Fr(1631, 55296), Fr(175, 512), Fr(575, 13824), Fr(44275, 110592), Fr(253, 4096)]]
+    b5 = [Fr(37, 378), 0, Fr(250, 621), Fr(125, 594), 0, Fr(512, 1771)]
+    b4 = [Fr(2825, 27648), 0, Fr(18575, 48384), Fr(13525, 55296), Fr(277, 14336), Fr(1, 4)]
+    alpha_f = [float(x) for x in alpha] + [1.0]
+    beta_f = [[float(x) for x in r] for r in a] + [[float(x) for x in b5]]
+    c_sol = [float(x) for x in b5] + [0.0]
+    c_err = [float(x - y) for x, y in zip(b5, b4)] + [0.0]
+    mid = [x / 2 for x in c_sol]            # cubic Hermite midpoint: (y0 + y1) / 2 + dt / 8 (f0 - f1)
+    mid[0] += 0.125
+    mid[-1] -= 0.125
+    f64 = lambda v: torch.tensor(v, dtype=torch.float64)
+
+    class RefCashKarp(rk_common.RKAdaptiveStepsizeODESolver):
+        order = 5
+        tableau = rk_common._ButcherTableau(alpha=f64(alpha_f), beta=[f64(r) for r in beta_f], c_sol=f64(c_sol),
+                                            c_error=f64(c_err))
+    RefCashKarp.mid = f64(mid)
+    from torchdiffeq._impl.odeint import SOLVERS as REF_SOLVERS
+    REF_SOLVERS["cashkarp"] = RefCashKarp
+    A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64)
+    y0 = torch.tensor([[2.0, 0.0], [1.0, 0.5]], dtype=torch.float64)
+    for tag, t in (("fwd", torch.linspace(0, 2, 7, dtype=torch.float64)), ("rev", torch.linspace(2, 0, 7, dtype=torch.float64))):
+        y, nfe, c = solve(lambda t_, y_: torch.tanh(y_ @ A) * torch.cos(t_), y0, t, method="cashkarp", rtol=1e-8, atol=1e-10)
+        arrays[f"cashkarp_{tag}_t"], arrays[f"cashkarp_{tag}_y"], arrays[f"cashkarp_{tag}_nfe"] = t, y, nfe
+        arrays[f"cashkarp_{tag}_accept_dt"] = np.array(c.accept)
+    del REF_SOLVERS["cashkarp"]
+    arrays["cashkarp_alpha"], arrays["cashkarp_c_sol"], arrays["cashkarp_c_err"], arrays["cashkarp_mid"] = \
+        np.array(alpha_f), np.array(c_sol), np.array(c_err), np.array(mid)
+    for i, r in enumerate(beta_f):
+        arrays[f"cashkarp_beta{i}"] = np.array(r)
+    arrays["cashkarp_A"], arrays["cashkarp_y0"] = A, y0
     save("dropin.npz", **arrays)
 
 
