@@ -365,8 +365,8 @@ def test_norm_receives_the_users_view_of_the_state(dev):
     assert seen
 
 
-# ---- norm_tests.py:99-236 test_adjoint_norm (tensor state; the tuple case digs through the reference's own
-#      autograd graph shape and is covered by the user-norm cases below) ---------------------------------------
+# ---- norm_tests.py:99-236 test_adjoint_norm (tensor state; the tuple-state half — reached through the views of the
+#      tuple output, flat y / adj_y — is tests/test_dropin_golden.py::test_tuple_state_adjoint_norm_calling_convention) ----
 @pytest.mark.parametrize("shape", [(), (1,), (2, 2)])
 @pytest.mark.parametrize("use_adjoint_options,seminorm", [(False, False), (True, False), (True, True)])
 def test_auto_adjoint_norm_is_a_callable_with_the_reference_semantics(dev, shape, use_adjoint_options, seminorm):
