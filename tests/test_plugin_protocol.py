@@ -207,3 +207,38 @@ def test_user_defined_tableau_on_the_native_solver(dev, direction):
         assert float((y.cpu() - T(z[f"cashkarp_{direction}_y"])).abs().max()) < 1e-11
     finally:
         del tda.SOLVERS["cashkarp"]
+
+
+def test_user_tableau_with_an_all_zero_error_row(dev):
+    """Found by the random-tableau fuzz (tools/fuzz_vs_reference.py tableau): an error row that estimates nothing is a
+    legal table — the reference's dense sum gives 0, every step is accepted and grows by `ifactor` (misc.py:86-95).  The
+    sparse rows keep one explicit zero term so that the kernels, which take >= 1 term, compute the same 0 * k_0."""
+    from torchdiffeq_amd.solvers import RKAdaptiveStepsizeODESolver
+    from torchdiffeq_amd.tableaus import SparseRow, Tableau
+    assert SparseRow.from_dense((0.0, 0.0, 0.0)) == SparseRow((0,), (0.0,))
+    b = (0.34516902151778417, 0.6548309784822158)
+    tab = Tableau("zeroerr", 2, (0.3, 1.0), ((0.3,), b), b + (0.0,), (0.0, 0.0, 0.0), (0.2975845107588921, 0.3274154892411079, -0.125))
+
+    class ZeroErr(RKAdaptiveStepsizeODESolver):
+        order = 2
+        tableau = tab
+    tda.SOLVERS["zeroerr"] = ZeroErr
+    try:
+        steps = []
+
+        class F(torch.nn.Module):
+            def forward(self, t_, y):
+                return -y * (1 + 0.3 * t_)
+
+            def callback_accept_step(self, t0, y_, dt):
+                steps.append(float(dt))
+
+            def callback_reject_step(self, t0, y_, dt):
+                raise AssertionError("a zero error estimate never rejects")
+        with torch.no_grad():
+            y = tda.odeint(F(), torch.linspace(0.5, 2.0, 17, dtype=torch.float64), torch.tensor([0.0, 0.3, 1.0], dtype=torch.float64),
+                           method="zeroerr", options=dict(first_step=0.02))
+        assert torch.isfinite(y).all() and y.shape == (3, 17)
+        assert steps[0] == pytest.approx(0.02) and all(b_ == pytest.approx(10 * a_) for a_, b_ in zip(steps, steps[1:]))
+    finally:
+        del tda.SOLVERS["zeroerr"]

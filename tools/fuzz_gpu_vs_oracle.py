@@ -33,8 +33,44 @@ _native.get_kernels = backend
 ADAPTIVE = ["dopri5", "dopri8", "tsit5", "bosh3", "fehlberg2", "adaptive_heun"]
 FIXED = ["euler", "midpoint", "heun2", "heun3", "rk4"]
 bad = 0
+def random_tableau_method(case):
+    """A random explicit embedded RK table (2..9 stages, structural zeros, FSAL or not) registered as a method of the
+    native adaptive solver: the kernels, the end-of-step fusion and the dense output are generic in the table."""
+    from torchdiffeq_amd.solvers import RKAdaptiveStepsizeODESolver
+    from torchdiffeq_amd.tableaus import Tableau
+    S = rng.randint(2, 9)
+    rnd = lambda: 0.0 if rng.random() < 0.25 else rng.uniform(-0.6, 0.9)
+    beta = [[rnd() for _ in range(i + 1)] for i in range(S)]
+    for r in beta:
+        if all(v == 0.0 for v in r):
+            r[0] = 0.3
+    alpha = [min(1.0, abs(sum(r))) for r in beta]
+    if rng.random() < 0.5:
+        alpha[-1] = 1.0
+        tot = sum(beta[-1])
+        beta[-1] = [v / tot for v in beta[-1]] if abs(tot) > 1e-3 else [1.0 / S] * S
+        c_sol = list(beta[-1]) + [0.0]
+    else:
+        w = [abs(rnd()) + 0.05 for _ in range(S + 1)]
+        c_sol = [v / sum(w) for v in w]
+    c_err = [rng.uniform(-1, 1) * 1e-2 * (rng.random() < 0.8) for _ in range(S + 1)]
+    if rng.random() < 0.3:
+        c_err = [c * 1e-2 for c in c_sol[:-1]] + [rng.uniform(-1, 1) * 1e-3]
+    c_err[0] -= sum(c_err)               # like a real pair: the two solutions agree to first order
+    mid = [0.5 * c for c in c_sol]
+    mid[0] += 0.125
+    mid[-1] -= 0.125
+    name = f"randtab{case}"
+    tda.SOLVERS[name] = type("RandTab", (RKAdaptiveStepsizeODESolver,), dict(order=rng.choice([2, 3, 5, 8]), tableau=Tableau(
+        name, 5, tuple(alpha), tuple(tuple(r) for r in beta), tuple(c_sol), tuple(c_err), tuple(mid))))
+    return name
+
+
 for case in range(n_cases):
     method = rng.choice(ADAPTIVE + FIXED)
+    if rng.random() < float(os.environ.get("FUZZ_RANDTAB", "0.15")):
+        method = random_tableau_method(case)
+        ADAPTIVE.append(method)
     shape = rng.choice([(), (1,), (5,), (3, 4), (33, 7), (1025,), (2, 3, 5)])
     is_tuple = rng.random() < 0.3
     rev = rng.random() < 0.4
@@ -67,6 +103,9 @@ for case in range(n_cases):
             opts["interp"] = "cubic"
     graph = rng.choice([None, True, "auto"]) if not (opts.get("step_t") is not None or opts.get("jump_t") is not None) else None
     kw = dict(rtol=rng.choice([1e-5, 1e-8]), atol=rng.choice([1e-7, 1e-10]))
+    if method.startswith("randtab"):
+        kw = dict(rtol=1e-4, atol=1e-5)          # an inconsistent random method converges nowhere: bound its step count
+        opts["max_num_steps"] = 2000
 
     class Field(torch.nn.Module):
         def __init__(self, dev):

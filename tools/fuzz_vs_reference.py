@@ -1,6 +1,6 @@
 """Differential fuzzing against the reference (build container only: imports /root/reference).
 
-  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex} [seed] [cases]
+  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau} [seed] [cases]
   (TDEQ_FUZZ_BACKEND=host: the product's torch-op host path for CPU states instead of the oracle test backend)
 
 Random states (0-dim .. 3-dim, tuples), dtypes, time grids (both directions), options and methods are solved by the
@@ -366,5 +366,84 @@ elif mode == "complex":
             d=float((p-q)[fin].abs().max()/(p[fin].abs().max()+1e-30)) if fin.any() else 0.0
             if not d<=tol: bad+=1; print('VALUE',desc,i,d); break
     print('done',n,'bad',bad)
+elif mode == "tableau":
+    # r03: RANDOM explicit embedded Runge-Kutta tableaus (2..9 stages, random structural zeros, FSAL or not, error row
+    # leading with the solution row or not) on this package's native adaptive solver against the reference's
+    # RKAdaptiveStepsizeODESolver given the same table — the kernels, the end-of-step fusion and the dense output are
+    # generic in the table.  Consistency of the method is irrelevant here (both libraries run the same arithmetic);
+    # evaluation counts must be equal and solutions agree to 1e-10.
+    from torchdiffeq._impl import rk_common as ref_rk
+    from torchdiffeq._impl.odeint import SOLVERS as REF_SOLVERS
+    from torchdiffeq_amd.solvers import RKAdaptiveStepsizeODESolver
+    from torchdiffeq_amd.tableaus import Tableau
+    rng = random.Random(int(sys.argv[1]))
+    n = int(sys.argv[2])
+    bad = 0
+    for case in range(n):
+        S = rng.randint(2, 9)
+        fsal = rng.random() < 0.5
+        def rnd(): return 0.0 if rng.random() < 0.25 else rng.uniform(-0.6, 0.9)
+        beta = [[rnd() for _ in range(i + 1)] for i in range(S)]
+        for r in beta:                      # rows sum to their abscissa, like a real method (keeps the problem tame)
+            if all(v == 0.0 for v in r): r[0] = 0.3
+        alpha = [min(1.0, abs(sum(r))) for r in beta]
+        if fsal:
+            alpha[-1] = 1.0
+            tot = sum(beta[-1]); beta[-1] = [v / tot for v in beta[-1]] if abs(tot) > 1e-3 else [1.0 / S] * S
+            c_sol = list(beta[-1]) + [0.0]
+        else:
+            w = [abs(rnd()) + 0.05 for _ in range(S + 1)]
+            c_sol = [v / sum(w) for v in w]
+        c_err = [rng.uniform(-1, 1) * 1e-2 * (rng.random() < 0.8) for _ in range(S + 1)]
+        if rng.random() < 0.3:
+            c_err = [c * 1e-2 for c in c_sol[:-1]] + [rng.uniform(-1, 1) * 1e-3]          # leads with the solution row
+        c_err[0] -= sum(c_err)               # like a real pair: the two solutions agree to first order
+        mid = [0.5 * c for c in c_sol]; mid[0] += 0.125; mid[-1] -= 0.125
+        order = rng.choice([2, 3, 5, 8])
+        f64 = lambda v: torch.tensor(v, dtype=torch.float64)
+        name = f"fuzztab{case}"
+        RefCls = type("RefFuzz", (ref_rk.RKAdaptiveStepsizeODESolver,), dict(order=order, tableau=ref_rk._ButcherTableau(
+            alpha=f64(alpha), beta=[f64(r) for r in beta], c_sol=f64(c_sol), c_error=f64(c_err)), mid=f64(mid)))
+        Cls = type("Fuzz", (RKAdaptiveStepsizeODESolver,), dict(order=order, tableau=Tableau(
+            name, order, tuple(alpha), tuple(tuple(r) for r in beta), tuple(c_sol), tuple(c_err), tuple(mid))))
+        REF_SOLVERS[name] = RefCls; tda.SOLVERS[name] = Cls
+        dtype = rng.choice([torch.float32, torch.float64])
+        shape = rng.choice([(3,), (2, 3), (17,)])
+        is_tuple = rng.random() < 0.3
+        g = torch.Generator().manual_seed(rng.randrange(10 ** 6))
+        y0 = torch.randn(shape, generator=g, dtype=torch.float64).to(dtype)
+        y0b = torch.randn(4, generator=g, dtype=torch.float64).to(dtype)
+        t = torch.sort(torch.rand(rng.choice([2, 3, 6]), generator=g, dtype=torch.float64)).values.to(dtype)
+        if float((t[1:] - t[:-1]).min()) < 1e-3: continue
+        if rng.random() < 0.4: t = t.flip(0)
+        kw = dict(rtol=rng.choice([1e-3, 1e-5]), atol=rng.choice([1e-4, 1e-7]))
+        opts = {"max_num_steps": 3000}
+        if rng.random() < 0.3: opts["first_step"] = 0.02
+        res = []
+        for lib in (ref, tda):
+            nfe = [0]
+            def fn(t_, y):
+                nfe[0] += 1
+                if is_tuple: return (-y[0] * (1 + 0.3 * t_) + 0.1 * torch.sin(y[0]) + y[1].sum() * 0.01, -0.5 * y[1])
+                return -y * (1 + 0.3 * t_) + 0.1 * torch.sin(y)
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    with torch.no_grad():
+                        out = lib.odeint(fn, (y0, y0b) if is_tuple else y0, t, method=name, options=dict(opts), **kw)
+                res.append(("ok", out[0] if is_tuple else out, nfe[0]))
+            except Exception as e:
+                res.append(("err", type(e).__name__ + ": " + str(e)[:80], None))
+        del REF_SOLVERS[name], tda.SOLVERS[name]
+        a, b = res
+        desc = (case, S, fsal, order, str(dtype)[6:], shape, is_tuple, kw, opts)
+        if a[0] != b[0]: bad += 1; print("STATUS", desc, a[1] if a[0] == "err" else "ok", b[1] if b[0] == "err" else "ok"); continue
+        if a[0] == "err": continue
+        fin = torch.isfinite(a[1]) & torch.isfinite(b[1])
+        d = float(((a[1] - b[1])[fin]).abs().max() / (a[1][fin].abs().max() + 1e-30)) if fin.any() else 0.0
+        tol = 1e-4 if dtype == torch.float32 else 1e-10
+        if bool((torch.isfinite(a[1]) != torch.isfinite(b[1])).any()) or d > tol or (a[2] != b[2] and dtype == torch.float64):
+            bad += 1; print("VALUE", desc, d, a[2], b[2])
+    print("done", n, "bad", bad)
 else:
-    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex")
+    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau")

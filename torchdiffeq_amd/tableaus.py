@@ -48,6 +48,11 @@ def _sparse_row(values: Tuple[float, ...]) -> SparseRow:
     """Memoised: the rows of the (few, immutable) tableaus are rebuilt by every solver construction otherwise — the
     adjoint constructs one solver per output interval."""
     nz = [(i, v) for i, v in enumerate(values) if v != 0.0]
+    if not nz and values:
+        # an all-zero row of a user-defined table (a stage that restarts from y0, an error row that estimates nothing):
+        # the kernels take >= 1 term, so keep one explicit zero — 0 * k_0, which is also what the reference's dense
+        # sum computes (rk_common.py:79, :88), non-finite k_0 included
+        nz = [(0, 0.0)]
     return SparseRow(tuple(i for i, _ in nz), tuple(v for _, v in nz))
 
 
