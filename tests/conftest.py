@@ -10,6 +10,27 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("TDEQ_TEST_POISON") == "1":
+        _poison_uninitialised_memory()
+
+
+def _poison_uninitialised_memory():
+    """TDEQ_TEST_POISON=1: every floating-point `torch.empty` / `empty_like` / `new_empty` comes back filled with NaN —
+    a read of memory the package never wrote turns into a wrong or non-finite result instead of passing by luck
+    (how the uninitialised flat-state padding of r03 was provoked; the whole suite is run this way once per round)."""
+    import torch
+
+    def poisoned(fn):
+        def wrapper(*args, **kw):
+            out = fn(*args, **kw)
+            if isinstance(out, torch.Tensor) and (out.is_floating_point() or out.is_complex()) and out.numel():
+                with torch.no_grad():
+                    out.fill_(float("nan"))
+            return out
+        return wrapper
+    torch.empty = poisoned(torch.empty)
+    torch.empty_like = poisoned(torch.empty_like)
+    torch.Tensor.new_empty = poisoned(torch.Tensor.new_empty)
 
 
 @pytest.fixture(scope="session")
