@@ -20,15 +20,18 @@ def _poison_uninitialised_memory():
     (how the uninitialised flat-state padding of r03 was provoked; the whole suite is run this way once per round)."""
     import torch
 
-    def poisoned(fn):
+    def poisoned(fn, factory=False):
         def wrapper(*args, **kw):
+            if factory and kw.get("device") is None:
+                # torch.set_default_device works through a function mode that recognises the ORIGINAL torch.empty object
+                kw["device"] = torch.get_default_device()
             out = fn(*args, **kw)
             if isinstance(out, torch.Tensor) and (out.is_floating_point() or out.is_complex()) and out.numel():
                 with torch.no_grad():
                     out.fill_(float("nan"))
             return out
         return wrapper
-    torch.empty = poisoned(torch.empty)
+    torch.empty = poisoned(torch.empty, factory=True)
     torch.empty_like = poisoned(torch.empty_like)
     torch.Tensor.new_empty = poisoned(torch.Tensor.new_empty)
 
