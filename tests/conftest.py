@@ -66,7 +66,17 @@ def dev(request, monkeypatch, oracle_kernels):
         assert torch.cuda.is_available(), "gpu test on a box without a GPU"
     prev = torch.get_default_device()
     torch.set_default_device(request.param)
-    yield request.param
+    if request.param == "cuda":
+        # a "cuda" parity test whose state silently stayed on the CPU would exercise the host path, not the HIP
+        # kernels: the package's HostPathWarning is an error here (real-valued states; complex ones are host by design)
+        import warnings
+        from torchdiffeq_amd import _fallback
+        monkeypatch.setattr(_fallback, "_warned", False)
+        with warnings.catch_warnings():
+            warnings.filterwarnings("error", message=".*lives on 'cpu'.*", category=_fallback.HostPathWarning)
+            yield request.param
+    else:
+        yield request.param
     torch.set_default_device(prev)
 
 

@@ -189,3 +189,19 @@ def test_flat_state_padding_is_zero_so_step_size_gradients_stay_finite(where, mo
     (z_t[-1].pow(2).sum() + l_t[-1].sum()).backward()
     for p in lin.parameters():
         assert torch.isfinite(p.grad).all()
+
+
+@pytest.mark.parametrize("method", ["dopri5", "dopri8", "bosh3", "rk4", "euler", "implicit_adams"])
+def test_empty_states(where, method):
+    """Edge case: a state without elements.  Fixed-grid methods and empty COMPONENTS of a tuple behave as in the
+    reference (shapes [len(t), 0, ...]); an entirely empty state under an adaptive method returns the empty solution
+    here, where the reference fails with 'underflow in dt 0.0' (its RMS norm of nothing is NaN) — DESIGN.md §8."""
+    t = torch.tensor([0.0, 0.5, 1.0])
+    with torch.no_grad():
+        y = tda.odeint(lambda t_, y_: -y_, torch.empty(0, 3), t, method=method)
+        assert y.shape == (3, 0, 3)
+        y = tda.odeint_adjoint(lambda t_, y_: -y_, torch.empty(0), t, method=method, adjoint_params=())
+        assert y.shape == (3, 0)
+        ya, yb = tda.odeint(lambda t_, s: (-s[0], -s[1]), (torch.ones(2), torch.empty(0)), t, method=method)
+    assert ya.shape == (3, 2) and yb.shape == (3, 0)
+    assert torch.allclose(ya[-1].cpu(), torch.full((2,), 0.36787944, device="cpu"), rtol=0.4 if method == "euler" else 1e-3)

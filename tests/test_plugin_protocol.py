@@ -185,7 +185,7 @@ def test_user_defined_tableau_on_the_native_solver(dev, direction):
         tableau = tab
     tda.SOLVERS["cashkarp"] = CashKarp
     try:
-        A, y0, t = T(z["cashkarp_A"]), T(z["cashkarp_y0"]), T(z[f"cashkarp_{direction}_t"])
+        A, y0, t = T(z["cashkarp_A"]).to(dev), T(z["cashkarp_y0"]).to(dev), T(z[f"cashkarp_{direction}_t"]).to(dev)
         accepted = []
 
         class F(torch.nn.Module):

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from ._native import device_guard
 from .misc import (ALL_ADJOINT_CALLBACK_NAMES, ALL_CALLBACK_NAMES, BuiltinNorm, OdeFunc, Perturb, StateLayout,
-                   check_inputs, pack_differentiable, plugin_solver_inputs)
+                   check_inputs, empty_solution, pack_differentiable, plugin_solver_inputs)
 from .odeint import SOLVERS
 
 
@@ -523,6 +523,8 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
         raise ValueError('Invalid method "{}". Must be one of {}'.format(
             adjoint_method, '{"' + '", "'.join(SOLVERS.keys()) + '"}.'))
     layout = ci.layout
+    if sum(layout.numels) == 0 and ci.event_fn is None:
+        return empty_solution(ci, ci.y0_flat)
     handle_adjoint_norm_(adjoint_options, len(adjoint_params), ci.options["norm"], layout)
 
     cfg = dict(func=ci.func, rtol=ci.rtol, atol=ci.atol, method=ci.method, options=ci.options,

@@ -206,6 +206,14 @@ def _per_segment(tol, n_seg: int, name: str) -> List[float]:
     return vals
 
 
+def empty_solution(ci: "CheckedInputs", like: torch.Tensor):
+    """The solution of a state without a single element: `[len(t), *shape]` per component, nothing to integrate (the
+    kernels are never asked to run on a null buffer; the reference's fixed-grid solvers return the same, its adaptive
+    ones trip over the NaN norm of nothing — DESIGN.md §8)."""
+    rows = [torch.empty((len(ci.t), *shape), dtype=like.dtype, device=like.device) for shape in ci.layout.shapes]
+    return tuple(rows) if ci.layout.is_tuple else rows[0]
+
+
 def plugin_solver_inputs(solver_cls, layout: "StateLayout", options: dict, rtol, atol, device):
     """`(options, rtol, atol)` for constructing `solver_cls`.  This package's own classes take them as they are.  Anything
     else registered in `SOLVERS` that follows the reference's protocol `cls(func=, y0=, rtol=, atol=, **options)

@@ -5,7 +5,7 @@ from __future__ import annotations
 import torch
 
 from ._native import device_guard
-from .misc import check_inputs, pack_differentiable, plugin_solver_inputs
+from .misc import check_inputs, empty_solution, pack_differentiable, plugin_solver_inputs
 from .implicit import (SDIRK2, TRBDF2, GaussLegendre4, GaussLegendre6, ImplicitEuler, ImplicitMidpoint, RadauIIA3,
                        RadauIIA5, Trapezoid)
 from .scipy_wrapper import ScipyWrapperODESolver
@@ -90,6 +90,8 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
         return odeint(promoted, y0.double(), t, rtol=rtol, atol=atol, method=method, options=options).to(y0.dtype)
     ci = check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS)
     y0_flat = ci.y0_flat
+    if sum(ci.layout.numels) == 0 and ci.event_fn is None:
+        return empty_solution(ci, y0_flat)
     if torch.is_grad_enabled():
         y0_list = y0 if ci.layout.is_tuple else (y0,)
         if any(y_.requires_grad for y_ in y0_list):
