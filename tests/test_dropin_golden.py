@@ -205,3 +205,32 @@ def test_empty_states(where, method):
         ya, yb = tda.odeint(lambda t_, s: (-s[0], -s[1]), (torch.ones(2), torch.empty(0)), t, method=method)
     assert ya.shape == (3, 2) and yb.shape == (3, 0)
     assert torch.allclose(ya[-1].cpu(), torch.full((2,), 0.36787944, device="cpu"), rtol=0.4 if method == "euler" else 1e-3)
+
+
+@pytest.mark.parametrize("inner_method", ["rk4", "dopri5"])
+def test_nested_solves(where, inner_method):
+    """Re-entrancy ('nested odeint calls'): `func` integrates an inner ODE per evaluation — the inner
+    solver runs while the outer one has a trial step (and, on the GPU, its look-ahead read-back) in flight.  Closed form
+    of the inner solve: z(t + 0.1) = y exp(-(0.1 + 0.1 t + 0.005))."""
+    import math
+    w = torch.tensor(0.1, dtype=torch.float64, requires_grad=True)
+    opts = dict(step_size=0.025) if inner_method == "rk4" else None
+
+    def nested(t_, y):
+        z = tda.odeint(lambda s, z_: -z_ * (1 + s), y, torch.stack([t_, t_ + 0.1]), method=inner_method, options=opts,
+                       rtol=1e-10, atol=1e-12)[-1]
+        return -y + w * z
+
+    def closed(t_, y):
+        return -y + w * y * torch.exp(-(0.105 + 0.1 * t_))
+    y0 = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
+    t = torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64)
+    grads = []
+    for field in (nested, closed):
+        w.grad = None
+        y = tda.odeint(field, y0, t, rtol=1e-8, atol=1e-10)
+        y[-1].sum().backward()
+        grads.append((y.detach(), w.grad.clone()))
+    assert torch.allclose(grads[0][0], grads[1][0], rtol=1e-7, atol=1e-9)
+    assert torch.allclose(grads[0][1], grads[1][1], rtol=1e-6)
+    assert math.isfinite(float(grads[0][1]))
