@@ -234,3 +234,45 @@ def test_nested_solves(where, inner_method):
     assert torch.allclose(grads[0][0], grads[1][0], rtol=1e-7, atol=1e-9)
     assert torch.allclose(grads[0][1], grads[1][1], rtol=1e-6)
     assert math.isfinite(float(grads[0][1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("own_streams", [False, True], ids=["one-stream", "stream-per-thread"])
+def test_concurrent_solves_from_python_threads(own_streams):
+    """Four Python threads solve different problems at once (shared current stream, or a stream each): the C-ABI is
+    stateless, every solver has its own norm plan / read-back words, the look-ahead controller's polling is per plan —
+    results must be the serial ones bit for bit."""
+    import threading
+    dev = torch.device("cuda:0")
+    probs = []
+    for i in range(4):
+        g = torch.Generator().manual_seed(100 + i)
+        A = (torch.randn(16, 16, generator=g, dtype=torch.float64) / 6 - 0.2 * torch.eye(16, dtype=torch.float64))
+        dtype = torch.float32 if i % 2 else torch.float64
+        probs.append((A.to(dtype).to(dev), torch.randn(256 * (i + 1), 16, generator=g, dtype=torch.float64).to(dtype).to(dev),
+                      torch.tensor([0.0, 0.7, 1.5], dtype=dtype, device=dev), ["dopri5", "dopri8", "bosh3", "rk4"][i]))
+
+    def solve(A, y0, t, method):
+        with torch.no_grad():
+            return tda.odeint(lambda t_, y: torch.tanh(y @ A.T) * torch.cos(t_), y0, t, method=method, rtol=1e-6, atol=1e-8,
+                              options=dict(step_size=0.01) if method == "rk4" else None)
+    serial = [solve(*p) for p in probs]
+    torch.cuda.synchronize()
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            ctx = torch.cuda.stream(torch.cuda.Stream(dev)) if own_streams else torch.cuda.device(dev)
+            with ctx:
+                for _ in range(5):
+                    out[i] = solve(*probs[i])
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:       # noqa: BLE001
+            errs.append(repr(e))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [th.start() for th in threads]
+    [th.join(120) for th in threads]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for a, b in zip(serial, out):
+        assert b is not None and torch.equal(a, b)
