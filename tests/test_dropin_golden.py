@@ -237,8 +237,9 @@ def test_nested_solves(where, inner_method):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hip_graph"])
 @pytest.mark.parametrize("own_streams", [False, True], ids=["one-stream", "stream-per-thread"])
-def test_concurrent_solves_from_python_threads(own_streams):
+def test_concurrent_solves_from_python_threads(own_streams, graph):
     """Four Python threads solve different problems at once (shared current stream, or a stream each): the C-ABI is
     stateless, every solver has its own norm plan / read-back words, the look-ahead controller's polling is per plan —
     results must be the serial ones bit for bit."""
@@ -252,10 +253,15 @@ def test_concurrent_solves_from_python_threads(own_streams):
         probs.append((A.to(dtype).to(dev), torch.randn(256 * (i + 1), 16, generator=g, dtype=torch.float64).to(dtype).to(dev),
                       torch.tensor([0.0, 0.7, 1.5], dtype=dtype, device=dev), ["dopri5", "dopri8", "bosh3", "rk4"][i]))
 
-    def solve(A, y0, t, method):
+    fields = [(lambda A: (lambda t_, y: torch.tanh(y @ A.T) * torch.cos(t_)))(p[0]) for p in probs]     # one func object per problem
+
+    def solve(A, y0, t, method, captured=False):
+        o = dict(step_size=0.01) if method == "rk4" else {}
+        if captured and method != "rk4":        # (the rk4 graph mode steps between the output times only)
+            o["hip_graph"] = True               # concurrent stream captures: thread_local capture mode, one graph per func
+        field = fields[[id(p[0]) for p in probs].index(id(A))]
         with torch.no_grad():
-            return tda.odeint(lambda t_, y: torch.tanh(y @ A.T) * torch.cos(t_), y0, t, method=method, rtol=1e-6, atol=1e-8,
-                              options=dict(step_size=0.01) if method == "rk4" else None)
+            return tda.odeint(field, y0, t, method=method, rtol=1e-6, atol=1e-8, options=o or None)
     serial = [solve(*p) for p in probs]
     torch.cuda.synchronize()
     out, errs = [None] * 4, []
@@ -265,7 +271,7 @@ def test_concurrent_solves_from_python_threads(own_streams):
             ctx = torch.cuda.stream(torch.cuda.Stream(dev)) if own_streams else torch.cuda.device(dev)
             with ctx:
                 for _ in range(5):
-                    out[i] = solve(*probs[i])
+                    out[i] = solve(*probs[i], captured=graph)
                 torch.cuda.current_stream().synchronize()
         except Exception as e:       # noqa: BLE001
             errs.append(repr(e))
