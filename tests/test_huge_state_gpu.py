@@ -14,6 +14,12 @@ N = (1 << 31) + 4099
 STEP = 1 << 27
 
 
+@pytest.fixture(autouse=True)
+def _release_cached_blocks():
+    yield
+    torch.cuda.empty_cache()          # hand the ~100 GB back: later tests start subprocesses on the same GPU
+
+
 def _need_memory(gb):
     free, _ = torch.cuda.mem_get_info()
     if free < gb * (1 << 30):
