@@ -152,14 +152,16 @@ y0 = torch.ones(2, dtype=torch.float64)
 full = tda.odeint(lambda t_, y_: y_ @ A.T, y0, t, method="scipy_solver", options=dict(solver="LSODA"))
 short = tda.odeint(lambda t_, y_: y_ @ A.T * math.exp(3.0), y0, t, method="scipy_solver",
                    options=dict(solver="LSODA", min_step=2.0, max_step=5.0))
-print("SHAPES", tuple(full.shape), tuple(short.shape))
+import json
+print("SHAPES", json.dumps([list(full.shape), list(short.shape)]))
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("SHAPES")][0]
-    full_shape, short_shape = eval(line[len("SHAPES"):].replace(") (", "), ("))
-    assert full_shape == (10, 2)
-    assert short_shape[1:] == (2,) and 1 <= short_shape[0] <= 10
+    import json
+    full_shape, short_shape = json.loads(line[len("SHAPES"):])
+    assert full_shape == [10, 2]
+    assert short_shape[1:] == [2] and 1 <= short_shape[0] <= 10
 
 
 def test_flat_state_padding_is_zero_so_step_size_gradients_stay_finite(where, monkeypatch):
