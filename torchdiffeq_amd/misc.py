@@ -437,7 +437,7 @@ def find_event(interp_fn, sign0, t0, t1, event_fn, tol: float, time_tensor, scal
         for _ in range(nitrs):
             t_mid = scalar(scalar(t1 + t0) / scalar(2.0))
             y_mid = interp_fn(t_mid)
-            sign_mid = float(torch.sign(event_fn(time_tensor(t_mid), y_mid)))
+            sign_mid = float(torch.sign(event_fn(time_tensor(t_mid), y_mid)).detach())
             if sign0 == sign_mid:
                 t0 = t_mid
             else:

@@ -800,8 +800,8 @@ class RKAdaptiveStepsizeODESolver:
         if ev() == 0:
             return self.t1, self.y1
         n_steps = 0
-        sign0 = float(torch.sign(ev()))
-        while sign0 == float(torch.sign(ev())):
+        sign0 = float(torch.sign(ev()).detach())
+        while sign0 == float(torch.sign(ev()).detach()):
             assert n_steps < self.max_num_steps, \
                 "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
             self._adaptive_step()
@@ -1538,14 +1538,14 @@ class FixedGridODESolver(object):
         if self.interp not in ("linear", "cubic"):
             raise ValueError(f"Unknown interpolation method {self.interp}")
 
-        sign0 = float(torch.sign(event_fn(time_tensor(t0), y0)))
+        sign0 = float(torch.sign(event_fn(time_tensor(t0), y0)).detach())
         max_itrs = 20000
         itr = 0
         while True:
             itr += 1
             t1 = scalar(t0 + scalar(dt))
             y1, f0 = self._step(t0, dt, t1, y0, None, _NO_SHADOW)
-            sign1 = float(torch.sign(event_fn(time_tensor(t1), y1)))
+            sign1 = float(torch.sign(event_fn(time_tensor(t1), y1)).detach())
             if sign0 != sign1:
                 if self.interp == "linear":
                     def interp_fn(t, t0=t0, t1=t1, y0=y0, y1=y1):
