@@ -943,17 +943,10 @@ def gen_dropin():
             arrays[f"{key}_y"], arrays[f"{key}_gx"], arrays[f"{key}_gt"], arrays[f"{key}_gw"] = y.detach(), x.grad, t.grad, w.grad
     # event_tests.py: the sine problem (problems.py:27-37), fp32, 0-dim, explicit Adams at step 0.01 (diverging run: the
     # event time is decided by rounding — 2.3979 in the reference)
-    class Sine(torch.nn.Module):
-        def forward(self, t_, y_):
-            return 2 * y_ / t_ + t_ ** 4 * torch.sin(2 * t_) - t_ ** 2 + 4 * t_ ** 3
-
-        def y_exact(self, t_):
-            return -0.5 * t_ ** 4 * torch.cos(2 * t_) + 0.5 * t_ ** 3 * torch.sin(2 * t_) + 0.25 * t_ ** 2 * torch.cos(
-                2 * t_) - t_ ** 3 + 2 * t_ ** 4 + (math.pi - 0.25) * t_ ** 2
-    f = Sine()
-    t_points = torch.linspace(1, 8, 10, dtype=torch.float64)
-    sol = f.y_exact(t_points).to(torch.float32)
-    y0 = sol[0]
+    sys.path.insert(0, "/root/reference/tests")         # the reference's own problem set (tests/problems.py:27-37)
+    from problems import construct_problem
+    f, y0, t_points, sol = construct_problem(dtype=torch.float32, device="cpu", ode="sine")
+    t_points, sol = t_points.detach(), sol.detach()
     event_fn = lambda t_, y_: torch.sum(y_ - sol[2]).real
     et, ys = torchdiffeq.odeint(f, y0, t_points[0:2], event_fn=event_fn, method="explicit_adams",
                                 options={"step_size": 0.01, "interp": "cubic"})
