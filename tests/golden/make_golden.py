@@ -1015,6 +1015,22 @@ def gen_dropin():
     for i, r in enumerate(beta_f):
         arrays[f"cashkarp_beta{i}"] = np.array(r)
     arrays["cashkarp_A"], arrays["cashkarp_y0"] = A, y0
+
+    # (4) odeint_event gradients incl. the START time (odeint.py:160-231, solvers.py:130-164): the fixed-grid solvers form
+    # t1 = t0 + dt and the interpolation fraction on the tensor t0, so d(event time)/d t0 exists for them as well
+    for method, opts in (("rk4", dict(step_size=0.03, interp="cubic")), ("euler", dict(step_size=0.01, interp="linear")),
+                         ("midpoint", dict(step_size=0.02, interp="cubic")), ("dopri5", {})):
+        for rev in (False, True):
+            y0g = torch.tensor([1.0, 0.1], dtype=torch.float64, requires_grad=True)
+            t0g = torch.tensor(0.3, dtype=torch.float64, requires_grad=True)
+            kg = torch.tensor(1.0, dtype=torch.float64, requires_grad=True)
+            et, ys = torchdiffeq.odeint_event(lambda t_, y_: torch.stack([y_[1], -y_[0] * kg * (1 + 0.5 * t_)]), y0g, t0g,
+                                              event_fn=lambda t_, y_: y_[0] - 0.3, method=method, options=dict(opts),
+                                              reverse_time=rev, atol=1e-9, rtol=1e-7)
+            g = torch.autograd.grad(et * 2.0 + (ys[-1] ** 2).sum(), [y0g, t0g, kg])
+            key = f"evgrad_{method}_{'rev' if rev else 'fwd'}"
+            arrays[f"{key}_t"], arrays[f"{key}_y"] = et.detach(), ys.detach()
+            arrays[f"{key}_gy0"], arrays[f"{key}_gt0"], arrays[f"{key}_gk"] = g
     save("dropin.npz", **arrays)
 
 

@@ -284,3 +284,29 @@ def test_concurrent_solves_from_python_threads(own_streams, graph):
     assert not errs, errs
     for a, b in zip(serial, out):
         assert b is not None and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("direction", ["fwd", "rev"])
+@pytest.mark.parametrize("method,opts", [("rk4", dict(step_size=0.03, interp="cubic")), ("euler", dict(step_size=0.01, interp="linear")),
+                                         ("midpoint", dict(step_size=0.02, interp="cubic")), ("dopri5", {})],
+                         ids=["rk4", "euler", "midpoint", "dopri5"])
+def test_event_gradients_including_the_start_time(where, method, opts, direction):
+    """`odeint_event` gradients wrt the initial state, a parameter and the START time (found by a differential run of
+    odeint_event gradients against the reference, r03): the fixed-grid solvers keep t0 in the graph of `t1 = t0 + dt` and of
+    the interpolation fraction (solvers.py:130-164), so d(event time)/d t0 is there for them too — it used to come back
+    None.  Values from the reference (tests/golden/dropin.npz)."""
+    z = load("dropin.npz")
+    key = f"evgrad_{method}_{direction}"
+    y0 = torch.tensor([1.0, 0.1], dtype=torch.float64, requires_grad=True)
+    t0 = torch.tensor(0.3, dtype=torch.float64, requires_grad=True)
+    k = torch.tensor(1.0, dtype=torch.float64, requires_grad=True)
+    et, ys = tda.odeint_event(lambda t_, y_: torch.stack([y_[1], -y_[0] * k * (1 + 0.5 * t_)]), y0, t0,
+                              event_fn=lambda t_, y_: y_[0] - 0.3, method=method, options=dict(opts),
+                              reverse_time=direction == "rev", atol=1e-9, rtol=1e-7)
+    g = torch.autograd.grad(et * 2.0 + (ys[-1] ** 2).sum(), [y0, t0, k], allow_unused=True)
+    tol = 1e-6 if method == "dopri5" else 1e-9
+    assert float(et) == pytest.approx(float(z[f"{key}_t"]), rel=tol)
+    assert torch.allclose(ys.detach().cpu(), T(z[f"{key}_y"]), rtol=tol, atol=tol)
+    for got, name in zip(g, ("gy0", "gt0", "gk")):
+        assert got is not None, name
+        assert torch.allclose(got.cpu(), T(z[f"{key}_{name}"]), rtol=10 * tol, atol=10 * tol), name

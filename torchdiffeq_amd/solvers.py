@@ -1526,17 +1526,27 @@ class FixedGridODESolver(object):
     @_native.on_state_device
     def integrate_until_event(self, t0: torch.Tensor, event_fn):
         """Fixed steps of `step_size` until the event function changes sign, then bisection on the linear /
-        cubic interpolant of that step (solvers.py:129-164).  Times are kept in the state dtype (:132)."""
+        cubic interpolant of that step (solvers.py:129-164).  Times are kept in the state dtype (:132).
+        When the start time requires grad its gradient is carried by step shadows, as in `integrate`: the reference
+        forms `t1 = t0 + dt` and the interpolation fraction `(t - t0) / (t1 - t0)` on the tensor `t0` itself, so the
+        state at the (detached) event time depends on it — which is what `odeint_event` turns into d(event time)/d t0."""
         assert self.step_size is not None, \
             "Event handling for fixed step solvers currently requires `step_size` to be provided in options."
         func, ops = self.func, self.ops
         scalar = func.np_dtype
         time_tensor = lambda v: torch.tensor(float(v), dtype=self.dtype, device=self.device)
+        start = t0 if (torch.is_grad_enabled() and torch.is_tensor(t0) and t0.requires_grad) else None
         t0 = scalar(float(t0.detach()))
+        t_first = float(t0)
         y0 = self.y0
         dt = float(self.step_size)
         if self.interp not in ("linear", "cubic"):
             raise ValueError(f"Unknown interpolation method {self.interp}")
+
+        def shadow(ta, tb):
+            if start is None:
+                return _NO_SHADOW
+            return _StepShadow(start + (float(ta) - t_first), start + (float(tb) - t_first), func.sign)
 
         sign0 = float(torch.sign(event_fn(time_tensor(t0), y0)).detach())
         max_itrs = 20000
@@ -1544,21 +1554,22 @@ class FixedGridODESolver(object):
         while True:
             itr += 1
             t1 = scalar(t0 + scalar(dt))
-            y1, f0 = self._step(t0, dt, t1, y0, None, _NO_SHADOW)
+            sh = shadow(t0, t1)
+            y1, f0 = self._step(t0, dt, t1, y0, None, sh)
             sign1 = float(torch.sign(event_fn(time_tensor(t1), y1)).detach())
             if sign0 != sign1:
                 if self.interp == "linear":
-                    def interp_fn(t, t0=t0, t1=t1, y0=y0, y1=y1):
+                    def interp_fn(t, t0=t0, t1=t1, y0=y0, y1=y1, sh=sh):
                         if t == t0:
                             return y0
                         if t == t1:
                             return y1
-                        return ops.lerp(y0, y1, float(scalar(scalar(t - t0) / scalar(t1 - t0))))
+                        return ops.lerp(y0, y1, float(scalar(scalar(t - t0) / scalar(t1 - t0))), sh.fraction(None, t))
                 else:
-                    f1 = func.eval(t1, y1)
+                    f1 = func.eval(t1, y1, shadow=sh.time(1.0))
 
-                    def interp_fn(t, t0=t0, t1=t1, y0=y0, y1=y1, f0=f0, f1=f1):
-                        return self._cubic_hermite_interp(scalar, t0, y0, f0, t1, y1, f1, t, _NO_SHADOW, None)
+                    def interp_fn(t, t0=t0, t1=t1, y0=y0, y1=y1, f0=f0, f1=f1, sh=sh):
+                        return self._cubic_hermite_interp(scalar, t0, y0, f0, t1, y1, f1, t, sh, None)
                 event_time, y1 = find_event(interp_fn, sign0, t0, t1, event_fn, float(self.atol), time_tensor,
                                             scalar=scalar)
                 break
@@ -1588,7 +1599,7 @@ class FixedGridODESolver(object):
             d_h = [-6 * hf * (1 - hf), (1 - hf) * (1 - 3 * hf) * dtf * sg, 6 * hf * (1 - hf),
                    (3 * hf * hf - 2 * hf) * dtf * sg]
             d_dt = [0.0, float(h10) * sg, 0.0, float(h11) * sg]
-            scalars = [(sh.fraction(t_shadow), d_h), (sh.width(), d_dt)]
+            scalars = [(sh.fraction(t_shadow, t), d_h), (sh.width(), d_dt)]
         return self.ops.weighted_sum([y0, f0, y1, f1], ws, scalars, out=out)
 
 
@@ -1612,9 +1623,13 @@ class _StepShadow:
         """User time of the stage at t0 + c dt."""
         return (self.t0 + (self.t1 - self.t0) * c) * self.sign
 
-    def fraction(self, t_shadow):
-        """(t - t0) / (t1 - t0) for an output time t."""
-        num = (t_shadow - self.t0) if t_shadow is not None else -self.t0
+    def fraction(self, t_shadow, t_const=None):
+        """(t - t0) / (t1 - t0) for an output time t (`t_const`: the value of a time that is not in the graph — it
+        matters as soon as the step width itself carries a gradient)."""
+        if t_shadow is not None:
+            num = t_shadow - self.t0
+        else:
+            num = -self.t0 if t_const is None else float(t_const) - self.t0
         return num / (self.t1 - self.t0)
 
 
@@ -1628,7 +1643,7 @@ class _NoShadow:
     def time(self, c):
         return None
 
-    def fraction(self, t_shadow):
+    def fraction(self, t_shadow, t_const=None):
         return None
 
 
