@@ -1,6 +1,6 @@
 """Differential fuzzing against the reference (build container only: imports /root/reference).
 
-  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau} [seed] [cases]
+  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad} [seed] [cases]
   (TDEQ_FUZZ_BACKEND=host: the product's torch-op host path for CPU states instead of the oracle test backend)
 
 Random states (0-dim .. 3-dim, tuples), dtypes, time grids (both directions), options and methods are solved by the
@@ -445,5 +445,52 @@ elif mode == "tableau":
         if bool((torch.isfinite(a[1]) != torch.isfinite(b[1])).any()) or d > tol or (a[2] != b[2] and dtype == torch.float64):
             bad += 1; print("VALUE", desc, d, a[2], b[2])
     print("done", n, "bad", bad)
+elif mode == "eventgrad":
+    # r03: gradients THROUGH odeint_event (event time and final state wrt y0, the START time t0, a parameter, a second
+    # tuple component), adaptive and fixed-grid methods, reverse_time, odeint_adjoint as the interface.  Found: the
+    # fixed-grid event solve dropped d/d t0.
+    rng = random.Random(int(sys.argv[1]))
+    n = int(sys.argv[2])
+    bad = 0
+    M=['dopri5','bosh3','tsit5','dopri8','rk4','euler','midpoint','implicit_adams']
+    for case in range(n):
+        method=rng.choice(M); rev=rng.random()<0.35; is_tuple=rng.random()<0.4; adj=rng.random()<0.5
+        w0=rng.choice([1.0,2.0,0.7]); thr=rng.choice([0.0,-0.2,0.3])
+        opts={} if method in M[:4] else {'step_size':rng.choice([0.01,0.03]),'interp':rng.choice(['linear','cubic'])}
+        res=[]
+        for L in (ref, tda):
+            k=torch.tensor(w0*w0,dtype=torch.float64,requires_grad=True)
+            y0=torch.tensor([rng.choice([1.0]) ,0.1],dtype=torch.float64,requires_grad=True)
+            aux=torch.tensor([0.5],dtype=torch.float64,requires_grad=True)
+            t0=torch.tensor(0.3,dtype=torch.float64,requires_grad=True)
+            class F(torch.nn.Module):
+                def __init__(s): super().__init__(); s.k=torch.nn.Parameter(k.detach().clone())
+                def forward(s,t,st):
+                    if is_tuple:
+                        y,a=st; return (torch.stack([y[1],-y[0]*s.k]), -a*0.3)
+                    return torch.stack([st[1],-st[0]*s.k])
+            f=F()
+            ev=(lambda t,st: st[0][0]-thr+0.0*st[1].sum()) if is_tuple else (lambda t,st: st[0]-thr)
+            state=(y0,aux) if is_tuple else y0
+            try:
+                kw=dict(odeint_interface=L.odeint_adjoint) if adj else {}
+                et,ys=L.odeint_event(f,state,t0,event_fn=ev,method=method,options=dict(opts),reverse_time=rev,atol=1e-9,rtol=1e-7,**kw)
+                yl=ys[0][-1] if is_tuple else ys[-1]
+                loss=et*2.0+(yl**2).sum()+(ys[1][-1].sum() if is_tuple else 0)
+                g=torch.autograd.grad(loss,[y0,t0,f.k]+([aux] if is_tuple else []),allow_unused=True)
+                res.append(('ok',[et.detach().reshape(1),yl.detach()]+[x if x is not None else torch.zeros(1,dtype=torch.float64) for x in g]))
+            except Exception as e:
+                res.append(('err',type(e).__name__+': '+str(e)[:90]))
+        a,b=res; desc=(case,method,rev,is_tuple,adj,w0,thr,opts)
+        if a[0]!=b[0]: bad+=1; print('STATUS',desc,a[1] if a[0]=='err' else 'ok',b[1] if b[0]=='err' else 'ok'); continue
+        if a[0]=='err':
+            if a[1].split(':')[0]!=b[1].split(':')[0]: bad+=1; print('ERRTYPE',desc,a[1],b[1])
+            continue
+        tol=1e-6 if method in M[:4] else 1e-9
+        if adj: tol=max(tol,1e-5)
+        for i,(p,q) in enumerate(zip(a[1],b[1])):
+            d=float((p-q).abs().max()/(p.abs().max()+1e-12))
+            if not d<=tol: bad+=1; print('VALUE',desc,i,d); break
+    print('done',n,'bad',bad)
 else:
-    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau")
+    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad")
