@@ -310,3 +310,36 @@ def test_event_gradients_including_the_start_time(where, method, opts, direction
     for got, name in zip(g, ("gy0", "gt0", "gk")):
         assert got is not None, name
         assert torch.allclose(got.cpu(), T(z[f"{key}_{name}"]), rtol=10 * tol, atol=10 * tol), name
+
+
+@pytest.mark.parametrize("method", ["dopri5", "rk4"])
+def test_adjoint_callbacks_see_the_reference_tuple_for_a_tuple_state(where, method):
+    """adjoint.py:107-114 + misc.py:313-343: `callback_*_adjoint` receive the backward solve's state as
+    (t, y, adj_y, *adj_params) with a tuple forward state FLAT (the reference's autograd Function only ever sees the
+    flattened state), in un-negated time; forward callbacks see the components."""
+    rec = {"fwd": [], "adj": []}
+
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor([0.5, 0.2]))
+
+        def forward(self, t_, st):
+            return -st[0] * self.w[0], -st[1] * self.w[1] * torch.cos(t_)
+
+        def callback_step(self, t0, y0, dt):
+            rec["fwd"].append((float(t0), [tuple(v.shape) for v in y0]))
+
+        def callback_step_adjoint(self, t0, y0, dt):
+            assert isinstance(y0, tuple)
+            rec["adj"].append((float(t0), [tuple(v.shape) for v in y0], float(dt)))
+    x0 = (torch.tensor(1.0, requires_grad=True), torch.tensor([[0.5, 0.5], [0.1, 0.1]]))
+    out = tda.odeint_adjoint(F(), x0, torch.tensor([0.0, 0.5, 1.0]), method=method,
+                             options=dict(step_size=0.25) if method == "rk4" else None)
+    (out[0][-1] + out[1][-1].sum()).backward()
+    assert rec["fwd"][0] == (0.0, [(), (2, 2)])
+    assert all(shapes == [(), (5,), (5,), (2,)] for _, shapes, _ in rec["adj"])
+    times = [t for t, _, _ in rec["adj"]]
+    assert times[0] == 1.0 and all(dt > 0 for _, _, dt in rec["adj"])
+    if method == "rk4":
+        assert times == [1.0, 0.75, 0.5, 0.25]
