@@ -1,6 +1,6 @@
 """Differential fuzzing against the reference (build container only: imports /root/reference).
 
-  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad} [seed] [cases]
+  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad|callbacks} [seed] [cases]
   (TDEQ_FUZZ_BACKEND=host: the product's torch-op host path for CPU states instead of the oracle test backend)
 
 Random states (0-dim .. 3-dim, tuples), dtypes, time grids (both directions), options and methods are solved by the
@@ -492,5 +492,63 @@ elif mode == "eventgrad":
             d=float((p-q).abs().max()/(p.abs().max()+1e-12))
             if not d<=tol: bad+=1; print('VALUE',desc,i,d); break
     print('done',n,'bad',bad)
+elif mode == "callbacks":
+    # r03: the (t0, dt) sequences every callback sees — callback_step / accept / reject and their *_adjoint twins — for
+    # all explicit and Adams methods, tuple states, both directions, step options; forward 1e-9, backward solve 1e-6.
+    rng = random.Random(int(sys.argv[1]))
+    n = int(sys.argv[2])
+    bad = 0
+    AD=['dopri5','bosh3','tsit5','fehlberg2','adaptive_heun','dopri8']; FX=['euler','midpoint','heun2','heun3','rk4','explicit_adams','implicit_adams']
+    for case in range(n):
+        method=rng.choice(AD+FX); rev=rng.random()<0.4; is_tuple=rng.random()<0.3; adj=rng.random()<0.4
+        g=torch.Generator().manual_seed(rng.randrange(10**6))
+        A=torch.randn(3,3,generator=g,dtype=torch.float64)*0.7-0.3*torch.eye(3,dtype=torch.float64)
+        y0=torch.randn(4,3,generator=g,dtype=torch.float64); yb=torch.randn(2,generator=g,dtype=torch.float64)
+        t=torch.sort(torch.rand(rng.choice([2,3,5]),generator=g,dtype=torch.float64)*2).values
+        if float((t[1:]-t[:-1]).min())<1e-2: continue
+        if rev: t=t.flip(0)
+        opts={}
+        if method in AD:
+            if rng.random()<0.3: opts['first_step']=0.05
+            if rng.random()<0.2: opts['max_step']=0.2
+            if rng.random()<0.2: opts['min_step']=0.01
+        else:
+            if rng.random()<0.5: opts['step_size']=rng.choice([0.05,0.13])
+            if rng.random()<0.2: opts['perturb']=True
+        res=[]
+        for L in (ref,tda):
+            rec={k:[] for k in ('s','a','r','sa','aa','ra')}
+            class F(torch.nn.Module):
+                def __init__(s): super().__init__(); s.A=torch.nn.Parameter(A.clone())
+                def forward(s,tt,y):
+                    if is_tuple: return (torch.tanh(y[0]@s.A)*torch.cos(tt), -0.5*y[1])
+                    return torch.tanh(y@s.A)*torch.cos(tt)
+                def callback_step(s,t0,y,dt): rec['s'].append((float(t0),float(dt)))
+                def callback_accept_step(s,t0,y,dt): rec['a'].append((float(t0),float(dt)))
+                def callback_reject_step(s,t0,y,dt): rec['r'].append((float(t0),float(dt)))
+                def callback_step_adjoint(s,t0,y,dt): rec['sa'].append((float(t0),float(dt)))
+                def callback_accept_step_adjoint(s,t0,y,dt): rec['aa'].append((float(t0),float(dt)))
+                def callback_reject_step_adjoint(s,t0,y,dt): rec['ra'].append((float(t0),float(dt)))
+            f=F(); x=y0.clone().requires_grad_(adj)
+            st=(x,yb) if is_tuple else x
+            try:
+                if adj:
+                    out=L.odeint_adjoint(f,st,t,method=method,options=dict(opts) or None,rtol=1e-6,atol=1e-8)
+                    (out[0] if is_tuple else out)[-1].pow(2).sum().backward()
+                else:
+                    with torch.no_grad(): out=L.odeint(f,st,t,method=method,options=dict(opts) or None,rtol=1e-6,atol=1e-8)
+                res.append(('ok',rec))
+            except Exception as e:
+                res.append(('err',type(e).__name__+': '+str(e)[:80]))
+        a,b=res; desc=(case,method,rev,is_tuple,adj,opts,len(t))
+        if a[0]!=b[0]: bad+=1; print('STATUS',desc,a[1] if a[0]=='err' else 'ok',b[1] if b[0]=='err' else 'ok'); continue
+        if a[0]=='err': continue
+        for k in a[1]:
+            p,q=a[1][k],b[1][k]
+            if len(p)!=len(q): bad+=1; print('COUNT',desc,k,len(p),len(q)); break
+            d=max([abs(x[0]-y[0])+abs(x[1]-y[1]) for x,y in zip(p,q)],default=0.0)
+            tol=1e-9 if k in ('s','a','r') else 1e-6
+            if d>tol: bad+=1; print('SEQ',desc,k,d); break
+    print('done',n,'bad',bad)
 else:
-    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad")
+    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad | callbacks")
