@@ -19,6 +19,7 @@ from __future__ import annotations
 import bisect
 import collections
 import contextlib
+import threading
 import functools
 import gc
 import math
@@ -245,6 +246,26 @@ class _CaptureFailed(RuntimeError):
     """The step body could not be captured into a hipGraph; no kernel of it has run."""
 
 
+_SIDE_STREAMS = threading.local()
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    """The side stream of warm-up steps and stream captures: ONE per thread and device, reused.  PyTorch keeps a BLAS
+    workspace (128 MiB on ROCm) per (handle, stream) that has ever run a GEMM and never returns it; a fresh
+    `torch.cuda.Stream` per capture grew the process by that much for every newly captured func (measured:
+    `tools/soak_training.py`, +478 MB after one captured adjoint loop), up to PyTorch's pool of 32 streams.  Per thread
+    because a stream can be in one capture at a time."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    streams = getattr(_SIDE_STREAMS, "by_device", None)
+    if streams is None:
+        streams = _SIDE_STREAMS.by_device = {}
+    stream = streams.get(key)
+    if stream is None:
+        stream = streams[key] = torch.cuda.Stream(torch.device("cuda", key))
+    return stream
+
+
 @contextlib.contextmanager
 def _capture(graph, pool=None):
     """Stream capture of a step body into `graph`.  Unlike the `torch.cuda.graph` context this neither synchronises
@@ -252,7 +273,7 @@ def _capture(graph, pool=None):
     the cyclic garbage collector: a collection in the middle of a capture may finalize unrelated objects that own HIP
     resources (pinned buffers, events, other graphs), whose release calls are illegal while a stream is capturing."""
     current = torch.cuda.current_stream()
-    side = torch.cuda.Stream(current.device)
+    side = _side_stream(current.device)
     side.wait_stream(current)
     was_enabled = gc.isenabled()
     gc.disable()
@@ -449,7 +470,7 @@ class _GraphStep:
         side = self.side
         if self.calls == 1:
             current = torch.cuda.current_stream(s.y0.device)
-            stream = torch.cuda.Stream(s.y0.device)
+            stream = _side_stream(s.y0.device)
             stream.wait_stream(current)
             with torch.cuda.stream(stream):
                 self.body(s, 0)
@@ -1496,7 +1517,7 @@ class FixedGridODESolver(object):
 
         # the first step runs eagerly on a side stream (library / allocator warm-up before capture) ...
         current = torch.cuda.current_stream(self.device)
-        side = torch.cuda.Stream(self.device)
+        side = _side_stream(self.device)
         side.wait_stream(current)
         with torch.cuda.stream(side):
             step()
