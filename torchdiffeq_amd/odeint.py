@@ -55,19 +55,25 @@ def _zero_dim_promotion(func, y0, t, method, options, event_fn):
     whole solve runs in fp64 and only the stored outputs are rounded to fp32 (solvers.py:104-127, rk_common.py:110-157,
     fixed_adams.py:196-223).  Returned: the func to integrate in fp64, or None when the case does not apply (also with
     `perturb`, whose first evaluation time the reference perturbs in fp32, and with step callbacks)."""
-    if not (event_fn is None and isinstance(y0, torch.Tensor) and y0.dim() == 0 and y0.dtype == torch.float32
+    if not (event_fn is None and isinstance(y0, torch.Tensor) and y0.dim() == 0
+            and y0.dtype in (torch.float32, torch.complex64)             # complex64 promotes to complex128 the same way
             and isinstance(t, torch.Tensor) and t.dtype == torch.float64 and method in _PROMOTING_METHODS):
         return None
     if (options or {}).get("perturb") or getattr(func, "callback_step", None) is not None:
         return None
     first = [True]
+    low, wide = y0.dtype, _wide_dtype(y0.dtype)
 
     def promoted(t_, y_):
         if first[0]:
             first[0] = False
-            return func(t_.to(torch.float32), y_.to(torch.float32)).to(torch.float64)
+            return func(t_.to(torch.float32), y_.to(low)).to(wide)
         return func(t_, y_)
     return promoted
+
+
+def _wide_dtype(dtype):
+    return torch.complex128 if dtype == torch.complex64 else torch.float64
 
 
 def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None):
@@ -87,7 +93,8 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, even
     """
     promoted = _zero_dim_promotion(func, y0, t, method, options, event_fn)
     if promoted is not None:
-        return odeint(promoted, y0.double(), t, rtol=rtol, atol=atol, method=method, options=options).to(y0.dtype)
+        return odeint(promoted, y0.to(_wide_dtype(y0.dtype)), t, rtol=rtol, atol=atol, method=method,
+                      options=options).to(y0.dtype)
     ci = check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS)
     y0_flat = ci.y0_flat
     if sum(ci.layout.numels) == 0 and ci.event_fn is None:

@@ -1875,7 +1875,7 @@ class AdamsBashforthMoulton(FixedGridODESolver):
         # to fp64 (a dimensioned fp32 tensor would stay fp32): products and sums of `_dot_product` run in fp64 and are
         # rounded once by `.type_as(y0)` — see _step_zero_dim.
         self._zero_dim_f32 = (not self.layout.is_tuple and tuple(self.layout.shapes[0]) == ()
-                              and y0.dtype == torch.float32)
+                              and y0.dtype in (torch.float32, torch.complex64))        # complex64 promotes to complex128 alike
 
     def _step_zero_dim(self, t1, y0, f0, hist, order, dt64, sh):
         """The step for a 0-dim fp32 state with the reference's type promotion (fixed_adams.py:205-216): the history
@@ -1887,8 +1887,9 @@ class AdamsBashforthMoulton(FixedGridODESolver):
         dsh = sh.dt_signed()
         wrt_dt = lambda dw: [(dsh, list(dw))] if dsh is not None else []
         bash, _ = adams_coefficients(order)
-        h64 = [h.double() for h in hist]
-        dot64 = lambda coefs, sc=(): ops._long_sum(h64, list(coefs), list(sc)).float()     # left to right in fp64, one rounding
+        low, wide = y0.dtype, (torch.float64 if y0.dtype == torch.float32 else torch.complex128)
+        h64 = [h.to(wide) for h in hist]
+        dot64 = lambda coefs, sc=(): ops._long_sum(h64, list(coefs), list(sc)).to(low)     # left to right in fp64, one rounding
         add = lambda a, b: ops.weighted_sum([a, b], [1.0, 1.0])
 
         dy = dot64([dt64 * b * sign for b in bash], wrt_dt(bash))
@@ -1905,7 +1906,7 @@ class AdamsBashforthMoulton(FixedGridODESolver):
         converged = False
         for _ in range(self.max_iters):
             f = func.eval(t1, y, last, shadow=sh.time(1.0))
-            dy_new = add(ops.weighted_sum([f.double()], [c], wrt_dt([moulton[0]])).float(), delta)
+            dy_new = add(ops.weighted_sum([f.to(wide)], [c], wrt_dt([moulton[0]])).to(low), delta)
             y = add(y0, dy_new)
             self.kernels.adams_correct(self._plan, dy_new.detach(), dy.detach(), compute=False)
             dy = dy_new
