@@ -54,20 +54,29 @@ def _zero_dim_promotion(func, y0, t, method, options, event_fn):
     dtype, so `dy`, `y1` and every later stage are fp64: after the very first evaluation (t and y still fp32) the
     whole solve runs in fp64 and only the stored outputs are rounded to fp32 (solvers.py:104-127, rk_common.py:110-157,
     fixed_adams.py:196-223).  Returned: the func to integrate in fp64, or None when the case does not apply (also with
-    `perturb`, whose first evaluation time the reference perturbs in fp32, and with step callbacks)."""
+    step callbacks, which would see the promoted state)."""
     if not (event_fn is None and isinstance(y0, torch.Tensor) and y0.dim() == 0
             and y0.dtype in (torch.float32, torch.complex64)             # complex64 promotes to complex128 the same way
             and isinstance(t, torch.Tensor) and t.dtype == torch.float64 and method in _PROMOTING_METHODS):
         return None
-    if (options or {}).get("perturb") or getattr(func, "callback_step", None) is not None:
+    if getattr(func, "callback_step", None) is not None:
         return None
     first = [True]
     low, wide = y0.dtype, _wide_dtype(y0.dtype)
+    perturb = bool((options or {}).get("perturb"))
+    increasing = bool(len(t) < 2 or t[1] > t[0])
 
     def promoted(t_, y_):
         if first[0]:
             first[0] = False
-            return func(t_.to(torch.float32), y_.to(low)).to(wide)
+            t32 = t_.to(torch.float32)
+            if perturb:
+                # the reference perturbs the first evaluation time in the STATE's precision, which is still fp32 there
+                # (misc.py:185-196: cast, then nextafter towards the interior of the step); t_ arrives perturbed by one
+                # fp64 ulp, which the cast to fp32 rounds away again
+                toward = float("inf") if increasing else -float("inf")
+                t32 = torch.nextafter(t32, torch.full_like(t32, toward))
+            return func(t32, y_.to(low)).to(wide)
         return func(t_, y_)
     return promoted
 
