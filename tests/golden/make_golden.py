@@ -1031,6 +1031,15 @@ def gen_dropin():
             key = f"evgrad_{method}_{'rev' if rev else 'fwd'}"
             arrays[f"{key}_t"], arrays[f"{key}_y"] = et.detach(), ys.detach()
             arrays[f"{key}_gy0"], arrays[f"{key}_gt0"], arrays[f"{key}_gk"] = g
+    # (5) a 0-dim fp32 state on an fp64 grid WITH the perturb option (misc.py:174-197): the first evaluation time is
+    # perturbed in fp32 (the state is still fp32 there), every later one in fp64 (0-dim x 0-dim promotion)
+    for method in ("euler", "midpoint", "heun3", "rk4", "explicit_adams", "implicit_adams"):
+        for tag, tt in (("fwd", torch.linspace(0.1, 0.6, 11, dtype=torch.float64)),
+                        ("rev", torch.linspace(0.6, 0.1, 11, dtype=torch.float64))):
+            with torch.no_grad():
+                y = torchdiffeq.odeint(lambda t_, y_: -y_ * (1 + 0.3 * t_) + 0.2 * t_ * t_, torch.tensor(0.7), tt, method=method,
+                                       options=dict(perturb=True, step_size=0.013))
+            arrays[f"zerodim_perturb_{method}_{tag}"] = y
     save("dropin.npz", **arrays)
 
 

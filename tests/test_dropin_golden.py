@@ -343,3 +343,20 @@ def test_adjoint_callbacks_see_the_reference_tuple_for_a_tuple_state(where, meth
     assert times[0] == 1.0 and all(dt > 0 for _, _, dt in rec["adj"])
     if method == "rk4":
         assert times == [1.0, 0.75, 0.5, 0.25]
+
+
+@pytest.mark.parametrize("direction", ["fwd", "rev"])
+@pytest.mark.parametrize("method", ["euler", "midpoint", "heun3", "rk4", "explicit_adams", "implicit_adams"])
+def test_zero_dim_fp32_state_on_an_fp64_grid_with_perturb(where, method, direction):
+    """The last piece of the 0-dim promotion artefact: with `perturb` the reference perturbs the FIRST
+    evaluation time in fp32 (the state is still fp32 there) and every later one in fp64.  Polynomial field (no libm), so
+    the MI355X result equals the CPU reference bit for bit as well."""
+    z = load("dropin.npz")
+    t = torch.linspace(0.1, 0.6, 11, dtype=torch.float64)
+    if direction == "rev":
+        t = torch.linspace(0.6, 0.1, 11, dtype=torch.float64)
+    with torch.no_grad():
+        y = tda.odeint(lambda t_, y_: -y_ * (1 + 0.3 * t_) + 0.2 * t_ * t_, torch.tensor(0.7), t, method=method,
+                       options=dict(perturb=True, step_size=0.013))
+    want = T(z[f"zerodim_perturb_{method}_{direction}"])
+    assert y.dtype == torch.float32 and torch.equal(y.cpu(), want), float((y.cpu() - want).abs().max())
