@@ -1031,6 +1031,24 @@ def gen_dropin():
             key = f"evgrad_{method}_{'rev' if rev else 'fwd'}"
             arrays[f"{key}_t"], arrays[f"{key}_y"] = et.detach(), ys.detach()
             arrays[f"{key}_gy0"], arrays[f"{key}_gt0"], arrays[f"{key}_gk"] = g
+    # (6) second-order gradients with the output TIMES in the graph and CUBIC Hermite interpolation between grid points
+    # (solvers.py:166-173): the basis is cubic in h = (t - t0) / (t1 - t0), so the Hessian needs its curvature
+    g = torch.Generator().manual_seed(9)
+    W0 = torch.randn(3, 3, generator=g, dtype=torch.float64) * 0.5
+    x0 = torch.randn(2, 3, generator=g, dtype=torch.float64)
+    arrays["hesscubic_W"], arrays["hesscubic_x"] = W0, x0
+    for method, step in (("rk4", 0.1), ("heun3", 0.07), ("euler", 0.05)):
+        W = W0.clone().requires_grad_(True)
+        x = x0.clone().requires_grad_(True)
+        tt = torch.tensor([0.05, 0.43, 0.96], dtype=torch.float64, requires_grad=True)
+        y = torchdiffeq.odeint(lambda t_, y_: torch.tanh(y_ @ W.T) * torch.cos(t_), x, tt, method=method,
+                               options=dict(step_size=step, interp="cubic"))
+        loss = (y[-1] ** 2).sum() + (y[1] ** 3).sum()
+        g1 = torch.autograd.grad(loss, (x, W, tt), create_graph=True)
+        g2 = torch.autograd.grad(sum((v ** 2).sum() for v in g1), (x, W, tt))
+        for name, v in zip(("gx", "gW", "gt", "hx", "hW", "ht"), list(g1) + list(g2)):
+            arrays[f"hesscubic_{method}_{name}"] = v.detach()
+
     # (5) a 0-dim fp32 state on an fp64 grid WITH the perturb option (misc.py:174-197): the first evaluation time is
     # perturbed in fp32 (the state is still fp32 there), every later one in fp64 (0-dim x 0-dim promotion)
     for method in ("euler", "midpoint", "heun3", "rk4", "explicit_adams", "implicit_adams"):

@@ -360,3 +360,22 @@ def test_zero_dim_fp32_state_on_an_fp64_grid_with_perturb(where, method, directi
                        options=dict(perturb=True, step_size=0.013))
     want = T(z[f"zerodim_perturb_{method}_{direction}"])
     assert y.dtype == torch.float32 and torch.equal(y.cpu(), want), float((y.cpu() - want).abs().max())
+
+
+@pytest.mark.parametrize("method,step", [("rk4", 0.1), ("heun3", 0.07), ("euler", 0.05)])
+def test_second_order_time_gradients_through_cubic_interpolation(where, method, step):
+    """Found by a differential run of Hessians against the reference (r03): with `interp='cubic'` the output between two
+    grid points is a cubic Hermite polynomial in h = (t - t0) / (t1 - t0); its recorded node carried the first derivative
+    of the basis only, so d2/dt2 of anything interpolated was wrong (heun3: 42 %).  Values from the reference."""
+    z = load("dropin.npz")
+    W = T(z["hesscubic_W"]).to(where).requires_grad_(True)
+    x = T(z["hesscubic_x"]).to(where).requires_grad_(True)
+    tt = torch.tensor([0.05, 0.43, 0.96], dtype=torch.float64, requires_grad=True)
+    y = tda.odeint(lambda t_, y_: torch.tanh(y_ @ W.T) * torch.cos(t_), x, tt, method=method,
+                   options=dict(step_size=step, interp="cubic"))
+    loss = (y[-1] ** 2).sum() + (y[1] ** 3).sum()
+    g1 = torch.autograd.grad(loss, (x, W, tt), create_graph=True)
+    g2 = torch.autograd.grad(sum((v ** 2).sum() for v in g1), (x, W, tt))
+    for name, got in zip(("gx", "gW", "gt", "hx", "hW", "ht"), list(g1) + list(g2)):
+        want = T(z[f"hesscubic_{method}_{name}"])
+        assert torch.allclose(got.detach().cpu(), want, rtol=1e-8, atol=1e-10 * float(want.abs().max())), name

@@ -186,9 +186,9 @@ class Ops:
 
     # -- generic --------------------------------------------------------------------------------------
     def _record(self, launch: Callable, xs: List[torch.Tensor], w: List[float],
-                scalars: Sequence[Tuple[Scalar, List[float]]]) -> torch.Tensor:
+                scalars: Sequence[Tuple[Scalar, List[float]]], w_fn=None) -> torch.Tensor:
         """Run `launch` as one autograd node (the kernels only read data pointers, so the inputs need no detach)."""
-        spec = _Spec(self.k, launch, w, [dw for _, dw in scalars], xs[0])
+        spec = _Spec(self.k, launch, w, [dw for _, dw in scalars], xs[0], w_fn=w_fn)
         return _LinearOp.apply(spec, len(scalars), *[s for s, _ in scalars], *xs)
 
     # -- RK stage combines ------------------------------------------------------------------------------
@@ -291,15 +291,17 @@ class Ops:
         return self._record(lambda o: self.k.lerp(o, y0, y1, slope), [y0, y1], [1.0 - s, s],
                             [(slope_shadow, [-1.0, 1.0])])
 
-    def weighted_sum(self, xs, ws, scalars: Sequence[Tuple[Scalar, List[float]]] = (), out=None):
-        """sum_m ws_m xs_m (tdeq_weighted_sum); `scalars` = [(shadow, d ws / d scalar)]."""
+    def weighted_sum(self, xs, ws, scalars: Sequence[Tuple[Scalar, List[float]]] = (), out=None, w_fn=None):
+        """sum_m ws_m xs_m (tdeq_weighted_sum); `scalars` = [(shadow, d ws / d scalar)]; `w_fn(scalars) -> (weights,
+        [d weights / d scalar_i])` as torch expressions when the weights are NOT linear in the scalars (second-order
+        gradients need the curvature: the cubic Hermite basis, see _Spec.w_fn)."""
         if not _needs_graph(xs, [s for s, _ in scalars]):
             if out is None:
                 out = torch.empty_like(xs[0])
             self.k.weighted_sum(out, xs, ws)
             return out
         w = [float(self.T(v)) for v in ws]
-        return self._record(lambda o: self.k.weighted_sum(o, xs, ws), list(xs), w, list(scalars))
+        return self._record(lambda o: self.k.weighted_sum(o, xs, ws), list(xs), w, list(scalars), w_fn=w_fn)
 
     def dense_eval(self, y0, y1, k: Sequence[torch.Tensor], mid_idx, mid_coef, dt: float, x: float,
                    dt_shadow: Scalar = None, x_shadow: Scalar = None, out=None):

@@ -1614,14 +1614,34 @@ class FixedGridODESolver(object):
         dt = scalar(t1 - t0)
         sign = scalar(self.func.sign)       # f0 / f1 are raw func outputs: fold the time sign into their weights
         ws = [float(h00), float(scalar(h10 * dt) * sign), float(h01), float(scalar(h11 * dt) * sign)]
-        scalars = ()
+        scalars, w_fn = (), None
         if sh is not _NO_SHADOW:
             hf, dtf, sg = float(h), float(dt), float(sign)
             d_h = [-6 * hf * (1 - hf), (1 - hf) * (1 - 3 * hf) * dtf * sg, 6 * hf * (1 - hf),
                    (3 * hf * hf - 2 * hf) * dtf * sg]
             d_dt = [0.0, float(h10) * sg, 0.0, float(h11) * sg]
             scalars = [(sh.fraction(t_shadow, t), d_h), (sh.width(), d_dt)]
-        return self.ops.weighted_sum([y0, f0, y1, f1], ws, scalars, out=out)
+            device = y0.device
+
+            def w_fn(live):
+                """The basis as torch expressions of (h, dt) — cubic in h, so second-order time gradients need its
+                curvature (values from the host scalars, gradients through the shadows)."""
+                h_s, dt_s = live
+                h_t = torch.full((), hf, dtype=torch.float64, device=device)
+                dt_t = torch.full((), dtf, dtype=torch.float64, device=device)
+                if h_s is not None:
+                    h_t = h_t + (h_s - h_s.detach()).double()
+                if dt_s is not None:
+                    dt_t = dt_t + (dt_s - dt_s.detach()).double()
+                omh_t = 1 - h_t
+                b00, b10 = (1 + 2 * h_t) * omh_t * omh_t, h_t * omh_t * omh_t
+                b01, b11 = h_t * h_t * (3 - 2 * h_t), h_t * h_t * (h_t - 1)
+                d00, d10 = -6 * h_t * omh_t, omh_t * (1 - 3 * h_t)
+                d01, d11 = 6 * h_t * omh_t, 3 * h_t * h_t - 2 * h_t
+                zero = torch.zeros((), dtype=torch.float64, device=device)
+                return ([b00, b10 * dt_t * sg, b01, b11 * dt_t * sg],
+                        [[d00, d10 * dt_t * sg, d01, d11 * dt_t * sg], [zero, b10 * sg, zero, b11 * sg]])
+        return self.ops.weighted_sum([y0, f0, y1, f1], ws, scalars, out=out, w_fn=w_fn)
 
 
 class _StepShadow:
