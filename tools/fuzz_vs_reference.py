@@ -1,6 +1,6 @@
 """Differential fuzzing against the reference (build container only: imports /root/reference).
 
-  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad|callbacks} [seed] [cases]
+  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad|callbacks|hessian} [seed] [cases]
   (TDEQ_FUZZ_BACKEND=host: the product's torch-op host path for CPU states instead of the oracle test backend)
 
 Random states (0-dim .. 3-dim, tuples), dtypes, time grids (both directions), options and methods are solved by the
@@ -550,5 +550,48 @@ elif mode == "callbacks":
             tol=1e-9 if k in ('s','a','r') else 1e-6
             if d>tol: bad+=1; print('SEQ',desc,k,d); break
     print('done',n,'bad',bad)
+elif mode == "hessian":
+    # r03: SECOND-order gradients through plain odeint (create_graph=True) wrt y0, a weight matrix and the output times,
+    # explicit RK fixed-grid (linear / cubic interpolation), adaptive and Adams methods, tuple states, both directions.
+    # Found: the cubic Hermite interpolation node lacked the curvature of its basis.  1e-8 (dopri8 1e-6: noise-level
+    # first step); low-order adaptive methods at tight tolerances accumulate 1e-7 in d2/dt2 over thousands of steps.
+    rng = random.Random(int(sys.argv[1]))
+    n = int(sys.argv[2])
+    bad = 0
+    M=['euler','midpoint','heun2','heun3','rk4','dopri5','bosh3','tsit5','fehlberg2','adaptive_heun','explicit_adams','implicit_adams','dopri8']
+    for case in range(n):
+        method=rng.choice(M); rev=rng.random()<0.3; tgrad=rng.random()<0.4; is_tuple=rng.random()<0.25
+        g=torch.Generator().manual_seed(rng.randrange(10**6))
+        W0=torch.randn(3,3,generator=g,dtype=torch.float64)*0.5; x0=torch.randn(2,3,generator=g,dtype=torch.float64); b0=torch.randn(2,generator=g,dtype=torch.float64)
+        tt=torch.sort(torch.rand(3,generator=g,dtype=torch.float64)).values
+        if float((tt[1:]-tt[:-1]).min())<0.05: continue
+        if rev: tt=tt.flip(0)
+        opts={}
+        if method in M[:5]+M[10:12] and rng.random()<0.6: opts['step_size']=rng.choice([0.1,0.07])
+        if method in M[:5] and rng.random()<0.3: opts['interp']='cubic'
+        res=[]
+        for L in (ref,tda):
+            W=W0.clone().requires_grad_(True); x=x0.clone().requires_grad_(True); t=tt.clone().requires_grad_(tgrad)
+            def f(t_,y):
+                if is_tuple: return (torch.tanh(y[0]@W.T)*torch.cos(t_), -y[1]*y[1]*0.3)
+                return torch.tanh(y@W.T)*torch.cos(t_)
+            try:
+                out=L.odeint(f,(x,b0) if is_tuple else x,t,method=method,options=dict(opts) or None,rtol=1e-8,atol=1e-10)
+                o=out[0] if is_tuple else out
+                loss=(o[-1]**2).sum()+(o[1]**3).sum()
+                ins=[x,W]+([t] if tgrad else [])
+                g1=torch.autograd.grad(loss,ins,create_graph=True)
+                second=sum((gi**2).sum() for gi in g1)
+                g2=torch.autograd.grad(second,ins,allow_unused=True)
+                res.append(('ok',[gi.detach() for gi in g1]+[gi if gi is not None else torch.zeros(1,dtype=torch.float64) for gi in g2]))
+            except Exception as e:
+                res.append(('err',type(e).__name__+': '+str(e)[:100]))
+        a,b=res; desc=(case,method,rev,tgrad,is_tuple,opts)
+        if a[0]!=b[0]: bad+=1; print('STATUS',desc,a[1] if a[0]=='err' else 'ok',b[1] if b[0]=='err' else 'ok'); continue
+        if a[0]=='err': continue
+        for i,(p,q) in enumerate(zip(a[1],b[1])):
+            d=float((p-q).abs().max()/(p.abs().max()+1e-12))
+            if not d<=(1e-6 if method=='dopri8' else 1e-8): bad+=1; print('VALUE',desc,i,d); break
+    print('done',n,'bad',bad)
 else:
-    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad | callbacks")
+    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad | callbacks | hessian")
