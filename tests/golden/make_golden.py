@@ -1049,6 +1049,19 @@ def gen_dropin():
         for name, v in zip(("gx", "gW", "gt", "hx", "hW", "ht"), list(g1) + list(g2)):
             arrays[f"hesscubic_{method}_{name}"] = v.detach()
 
+    # (7) per-component tolerances of the BACKWARD solve with a tuple forward state: given for the reference's backward
+    # state (t, y, adj_y, *adj_params) — 3 + P entries (adjoint.py:64-65, misc.py:115-123)
+    p1 = torch.tensor([0.5, 0.2], dtype=torch.float64, requires_grad=True)
+    p2 = torch.tensor(0.3, dtype=torch.float64, requires_grad=True)
+    xg = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64, requires_grad=True)
+    zg = torch.tensor([[0.5, 0.1]], dtype=torch.float64)
+    out = torchdiffeq.odeint_adjoint(lambda t_, s: (-s[0] * p1[0] * torch.cos(t_) + s[1].sum() * p2, -s[1] * p1[1]), (xg, zg),
+                                     torch.tensor([0.0, 0.6, 1.0], dtype=torch.float64), adjoint_params=(p1, p2), method="dopri5",
+                                     rtol=1e-6, atol=1e-8, adjoint_rtol=(1e-3, 1e-6, 1e-5, 1e-4, 1e-4),
+                                     adjoint_atol=(1e-4, 1e-8, 1e-7, 1e-6, 1e-6))
+    (out[0][-1].pow(2).sum() + out[1][-1].sum()).backward()
+    arrays["adjtol_gx"], arrays["adjtol_gp1"], arrays["adjtol_gp2"] = xg.grad, p1.grad, p2.grad
+
     # (5) a 0-dim fp32 state on an fp64 grid WITH the perturb option (misc.py:174-197): the first evaluation time is
     # perturbed in fp32 (the state is still fp32 there), every later one in fp64 (0-dim x 0-dim promotion)
     for method in ("euler", "midpoint", "heun3", "rk4", "explicit_adams", "implicit_adams"):

@@ -379,3 +379,29 @@ def test_second_order_time_gradients_through_cubic_interpolation(where, method, 
     for name, got in zip(("gx", "gW", "gt", "hx", "hW", "ht"), list(g1) + list(g2)):
         want = T(z[f"hesscubic_{method}_{name}"])
         assert torch.allclose(got.detach().cpu(), want, rtol=1e-8, atol=1e-10 * float(want.abs().max())), name
+
+
+def test_per_component_adjoint_tolerances_follow_the_reference_backward_state(where):
+    """`adjoint_rtol` / `adjoint_atol` as sequences are per component of the REFERENCE's backward state
+    (t, y, adj_y, *adj_params): 3 + P entries, also for a tuple forward state (whose y / adj_y are flat there) — spread over
+    this package's 1 + 2 n_y + P segments.  A tuple forward `rtol` is inherited unchanged and fails the length check in the
+    backward pass, in the reference as here (adjoint.py:167-170)."""
+    z = load("dropin.npz")
+
+    def run(**kw):
+        p1 = torch.tensor([0.5, 0.2], dtype=torch.float64, requires_grad=True)
+        p2 = torch.tensor(0.3, dtype=torch.float64, requires_grad=True)
+        x = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64, requires_grad=True)
+        zz = torch.tensor([[0.5, 0.1]], dtype=torch.float64)
+        out = tda.odeint_adjoint(lambda t_, s: (-s[0] * p1[0] * torch.cos(t_) + s[1].sum() * p2, -s[1] * p1[1]), (x, zz),
+                                 torch.tensor([0.0, 0.6, 1.0], dtype=torch.float64), adjoint_params=(p1, p2), method="dopri5", **kw)
+        (out[0][-1].pow(2).sum() + out[1][-1].sum()).backward()
+        return x.grad.cpu(), p1.grad.cpu(), p2.grad.cpu()
+    got = run(rtol=1e-6, atol=1e-8, adjoint_rtol=(1e-3, 1e-6, 1e-5, 1e-4, 1e-4), adjoint_atol=(1e-4, 1e-8, 1e-7, 1e-6, 1e-6))
+    for g, name in zip(got, ("gx", "gp1", "gp2")):
+        assert torch.allclose(g, T(z[f"adjtol_{name}"]), rtol=1e-9, atol=1e-12), name
+    with pytest.raises(AssertionError, match="tupled rtol"):        # 1 + 2 n_y + P entries is NOT the convention
+        run(rtol=1e-6, atol=1e-8, adjoint_rtol=(1e-3, 1e-6, 1e-6, 1e-5, 1e-5, 1e-4, 1e-4))
+    with pytest.raises(AssertionError, match="tupled rtol"):        # inherited tuple rtol: length 2, not 3 + P
+        run(rtol=(1e-5, 1e-7), atol=(1e-7, 1e-9))
+    run(rtol=(1e-5, 1e-7), atol=(1e-7, 1e-9), adjoint_rtol=1e-6, adjoint_atol=1e-8)

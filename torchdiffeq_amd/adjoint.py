@@ -304,8 +304,9 @@ class OdeintAdjointMethod(torch.autograd.Function):
                     aug_views[0].sub_(dLd_cur_t)
                     time_vjps[i] = dLd_cur_t
                 bwd_cls = SOLVERS[ctx.adjoint_method]
-                bwd_options, bwd_rtol, bwd_atol = plugin_solver_inputs(bwd_cls, aug_layout, options, ctx.adjoint_rtol,
-                                                                       ctx.adjoint_atol, device)
+                bwd_options, bwd_rtol, bwd_atol = plugin_solver_inputs(
+                    bwd_cls, aug_layout, options, _adjoint_tolerance(ctx.adjoint_rtol, n_y, len(adjoint_params), "rtol"),
+                    _adjoint_tolerance(ctx.adjoint_atol, n_y, len(adjoint_params), "atol"), device)
                 solver = bwd_cls(func=aug_func, y0=aug, rtol=bwd_rtol, atol=bwd_atol, **bwd_options)
                 if aug_func.use_proxy and not getattr(solver, "hip_graph", False):
                     aug_func.use_proxy = False      # the solver runs eagerly after all (state too large, user norm ...):
@@ -379,6 +380,23 @@ def find_parameters(module):
         return list(module.parameters())
     grad_attrs = lambda m: [(name, v) for name, v in vars(m).items() if torch.is_tensor(v) and v.requires_grad]
     return [tensor for _, tensor in module._named_members(get_members_fn=grad_attrs)]
+
+
+def _adjoint_tolerance(tol, n_y: int, n_params: int, name: str):
+    """Per-component tolerances of the backward solve are given for the REFERENCE's backward state
+    `(t, y, adj_y, *adj_params)` — 3 + P entries, `y` and `adj_y` of a tuple forward state being one flat component each
+    there (adjoint.py:64-65, misc.py:115-123) — and spread over this package's segments (1 + 2 n_y + P).  Note that
+    a tuple forward `rtol` is inherited as it is (adjoint.py:167-170) and then fails this length check in the reference
+    as well: with a tuple state and tuple tolerances `adjoint_rtol` / `adjoint_atol` have to be passed."""
+    if isinstance(tol, torch.Tensor):
+        if tol.dim() == 0:
+            return tol
+        tol = tol.tolist()
+    if not isinstance(tol, (list, tuple)):
+        return tol
+    assert len(tol) == 3 + n_params, "If using tupled {} it must have the same length as the tuple y0".format(name)
+    vals = list(tol)
+    return [vals[0]] + [vals[1]] * n_y + [vals[2]] * n_y + vals[3:]
 
 
 def _reference_state(aug_layout: StateLayout, fwd_layout: StateLayout, flat: torch.Tensor):
