@@ -1062,6 +1062,27 @@ def gen_dropin():
     (out[0][-1].pow(2).sum() + out[1][-1].sum()).backward()
     arrays["adjtol_gx"], arrays["adjtol_gp1"], arrays["adjtol_gp2"] = xg.grad, p1.grad, p2.grad
 
+    # (8) PER-ELEMENT tolerances: tensors / lists that broadcast against the state (misc.py:80-82 is plain broadcasting;
+    # rk_common.py:186-187 makes them fp64), and vector entries of a tuple tolerance (misc.py:115-123)
+    yv = torch.tensor([[1.0, 2.0, 3.0], [0.5, 1.0, 1.5]], dtype=torch.float64)
+    cv = torch.tensor([1.0, 5.0, 0.2], dtype=torch.float64)
+    tv = torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64)
+    cases = {"rtolvec": dict(rtol=torch.tensor([1e-3, 1e-6, 1e-9], dtype=torch.float64), atol=1e-9),
+             "atollist": dict(rtol=1e-6, atol=[1e-3, 1e-6, 1e-9]),
+             "both": dict(rtol=torch.tensor([1e-3, 1e-6, 1e-7]), atol=[1e-4, 1e-8, 1e-9])}
+    for tag, kw in cases.items():
+        for method in ("dopri5", "bosh3"):
+            y, nfe, c = solve(lambda t_, y_: -y_ * cv * (1 + 0.2 * t_), yv, tv, method=method, **kw)
+            arrays[f"vectol_{tag}_{method}_y"], arrays[f"vectol_{tag}_{method}_nfe"] = y, nfe
+            arrays[f"vectol_{tag}_{method}_accept_dt"] = np.array(c.accept)
+    wv = torch.tensor(0.7, dtype=torch.float64, requires_grad=True)
+    xv = yv[0].clone().requires_grad_(True)
+    out = torchdiffeq.odeint(lambda t_, s: (-s[0] * cv * wv, -s[1] * 0.3), (xv, torch.ones(2, dtype=torch.float64)), tv,
+                             rtol=(torch.tensor([1e-3, 1e-6, 1e-8], dtype=torch.float64), 1e-5),
+                             atol=(1e-9, torch.tensor([1e-7, 1e-9], dtype=torch.float64)))
+    out[0][-1].pow(2).sum().backward()
+    arrays["vectol_tuple_y"], arrays["vectol_tuple_gx"], arrays["vectol_tuple_gw"] = out[0].detach(), xv.grad, wv.grad
+
     # (5) a 0-dim fp32 state on an fp64 grid WITH the perturb option (misc.py:174-197): the first evaluation time is
     # perturbed in fp32 (the state is still fp32 there), every later one in fp64 (0-dim x 0-dim promotion)
     for method in ("euler", "midpoint", "heun3", "rk4", "explicit_adams", "implicit_adams"):

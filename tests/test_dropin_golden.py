@@ -405,3 +405,53 @@ def test_per_component_adjoint_tolerances_follow_the_reference_backward_state(wh
     with pytest.raises(AssertionError, match="tupled rtol"):        # inherited tuple rtol: length 2, not 3 + P
         run(rtol=(1e-5, 1e-7), atol=(1e-7, 1e-9))
     run(rtol=(1e-5, 1e-7), atol=(1e-7, 1e-9), adjoint_rtol=1e-6, adjoint_atol=1e-8)
+
+
+@pytest.mark.parametrize("method", ["dopri5", "bosh3"])
+@pytest.mark.parametrize("tag", ["rtolvec", "atollist", "both"])
+def test_per_element_tolerances(where, tag, method):
+    """Tolerances given PER ELEMENT — a tensor or list that broadcasts against the state (in the reference
+    `atol + rtol * max(|y0|, |y1|)` simply broadcasts, misc.py:80-82; the tolerances are fp64 tensors by then,
+    rk_common.py:186-187).  They used to be rejected ('tupled rtol must have the same length as the tuple y0').  The
+    kernels deliver the raw error / initial-step quantities, scaling and norm run as torch ops in fp64: the reference's
+    steps exactly (accepted step sizes, evaluation counts, solution)."""
+    z = load("dropin.npz")
+    kw = {"rtolvec": dict(rtol=torch.tensor([1e-3, 1e-6, 1e-9], dtype=torch.float64), atol=1e-9),
+          "atollist": dict(rtol=1e-6, atol=[1e-3, 1e-6, 1e-9]),
+          "both": dict(rtol=torch.tensor([1e-3, 1e-6, 1e-7]), atol=[1e-4, 1e-8, 1e-9])}[tag]
+    y0 = torch.tensor([[1.0, 2.0, 3.0], [0.5, 1.0, 1.5]], dtype=torch.float64)
+    c = torch.tensor([1.0, 5.0, 0.2], dtype=torch.float64)
+    t = torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64)
+    accepted = []
+
+    class F(torch.nn.Module):
+        nfe = 0
+
+        def forward(self, t_, y):
+            self.nfe += 1
+            return -y * c * (1 + 0.2 * t_)
+
+        def callback_accept_step(self, t0, y_, dt):
+            accepted.append(float(dt))
+    f = F()
+    with torch.no_grad():
+        y = tda.odeint(f, y0, t, method=method, **kw)
+    key = f"vectol_{tag}_{method}"
+    assert f.nfe == int(z[f"{key}_nfe"])
+    assert torch.allclose(torch.tensor(accepted, dtype=torch.float64), torch.as_tensor(z[f"{key}_accept_dt"], dtype=torch.float64), rtol=1e-9)
+    assert float((y.cpu() - T(z[f"{key}_y"])).abs().max()) < 1e-11
+
+
+def test_per_element_tolerances_inside_a_tuple_tolerance_with_gradients(where):
+    """misc.py:115-123: an entry of a tuple tolerance may itself be a vector over its component."""
+    z = load("dropin.npz")
+    c = torch.tensor([1.0, 5.0, 0.2], dtype=torch.float64)
+    w = torch.tensor(0.7, dtype=torch.float64, requires_grad=True)
+    x = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64, requires_grad=True)
+    out = tda.odeint(lambda t_, s: (-s[0] * c * w, -s[1] * 0.3), (x, torch.ones(2, dtype=torch.float64)),
+                     torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64),
+                     rtol=(torch.tensor([1e-3, 1e-6, 1e-8], dtype=torch.float64), 1e-5),
+                     atol=(1e-9, torch.tensor([1e-7, 1e-9], dtype=torch.float64)))
+    out[0][-1].pow(2).sum().backward()
+    assert torch.allclose(out[0].detach().cpu(), T(z["vectol_tuple_y"]), rtol=1e-12, atol=1e-14)
+    assert torch.allclose(x.grad.cpu(), T(z["vectol_tuple_gx"]), rtol=1e-10) and torch.allclose(w.grad.cpu(), T(z["vectol_tuple_gw"]), rtol=1e-10)

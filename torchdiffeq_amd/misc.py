@@ -206,6 +206,62 @@ def _per_segment(tol, n_seg: int, name: str) -> List[float]:
     return vals
 
 
+def component_norm(layout: "StateLayout", n_skip_tail: int = 0):
+    """The built-in norm (max over the components of sqrt(mean(x^2)), misc.py:22-33) as a plain callable on the flat,
+    per-component padded state — for code that cannot go through the segmented norm kernel."""
+    def _norm(flat, _lay=layout, _skip=n_skip_tail):
+        parts = [c for c in _lay.unpack(flat) if c.numel() > 0]
+        if _skip:
+            parts = parts[:len(parts) - _skip]
+        return max(c.abs().pow(2).mean().sqrt() for c in parts)
+    return _norm
+
+
+def vector_tolerances(rtol, atol, layout: "StateLayout", device):
+    """`(rtol, atol)` as fp64 tensors over the flat (padded) state when a tolerance is given PER ELEMENT — a tensor /
+    list that broadcasts against a tensor state, or tuple entries that are vectors over their component — else None.
+    The reference needs no code for this: `atol + rtol * max(|y0|, |y1|)` simply broadcasts (misc.py:80-82, the
+    tolerances having become fp64 tensors in rk_common.py:186-187; tuple entries are expanded by misc.py:115-123), and the
+    quotient, the norm and the error ratio are then fp64.  Padding gets (0, 1): quotients there stay finite."""
+    def per_element(tol, shape):
+        t = torch.as_tensor(tol, dtype=torch.float64, device=device)
+        return torch.broadcast_to(t, shape).reshape(-1) if t.numel() > 1 else None
+
+    def is_vector(tol):
+        if isinstance(tol, torch.Tensor):
+            return tol.numel() > 1
+        return isinstance(tol, (list, tuple))
+    if not layout.is_tuple:
+        if not (is_vector(rtol) or is_vector(atol)):
+            return None
+        shape = layout.shapes[0]
+        out = []
+        for tol in (rtol, atol):
+            v = per_element(tol, shape) if is_vector(tol) else None
+            out.append(v if v is not None else torch.full((layout.total,), float(torch.as_tensor(tol).reshape(-1)[0]),
+                                                           dtype=torch.float64, device=device))
+        return out[0], out[1]
+    # tuple state: a sequence with one entry per component is the ordinary case (scalars: handled per segment by the
+    # kernels); only vector ENTRIES need the per-element form
+    def entries(tol):
+        if isinstance(tol, (list, tuple)) and len(tol) == layout.n_seg:
+            return list(tol)
+        return None
+    er, ea = entries(rtol), entries(atol)
+    has_vec = any(e is not None and any(isinstance(v, torch.Tensor) and v.numel() > 1 for v in e) for e in (er, ea))
+    if not has_vec:
+        return None
+    flat = []
+    for tol, ent, pad in ((rtol, er, 0.0), (atol, ea, 1.0)):
+        v = torch.full((layout.total,), pad, dtype=torch.float64, device=device)
+        for i, (off, n) in enumerate(zip(layout.offsets, layout.numels)):
+            e = ent[i] if ent is not None else tol
+            v[off:off + n] = torch.as_tensor(e, device=device).to(torch.float64).reshape(-1).expand(n) \
+                if torch.as_tensor(e).numel() in (1, n) else torch.as_tensor(e, device=device).to(torch.float64).reshape(-1)
+        flat.append(v)
+    return flat[0], flat[1]
+
+
 def empty_solution(ci: "CheckedInputs", like: torch.Tensor):
     """The solution of a state without a single element: `[len(t), *shape]` per component, nothing to integrate (the
     kernels are never asked to run on a null buffer; the reference's fixed-grid solvers return the same, its adaptive
@@ -227,12 +283,7 @@ def plugin_solver_inputs(solver_cls, layout: "StateLayout", options: dict, rtol,
     options = dict(options)
     norm = options.get("norm")
     if isinstance(norm, BuiltinNorm):
-        def _component_norm(flat, _lay=layout, _skip=norm.n_skip_tail):
-            parts = [c for c in _lay.unpack(flat) if c.numel() > 0]
-            if _skip:
-                parts = parts[:len(parts) - _skip]
-            return max(c.abs().pow(2).mean().sqrt() for c in parts)
-        options["norm"] = _component_norm
+        options["norm"] = component_norm(layout, norm.n_skip_tail)
 
     def per_element(tol, name):
         vals = _per_segment(tol, layout.n_seg, name)

@@ -33,7 +33,8 @@ import torch
 
 from . import _native
 from .autodiff import Ops, stitch
-from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, find_event, handle_unused_kwargs, rms_norm)
+from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, component_norm, find_event, handle_unused_kwargs, rms_norm,
+                   vector_tolerances)
 from .misc import _null_callback as _null
 from .tableaus import (ADAPTIVE_HEUN, ADAPTIVE_TABLEAUS, BOSH3, CARRY_DEFAULT_ON, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau,
                        adams_coefficients, carry_plan)
@@ -522,9 +523,13 @@ class _InitialStepShadow:
     def __init__(self, solver, y0, f0, h0_value: float, h0_is_const: bool):
         s = self.s = solver
         lay = s.layout
-        self.segs = [(off, n, rt, at) for off, n, rt, at in lay.segments(s.rtol, s.atol) if n > 0]
+        self.segs = [(off, n, rt, at) for off, n, rt, at in lay.segments(*s._seg_tol) if n > 0]
         self.y0, self.f0 = y0, f0
-        self.scale = [at + y0[off:off + n].abs() * rt for off, n, rt, at in self.segs]
+        if s._vec_tol is not None:      # per-element tolerances
+            self.scale = [s._vec_tol[1][off:off + n] + y0[off:off + n].abs() * s._vec_tol[0][off:off + n]
+                          for off, n, _, _ in self.segs]
+        else:
+            self.scale = [at + y0[off:off + n].abs() * rt for off, n, rt, at in self.segs]
         self.d0 = self._norm(y0)
         self.d1 = self._norm(f0)
         if h0_is_const:
@@ -598,6 +603,16 @@ class RKAdaptiveStepsizeODESolver:
         self.dtype = torch.promote_types(dtype, func.time_dtype)   # accepted for API parity; host math is fp64
         self.norm = rms_norm if norm is None else norm
         self.rtol, self.atol = rtol, atol
+        # Per-element tolerances (a tensor / list broadcasting against the state — plain broadcasting in the reference,
+        # misc.py:80-82): the kernels take one (rtol, atol) per segment, so they are asked for the RAW error and initial-
+        # step quantities (tolerances 0 and 1) and the per-element scaling and the norm run as torch ops in fp64, which is
+        # also the reference's precision for this case.  Routed like a user norm: host-driven steps, no captured graphs.
+        self._vec_tol = vector_tolerances(rtol, atol, self.layout, y0.device)
+        if self._vec_tol is not None:
+            rtol, atol = 0.0, 1.0
+            if isinstance(self.norm, BuiltinNorm):
+                self.norm = component_norm(self.layout, self.norm.n_skip_tail)
+        self._seg_tol = (rtol, atol)
         self.min_step = _as_float(min_step)
         self.max_step = _as_float(max_step)
         self.first_step = None if first_step is None else _as_float(first_step)
@@ -888,6 +903,9 @@ class RKAdaptiveStepsizeODESolver:
             # user's callable reduce them
             q0, q1 = torch.empty_like(y0), torch.empty_like(y0)
             kern.init_scaled(plan, 0, y0, f0, y0, q0, q1)
+            if self._vec_tol is not None:
+                vec_scale = self._vec_tol[1] + y0.abs() * self._vec_tol[0]      # misc.py:50, per element, fp64
+                q0, q1 = q0 / vec_scale, q1 / vec_scale
             with torch.no_grad():
                 d0, d1 = T(abs(float(self.norm(q0)))), T(abs(float(self.norm(q1))))
         else:
@@ -908,7 +926,10 @@ class RKAdaptiveStepsizeODESolver:
             with torch.no_grad():
                 f1 = self.func.eval(t0 + float(h0), y1)
         if user_norm:
+            q0 = torch.empty_like(y0)
             kern.init_scaled(plan, 1, f1, f0, y0, q0)
+            if self._vec_tol is not None:
+                q0 = q0 / vec_scale
             with torch.no_grad():
                 d2_num = T(abs(float(self.norm(q0))))
         else:
@@ -1269,6 +1290,8 @@ class RKAdaptiveStepsizeODESolver:
         self.kernels.error_scaled(self.plan, scaled, y0, y1, [k[j].detach() for j in err.idx], err.coef, dt_signed)
         _, _, bad = self.kernels.read_norms(self.plan)
         with torch.no_grad():
+            if self._vec_tol is not None:       # `scaled` is the raw error estimate here (segment tolerances 0 / 1)
+                scaled = scaled / (self._vec_tol[1] + self._vec_tol[0] * torch.maximum(y0.abs(), y1.abs()))
             ratio = self.norm(scaled)
         ratio = abs(float(ratio))
         return ratio, any(b != 0 for b in bad)
