@@ -1,6 +1,6 @@
 """Differential fuzzing against the reference (build container only: imports /root/reference).
 
-  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad|callbacks|hessian} [seed] [cases]
+  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad|callbacks|hessian|vectol} [seed] [cases]
   (TDEQ_FUZZ_BACKEND=host: the product's torch-op host path for CPU states instead of the oracle test backend)
 
 Random states (0-dim .. 3-dim, tuples), dtypes, time grids (both directions), options and methods are solved by the
@@ -593,5 +593,60 @@ elif mode == "hessian":
             d=float((p-q).abs().max()/(p.abs().max()+1e-12))
             if not d<=(1e-6 if method=='dopri8' else 1e-8): bad+=1; print('VALUE',desc,i,d); break
     print('done',n,'bad',bad)
+elif mode == "vectol":
+    # r03: tolerances given PER ELEMENT (tensors / lists broadcasting against the state, vector entries of tuple
+    # tolerances), all adaptive methods, fp32 / fp64, tuple states, odeint_adjoint's forward solve.  Evaluation counts
+    # equal, solutions / gradients 1e-9 (the reference rejects a multi-dimensional vector ENTRY of a tuple tolerance,
+    # which is accepted here: reported as STATUS, not a parity defect).
+    rng = random.Random(int(sys.argv[1]))
+    n = int(sys.argv[2])
+    bad = 0
+    AD=['dopri5','bosh3','tsit5','fehlberg2','adaptive_heun','dopri8']
+    for case in range(n):
+        method=rng.choice(AD); dtype=rng.choice([torch.float64,torch.float64,torch.float32]); rev=rng.random()<0.3
+        shape=rng.choice([(3,),(2,3),(4,1,3)]); is_tuple=rng.random()<0.3; adj=rng.random()<0.3 and dtype==torch.float64
+        g=torch.Generator().manual_seed(rng.randrange(10**6))
+        y0=torch.randn(shape,generator=g,dtype=torch.float64).to(dtype); yb=torch.randn(2,generator=g,dtype=torch.float64).to(dtype)
+        t=torch.sort(torch.rand(rng.choice([2,3]),generator=g,dtype=torch.float64)).values.to(dtype)
+        if float((t[1:]-t[:-1]).min())<0.05: continue
+        if rev: t=t.flip(0)
+        def vec(lo,hi):
+            e=[10**rng.uniform(lo,hi) for _ in range(3)]
+            r=rng.random()
+            if r<0.4: return torch.tensor(e,dtype=rng.choice([torch.float64,torch.float32]))
+            if r<0.6: return e
+            if r<0.8 and len(shape)>1: return torch.tensor(e,dtype=torch.float64).expand(shape).clone()
+            return 10**rng.uniform(lo,hi)
+        rtol=vec(-7,-3); atol=vec(-9,-5)
+        if is_tuple:
+            rtol=(rtol, 10**rng.uniform(-6,-3)); atol=(atol, torch.tensor([1e-7,1e-8]) if rng.random()<0.5 else 1e-8)
+        res=[]
+        for L in (ref,tda):
+            nfe=[0]
+            w=torch.tensor([1.0,3.0,0.3],dtype=dtype,requires_grad=adj)
+            def f(tt,y):
+                nfe[0]+=1
+                if is_tuple: return (-y[0]*w*(1+0.2*tt)+0.1*torch.sin(y[0]), -0.4*y[1])
+                return -y*w*(1+0.2*tt)+0.1*torch.sin(y)
+            x=y0.clone().requires_grad_(adj)
+            try:
+                if adj:
+                    out=L.odeint_adjoint(f,(x,yb) if is_tuple else x,t,method=method,rtol=rtol,atol=atol,adjoint_rtol=1e-7,adjoint_atol=1e-9,adjoint_params=(w,))
+                    o=out[0] if is_tuple else out; o[-1].pow(2).sum().backward()
+                    res.append(('ok',[o.detach(),x.grad,w.grad],nfe[0]))
+                else:
+                    with torch.no_grad(): out=L.odeint(f,(x,yb) if is_tuple else x,t,method=method,rtol=rtol,atol=atol)
+                    res.append(('ok',[out[0] if is_tuple else out],nfe[0]))
+            except Exception as e:
+                res.append(('err',type(e).__name__+': '+str(e)[:90],0))
+        a,b=res; desc=(case,method,str(dtype)[6:],shape,is_tuple,adj,rev,type(rtol).__name__,type(atol).__name__)
+        if a[0]!=b[0]: bad+=1; print('STATUS',desc,a[1] if a[0]=='err' else 'ok',b[1] if b[0]=='err' else 'ok'); continue
+        if a[0]=='err': continue
+        tol=(1e-9 if method!='dopri8' else 1e-6) if dtype==torch.float64 else 2e-5
+        if a[2]!=b[2] and dtype==torch.float64 and method!='dopri8': bad+=1; print('NFE',desc,a[2],b[2]); continue
+        for i,(p,q) in enumerate(zip(a[1],b[1])):
+            d=float((p-q).abs().max()/(p.abs().max()+1e-30))
+            if not d<=tol: bad+=1; print('VALUE',desc,i,d); break
+    print('done',n,'bad',bad)
 else:
-    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad | callbacks | hessian")
+    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad | callbacks | hessian | vectol")
