@@ -457,6 +457,76 @@ def reference_rel_err(y_end):
     return fs.sample_rel_err(y_end[rows], z["y_end_rows"], z["y_end_absmax"]), int(z["nfe"])
 
 
+def kernel_breakdown(step_fn, steps, is_solver=lambda name: "tdeq::" in name):
+    """Where the GPU time of `steps` calls of step_fn goes: every device kernel's own duration (roctracer activity
+    records through torch.profiler — also the kernels a hipGraph replay launches), split into the package's kernels
+    (`tdeq::*`) and everything else (= the user's func: GEMMs, activation / autograd kernels, copies), next to the wall
+    time of the same calls.  `floor_us` = the sum of kernel durations per call: what a call would cost if not a single
+    microsecond were lost between dispatches — with an opaque func the lower bound of this launch sequence."""
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    solver_us = func_us = 0.0
+    n_solver = n_func = 0
+    per_kernel = {}
+    for ev in prof.events():
+        if str(getattr(ev, "device_type", "")).upper().endswith("CPU"):
+            continue
+        dur = float(getattr(ev, "device_time", None) or getattr(ev, "cuda_time", None) or 0.0)
+        if dur <= 0.0:
+            continue
+        name = ev.name
+        k = per_kernel.setdefault(name, [0, 0.0])
+        k[0] += 1
+        k[1] += dur
+        if is_solver(name):
+            solver_us += dur
+            n_solver += 1
+        else:
+            func_us += dur
+            n_func += 1
+    top = sorted(per_kernel.items(), key=lambda kv: -kv[1][1])[:8]
+    return {"calls": steps, "wall_us_per_call_profiled": 1e6 * wall / steps,
+            "solver_kernel_us": solver_us / steps, "func_kernel_us": func_us / steps,
+            "floor_us": (solver_us + func_us) / steps,
+            "dispatches_per_call": (n_solver + n_func) / steps, "solver_dispatches_per_call": n_solver / steps,
+            "func_dispatches_per_call": n_func / steps,
+            "top_kernels": {n[:80]: {"calls_per_call": c / steps, "avg_us": t / c} for n, (c, t) in top},
+            "source": "torch.profiler (roctracer kernel activity records); the profiled wall is slower than the timed "
+                      "blocks' — use `wall_us` from the timed blocks next to `floor_us`"}
+
+
+def strong_breakdown(step_fn, steps, wall_ms, world, rank):
+    """The per-rank answer to 'launch gaps or kernel floor?' for a strong-scaling shard: gathers every rank's
+    kernel_breakdown and derives the floor of the whole job (the slowest rank's)."""
+    try:
+        mine = kernel_breakdown(step_fn, steps)
+    except Exception as exc:          # the profiler is evidence, never a reason to lose the line
+        mine = {"error": repr(exc)}
+    mine["rank"] = rank
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        torch.distributed.all_gather_object(ranks, mine)
+    floors = [r["floor_us"] for r in ranks if "floor_us" in r]
+    out = {"per_rank": ranks, "wall_ms_per_step": wall_ms}
+    if floors:
+        floor_ms = max(floors) * 1e-3
+        out.update({"floor_ms": floor_ms, "gap_ms": max(0.0, wall_ms - floor_ms),
+                    "gap_is": "wall - floor, clamped at 0: the end stamp of a graph node and the start stamp of the next "
+                              "overlap by a fraction of a microsecond, so a gap-free replay can sum to slightly MORE than its wall",
+                    "floor_is": "max over ranks of (sum of kernel durations per step): func (opaque to the package) + "
+                                "solver kernels, zero time between dispatches",
+                    "func_floor_ms": max(r["func_kernel_us"] for r in ranks if "floor_us" in r) * 1e-3,
+                    "solver_floor_ms": max(r["solver_kernel_us"] for r in ranks if "floor_us" in r) * 1e-3})
+    return out
+
+
 def shard_regime_linear(device, steps=100, warmup=20):
     """One GPU on the 8192 x 128 shard (1/8 of cfg2): ms per trial step on the three step paths."""
     A, y0 = make_problem(device, rows=slice(0, BATCH // 8))
@@ -471,6 +541,15 @@ def shard_regime_linear(device, steps=100, warmup=20):
             st = block_stats(blocks, steps)
             out[name] = {"ms_per_step": st["median"], "min": st["min"], "max": st["max"],
                          "stages_per_s_of_the_shard": 6e3 / st["median"]}
+            if name == "hip_graph":
+                solver = make_stepper(field, y0, **kw)
+                with torch.no_grad():
+                    for _ in range(warmup):
+                        solver._trial_step()
+                    out[name]["breakdown"] = strong_breakdown(solver._trial_step, 50, st["median"], 1, 0)
+                    if solver._g is not None:
+                        torch.cuda.synchronize()
+                        solver._g.release()
         except Exception as exc:
             out[name] = {"error": repr(exc)}
     return out
@@ -536,6 +615,12 @@ def run_linear(args, rank, world, device, parity=True):
     # weak: every rank did its own stages; strong: a stage of the global batch is done when every shard's is
     value = 6e3 / ms_per_step * (1 if strong else world)
 
+    breakdown = None
+    if strong:
+        # launch gaps or kernel floor?  (every rank profiles its own shard's steps; collective: all ranks call this)
+        with torch.no_grad():
+            breakdown = strong_breakdown(solver._trial_step, min(50, args.steps), ms_per_step, world, rank)
+
     out = None
     if rank == 0:
         kernel_ms = [a.elapsed_time(b) for a, b in timed.events]
@@ -568,6 +653,8 @@ def run_linear(args, rank, world, device, parity=True):
                                   "own fp32 result scores 2.2-2.8e-6 on this)",
             "odeint_t01_wall_s": odeint_wall,
         }
+        if breakdown is not None:
+            out["breakdown"] = breakdown
         if n == BATCH * DIM:
             out["roofline"] = {
                 "bound": "hbm", "kernel": timed.kernel, "achieved": achieved,
@@ -1054,10 +1141,14 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=("linear", "adjoint"), default="linear")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="default: strong when --gpus > 1 (BASELINE.json's metric is quoted at batch 65536 in total: the "
+                         "ONE batch split over the GPUs), weak = every GPU its own 65536 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the contract line's own measurement")
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
     if args.steps is None:
         args.steps = 200 if args.workload == "linear" else 5
     if args.warmup is None:

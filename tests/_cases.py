@@ -116,3 +116,23 @@ class PlanarCNF(torch.nn.Module):
         dz = (h @ U) / width
         trace = ((1 - h * h) * (W * U).sum(-1)).sum(-1, keepdim=True) / width
         return dz, -trace
+
+
+# func outputs of the wrong shape (tests/golden/brow.npz `shape_*`: what the reference accepts, per method)
+FUNC_SHAPE_CASES = {
+    # name: (state shape(s), which slice / view of -y func returns)
+    "vec2_first1": ((2,), lambda y: -y[:1]),
+    "vec2_0dim": ((2,), lambda y: -y[0]),
+    "mat32_row2": ((3, 2), lambda y: -y[0]),
+    "mat32_1x2": ((3, 2), lambda y: -y[:1]),
+    "mat32_col31": ((3, 2), lambda y: -y[:, :1]),
+    "mat32_flat6": ((3, 2), lambda y: -y.reshape(-1)),
+    "mat32_T23": ((3, 2), lambda y: -y.T),
+    "mat32_lead1": ((3, 2), lambda y: -y[None]),
+    "mat32_lead2": ((3, 2), lambda y: -torch.stack([y, y])),
+    "zero_dim_to_1": ((), lambda y: -y.reshape(1)),
+    "one_to_zero_dim": ((1,), lambda y: -y[0]),
+    "tuple_short": (((2,), (3,)), lambda y: (-y[0][:1], -y[1])),
+    "tuple_reshaped": (((2, 3), (3,)), lambda y: (-y[0].T, -y[1].reshape(3, 1))),
+}
+FUNC_SHAPE_METHODS = ("dopri5", "dopri8", "bosh3", "adaptive_heun", "rk4", "euler", "midpoint")

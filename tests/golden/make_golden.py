@@ -1095,10 +1095,121 @@ def gen_dropin():
     save("dropin.npz", **arrays)
 
 
+# ---------------------------------------------------------------------------------------------------
+sys.path.insert(0, os.path.dirname(HERE))
+from _cases import FUNC_SHAPE_CASES, FUNC_SHAPE_METHODS  # noqa: E402  (shared with tests/test_brow_golden.py)
+
+
+def gen_brow():
+    """SURVEY.md §8(b) corners the r03 differential run found (Weak 2): the adaptive solvers' `dtype` option
+    (rk_common.py:176-194), states below fp32 (misc.py:185-187, rk_common.py:61-65 — bf16 runs, fp16 underflows) and
+    what the reference does with a func output of the wrong shape."""
+    arrays = {}
+    # ---- `dtype` option: every time-like scalar in promote_types(dtype, y0.abs().dtype) ----
+    for sname, sdtype in (("f32", torch.float32), ("f64", torch.float64)):
+        A, y0 = linear_problem(16, 8, sdtype, seed=11)
+        arrays[f"dt_{sname}_A"], arrays[f"dt_{sname}_y0"] = A, y0
+        for method, kw in (("dopri5", dict(rtol=1e-5, atol=1e-7)), ("dopri8", dict(rtol=1e-5, atol=1e-7)),
+                           ("bosh3", dict(rtol=1e-4, atol=1e-6))):
+            for oname, odtype in (("o32", torch.float32), ("o64", torch.float64), ("o16", torch.float16)):
+                for dname, t in (("fwd", torch.linspace(0.0, 1.5, 7)), ("rev", torch.linspace(1.5, 0.0, 7))):
+                    y, nfe, c = solve(lambda t_, y_: (y_ @ A.T) * torch.cos(t_), y0, t, method=method,
+                                      options=dict(dtype=odtype), **kw)
+                    key = f"dt_{sname}_{method}_{oname}_{dname}"
+                    arrays[key + "_y"], arrays[key + "_nfe"] = y, nfe
+                    arrays[key + "_accept_dt"], arrays[key + "_reject_dt"] = np.array(c.accept), np.array(c.reject)
+        # step_t / jump_t / first_step / event time with dtype=float32
+        t = torch.linspace(0.0, 1.0, 4)
+        opts = dict(dtype=torch.float32, step_t=torch.tensor([0.31, 0.77]), jump_t=torch.tensor([0.5]), first_step=0.013)
+        y, nfe, c = solve(lambda t_, y_: (y_ @ A.T) * torch.cos(t_), y0, t, method="dopri5", rtol=1e-5, atol=1e-7, options=opts)
+        arrays[f"dt_{sname}_grid_y"], arrays[f"dt_{sname}_grid_nfe"] = y, nfe
+        arrays[f"dt_{sname}_grid_accept_dt"] = np.array(c.accept)
+        ev_t, ev_y = torchdiffeq.odeint_event(lambda t_, y_: (y_ @ A.T) * torch.cos(t_), y0, torch.tensor(0.0),
+                                              event_fn=lambda t_, y_: y_[0, 0] - 0.5 * y0[0, 0], method="dopri5",
+                                              rtol=1e-5, atol=1e-7, options=dict(dtype=torch.float32))
+        arrays[f"dt_{sname}_event_t"], arrays[f"dt_{sname}_event_y"] = ev_t, ev_y
+        arrays[f"dt_{sname}_event_t_is_f32"] = np.array(ev_t.dtype == torch.float32)
+    # adjoint with dtype=float32 (adjoint_options inherit it)
+    A, y0 = linear_problem(16, 8, torch.float32, seed=11)
+    lin = torch.nn.Linear(8, 8, bias=False)
+    with torch.no_grad():
+        lin.weight.copy_(A)
+
+    class Field(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = lin
+
+        def forward(self, t, y):
+            return self.lin(y) * torch.cos(t)
+    y0g = y0.clone().requires_grad_(True)
+    y = torchdiffeq.odeint_adjoint(Field(), y0g, torch.tensor([0.0, 0.7, 1.5]), method="dopri5", rtol=1e-5, atol=1e-7,
+                                   options=dict(dtype=torch.float32))
+    y[-1].pow(2).sum().backward()
+    arrays["dt_adj_y"], arrays["dt_adj_gy"], arrays["dt_adj_gW"] = y.detach(), y0g.grad, lin.weight.grad
+
+    # ---- states below fp32 ----
+    A2 = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]])
+    arrays["low_A"] = A2
+    y0 = torch.tensor([[2.0, 0.0], [1.0, 1.0], [-0.5, 0.75]])
+    arrays["low_y0"] = y0
+    for lname, ldtype in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        for method, kw in (("dopri5", dict(rtol=1e-2, atol=1e-3)), ("dopri8", dict(rtol=1e-2, atol=1e-3)),
+                           ("bosh3", dict(rtol=1e-2, atol=1e-3)), ("tsit5", dict(rtol=1e-2, atol=1e-3)),
+                           ("adaptive_heun", dict(rtol=1e-2, atol=1e-3)), ("rk4", {}),
+                           ("rk4_step", dict(options=dict(step_size=0.0625)))):
+            for dname, t in (("fwd", torch.linspace(0.0, 1.0, 5)), ("rev", torch.linspace(1.0, 0.0, 5))):
+                key = f"low_{lname}_{method}_{dname}"
+                try:
+                    y, nfe, c = solve(lambda t_, y_: (y_ @ A2.to(y_.dtype).T) * torch.cos(t_), y0.to(ldtype), t,
+                                      method=method.split("_step")[0], **kw)
+                    arrays[key + "_y"], arrays[key + "_nfe"] = y.float(), nfe
+                    arrays[key + "_raises"] = np.array("")
+                    assert y.dtype == ldtype
+                except AssertionError as exc:
+                    arrays[key + "_raises"] = np.array(str(exc))
+        # tuple state, explicit dtype below fp32 (W = the state's own type), adjoint
+    for method in ("dopri5", "bosh3"):
+        ya, yb = y0.to(torch.bfloat16), y0[:, :1].to(torch.bfloat16) * 0.5
+        out = torchdiffeq.odeint(lambda t_, y_: ((y_[0] @ A2.to(torch.bfloat16).T), -y_[1] * y_[0][:, :1]), (ya, yb),
+                                 torch.linspace(0.0, 1.0, 3), method=method, rtol=1e-2, atol=1e-3)
+        arrays[f"low_tuple_{method}_a"], arrays[f"low_tuple_{method}_b"] = out[0].float(), out[1].float()
+        y = torchdiffeq.odeint(lambda t_, y_: y_ @ A2.to(torch.bfloat16).T, ya, torch.linspace(0.0, 1.0, 3), method=method,
+                               rtol=1e-2, atol=1e-3, options=dict(dtype=torch.bfloat16))
+        arrays[f"low_w16_{method}_y"] = y.float()
+
+    # ---- func outputs of the wrong shape: which (method, case) pairs the reference accepts ----
+    table = np.zeros((len(FUNC_SHAPE_METHODS), len(FUNC_SHAPE_CASES)), dtype=np.int8)
+    finals = np.zeros(table.shape, dtype=np.float64)
+    for i, method in enumerate(FUNC_SHAPE_METHODS):
+        for j, (name, (shape, view)) in enumerate(FUNC_SHAPE_CASES.items()):
+            if shape and isinstance(shape[0], tuple):
+                state = tuple(torch.arange(1, 1 + int(np.prod(s)), dtype=torch.float64).reshape(s) for s in shape)
+            else:
+                state = torch.arange(1, 1 + int(np.prod(shape)), dtype=torch.float64).reshape(shape)
+            try:
+                with torch.no_grad():
+                    y = torchdiffeq.odeint(lambda t_, y_: view(y_), state, torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64),
+                                           method=method, rtol=1e-4, atol=1e-6)
+                table[i, j] = 1
+                last = y[0][-1] if isinstance(y, tuple) else y[-1]
+                finals[i, j] = float(last.reshape(-1)[-1])
+            except RuntimeError:
+                table[i, j] = 0
+    # ---- known residue (DESIGN.md §8, ADVICE r03): a 0-dim fp32 state on an fp64 time grid under an adaptive method ----
+    y = torchdiffeq.odeint(lambda t_, y_: -y_ * torch.cos(t_), torch.tensor(1.5), torch.linspace(0.0, 2.0, 5, dtype=torch.float64),
+                           method="dopri5")
+    arrays["zero_dim_f32_on_f64_grid_dopri5"] = y
+    arrays["shape_methods"] = np.array(FUNC_SHAPE_METHODS)
+    arrays["shape_cases"] = np.array(list(FUNC_SHAPE_CASES))
+    arrays["shape_accepts"], arrays["shape_final"] = table, finals
+    save("brow.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
                      ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
-                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin), ("dropin", gen_dropin)]:
+                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin), ("dropin", gen_dropin), ("brow", gen_brow)]:
         if not only or name in only:
             fn()

@@ -7,29 +7,49 @@ import torch
 import torchdiffeq_amd as tda
 
 
-def test_broadcastable_func_output_is_expanded(dev):
-    """The reference computes `y0 + dt * f` with broadcasting (rk_common.py:79): a 0-dim or [1]-shaped derivative is
-    valid for any state shape.  Here it is expanded before the kernels read `numel` elements."""
-    y0 = torch.tensor([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]], dtype=torch.float64)
-    t = torch.tensor([0.0, 0.5, 2.0], dtype=torch.float64)
+def test_broadcastable_func_output_is_expanded_by_fixed_grid_methods_only(dev):
+    """What the reference's own arithmetic accepts (measured against it, r04): the fixed-grid steps compute
+    `y0 + dt * f` with broadcasting (rk_common.py:110-157) — a 0-dim or row-shaped derivative is valid for any state
+    shape; the adaptive steps store func's output in the stage buffer and view it as the state (rk_common.py:69-79,366),
+    so an output with fewer elements raises there.  Extra leading 1-dims are fine for both."""
+    y0 = torch.tensor([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]], dtype=torch.float64, device=dev)
+    t = torch.tensor([0.0, 0.5, 2.0], dtype=torch.float64, device=dev)
+    scalar = lambda tt, yy: torch.tensor(1.5, dtype=torch.float64, device=yy.device)
+    row = lambda tt, yy: yy.new_tensor([1.0, 0.0, -1.0])
     with torch.no_grad():
-        for method in ("dopri5", "rk4"):
-            y = tda.odeint(lambda tt, yy: torch.tensor(1.5, dtype=torch.float64, device=yy.device), y0, t, method=method)
+        for method in ("rk4", "euler", "midpoint"):
+            y = tda.odeint(scalar, y0, t, method=method)
             assert torch.allclose(y[-1].cpu(), (y0 + 3.0).cpu(), atol=1e-12)
-            y = tda.odeint(lambda tt, yy: yy.new_tensor([1.0, 0.0, -1.0]), y0, t, method=method)      # a row
+            y = tda.odeint(row, y0, t, method=method)
             assert torch.allclose(y[-1].cpu(), (y0 + y0.new_tensor([2.0, 0.0, -2.0])).cpu(), atol=1e-12)
+        for method in ("dopri5", "dopri8", "bosh3"):
+            for f in (scalar, row, lambda tt, yy: yy[:1], lambda tt, yy: yy[:, :1]):
+                with pytest.raises(RuntimeError, match="does not match the state shape"):
+                    tda.odeint(f, y0, t, method=method)
+            y = tda.odeint(lambda tt, yy: torch.full_like(yy, 1.5)[None], y0, t, method=method)      # [1, 2, 3]
+            assert torch.allclose(y[-1].cpu(), (y0 + 3.0).cpu(), atol=1e-9)
 
 
 def test_wrong_sized_func_output_raises(dev):
-    y0 = torch.ones(4, 3, dtype=torch.float64)
-    t = torch.tensor([0.0, 1.0], dtype=torch.float64)
+    y0 = torch.ones(4, 3, dtype=torch.float64, device=dev)
+    t = torch.tensor([0.0, 1.0], dtype=torch.float64, device=dev)
     with torch.no_grad():
-        with pytest.raises(RuntimeError, match="does not broadcast"):
+        with pytest.raises(RuntimeError, match="does not match"):
             tda.odeint(lambda tt, yy: yy[:2], y0, t)
+        with pytest.raises(RuntimeError, match="does not broadcast"):
+            tda.odeint(lambda tt, yy: yy[:2], y0, t, method="rk4")
+        # same element count, not broadcastable: the reference's `y0 + dt * f` fails for every method
+        for method in ("dopri5", "rk4"):
+            with pytest.raises(RuntimeError):
+                tda.odeint(lambda tt, yy: yy.reshape(-1), y0, t, method=method)
+            with pytest.raises(RuntimeError):
+                tda.odeint(lambda tt, yy: yy.T, y0, t, method=method)
         with pytest.raises(RuntimeError, match="components"):
             tda.odeint(lambda tt, yy: (yy[0],), (y0, y0.clone()), t)
-        with pytest.raises(RuntimeError, match="does not broadcast"):
-            tda.odeint(lambda tt, yy: (yy[0], yy[1][:1, :2]), (y0, y0.clone()), t)
+        # tuple components are flattened into the state vector (misc.py:145): the element count must match, for every method
+        for method in ("dopri5", "rk4"):
+            with pytest.raises(RuntimeError, match="elements"):
+                tda.odeint(lambda tt, yy: (yy[0], yy[1][:1, :2]), (y0, y0.clone()), t, method=method)
         with pytest.raises(TypeError):
             tda.odeint(lambda tt, yy: 1.0, y0, t)
 

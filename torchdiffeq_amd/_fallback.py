@@ -23,6 +23,8 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from ._scalars import operand, scalar_type
+
 
 class HostPathWarning(UserWarning):
     """torchdiffeq_amd is integrating a state with torch ops instead of the MI355X HIP kernels."""
@@ -41,8 +43,8 @@ def warn_once(reason: str) -> None:
 
 
 def real_np_dtype(dtype: torch.dtype):
-    """numpy scalar type of `y0.abs().dtype` (misc.py:185, rk_common.py:61)."""
-    return np.float32 if dtype in (torch.float32, torch.complex64) else np.float64
+    """Host scalar type of `y0.abs().dtype` (misc.py:185, rk_common.py:61)."""
+    return scalar_type(dtype)
 
 
 class HostPlan:
@@ -60,11 +62,6 @@ class HostPlan:
         self.sums0 = [0.0] * self.n_seg
         self.sums1 = [0.0] * self.n_seg
         self.bad = [0.0] * self.n_seg
-
-
-def _sumsq(r: torch.Tensor) -> float:
-    a = r.abs() if r.is_complex() else r
-    return float(a.double().pow(2).sum())
 
 
 def _nonfinite(*xs: torch.Tensor) -> float:
@@ -118,6 +115,12 @@ class HostKernels:
             acc = p if acc is None else acc + p
         return acc
 
+    @staticmethod
+    def _sumsq(r: torch.Tensor) -> float:
+        """Sum of |r|^2 in fp64 — what the norm kernels hand back per segment (the host forms sqrt(sum / n))."""
+        a = r.abs() if r.is_complex() else r
+        return float(a.double().pow(2).sum())
+
     def make_plan(self, segments, total, chunk, device) -> HostPlan:
         return HostPlan(segments, total, chunk)
 
@@ -150,7 +153,7 @@ class HostKernels:
             sl = slice(off, off + n)
             tol = torch.fmax(y0[sl].abs(), y1[sl].abs()) * float(T(rtol)) + float(T(atol))
             r = e[sl] / tol
-            plan.sums0[s] = _sumsq(r)
+            plan.sums0[s] = self._sumsq(r)
             plan.bad[s] = _nonfinite(y0[sl], y1[sl])
             if scaled_out is not None:
                 scaled_out[sl] = r
@@ -176,7 +179,7 @@ class HostKernels:
         T = self._T(yscale)
         for s, (off, n, rtol, atol) in enumerate(plan.segs):
             sl = slice(off, off + n)
-            scale = yscale[sl].abs() * float(T(rtol)) + float(T(atol))
+            scale = yscale[sl].abs() * operand(T, rtol) + float(T(atol))       # misc.py:50: |y0| * rtol, then atol + ...
             if mode == 0:
                 yield s, sl, a[sl] / scale, b[sl] / scale
             else:
@@ -184,9 +187,9 @@ class HostKernels:
 
     def init_norms(self, plan, mode: int, a, b, yscale) -> None:
         for s, sl, q0, q1 in self._init_quotients(plan, mode, a, b, yscale):
-            plan.sums0[s] = _sumsq(q0)
+            plan.sums0[s] = self._sumsq(q0)
             if q1 is not None:
-                plan.sums1[s] = _sumsq(q1)
+                plan.sums1[s] = self._sumsq(q1)
             plan.bad[s] = _nonfinite(yscale[sl])
 
     def init_scaled(self, plan, mode: int, a, b, yscale, out0, out1=None) -> None:
@@ -322,3 +325,50 @@ class HostKernels:
 
     # `arm_readback` / `read_ctrl` / `stage_combine_sel` / `stage_combine_dev` / `step_commit` / `step_controller`:
     # deliberately absent (see the class docstring); solvers.py checks `device_controller`.
+
+
+@_no_grad_methods
+class LowPrecisionHostKernels(HostKernels):
+    """bfloat16 / float16 states: the reference integrates them in their own precision (misc.py:185-187,
+    rk_common.py:61-65 — every time-like scalar is cast to `y0.abs().dtype`), and so does this backend.  What differs
+    from the fp32 / fp64 arithmetic is how ATen rounds reduced-precision work (measured, tools/lowfloat_semantics.py):
+    elementwise operations compute in float32 and round once; `torch.sum` accumulates a row in float32 and rounds
+    ONCE (so a tableau row is not a chain of separately rounded additions); a Python number after `*` is taken at
+    float32 precision.  The norm is the reference's literal `x.abs().pow(2).mean().sqrt()` in the state's type, handed
+    back through the sums interface as rms^2 * n (exact in fp64: the host's sqrt(sum / n) returns rms bit for bit).
+    The solver drivers switch off the fused error combine and the carried partial sums for these states (both split a
+    row's sum).  Exact for the adaptive methods and rk4; the other fixed-grid methods follow the fp32 / fp64 operation
+    order, which is close but not bit-faithful in 16 bits."""
+
+    name = "host-low"
+
+    @staticmethod
+    def _lsum(ks, cs, start=None):
+        """round_T( start + sum_j float32(round_T(k_j * c_j)) ): products rounded to the state type, summed in float32."""
+        acc = None if start is None else start.float()
+        for k, c in zip(ks, cs):
+            p = (k * c).float()
+            acc = p if acc is None else acc + p
+        return acc.to(ks[0].dtype)
+
+    @staticmethod
+    def _sumsq(r: torch.Tensor) -> float:
+        if r.numel() == 0:
+            return 0.0
+        rms = float(r.abs().pow(2).mean().sqrt())
+        return rms * rms * r.numel()
+
+    def rk4_stage(self, stage: int, out, y0, k1, k2, k3, k4, dt: float) -> None:
+        # rk_common.py:110-118 with dt a 0-dim tensor: `dt * k` rounds dt to the state type first, `k * dt` and
+        # `... * _one_third` take the scalar at float32
+        T = self._T(y0)
+        dt_first, dt_second, third = float(T(dt)), operand(T, dt), operand(T, 1.0 / 3.0)
+        if stage == 1:
+            r = y0 + (dt_first * k1) * third
+        elif stage == 2:
+            r = y0 + dt_first * (k2 - k1 * third)
+        elif stage == 3:
+            r = y0 + dt_first * ((k1 - k2) + k3)
+        else:
+            r = y0 + (((k1 + 3 * (k2 + k3)) + k4) * dt_second) * 0.125
+        out.copy_(r)

@@ -730,6 +730,7 @@ def on_state_device(method):
 
 _KERNELS: Optional[HipKernels] = None
 _HOST_KERNELS = None
+_LOW_KERNELS = None
 
 
 def get_kernels(device: torch.device, dtype: Optional[torch.dtype] = None):
@@ -740,9 +741,17 @@ def get_kernels(device: torch.device, dtype: Optional[torch.dtype] = None):
     on a ROCm device (BASELINE.json configs[0] is a CPU case; the reference runs wherever its tensors live,
     odeint.py:49-108) or complex (misc.py:185) — -> `_fallback.HostKernels`, the same interface in torch ops, with
     one `HostPathWarning` per process."""
-    global _KERNELS, _HOST_KERNELS
+    global _KERNELS, _HOST_KERNELS, _LOW_KERNELS
     device = torch.device(device)
     is_complex = dtype is not None and dtype.is_complex
+    if dtype in (torch.bfloat16, torch.float16):
+        # states below fp32: integrated in their own precision like the reference's (misc.py:185-187), with ATen's
+        # reduced-precision rounding — torch ops by nature, on whatever device the state lives
+        from . import _fallback
+        _fallback.warn_once(f"the state is {dtype}")
+        if _LOW_KERNELS is None:
+            _LOW_KERNELS = _fallback.LowPrecisionHostKernels()
+        return _LOW_KERNELS
     if device.type != "cuda" or is_complex:
         from . import _fallback
         _fallback.warn_once(f"the state is complex ({dtype})" if (is_complex and device.type == "cuda")

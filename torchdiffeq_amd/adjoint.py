@@ -115,6 +115,13 @@ class _AugmentedDynamics(OdeFunc):
         if hit is not None and hit[0] == key:
             return hit[1]
         n_y = self.n_y
+        # cotangent of the probe: a fixed non-zero pattern, not the solve's adj_y — a loss that ignores the last output
+        # has adj_y(t[-1]) = 0, every VJP 0 = 0, and the comparison would pass (and be cached) without having compared
+        # anything.  (No random numbers: the user's generator state is not ours to advance.)
+        aug = aug.clone()
+        for v in self.layout.unpack(aug, lo=1 + n_y, hi=1 + 2 * n_y):
+            flat = v.reshape(-1)
+            flat.copy_(torch.cos(torch.arange(flat.numel(), device=flat.device, dtype=torch.float64) * 1.618).to(flat.dtype))
         _, direct = self._vjps(t_user, aug, False)
         _, proxied = self._vjps(t_user, aug, True)
         ok = True
@@ -261,8 +268,9 @@ class OdeintAdjointMethod(torch.autograd.Function):
             elif wanted:
                 # parameter VJPs through leaf aliases (functional_call) only if they are the real ones: checked by one
                 # evaluation both ways, once per func (see proxy_is_faithful)
-                t_end_user = torch.full((), fwd.user_time(float(t[-1])) if hasattr(fwd, "user_time") else float(t[-1]),
-                                        dtype=fwd.time_dtype, device=device)
+                # the forward solve's SOLVER time of the last output: `_vjps` turns it into the user's time itself (a
+                # sign-corrected value here would evaluate a reversed-time func at -t, possibly outside its domain)
+                t_end_user = torch.full((), float(fwd.np_dtype(float(t[-1]))), dtype=fwd.time_dtype, device=device)
                 if aug_func.proxy_is_faithful(t_end_user, aug):
                     aug_func.use_proxy = True
                 else:

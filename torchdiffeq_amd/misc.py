@@ -22,7 +22,10 @@ import numpy as np
 import torch
 
 from . import _native
+from ._scalars import nextafter, real_dtype, scalar_type
 from .autodiff import stitch
+
+SUPPORTED_STATE_DTYPES = (torch.float32, torch.float64, torch.complex64, torch.complex128, torch.bfloat16, torch.float16)
 
 ALL_CALLBACK_NAMES = ["callback_step", "callback_accept_step", "callback_reject_step"]
 ALL_ADJOINT_CALLBACK_NAMES = [name + "_adjoint" for name in ALL_CALLBACK_NAMES]
@@ -317,11 +320,12 @@ class OdeFunc:
         self.dtype = dtype
         self.device = device
         # T = y0.abs().dtype: the precision of every time-like scalar func sees (misc.py:185; real for complex states)
-        self.np_dtype = np.float32 if dtype in (torch.float32, torch.complex64) else np.float64
-        self.time_dtype = torch.float32 if self.np_dtype is np.float32 else torch.float64
+        self.np_dtype = scalar_type(dtype)          # host stand-in for 0-dim tensors of that type (_scalars.py)
+        self.time_dtype = real_dtype(dtype)
         self.nfe = 0
         self._kernels = None
         self._anchor_user = None     # user-time t[0] when `t` requires grad (adaptive solvers)
+        self.strict_numel = False    # see _conform; set by check_inputs from the solver class
         for name in ALL_CALLBACK_NAMES:
             setattr(self, name, _null_callback)
 
@@ -347,9 +351,9 @@ class OdeFunc:
         """Solver time -> the value the user's func sees (state-precision, perturbed, un-negated)."""
         tt = self.np_dtype(t)
         if perturb is Perturb.NEXT:
-            tt = np.nextafter(tt, tt + self.np_dtype(1))
+            tt = nextafter(tt, tt + 1)
         elif perturb is Perturb.PREV:
-            tt = np.nextafter(tt, tt - self.np_dtype(1))
+            tt = nextafter(tt, tt - 1)
         return float(self.sign * tt)
 
     def time_tensor(self, value: float, shadow=None) -> torch.Tensor:
@@ -383,9 +387,16 @@ class OdeFunc:
         return self.call_base(t_user, y_flat)
 
     def _conform(self, f, shape: torch.Size, what: str) -> torch.Tensor:
-        """func's output as the kernels need it: on the state's device, with the state's element count.  An output
-        that only broadcasts to the state shape (0-dim, [1], a row ...) is expanded, as `y0 + dt * f` does in the
-        reference (rk_common.py:79); anything else raises here instead of being read out of bounds by a kernel."""
+        """func's output as the kernels need it: on the state's device, with the state's element count.  Accepted is
+        what the reference's own arithmetic accepts, no more — a user bug must not be integrated silently:
+        * tensor state, fixed-grid methods: anything that BROADCASTS to the state shape (0-dim, [1], a row, extra
+          leading 1-dims), expanded as `y0 + dt * f` expands it (rk_common.py:110-157, fixed_grid.py);
+        * tensor state, adaptive methods (`strict_numel`): the stage buffer takes func's shape and is viewed as the
+          state (rk_common.py:69-79, 366), so the output must broadcast AND have the state's element count;
+        * tuple state: every component is flattened into the state vector (misc.py:145), so its element count must be
+          the component's (any shape).
+        Everything else raises RuntimeError here (the reference: a broadcasting / view error from inside the step)
+        instead of being read out of bounds by a kernel."""
         if not isinstance(f, torch.Tensor):
             raise TypeError("func must return a Tensor{}; got {}".format(what, type(f).__name__))
         if f.device != self.device and f.dim() == 0:
@@ -393,13 +404,24 @@ class OdeFunc:
         if f.device != self.device:
             raise RuntimeError("func returned a tensor on '{}'{} but the state lives on '{}'".format(
                 f.device, what, self.device))
-        if f.shape != shape and f.numel() != shape.numel():
-            try:
-                f = f.expand(shape)
-            except RuntimeError:
-                raise RuntimeError("func returned shape {}{} which does not broadcast to the state shape {}".format(
-                    tuple(f.shape), what, tuple(shape))) from None
-        return f
+        if f.shape == shape:
+            return f
+        if self.layout.is_tuple:
+            if f.numel() != shape.numel():
+                raise RuntimeError("func returned shape {}{} ({} elements) for a state component of shape {} ({} elements)"
+                                   .format(tuple(f.shape), what, f.numel(), tuple(shape), shape.numel()))
+            return f
+        lead = f.dim() - len(shape)
+        try:
+            ok = torch.broadcast_shapes(f.shape, shape) == ((1,) * lead + tuple(shape) if lead > 0 else tuple(shape))
+        except RuntimeError:
+            ok = False
+        if ok and self.strict_numel and f.numel() != shape.numel():
+            ok = False
+        if not ok:
+            raise RuntimeError("func returned shape {}{} which {} the state shape {}".format(
+                tuple(f.shape), what, "does not match" if self.strict_numel else "does not broadcast to", tuple(shape)))
+        return f.reshape(f.shape[lead:]).expand(shape) if lead > 0 else f.expand(shape)
 
     def call_base(self, t_user: torch.Tensor, y_flat: torch.Tensor) -> torch.Tensor:
         lay = self.layout
@@ -524,10 +546,11 @@ def check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS) ->
         first = y0
     dtype = first.dtype
     device = first.device
-    if not torch.is_complex(first):
-        _native.dtype_code(dtype)   # float32 / float64 (HIP kernels); complex64 / complex128 take the host path
-    elif dtype not in (torch.complex64, torch.complex128):
-        raise TypeError(f"torchdiffeq_amd supports complex64 / complex128 complex states, got {dtype}")
+    # float32 / float64 (and complex64 / complex128 through their real views) run on the HIP kernels; bfloat16 / float16
+    # states are integrated in their own precision on the host path, as the reference does (misc.py:185-187)
+    if dtype not in SUPPORTED_STATE_DTYPES:
+        raise TypeError("torchdiffeq_amd supports float32 / float64 / complex64 / complex128 states (and bfloat16 / "
+                        f"float16 on the torch-op host path), got {dtype}")
 
     if options is None:
         options = {}
@@ -581,6 +604,7 @@ def check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS) ->
         t = t.to(device)
 
     wrapped = OdeFunc(func, layout, -1.0 if t_is_reversed else 1.0, dtype, device)
+    wrapped.strict_numel = bool(getattr(SOLVERS[method], "func_output_numel_must_match", False))
     if event_fn is not None:
         # the solvers call event_fn(t, y_flat) with t a 0-dim tensor in (ascending) solver time
         # (misc.py:137-165: _TupleInputOnlyFunc, _ReverseFunc)

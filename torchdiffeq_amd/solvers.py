@@ -32,6 +32,7 @@ import numpy as np
 import torch
 
 from . import _native
+from ._scalars import is_low, power, rdiv, scalar_type
 from .autodiff import Ops, stitch
 from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, component_norm, find_event, handle_unused_kwargs, rms_norm,
                    vector_tolerances)
@@ -80,6 +81,20 @@ def optimal_step_size(last_step: float, error_ratio: float, safety: float, ifact
         scaled = math.inf
     factor = _nan_min(ifactor, _nan_max(scaled, dfactor))
     return last_step * factor
+
+
+def optimal_step_size_in(W, last_step, error_ratio, safety, ifactor, dfactor, order) -> float:
+    """The same controller with every operation rounded in the host scalar type W (misc.py:85-95 on 0-dim tensors of
+    the solver option `dtype`, rk_common.py:176-194) — for W other than fp64."""
+    with np.errstate(all="ignore"):
+        last_step, ratio = W(last_step), W(error_ratio)
+        if ratio == 0:
+            return float(last_step * W(ifactor))
+        floor = W(1.0) if ratio < 1 else W(dfactor)
+        exponent = W(1.0) / W(order)                  # torch.tensor(order, dtype).reciprocal()
+        scaled = W(safety) / ratio ** exponent
+        factor = _nan_min(W(ifactor), _nan_max(scaled, floor))
+        return float(last_step * factor)
 
 
 class _LockStep:
@@ -582,6 +597,7 @@ class RKAdaptiveStepsizeODESolver:
     order: int
     tableau: Tableau
     flat_state_native = True         # takes the package's padded flat state / BuiltinNorm / per-segment tolerances (odeint.py)
+    func_output_numel_must_match = True     # misc.OdeFunc._conform: no silent expansion of a too-small func output
 
     def __init__(self, func: OdeFunc, y0: torch.Tensor, rtol, atol, min_step=0, max_step=float("inf"),
                  first_step=None, step_t=None, jump_t=None, safety=0.9, ifactor=10.0, dfactor=0.2,
@@ -600,7 +616,13 @@ class RKAdaptiveStepsizeODESolver:
         self.layout: StateLayout = func.layout
         self.state_dtype = y0.dtype
         self.np_dtype = func.np_dtype        # T = y0.abs().dtype (real also for complex states: rk_common.py:61)
-        self.dtype = torch.promote_types(dtype, func.time_dtype)   # accepted for API parity; host math is fp64
+        # `dtype` (rk_common.py:176-194): the type W of every time-like scalar — t, t0, t1, dt, the controller's
+        # constants —, promoted with T = y0.abs().dtype.  They are host numbers here; `_w` rounds one to W after each
+        # operation (identity for the default fp64: Python floats are W).  fp64 -> fp32 double rounding is innocuous for
+        # + - * /, so `_w(a op b)` on W-valued doubles is the W operation.
+        self.dtype = torch.promote_types(dtype, func.time_dtype)
+        self._W = scalar_type(self.dtype)
+        self._wide = self._W is np.float64
         self.norm = rms_norm if norm is None else norm
         self.rtol, self.atol = rtol, atol
         # Per-element tolerances (a tensor / list broadcasting against the state — plain broadcasting in the reference,
@@ -613,15 +635,16 @@ class RKAdaptiveStepsizeODESolver:
             if isinstance(self.norm, BuiltinNorm):
                 self.norm = component_norm(self.layout, self.norm.n_skip_tail)
         self._seg_tol = (rtol, atol)
-        self.min_step = _as_float(min_step)
-        self.max_step = _as_float(max_step)
-        self.first_step = None if first_step is None else _as_float(first_step)
-        self.safety = _as_float(safety)
-        self.ifactor = _as_float(ifactor)
-        self.dfactor = _as_float(dfactor)
+        w = self._w
+        self.min_step = w(_as_float(min_step))
+        self.max_step = w(_as_float(max_step))
+        self.first_step = None if first_step is None else w(_as_float(first_step))
+        self.safety = w(_as_float(safety))
+        self.ifactor = w(_as_float(ifactor))
+        self.dfactor = w(_as_float(dfactor))
         self.max_num_steps = int(_as_float(max_num_steps))
-        self.step_t = None if step_t is None else torch.as_tensor(step_t, dtype=torch.float64).reshape(-1).tolist()
-        self.jump_t = None if jump_t is None else torch.as_tensor(jump_t, dtype=torch.float64).reshape(-1).tolist()
+        self.step_t = None if step_t is None else torch.as_tensor(step_t, dtype=self.dtype).reshape(-1).tolist()
+        self.jump_t = None if jump_t is None else torch.as_tensor(jump_t, dtype=self.dtype).reshape(-1).tolist()
 
         self.kernels = _native.get_kernels(y0.device, y0.dtype)
         self.ops = Ops(self.kernels, self.np_dtype)      # elementwise kernels, differentiable when grad is needed
@@ -648,7 +671,9 @@ class RKAdaptiveStepsizeODESolver:
         last = self._beta[-1] if tab.fsal_solution else self._c_sol
         n_lead = len(last.idx)
         self._fuse = None
-        if self._c_err.idx[:n_lead] == last.idx and len(self._c_err.idx) - n_lead <= 2:
+        # (not for bf16 / fp16 states: ATen sums a reduced-precision row in float32 and rounds ONCE — splitting the
+        # error sum in two would round twice)
+        if self._c_err.idx[:n_lead] == last.idx and len(self._c_err.idx) - n_lead <= 2 and not is_low(self.np_dtype):
             self._fuse = (self._c_err.coef[:n_lead], self._c_err.idx[n_lead:], self._c_err.coef[n_lead:])
         # Carried partial sums (tableaus.carry_plan / tdeq_stage_combine_multi): fewer bytes per step for the same bits.
         # TDEQ_CARRY: unset / "auto" = the tableaus where it is a measured gain (CARRY_DEFAULT_ON); "1" = every
@@ -672,7 +697,8 @@ class RKAdaptiveStepsizeODESolver:
         device_ctrl = (getattr(self.kernels, "device_controller", True)
                        and self._fuse is not None and isinstance(self.norm, BuiltinNorm)
                        and len(self._beta) <= _native.TDEQ_MAX_STAGE_TIMES and n_norm_seg >= 0
-                       and self.step_t is None and self.jump_t is None and (self._sync is None or sync_dev))
+                       and self.step_t is None and self.jump_t is None and (self._sync is None or sync_dev)
+                       and self._wide)          # the device controller computes in fp64: W = fp64 only
         self._plan_dev = self._plan_glob = None
         if device_ctrl and self._sync is not None:
             segs = self.layout.segments(rtol, atol)
@@ -743,14 +769,18 @@ class RKAdaptiveStepsizeODESolver:
             s0, s1, bad = self._sync.reduce(s0, s1, bad, self.y0.device)
         return s0, s1, bad
 
+    def _w(self, x: float) -> float:
+        """`x` rounded to the time dtype W (see __init__)."""
+        return x if self._wide else float(self._W(x))
+
     def _time_tensor(self, value: float) -> torch.Tensor:
-        return torch.tensor(value, dtype=torch.float64, device=self.y0.device)
+        return torch.tensor(value, dtype=self.dtype, device=self.y0.device)
 
     # -- integrate ---------------------------------------------------------------------------------
     @_native.on_state_device
     def integrate(self, t: torch.Tensor) -> torch.Tensor:
         """solution[len(t), total] with solution[0] = y0 (solvers.py:28-35)."""
-        t_host = t.detach().to(torch.float64).cpu().tolist()
+        t_host = t.detach().to(self.dtype).cpu().tolist()
         self._set_time_anchor(t)
         self._before_integrate(t_host)
         self._t_end = t_host[-1]
@@ -796,7 +826,7 @@ class RKAdaptiveStepsizeODESolver:
         """Integrate over [t[0], t[-1]] keeping the dense output of EVERY accepted step (odeint.py:124-147):
         returns (times, coeffs) with `times` the n_steps + 1 accepted step boundaries (host doubles) and
         `coeffs[n_steps, 5, total]` the quartic coefficients [e, d, c, b, a] (`tdeq_interp_fit`)."""
-        t_host = t.detach().to(torch.float64).cpu().tolist()
+        t_host = t.detach().to(self.dtype).cpu().tolist()
         self._set_time_anchor(t.detach())
         self._before_integrate(t_host)
         self._t_end = t_host[-1]
@@ -826,7 +856,7 @@ class RKAdaptiveStepsizeODESolver:
         """(event_t, solution[2, total]): step until `event_fn(t, y)` changes sign, then bisect on the last
         step's dense output (solvers.py:44-49, rk_common.py:252-264, event_handling.py:5-20)."""
         self._set_time_anchor(t0.reshape(-1))
-        self._before_integrate([float(t0.detach())])
+        self._before_integrate([float(t0.detach().to(self.dtype))])
         event_time, y1 = self._advance_until_event(event_fn)
         solution = torch.stack([self.y0, y1], dim=0)
         return self._time_tensor(float(event_time)), solution
@@ -851,7 +881,8 @@ class RKAdaptiveStepsizeODESolver:
             atol = atol.min().item()
         elif not isinstance(atol, (int, float)):
             atol = min(float(a) for a in atol)
-        return find_event(interp_fn, sign0, self.t0, self.t1, event_fn, float(atol), self._time_tensor)
+        return find_event(interp_fn, sign0, self.t0, self.t1, event_fn, self._w(float(atol)), self._time_tensor,
+                          scalar=self._W)
 
     def _before_integrate(self, t_host: List[float]) -> None:
         t0 = t_host[0]
@@ -911,20 +942,22 @@ class RKAdaptiveStepsizeODESolver:
         else:
             d0 = T(self._segment_norm(s0, bad))
             d1 = T(self._segment_norm(s1, bad))
+        # Scalar arithmetic below: each operation as ATen rounds it for 0-dim tensors of type T with Python numbers
+        # mixed in (_scalars.py) — `0.01 / x` is reciprocal-then-multiply, `x ** e` is raised in double for fp32.
         if d0 < 1e-5 or d1 < 1e-5:
             h0 = T(1e-6)
         else:
-            h0 = T(T(0.01) * d0) / d1
+            h0 = 0.01 * d0 / d1
         h0 = abs(h0)
         if shadow_on:
             sh = _InitialStepShadow(self, y0_g, f0_g, float(h0), bool(d0 < 1e-5 or d1 < 1e-5))
-            f1_g = self.func.eval(t0 + float(h0), sh.y1, shadow=sh.time_shadow(self._anchor, self.func.sign))
+            f1_g = self.func.eval(self._w(t0 + float(h0)), sh.y1, shadow=sh.time_shadow(self._anchor, self.func.sign))
             f1 = f1_g.detach()
         else:
             y1 = torch.empty_like(y0)
             kern.stage_combine(y1, y0, [f0], [1.0], float(h0) * self.func.sign)
             with torch.no_grad():
-                f1 = self.func.eval(t0 + float(h0), y1)
+                f1 = self.func.eval(self._w(t0 + float(h0)), y1)
         if user_norm:
             q0 = torch.empty_like(y0)
             kern.init_scaled(plan, 1, f1, f0, y0, q0)
@@ -939,11 +972,11 @@ class RKAdaptiveStepsizeODESolver:
         with np.errstate(all="ignore"):
             d2 = abs(d2_num / h0)
             if d1 <= 1e-15 and d2 <= 1e-15:
-                h1 = max(T(1e-6), T(h0 * T(1e-3)))
+                h1 = max(T(1e-6), h0 * 1e-3)
             else:
-                h1 = T(T(0.01) / max(d1, d2)) ** T(1.0 / float(order + 1))
+                h1 = power(rdiv(0.01, max(d1, d2)), 1.0 / float(order + 1))
             h1 = abs(h1)
-            first_step = float(min(T(100) * h0, h1))
+            first_step = float(min(100 * h0, h1))
         if shadow_on:
             self._dt_shadow = sh.finish(f1_g, bool(d1 <= 1e-15 and d2 <= 1e-15), bool(d1 >= d2),
                                         bool(T(100) * h0 <= h1), order, first_step)
@@ -980,6 +1013,11 @@ class RKAdaptiveStepsizeODESolver:
         self._step_until(next_t)
         return self._interp_evaluate(next_t, out, t_shadow)
 
+    def _interp_fraction(self, rec, t: float) -> float:
+        """x = (t - t0) / (t1 - t0) formed in W, then cast to T (interp.py:39-40)."""
+        w = self._w
+        return float(self.np_dtype(w(w(t - rec.t0) / w(rec.t1 - rec.t0))))
+
     def _interp_evaluate_rows(self, times: Sequence[float], rows: torch.Tensor) -> None:
         """y(t) for several output times inside the last accepted step, written to the rows of `rows` (a slice of
         the solution tensor) by one launch; no autograd graph (the differentiable path evaluates row by row)."""
@@ -991,7 +1029,7 @@ class RKAdaptiveStepsizeODESolver:
         for t in times:
             assert rec is not None and rec.t0 <= t <= rec.t1, \
                 "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(self.t0, t, self.t1)
-            xs.append(float(self.np_dtype((t - rec.t0) / (rec.t1 - rec.t0))))
+            xs.append(self._interp_fraction(rec, t))
         mid = self._c_mid
         self.kernels.dense_eval_multi(rows, rec.y0, rec.y1, rec.k[0], rec.k[-1], [rec.k[j] for j in mid.idx],
                                       mid.coef, rec.dt_signed, xs)
@@ -1001,7 +1039,7 @@ class RKAdaptiveStepsizeODESolver:
         rec = self._dense
         assert rec is not None and rec.t0 <= t <= rec.t1, \
             "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(self.t0, t, self.t1)
-        x = float(self.np_dtype((t - rec.t0) / (rec.t1 - rec.t0)))
+        x = self._interp_fraction(rec, t)
         x_shadow = None
         if rec.dt_shadow is not None:
             # first step of a differentiated solve: x = (t - t0) / dt0 with dt0 a function of (y0, f0, f1) too
@@ -1029,25 +1067,26 @@ class RKAdaptiveStepsizeODESolver:
         dt = _clamp(dt, self.min_step, self.max_step)
         if func.callback_step is not _null:
             func.callback_step(self._time_tensor(t0), y0, self._time_tensor(dt))
-        t1 = t0 + dt
-        assert t0 + dt > t0, "underflow in dt {}".format(dt)
+        w = self._w
+        t1 = w(t0 + dt)
+        assert t1 > t0, "underflow in dt {}".format(dt)
         assert not self._y_nonfinite, "non-finite values in state `y`: {}".format(y0)
 
         on_step_t = False
         if len(self._step_t):
             next_step_t = self._step_t[self.next_step_index]
-            on_step_t = t0 < next_step_t < t0 + dt
+            on_step_t = t0 < next_step_t < w(t0 + dt)
             if on_step_t:
                 t1 = next_step_t
-                dt = t1 - t0
+                dt = w(t1 - t0)
         on_jump_t = False
         if len(self._jump_t):
             next_jump_t = self._jump_t[self.next_jump_index]
-            on_jump_t = t0 < next_jump_t < t0 + dt
+            on_jump_t = t0 < next_jump_t < w(t0 + dt)
             if on_jump_t:
                 on_step_t = False
                 t1 = next_jump_t
-                dt = t1 - t0
+                dt = w(t1 - t0)
 
         # ---- Runge–Kutta stages (rk_common.py:43-90); times in the state precision T ----
         t0_T, dt_T, t1_T = T(t0), T(dt), T(t1)
@@ -1225,7 +1264,11 @@ class RKAdaptiveStepsizeODESolver:
         if err_partial is not None and lookahead:
             self.dt = dt_next_dev         # already clamped (tdeq_error_norm_partial_ctrl)
         else:
-            dt_next = optimal_step_size(dt, error_ratio, self.safety, self.ifactor, self.dfactor, self.order)
+            if self._wide:
+                dt_next = optimal_step_size(dt, error_ratio, self.safety, self.ifactor, self.dfactor, self.order)
+            else:
+                dt_next = optimal_step_size_in(self._W, dt, error_ratio, self.safety, self.ifactor, self.dfactor,
+                                               self.order)
             self.dt = _clamp(dt_next, self.min_step, self.max_step)
 
     # -- hipGraph mode -----------------------------------------------------------------------------------
@@ -1336,6 +1379,18 @@ class AdaptiveHeunSolver(RKAdaptiveStepsizeODESolver):
 # ---------------------------------------------------------------------------------------------------
 # Fixed grid
 # ---------------------------------------------------------------------------------------------------
+def _uniform_grid(t: torch.Tensor, step_size) -> torch.Tensor:
+    """Points t[0] + i·step_size covering [t[0], t[-1]], the last one moved onto t[-1] exactly.  Formed with tensor
+    arithmetic in t.dtype on t.device — the point count ceil(span / step_size + 1) and every grid value must round as
+    the reference's do (solvers.py:86-96; on a ROCm device a tensor divided by a host scalar is a multiplication by
+    its reciprocal, which host arithmetic would not reproduce), and the grid keeps the autograd graph of `t`."""
+    first, last = t[0], t[-1]
+    count = int(torch.ceil((last - first) / step_size + 1))
+    grid = torch.arange(count, dtype=t.dtype, device=t.device) * step_size + first
+    grid[-1] = last
+    return grid
+
+
 class FixedGridODESolver(object):
     """Fixed-grid explicit RK driver (solvers.py:52-181): grid from `t`, `step_size` or `grid_constructor`;
     outputs by linear (default) or cubic Hermite interpolation between grid points.  Time-like scalars
@@ -1350,6 +1405,7 @@ class FixedGridODESolver(object):
         # instead of launching a step's kernels one by one — see RK4._integrate_graph.  "auto": where it applies
         # (rk4, small states), without the warning otherwise.
         self.hip_graph, self._graph_auto = _graph_request(hip_graph)
+        self._graph_explicit = hip_graph is not None
         unused_kwargs.pop("rtol", None)
         unused_kwargs.pop("norm", None)
         unused_kwargs.pop("dist_sync", None)          # fixed grids are in lock step by construction
@@ -1358,41 +1414,29 @@ class FixedGridODESolver(object):
         del unused_kwargs
         if not isinstance(func, OdeFunc):
             raise TypeError("solver classes of torchdiffeq_amd take the wrapped func built by check_inputs")
-        self.func = func
-        self.y0 = y0
-        self.layout = func.layout
-        self.dtype = y0.dtype
-        self.device = y0.device
-        self.step_size = step_size
-        self.interp = interp
-        self.perturb = perturb
+        if step_size is not None and grid_constructor is not None:
+            raise ValueError("step_size and grid_constructor are mutually exclusive arguments.")
+        self.func, self.y0, self.layout = func, y0, func.layout
+        self.dtype, self.device = y0.dtype, y0.device
         self.kernels = _native.get_kernels(y0.device, y0.dtype)
         self.ops = Ops(self.kernels, func.np_dtype)
-        if step_size is None:
-            if grid_constructor is None:
-                self.grid_constructor = lambda f, y0, t: t
-            else:
-                self.grid_constructor = grid_constructor
-        else:
-            if grid_constructor is None:
-                self.grid_constructor = self._grid_constructor_from_step_size(step_size)
-            else:
-                raise ValueError("step_size and grid_constructor are mutually exclusive arguments.")
+        self.interp, self.perturb = interp, perturb
+        # where the grid comes from: a user callable, a uniform spacing, or — neither given — the output times
+        self.step_size = step_size
+        self._user_grid = grid_constructor
 
     @classmethod
     def valid_callbacks(cls):
         return {"callback_step"}
 
-    @staticmethod
-    def _grid_constructor_from_step_size(step_size):
-        def _grid_constructor(func, y0, t):
-            start_time = t[0]
-            end_time = t[-1]
-            niters = torch.ceil((end_time - start_time) / step_size + 1).item()
-            t_infer = torch.arange(0, niters, dtype=t.dtype, device=t.device) * step_size + start_time
-            t_infer[-1] = t[-1]
-            return t_infer
-        return _grid_constructor
+    def _time_grid(self, t: torch.Tensor) -> torch.Tensor:
+        """The integration grid for output times `t` (solvers.py:70-96): the user's `grid_constructor(func, y0, t)`,
+        else the uniform `step_size` grid, else `t` itself (the same tensor object: that is what graph mode tests)."""
+        if self._user_grid is not None:
+            return self._user_grid(self.func, self.y0, t)
+        if self.step_size is None:
+            return t
+        return _uniform_grid(t, self.step_size)
 
     # -- one step ------------------------------------------------------------------------------------
     def _step(self, t0, dt, t1, y0: torch.Tensor, y1_out: Optional[torch.Tensor], sh: "_StepShadow"):
@@ -1421,7 +1465,7 @@ class FixedGridODESolver(object):
     @_native.on_state_device
     def integrate(self, t: torch.Tensor) -> torch.Tensor:
         func, ops = self.func, self.ops
-        time_grid = self.grid_constructor(func, self.y0, t)
+        time_grid = self._time_grid(t)
         assert time_grid[0] == t[0] and time_grid[-1] == t[-1]
         if self.interp not in ("linear", "cubic"):
             raise ValueError(f"Unknown interpolation method {self.interp}")
@@ -1429,7 +1473,8 @@ class FixedGridODESolver(object):
             if self._graph_capable(t, time_grid) and not (self._graph_auto and
                                                           self.layout.total > _GRAPH_AUTO_MAX_ELEMENTS):
                 return self._integrate_graph(t)
-            if not self._graph_auto:
+            if not self._graph_auto and self._graph_explicit:
+                # (asked for by option; a process-wide TDEQ_HIP_GRAPH=1 default applies where it can and stays silent)
                 warnings.warn("{}: hip_graph=True needs an explicit Runge-Kutta fixed-grid method (euler, midpoint, "
                               "heun2, heun3, rk4), the output times as the grid, linear interpolation, no callback, no "
                               "autograd graph and a ROCm device; running the eager path".format(self.__class__.__name__))
@@ -1501,10 +1546,22 @@ class FixedGridODESolver(object):
         raise NotImplementedError
 
     def _graph_capable(self, t: torch.Tensor, time_grid: torch.Tensor) -> bool:
-        return (self._graph_times is not None and time_grid is t and self.interp == "linear"
+        if not (self._graph_times is not None and time_grid is t and self.interp == "linear"
                 and self.func.callback_step is _null and self.device.type == "cuda"
-                and hasattr(self.kernels, "grid_advance_stages")
-                and not (torch.is_grad_enabled() and (t.requires_grad or self.y0.requires_grad)))
+                and hasattr(self.kernels, "grid_advance_stages")):
+            return False
+        if not torch.is_grad_enabled():
+            return True
+        if t.requires_grad or self.y0.requires_grad:
+            return False
+        # grad mode with neither y0 nor t in the graph: func's own parameters may still be (plain `odeint` training).
+        # The replayed kernels write into raw buffers — a solution without an autograd graph — so such a solve has to
+        # take the eager path.  One probe evaluation tells (as RKAdaptiveStepsizeODESolver._graph_step_ok reads f1);
+        # it is not counted.
+        nfe = self.func.nfe
+        probe = self.func.eval(float(t[0].detach()), self.y0, self._first_perturb())
+        self.func.nfe = nfe
+        return not probe.requires_grad
 
     def _integrate_graph(self, t: torch.Tensor) -> torch.Tensor:
         """`integrate` for small states, where a step costs launch latency, not bandwidth: ONE hipGraph — the method's
@@ -1903,15 +1960,11 @@ class AdamsBashforthMoulton(FixedGridODESolver):
     def __init__(self, func, y0, rtol=1e-3, atol=1e-4, implicit=True, max_iters=_ADAMS_MAX_ITERS,
                  max_order=_ADAMS_MAX_ORDER, dist_sync=None, **kwargs):
         super().__init__(func, y0, rtol=rtol, atol=atol, **kwargs)
-        assert max_order <= _ADAMS_MAX_ORDER, "max_order must be at most {}".format(_ADAMS_MAX_ORDER)
-        if max_order < _ADAMS_MIN_ORDER:
-            warnings.warn("max_order is below {}, so the solver reduces to `rk4`.".format(_ADAMS_MIN_ORDER))
-        self.rtol, self.atol = rtol, atol
-        self.implicit = implicit
-        self.max_iters = max_iters
-        self.max_order = int(max_order)
-        self.prev_f = collections.deque(maxlen=self.max_order - 1)
-        self.prev_t = None
+        self.max_order = self._checked_max_order(max_order)
+        self.implicit, self.max_iters = implicit, max_iters
+        self.rtol, self.atol = rtol, atol           # the corrector's convergence test (`_converged`)
+        # past derivatives, newest first, and the time the newest one belongs to (`_update_history`)
+        self.prev_t, self.prev_f = None, collections.deque(maxlen=self.max_order - 1)
         self._sync = _LockStep(dist_sync) if dist_sync is not None else None
         self._plan = None
         # A 0-dim fp32 state meets the reference's fp64 coefficient tensors as 0-dim x 0-dim, which PyTorch promotes
@@ -1919,6 +1972,15 @@ class AdamsBashforthMoulton(FixedGridODESolver):
         # rounded once by `.type_as(y0)` — see _step_zero_dim.
         self._zero_dim_f32 = (not self.layout.is_tuple and tuple(self.layout.shapes[0]) == ()
                               and y0.dtype in (torch.float32, torch.complex64))        # complex64 promotes to complex128 alike
+
+    @staticmethod
+    def _checked_max_order(max_order) -> int:
+        """The option's two documented reactions (fixed_adams.py:170-172): orders beyond the coefficient table are
+        refused, orders below the multistep minimum only ever take the RK4 start-up steps."""
+        assert max_order <= _ADAMS_MAX_ORDER, "max_order must be at most {}".format(_ADAMS_MAX_ORDER)
+        if max_order < _ADAMS_MIN_ORDER:
+            warnings.warn("max_order is below {}, so the solver reduces to `rk4`.".format(_ADAMS_MIN_ORDER))
+        return int(max_order)
 
     def _step_zero_dim(self, t1, y0, f0, hist, order, dt64, sh):
         """The step for a 0-dim fp32 state with the reference's type promotion (fixed_adams.py:205-216): the history
