@@ -514,6 +514,10 @@ def strong_breakdown(step_fn, steps, wall_ms, world, rank):
         ranks = [None] * world
         torch.distributed.all_gather_object(ranks, mine)
     floors = [r["floor_us"] for r in ranks if "floor_us" in r]
+    for r in ranks:         # the per-kernel table of rank 0 is enough in the line
+        if r.get("rank", 0) != 0:
+            r.pop("top_kernels", None)
+            r.pop("source", None)
     out = {"per_rank": ranks, "wall_ms_per_step": wall_ms}
     if floors:
         floor_ms = max(floors) * 1e-3
@@ -959,9 +963,13 @@ def adjoint_pass(world, rank, device, rows_per_rank, steps, warmup, group_forced
         y[-1].pow(2).sum().backward()
         stats["nfe_bwd"] = field.nfe
     blocks = timed_blocks(one, steps, warmup, world, device, n_blocks=3)
+    # launch gaps or kernel floor, per rank: one more pass under the kernel-activity profiler
+    breakdown = strong_breakdown(one, 1, block_stats(blocks, steps)["median"], world, rank)
+    breakdown["unit_note"] = "per forward + backward pass; func = the MLP, its autograd VJPs and torch glue kernels"
     if graph:
         st = block_stats(blocks, steps)
-        return {"rows_per_gpu": rows_per_rank, "ms_per_pass": st["median"], "blocks": st, "options": extra["options"]}
+        return {"rows_per_gpu": rows_per_rank, "ms_per_pass": st["median"], "blocks": st, "options": extra["options"],
+                "breakdown": breakdown}
     # one more instrumented pass: forward / backward split and the all-reduce on its own clock
     dist_sync(world)
     with AllReduceProbe() as probe:
@@ -986,7 +994,7 @@ def adjoint_pass(world, rank, device, rows_per_rank, steps, warmup, group_forced
                           "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                           "what": "parameter adjoints: the contiguous tail of the flat augmented state, one call "
                                   "(reference: adj_params = aug_state[3:], adjoint.py:150-153)"},
-            "param_grad_l2": grad_norm}
+            "param_grad_l2": grad_norm, "breakdown": breakdown}
 
 
 def run_adjoint(args, rank, world, device):

@@ -38,9 +38,15 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 16
+#define TDEQ_ABI_VERSION 17
 #define TDEQ_F32 0
 #define TDEQ_F64 1
+/* interleaved (re, im) complex states — accepted by the NORM entry points only (tdeq_error_norm, tdeq_error_norm_partial[_ctrl],
+ * tdeq_init_norms, tdeq_init_scaled): segment tables, chunk and counts are then in complex elements and T below is the
+ * real type; every other entry point is linear with real coefficients and takes the state's real view (2n elements of
+ * TDEQ_F32 / TDEQ_F64).  |z| = hypot(re, im), z / real = z * (1 / real): torchdiffeq/_impl/misc.py:80-82 as ATen rounds it. */
+#define TDEQ_C64 2
+#define TDEQ_C128 3
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
 #define TDEQ_MAX_SUM_TERMS 8    /* tdeq_weighted_sum */
 #define TDEQ_MAX_DENSE_OUTPUTS 16 /* tdeq_dense_eval_multi */

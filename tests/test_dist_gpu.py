@@ -34,8 +34,19 @@ def test_bench_self_launches_two_ranks_gloo():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    # r04: N > 1 defaults to STRONG scaling — BASELINE.json's metric is quoted at batch 65536 in total — and the line
+    # carries the per-rank kernel-floor breakdown that answers "launch gaps or kernel floor?"
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["global_batch"] == 65536 and out["config"]["rows_per_gpu"] == 32768
     assert out["strong"]["value"] > 0 and out["weak"]["value"] > 0 and out["lockstep"]["value"] > 0
+    assert out["weak"]["config"]["global_batch"] == 2 * 65536
+    bd = out["breakdown"]
+    assert [r["rank"] for r in bd["per_rank"]] == [0, 1] and bd["floor_ms"] > 0
+    for r in bd["per_rank"]:
+        assert r["solver_dispatches_per_call"] >= 7 and r["func_dispatches_per_call"] >= 6
+        assert r["solver_kernel_us"] > 0 and r["func_kernel_us"] > 0
+    assert abs(bd["floor_ms"] - (max(r["floor_us"] for r in bd["per_rank"]) * 1e-3)) < 1e-9
+    assert out["adjoint"]["strong"]["breakdown"]["floor_ms"] > 0
     for mode in ("strong", "weak"):
         ar = out["adjoint"][mode]["allreduce"]
         assert ar["calls"] == 1 and ar["bytes"] >= 4 * 98880 and ar["ms"] > 0

@@ -83,7 +83,9 @@ def test_cfg4_vs_reference(device):
     # accuracy rtol 1e-9 buys on this problem with dopri8's five large steps), so the two agree 20x closer than either
     # is to the truth; they differ by the step sizes the noise-driven second step leads to.
     assert err < 1e-7, err
-    assert abs(nfe - int(z["nfe"])) <= 13, (nfe, int(z["nfe"]))
+    # the reference's 5 trial steps, or one more (the noise-driven second step size overshoots and is rejected once);
+    # the exact companion with a fixed first step (test_cfg4_with_a_fixed_first_step_equals_the_reference) pins the rest
+    assert int(z["nfe"]) == 67 and nfe in (67, 80), nfe
 
 
 def _run_cfg3(case, rows, device, with_callbacks, fp64_field=False, shared_f64_module=False, f64_state=False):
@@ -146,7 +148,10 @@ def test_cfg3_adjoint_vs_reference(case, rows, device):
         ref = torch.from_numpy(z[f"grad_p{i}"])
         assert float((p.grad.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4, i
     assert nfe_fwd == int(z["nfe_fwd"])
-    assert abs(nfe_bwd - int(z["nfe_bwd"])) <= 18, (nfe_bwd, int(z["nfe_bwd"]))      # measured: +12 (full), +6 (shard)
+    # measured on the MI355X (r02, r03 driver lines): +12 evaluations on the full batch, +6 on the shard — two / one
+    # more accepted steps on the noise-limited growth phase (docstring); one trial step (6 evaluations) of slack
+    measured = {"cfg3": 12, "cfg3_shard": 6}[case]
+    assert measured - 6 <= nfe_bwd - int(z["nfe_bwd"]) <= measured + 6, (nfe_bwd, int(z["nfe_bwd"]))
     z, field, x, _, nfe_fwd2, nfe_bwd2, rec = _run_cfg3(case, rows, device, with_callbacks=True)
     assert (nfe_fwd2, nfe_bwd2) == (nfe_fwd, nfe_bwd)        # callbacks (host-driven loop) change nothing
     ok, msg = fs.steps_match(rec.acc, z["accepted"])
@@ -184,13 +189,15 @@ def test_cfg5_cnf_adjoint_vs_reference(trace, device):
     loss = lp[-1].mean() - zt[-1].pow(2).sum() / 100
     loss.backward()
     idx = torch.from_numpy(z["rows"]).to(device)
-    assert fs.sample_rel_err(zt[-1][idx], z["z_end_rows"], z["z_end_absmax"]) < 1e-4
-    assert fs.sample_rel_err(lp[-1][idx], z["logp_end_rows"], z["logp_end_absmax"]) < 1e-4
-    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
-    assert fs.sample_rel_err(x.grad[idx], z["grad_z0_rows"], z["grad_z0_absmax"]) < 1e-3
+    # bounds = 5x what the driver's own bench run measured on the MI355X (BENCH_r03 `configs.cfg5`: z 8.7e-7, logp 2.8e-5,
+    # loss 9.7e-7, dL/dz0 8.0e-7, parameter gradients <= 1.7e-6) — rtol = atol = 1e-5 is what the configuration asks for
+    assert fs.sample_rel_err(zt[-1][idx], z["z_end_rows"], z["z_end_absmax"]) < 5e-6
+    assert fs.sample_rel_err(lp[-1][idx], z["logp_end_rows"], z["logp_end_absmax"]) < 1.5e-4
+    assert abs(float(loss.detach()) - float(z["loss"])) < 5e-6 * abs(float(z["loss"]))
+    assert fs.sample_rel_err(x.grad[idx], z["grad_z0_rows"], z["grad_z0_absmax"]) < 5e-6
     for i, p in enumerate(cnf.parameters()):
         ref = torch.from_numpy(z[f"grad_p{i}"])
-        assert float((p.grad.cpu() - ref).abs().max() / ref.abs().max()) < 1e-3, i
+        assert float((p.grad.cpu() - ref).abs().max() / ref.abs().max()) < 1e-5, i
     assert nfe_fwd == int(z["nfe_fwd"]), nfe_fwd
     ok, msg = fs.steps_match(rec.acc, z["accepted"])
     assert ok, "forward: " + msg

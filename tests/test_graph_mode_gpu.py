@@ -402,3 +402,177 @@ def test_graph_cache_notices_rebound_closure_tensors_and_plain_attributes():
         yb = tda.odeint(g, y0, t, options=dict(hip_graph=True), **kw)
         assert torch.equal(yb, tda.odeint(g, y0, t, **kw)) and not torch.equal(ya, yb)
     tda.clear_graph_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# hip_graph="auto" (r04): capture lazily, and only what is verifiably safe to replay
+# ---------------------------------------------------------------------------------------------------------------------
+class _PureField(torch.nn.Module):
+    """A pure function of (t, y) and its parameters.  Python calls are counted in a hook's closure — outside the
+    module's attributes, so that counting them is not itself a visible side effect; `f.calls()` returns the counter."""
+
+    def __init__(self, d=8):
+        super().__init__()
+        torch.manual_seed(3)
+        self.lin = torch.nn.Linear(d, d).cuda()
+        calls = [0]
+        self.register_forward_pre_hook(lambda m, a: calls.__setitem__(0, calls[0] + 1))
+        self.calls = lambda: calls
+
+    def forward(self, t, y):
+        return torch.tanh(self.lin(y)) * torch.cos(t) - 0.3 * y
+
+
+def _auto_problem(n=64, d=8):
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(n, d, generator=g).cuda(), torch.tensor([0.0, 0.5, 1.0], device="cuda")
+
+
+def test_auto_mode_captures_a_pure_func_from_its_second_solve_on():
+    from torchdiffeq_amd.solvers import _GraphStep
+    y0, t = _auto_problem()
+    f = _PureField()
+    calls = f.calls()
+    with torch.no_grad():
+        y_eager = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8)
+        nfe = calls[0]
+        calls[0] = 0
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            y1 = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph="auto"))
+            assert calls[0] == nfe                    # first sight of (func, layout): a short solve stays eager
+            calls[0] = 0
+            y2 = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph="auto"))
+            second = calls[0]
+            calls[0] = 0
+            y3 = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph="auto"))
+            third = calls[0]
+    assert torch.equal(y1, y_eager) and torch.equal(y2, y_eager) and torch.equal(y3, y_eager)
+    # second solve: warm-up step + capture + the probe's eager twin run in Python, everything else is replayed
+    assert second < nfe or nfe <= 2 + 6 * 4, (second, nfe)
+    assert third <= 2 + 6                                 # third solve: the two initial evaluations + (at most) a side-1 capture
+    assert f not in _GraphStep._refused
+
+
+class _CountingField(torch.nn.Module):
+    def __init__(self, d=8):
+        super().__init__()
+        torch.manual_seed(3)
+        self.lin = torch.nn.Linear(d, d).cuda()
+        self.nfe = 0
+
+    def forward(self, t, y):
+        self.nfe += 1                                   # the classic evaluation counter of the reference's examples
+        return torch.tanh(self.lin(y)) * torch.cos(t) - 0.3 * y
+
+
+def test_auto_mode_refuses_a_func_with_an_evaluation_counter():
+    """A captured func runs in Python only while the graph is built: `self.nfe += 1` would stop counting.  "auto" sees
+    the attribute change during the first eager step, warns ONCE, and keeps every solve of that func eager — counts and
+    solution exactly the eager ones."""
+    y0, t = _auto_problem()
+    f = _CountingField()
+    with torch.no_grad():
+        y_eager = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8)
+        nfe = f.nfe
+        counts, ys = [], []
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for _ in range(3):
+                f.nfe = 0
+                ys.append(tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph="auto")))
+                counts.append(f.nfe)
+    assert counts == [nfe, nfe, nfe]
+    assert all(torch.equal(y, y_eager) for y in ys)
+    msgs = [str(x.message) for x in w if "hip_graph='auto'" in str(x.message)]
+    assert len(msgs) == 1 and "changed its own attributes" in msgs[0]
+
+
+def test_auto_mode_refuses_random_fields():
+    y0, t = _auto_problem()
+    lin = torch.nn.Linear(8, 8).cuda()
+    f = lambda t_, y_: lin(y_) * 0.1 + 1e-3 * torch.rand_like(y_)
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            tda.odeint(f, y0, t, method="dopri5", rtol=1e-3, atol=1e-4, options=dict(hip_graph="auto"))
+    msgs = [str(x.message) for x in w if "hip_graph='auto'" in str(x.message)]
+    assert len(msgs) == 1 and "random-number" in msgs[0]
+
+
+_HIDDEN = {"scale": 1.0}
+
+
+def test_auto_mode_probe_catches_state_the_fingerprint_cannot_see():
+    """State hidden in a module-level dict: no attribute, buffer or RNG offset changes, so the fingerprint passes — the
+    replay-vs-eager comparison of the first captured step does not: the solve stays correct (eager) and warns."""
+    y0, t = _auto_problem()
+    lin = torch.nn.Linear(8, 8).cuda()
+
+    def f(t_, y_):
+        _HIDDEN["scale"] = 1.0 + (0.05 if _HIDDEN["scale"] == 1.0 else 0.0)      # alternates per PYTHON call
+        return lin(y_) * (0.1 * _HIDDEN["scale"])
+    outs = []
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for mode in (False, "auto", "auto", "auto"):
+            _HIDDEN["scale"] = 1.0
+            outs.append(tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph=mode)))
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    msgs = [str(x.message) for x in w if "hip_graph='auto'" in str(x.message)]
+    assert len(msgs) == 1 and "bit for bit" in msgs[0]
+
+
+def test_auto_mode_switches_to_replays_inside_one_long_solve():
+    """First sight of a func, but the solve is long: after _AUTO_CAPTURE_AFTER_STEPS eager trial steps the rest is
+    replayed — same bits as the eager solve, most evaluations without Python."""
+    from torchdiffeq_amd import solvers
+    y0, _ = _auto_problem()
+    t = torch.linspace(0.0, 40.0, 5, device="cuda")
+    f = _PureField()
+    calls = f.calls()
+    with torch.no_grad():
+        y_eager = tda.odeint(f, y0, t, method="dopri5", rtol=1e-7, atol=1e-9)
+        nfe = calls[0]
+        calls[0] = 0
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            y_auto = tda.odeint(f, y0, t, method="dopri5", rtol=1e-7, atol=1e-9, options=dict(hip_graph="auto"))
+    steps = (nfe - 2) // 6
+    assert steps > solvers._AUTO_CAPTURE_AFTER_STEPS + 20, steps
+    assert torch.equal(y_auto, y_eager)
+    assert calls[0] <= 2 + 6 * (solvers._AUTO_CAPTURE_AFTER_STEPS + 4), (calls[0], nfe)
+
+
+def test_auto_mode_on_fixed_grids():
+    """rk4 under "auto": a counting func stays eager (one warning), a pure one is replayed; short grids are not captured."""
+    A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], device="cuda")
+    y0 = torch.tensor([[2.0, 0.0]], device="cuda")
+    t = torch.linspace(0.0, 5.0, 200, device="cuda")
+
+    class Counting(torch.nn.Module):
+        nfe = 0
+
+        def forward(self, t_, y_):
+            self.nfe += 1
+            return (y_ ** 3) @ A
+    f = Counting()
+    with torch.no_grad():
+        y_eager = tda.odeint(f, y0, t, method="rk4")
+        n = f.nfe
+        f.nfe = 0
+        with pytest.warns(UserWarning, match="hip_graph='auto'"):
+            y_auto = tda.odeint(f, y0, t, method="rk4", options=dict(hip_graph="auto"))
+    assert f.nfe == n and torch.equal(y_auto, y_eager)
+    calls = [0]
+    pure = torch.nn.Identity()
+    pure.register_forward_pre_hook(lambda m, a: calls.__setitem__(0, calls[0] + 1))
+    g = lambda t_, y_: (pure(y_) ** 3) @ A
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        y_auto = tda.odeint(g, y0, t, method="rk4", options=dict(hip_graph="auto"))
+        long_calls, calls[0] = calls[0], 0
+        y_short = tda.odeint(g, y0, t[:10], method="rk4", options=dict(hip_graph="auto"))
+        short_calls = calls[0]
+    assert torch.equal(y_auto, y_eager) and torch.equal(y_short, y_eager[:10])
+    assert long_calls == 8 and short_calls == 4 * 9          # replayed (first step + capture) / too short: eager

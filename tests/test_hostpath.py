@@ -51,7 +51,10 @@ def test_selection_is_by_the_state_alone(monkeypatch, tmp_path):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert isinstance(_native.get_kernels(torch.device("cpu"), torch.float32), _fallback.HostKernels)
-        assert isinstance(_native.get_kernels(torch.device("cuda:0"), torch.complex64), _fallback.HostKernels)
+        assert isinstance(_native.get_kernels(torch.device("cpu"), torch.complex64), _fallback.HostKernels)
+    # r04: complex states on a ROCm device take the HIP kernels too — or raise; never the host path
+    with pytest.raises(_native.NativeLibraryError):
+        _native.get_kernels(torch.device("cuda:0"), torch.complex64)
 
 
 @pytest.mark.gpu

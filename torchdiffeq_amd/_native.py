@@ -18,8 +18,9 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 16
+TDEQ_ABI_VERSION = 17
 TDEQ_F32, TDEQ_F64 = 0, 1
+TDEQ_C64, TDEQ_C128 = 2, 3        # interleaved complex: the norm entry points only (include/tdeq_hip.h)
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
 TDEQ_CHUNK_QUANTUM = 1024
@@ -206,6 +207,10 @@ def dtype_code(dtype: torch.dtype) -> int:
         return TDEQ_F32
     if dtype == torch.float64:
         return TDEQ_F64
+    if dtype == torch.complex64:
+        return TDEQ_C64
+    if dtype == torch.complex128:
+        return TDEQ_C128
     raise TypeError(f"torchdiffeq_amd supports float32 / float64 (and complex64 / complex128) states, got {dtype}")
 
 
@@ -708,6 +713,81 @@ class HipKernels:
                "tdeq_fill_scalars")
 
 
+class ComplexHipKernels:
+    """complex64 / complex128 states on the HIP kernels (r04; r03 ran them as torch ops).
+
+    Every LINEAR operation of a Runge–Kutta step has real coefficients (rk_common.py:79,89,201-205, interp.py,
+    rk_common.py:110-157), and ATen itself evaluates `complex * real` per component — so those calls go to the real
+    kernels on the state's interleaved (re, im) view: zero copy, 2n elements of the real type, bit-identical to the
+    torch-op path.  The tolerance-scaled norms (misc.py:80-82, 50-56 with |.| the complex modulus) have kernels of their
+    own (csrc/tdeq_kernels_complex.hpp, dtype codes TDEQ_C64 / TDEQ_C128): those calls pass the complex tensors through,
+    with segment tables, chunks and counts in complex elements."""
+
+    name = "hip-complex"
+    _NORM_CALLS = frozenset(("error_norm", "error_norm_partial", "error_norm_partial_ctrl", "error_scaled", "init_norms",
+                             "init_scaled"))
+    _AS_IS = frozenset(("make_plan", "read_norms", "read_ctrl", "arm_readback", "multi_spec", "_arm", "_read_out",
+                        "_stream", "_terms"))
+
+    def __init__(self, inner: "HipKernels"):
+        self._inner = inner
+        self.lib = inner.lib
+        self._host = None
+
+    @staticmethod
+    def _real(x):
+        if isinstance(x, torch.Tensor):
+            if not x.is_complex():
+                return x
+            r = torch.view_as_real(x)
+            return r.reshape(-1) if x.dim() <= 1 else r.reshape(x.shape[0], -1)
+        if isinstance(x, (list, tuple)) and any(isinstance(t, torch.Tensor) for t in x):
+            return type(x)(ComplexHipKernels._real(t) for t in x)
+        return x
+
+    def __getattr__(self, name):
+        attr = getattr(self._inner, name)          # AttributeError for what HipKernels does not have either
+        if not callable(attr) or name in self._AS_IS or name in self._NORM_CALLS:
+            return attr
+        real = self._real
+
+        def on_real_views(*args, **kwargs):
+            return attr(*[real(a) for a in args], **{k: real(v) for k, v in kwargs.items()})
+        on_real_views.__name__ = name
+        self.__dict__[name] = on_real_views         # next lookup skips __getattr__
+        return on_real_views
+
+    # -- the calls whose COUNTS are in complex elements ------------------------------------------------------------
+    def pack_segments(self, out, srcs, chunk_starts, numels, scales, chunk: int) -> None:
+        self._inner.pack_segments(self._real(out), [None if t is None else self._real(t.reshape(-1)) for t in srcs],
+                                  chunk_starts, [2 * int(n) for n in numels], scales, 2 * chunk)
+
+    def step_controller(self, plan, sums_plan, numel_plan, ctrl, next_times, dtype, state_in_dev: bool = False) -> None:
+        real = torch.float32 if dtype in (torch.complex64, torch.float32) else torch.float64
+        self._inner.step_controller(plan, sums_plan, numel_plan, ctrl, next_times, real, state_in_dev)
+
+    # -- Adams–Moulton corrector: its convergence census needs |.| (fixed_adams.py:189-192) and has no complex kernel;
+    #    SURVEY.md §2 puts the multistep methods out of scope, so this one step stays a torch-op evaluation on the device
+    def adams_correct(self, plan, dy_out, dy_old, y_out=None, f=None, delta=None, y0=None, c: float = 0.0,
+                      compute: bool = True) -> None:
+        from . import _fallback
+        if self._host is None:
+            self._host = _fallback.HostKernels()
+        hp = getattr(plan, "_host_plan", None)
+        if hp is None:
+            segs = [(int(sg.chunk_start) * plan.chunk, int(sg.numel), float(sg.rtol), float(sg.atol)) for sg in plan.segs]
+            hp = plan._host_plan = _fallback.HostPlan(segs, plan.n_chunks * plan.chunk, plan.chunk)
+        self._host.adams_correct(hp, dy_out, dy_old, y_out, f, delta, y0, c, compute)
+        n = plan.n_seg
+        if plan.pinned:
+            plan.out_np[:n] = hp.sums0
+            plan.out_np[2 * n:3 * n] = hp.bad
+        else:
+            plan.out[:n] = torch.tensor(hp.sums0, dtype=torch.float64)
+            plan.out[2 * n:3 * n] = torch.tensor(hp.bad, dtype=torch.float64)
+        plan.expect = ()
+
+
 def device_guard(device):
     """Context that makes `device` the current HIP device.  Every launch goes to `torch.cuda.current_stream()` — the
     CURRENT device's stream — and a kernel cannot be launched into another device's stream, so each entry point of the
@@ -731,17 +811,19 @@ def on_state_device(method):
 _KERNELS: Optional[HipKernels] = None
 _HOST_KERNELS = None
 _LOW_KERNELS = None
+_COMPLEX_KERNELS = None
 
 
 def get_kernels(device: torch.device, dtype: Optional[torch.dtype] = None):
     """The compute backend for a state of `dtype` on `device`.
 
-    A real fp32 / fp64 state on a ROCm device -> the HIP kernels, and ONLY those: a missing or stale libtdeq_hip.so
-    raises `NativeLibraryError` here (no silent substitute on the GPU).  A state that the kernels do not take — not
-    on a ROCm device (BASELINE.json configs[0] is a CPU case; the reference runs wherever its tensors live,
-    odeint.py:49-108) or complex (misc.py:185) — -> `_fallback.HostKernels`, the same interface in torch ops, with
-    one `HostPathWarning` per process."""
-    global _KERNELS, _HOST_KERNELS, _LOW_KERNELS
+    A real or complex fp32 / fp64 state on a ROCm device -> the HIP kernels, and ONLY those: a missing or stale
+    libtdeq_hip.so raises `NativeLibraryError` here (no silent substitute on the GPU); complex states through
+    `ComplexHipKernels` (real kernels on the (re, im) view + the complex norm kernels).  A state that the kernels do
+    not take — not on a ROCm device (BASELINE.json configs[0] is a CPU case; the reference runs wherever its tensors
+    live, odeint.py:49-108) or below fp32 (misc.py:185-187) — -> `_fallback.HostKernels` / `LowPrecisionHostKernels`,
+    the same interface in torch ops, with one `HostPathWarning` per process."""
+    global _KERNELS, _HOST_KERNELS, _LOW_KERNELS, _COMPLEX_KERNELS
     device = torch.device(device)
     is_complex = dtype is not None and dtype.is_complex
     if dtype in (torch.bfloat16, torch.float16):
@@ -752,13 +834,16 @@ def get_kernels(device: torch.device, dtype: Optional[torch.dtype] = None):
         if _LOW_KERNELS is None:
             _LOW_KERNELS = _fallback.LowPrecisionHostKernels()
         return _LOW_KERNELS
-    if device.type != "cuda" or is_complex:
+    if device.type != "cuda":
         from . import _fallback
-        _fallback.warn_once(f"the state is complex ({dtype})" if (is_complex and device.type == "cuda")
-                            else f"the state lives on '{device}'")
+        _fallback.warn_once(f"the state lives on '{device}'")
         if _HOST_KERNELS is None:
             _HOST_KERNELS = _fallback.HostKernels()
         return _HOST_KERNELS
     if _KERNELS is None:
         _KERNELS = HipKernels(load_library())
+    if is_complex:
+        if _COMPLEX_KERNELS is None:
+            _COMPLEX_KERNELS = ComplexHipKernels(_KERNELS)
+        return _COMPLEX_KERNELS
     return _KERNELS

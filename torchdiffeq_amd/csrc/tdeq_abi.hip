@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "tdeq_kernels.hpp"
+#include "tdeq_kernels_complex.hpp"
 
 namespace {
 using namespace tdeq;
@@ -484,6 +485,95 @@ int launch_init(int mode, const void* a_, const void* b_, const void* y_, const 
     return launch_finalize(st, ws, mode == 0 ? 2 : 1, out_sumsq, out_bad, s);
 }
 
+// ---- complex states: the norm launches (tdeq_kernels_complex.hpp); T = the real type -------------------------------
+template <typename T, int NT, bool PARTIAL>
+int launch_cplx_error(const void* partial, void* scaled, const void* y0, const void* y1, const void* const* k,
+                      const double* coef, double dt, const SegTable& st, double* out_sumsq, double* out_bad, double* ws,
+                      const CtrlBundle* cb, hipStream_t s) {
+    CplxErrArgs<T, NT> a;
+    a.partial = static_cast<const T*>(partial);
+    a.scaled = static_cast<T*>(scaled);
+    a.y0 = static_cast<const T*>(y0);
+    a.y1 = static_cast<const T*>(y1);
+    bool vec = aligned16(y0) && aligned16(y1) && (!PARTIAL || aligned16(partial)) && (!scaled || aligned16(scaled));
+    const bool dev_dt = cb && cb->state_in_dev;
+    const T dtT = (T)dt;
+    a.k[0] = nullptr;
+    a.c[0] = (T)0;
+    for (int j = 0; j < NT; ++j) {
+        a.k[j] = static_cast<const T*>(k[j]);
+        a.c[j] = dev_dt ? (T)coef[j] : (T)coef[j] * dtT;
+        vec = vec && aligned16(k[j]);
+    }
+    a.dt_dev = dev_dt ? cb->ctrl_dev + 1 : nullptr;
+    a.st = st;
+    a.part_sumsq = ws;
+    a.part_bad = ws + 2 * st.n_chunks;
+    const dim3 g((unsigned)st.n_chunks), b(kBlock);
+    if (scaled) {
+        if (vec) hipLaunchKernelGGL((cplx_error_norm_kernel<T, NT, true, PARTIAL, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((cplx_error_norm_kernel<T, NT, false, PARTIAL, true>), g, b, 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((cplx_error_norm_kernel<T, NT, true, PARTIAL, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((cplx_error_norm_kernel<T, NT, false, PARTIAL, false>), g, b, 0, s, a);
+    }
+    const int e = check_launch();
+    if (e) return e;
+    if (cb) return launch_finalize_ctrl(st, ws, out_sumsq, out_bad, *cb, sizeof(T) == 4, s);
+    return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
+}
+
+template <typename T>
+int dispatch_cplx_error(void* scaled, const void* y0, const void* y1, const void* const* k, const double* coef, int nt,
+                        double dt, const SegTable& st, double* out_sumsq, double* out_bad, double* ws, hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_cplx_error<T, N, false>(nullptr, scaled, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, nullptr, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
+template <typename T>
+int dispatch_cplx_error_partial(const void* partial, const void* y0, const void* y1, const void* const* k,
+                                const double* coef, int nt, double dt, const SegTable& st, double* out_sumsq,
+                                double* out_bad, double* ws, const CtrlBundle* cb, hipStream_t s) {
+    switch (nt) {
+        case 0: return launch_cplx_error<T, 0, true>(partial, nullptr, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s);
+        case 1: return launch_cplx_error<T, 1, true>(partial, nullptr, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s);
+        case 2: return launch_cplx_error<T, 2, true>(partial, nullptr, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s);
+    }
+    return TDEQ_EINVAL;
+}
+
+// mode 0 / 1; out0 given: the quotients are stored (tdeq_init_scaled), else their sums (tdeq_init_norms)
+template <typename T>
+int launch_cplx_init(int mode, const void* a_, const void* b_, const void* y_, const SegTable& st, double* out_sumsq,
+                     double* out_bad, double* ws, void* out0, void* out1, hipStream_t s) {
+    CplxInitArgs<T> a;
+    a.a = static_cast<const T*>(a_);
+    a.b = static_cast<const T*>(b_);
+    a.y = static_cast<const T*>(y_);
+    a.st = st;
+    a.part0 = ws;
+    a.part1 = ws ? ws + st.n_chunks : nullptr;
+    a.part_bad = ws ? ws + 2 * st.n_chunks : nullptr;
+    a.out0 = static_cast<T*>(out0);
+    a.out1 = static_cast<T*>(out1);
+    const dim3 g((unsigned)st.n_chunks), b(kBlock);
+    if (out0) {
+        if (mode == 0) hipLaunchKernelGGL((cplx_init_norms_kernel<T, 0, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((cplx_init_norms_kernel<T, 1, true>), g, b, 0, s, a);
+        return check_launch();
+    }
+    if (mode == 0) hipLaunchKernelGGL((cplx_init_norms_kernel<T, 0, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((cplx_init_norms_kernel<T, 1, false>), g, b, 0, s, a);
+    const int e = check_launch();
+    if (e) return e;
+    return launch_finalize(st, ws, mode == 0 ? 2 : 1, out_sumsq, out_bad, s);
+}
+
 // ---- dense output ----------------------------------------------------------------------------------
 template <typename T, int NT, bool FIT_ONLY>
 int launch_dense(void* out, const void* y0, const void* y1, const void* f0, const void* f1,
@@ -838,6 +928,8 @@ int launch_adams_correct(void* y_out, void* dy_out, const void* f, const void* d
 }
 
 inline bool bad_dtype(int dtype) { return dtype != TDEQ_F32 && dtype != TDEQ_F64; }
+// the norm entry points also take interleaved complex states (TDEQ_C64 / TDEQ_C128: tdeq_kernels_complex.hpp)
+inline bool bad_norm_dtype(int dtype) { return bad_dtype(dtype) && dtype != TDEQ_C64 && dtype != TDEQ_C128; }
 
 }  // namespace
 
@@ -891,7 +983,7 @@ int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void
                     const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
                     double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
                     void* stream) {
-    if (!y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype))
+    if (!y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || bad_norm_dtype(dtype))
         return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
@@ -901,6 +993,10 @@ int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void
     if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
+    if (dtype == TDEQ_C64)
+        return dispatch_cplx_error<float>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
+    if (dtype == TDEQ_C128)
+        return dispatch_cplx_error<double>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
     return dtype == TDEQ_F32
                ? dispatch_error<float>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s)
                : dispatch_error<double>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
@@ -957,7 +1053,7 @@ int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void*
                             const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
                             double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
                             void* stream) {
-    if (!err_partial || !y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype))
+    if (!err_partial || !y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_norm_dtype(dtype))
         return TDEQ_EINVAL;
     if (n_terms < 0 || n_terms > 2 || (n_terms > 0 && (!k || !coef))) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
@@ -967,6 +1063,10 @@ int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void*
     if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
+    if (dtype == TDEQ_C64)
+        return dispatch_cplx_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, nullptr, s);
+    if (dtype == TDEQ_C128)
+        return dispatch_cplx_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, nullptr, s);
     return dtype == TDEQ_F32
                ? dispatch_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, nullptr, s)
                : dispatch_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, nullptr, s);
@@ -978,7 +1078,7 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
                                  double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev,
                                  void* next_times, int state_in_dev, void* workspace, size_t workspace_bytes,
                                  int dtype, void* stream) {
-    if (!err_partial || !y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype))
+    if (!err_partial || !y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_norm_dtype(dtype))
         return TDEQ_EINVAL;
     if (!ctrl || !out_ctrl || !ctrl_dev || !next_times) return TDEQ_EINVAL;
     if (n_terms < 0 || n_terms > 2 || (n_terms > 0 && (!k || !coef))) return TDEQ_EINVAL;
@@ -992,6 +1092,10 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
     const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times, state_in_dev ? 1 : 0};
+    if (dtype == TDEQ_C64)
+        return dispatch_cplx_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s);
+    if (dtype == TDEQ_C128)
+        return dispatch_cplx_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s);
     return dtype == TDEQ_F32
                ? dispatch_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s)
                : dispatch_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s);
@@ -1065,7 +1169,7 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, 
                     double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
                     void* stream) {
     if ((mode != 0 && mode != 1) || !a || !b || !yscale || !out_sumsq || !out_nonfinite || !workspace ||
-        bad_dtype(dtype))
+        bad_norm_dtype(dtype))
         return TDEQ_EINVAL;
     SegTable st;
     const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
@@ -1073,6 +1177,8 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, 
     if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
+    if (dtype == TDEQ_C64) return launch_cplx_init<float>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, nullptr, nullptr, s);
+    if (dtype == TDEQ_C128) return launch_cplx_init<double>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, nullptr, nullptr, s);
     return dtype == TDEQ_F32 ? launch_init<float>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, s)
                              : launch_init<double>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, s);
 }
@@ -1080,12 +1186,14 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, 
 int tdeq_init_scaled(int mode, const void* a, const void* b, const void* yscale, const tdeq_segment* segs,
                      const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, void* out0, void* out1,
                      int dtype, void* stream) {
-    if ((mode != 0 && mode != 1) || !a || !b || !yscale || !out0 || (mode == 0 && !out1) || bad_dtype(dtype))
+    if ((mode != 0 && mode != 1) || !a || !b || !yscale || !out0 || (mode == 0 && !out1) || bad_norm_dtype(dtype))
         return TDEQ_EINVAL;
     SegTable st;
     const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
     if (e) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_C64) return launch_cplx_init<float>(mode, a, b, yscale, st, nullptr, nullptr, nullptr, out0, out1, s);
+    if (dtype == TDEQ_C128) return launch_cplx_init<double>(mode, a, b, yscale, st, nullptr, nullptr, nullptr, out0, out1, s);
     const dim3 g((unsigned)st.n_chunks), blk(kBlock);
     if (dtype == TDEQ_F32) {
         InitScaledArgs<float> x{static_cast<const float*>(a), static_cast<const float*>(b),

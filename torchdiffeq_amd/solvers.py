@@ -249,6 +249,77 @@ def _cell_is_set(cell) -> bool:
         return False
 
 
+# `hip_graph="auto"`: a first capture costs about as much as a hundred eager trial steps of a small state (≈12 ms
+# against 0.2 -> 0.08 ms per step, profiles/r03_config_times.json), so a (func, layout) seen for the FIRST time runs
+# eagerly and is captured only once its solve has taken this many trial steps — or at the first step of the NEXT solve
+# with the same key (a training loop), whichever comes first
+_AUTO_CAPTURE_AFTER_STEPS = 96
+_AUTO_MIN_GRID_STEPS = 24           # fixed grids: intervals below which "auto" does not capture (one capture ≈ 1 ms there)
+
+
+def _visible_state(obj, out, depth=0):
+    """Cheap identity of what `obj` visibly holds — plain numbers, flags, strings, container lengths, tensor storages
+    with their in-place version counters — appended to `out`."""
+    for name, v in list(getattr(obj, "__dict__", {}).items()):
+        if isinstance(v, torch.Tensor):
+            out.append((name, v.data_ptr(), v._version))
+        elif isinstance(v, (bool, int, float, complex, str, bytes, type(None))):
+            out.append((name, v))
+        elif isinstance(v, (list, tuple, set, frozenset, collections.deque)):
+            out.append((name, len(v), tuple((t.data_ptr(), t._version) for t in v if isinstance(t, torch.Tensor))))
+        elif isinstance(v, dict) and name not in ("_parameters", "_buffers", "_modules"):
+            out.append((name, len(v), tuple((t.data_ptr(), t._version) for t in v.values() if isinstance(t, torch.Tensor))))
+
+
+def _side_effect_fingerprint(fn, device):
+    """What an evaluation of `fn` could change OUTSIDE its return value, as far as it can be seen from here: the
+    attributes of the callable (all submodules of an nn.Module; the objects a function closes over / is bound to),
+    parameter and buffer version counters, and the device's random-number offset.  Equal before and after an eager
+    evaluation = no visible per-evaluation side effect — the premise of replaying `fn` from a captured hipGraph, where
+    its Python body does not run at all."""
+    out = []
+    if isinstance(fn, torch.nn.Module):
+        for m in fn.modules():
+            _visible_state(m, out)
+        out += [(n, t.data_ptr(), t._version) for n, t in fn.named_parameters()]
+        out += [(n, t.data_ptr(), t._version) for n, t in fn.named_buffers()]
+    else:
+        _visible_state(fn, out)
+        owner = getattr(fn, "__self__", None)
+        if owner is not None and not isinstance(owner, type):
+            out.append(_side_effect_fingerprint(owner, None) if isinstance(owner, torch.nn.Module) else None)
+            _visible_state(owner, out)
+        inner = getattr(fn, "__func__", fn)
+        for c in (getattr(inner, "__closure__", None) or ()):
+            if _cell_is_set(c):
+                v = c.cell_contents
+                if isinstance(v, torch.nn.Module):
+                    out.append(_side_effect_fingerprint(v, None))
+                elif isinstance(v, torch.Tensor):
+                    out.append((v.data_ptr(), v._version))
+                elif isinstance(v, (bool, int, float, str, type(None))):
+                    out.append(v)
+                elif isinstance(v, (list, dict, set)):
+                    out.append(len(v))      # e.g. `nfe = [0]` / a log list a lambda appends to
+                    if isinstance(v, list):
+                        out.append(tuple(x for x in v if isinstance(x, (bool, int, float))))
+                elif hasattr(v, "__dict__") and not callable(v):
+                    _visible_state(v, out)
+    if device is not None and torch.device(device).type == "cuda":
+        try:
+            idx = torch.device(device).index
+            gen = torch.cuda.default_generators[torch.cuda.current_device() if idx is None else idx]
+            out.append(("rng", gen.initial_seed(), gen.get_offset()))
+        except Exception:      # a build without generator offsets: the attribute checks still stand
+            pass
+    return tuple(out)
+
+
+def _same_words(a, b) -> bool:
+    """Equality of two flat lists of host doubles, NaN == NaN."""
+    return len(a) == len(b) and all(x == y or (x != x and y != y) for x, y in zip(a, b))
+
+
 class _DtCell:
     """A two-double device buffer shaped like a norm plan's `ctrl_dev` ({accept, sign*dt, ...}): lets the fixed-grid
     graph mode reuse tdeq_stage_combine_dev, which reads its step size from word 1."""
@@ -335,7 +406,7 @@ class _GraphStep:
         self.y = [torch.empty_like(s.y1), torch.empty_like(s.y1)]
         self.f0 = torch.empty_like(s.y1)
         self.epart = [torch.empty_like(s.y1), torch.empty_like(s.y1)]
-        self.tbuf = torch.empty(len(s._beta), dtype=s.y0.dtype, device=dev)
+        self.tbuf = torch.empty(len(s._beta), dtype=s.func.time_dtype, device=dev)      # stage times: real, also for complex states
         self.ts = self.tbuf.unbind(0)
         self.k: List[Optional[List[torch.Tensor]]] = [None, None]
         self.graphs = [None, None]
@@ -343,6 +414,9 @@ class _GraphStep:
         self.calls = 0
         self.plan = s.plan          # the graphs' norm kernels write into THIS plan's buffers
         self.in_use = True
+        self.auto = bool(getattr(s, "_graph_auto", False))    # `hip_graph="auto"`: verify before trusting replays
+        self.probed = False         # a replayed step has reproduced an eager one bit for bit
+        self.refused = None         # why this func must not be replayed (auto mode)
         self.reset(s, t0, dt)
 
     # -- the current pair ----------------------------------------------------------------------------------
@@ -369,6 +443,51 @@ class _GraphStep:
     # same parameter storages — what a captured graph requires anyway; `clear_graph_cache()` drops them.
     _cache = weakref.WeakKeyDictionary()
     _MAX_PER_FUNC = 4
+    _seen = weakref.WeakKeyDictionary()         # auto mode: func -> keys that have been solved (eagerly) once already
+    _refused = weakref.WeakKeyDictionary()      # auto mode: func -> why it is never captured
+
+    @classmethod
+    def auto_policy(cls, s) -> str:
+        """`hip_graph="auto"`, asked at the first trial step of a solve: "now" — a captured step for this (func, layout)
+        is cached or the pair has been solved before (second call of a training loop): capture / replay from the first
+        step; "later" — first sight: eager, captured only if this one solve turns out long
+        (_AUTO_CAPTURE_AFTER_STEPS); "never" — func was found to have per-evaluation side effects."""
+        base = s.func.base_func
+        try:
+            if base in cls._refused:
+                return "never"
+            if not _reusable_across_solves(base):
+                return "later"
+            key = cls._key(s)
+            per_func = cls._cache.get(base)
+            if per_func is not None and key in per_func:
+                return "now"
+            seen = cls._seen.get(base)
+            if seen is None:
+                seen = cls._seen[base] = set()
+            if key in seen:
+                return "now"
+            seen.add(key)
+        except TypeError:               # func object cannot be weakly referenced / hashed
+            pass
+        return "later"
+
+    def refuse(self, s, reason: str) -> None:
+        """Auto mode found `func` unfit for replay: remember it (per func object), drop the cached graphs, say so once."""
+        self.refused = reason
+        base = s.func.base_func
+        try:
+            first = base not in self._refused
+            self._refused[base] = reason
+            per_func = self._cache.get(base)
+            if per_func is not None:
+                for k in [k for k, g in per_func.items() if g is self]:
+                    del per_func[k]
+        except TypeError:
+            first = True
+        if first:
+            warnings.warn("hip_graph='auto': {} is not captured into a hipGraph — {}; its solves run on the eager "
+                          "path (pass hip_graph=True to capture it regardless)".format(type(base).__name__, reason))
 
     @staticmethod
     def _key(s):
@@ -485,13 +604,12 @@ class _GraphStep:
         self.calls += 1
         side = self.side
         if self.calls == 1:
-            current = torch.cuda.current_stream(s.y0.device)
-            stream = _side_stream(s.y0.device)
-            stream.wait_stream(current)
-            with torch.cuda.stream(stream):
-                self.body(s, 0)
-            current.wait_stream(stream)
+            before = _side_effect_fingerprint(func.base_func, s.y0.device) if self.auto else None
+            self._eager_body(s, 0)
             self.eager = True
+            if self.auto and _side_effect_fingerprint(func.base_func, s.y0.device) != before:
+                self.refuse(s, "evaluating it changed its own attributes, buffers or the device's random-number state "
+                               "(an evaluation counter, a cache, dropout ...), which a replay would not repeat")
             return
         self.eager = False
         if self.graphs[side] is None:
@@ -509,9 +627,50 @@ class _GraphStep:
                 raise _CaptureFailed(repr(exc)) from exc
             func.nfe = nfe
             self.graphs[side] = graph
+            if self.auto and not self.probed:
+                self._probe(s, side, graph)
+                func.nfe += len(s._beta)
+                return
         kern.arm_readback(s.plan)
         self.graphs[side].replay()
         func.nfe += len(s._beta)
+
+    def _eager_body(self, s, side: int) -> None:
+        current = torch.cuda.current_stream(s.y0.device)
+        stream = _side_stream(s.y0.device)
+        stream.wait_stream(current)
+        with torch.cuda.stream(stream):
+            self.body(s, side)
+        current.wait_stream(stream)
+
+    def _probe(self, s, side: int, graph) -> None:
+        """Auto mode, once per captured func: the trial step at hand is run TWICE from the same state — replayed from
+        the fresh graph, then evaluated eagerly — and everything a step produces must agree bit for bit: y1, the partial
+        error, the controller's decision words on the host and on the device, the next stage times.  The eager results
+        are the ones left in place (the caller reads them like any step's), so a mismatch costs nothing but the
+        capture: the solve goes on eagerly and `func` is not captured again."""
+        kern, func, plan = s.kernels, s.func, s.plan
+        ctrl0, times0 = plan.ctrl_dev.clone(), self.tbuf.clone()
+        kern.arm_readback(plan)
+        graph.replay()
+        accept, dt_next, ratio, bad = kern.read_ctrl(plan)
+        words_g = [float(accept), dt_next, ratio] + list(bad)
+        y1_g, ep_g = self.y[1 - side].clone(), self.epart[side].clone()
+        ctrl_g, times_g = plan.ctrl_dev.clone(), self.tbuf.clone()
+        plan.ctrl_dev.copy_(ctrl0)
+        self.tbuf.copy_(times0)
+        nfe = func.nfe
+        self._eager_body(s, side)
+        func.nfe = nfe
+        accept, dt_next, ratio, bad = kern.read_ctrl(plan)
+        words_e = [float(accept), dt_next, ratio] + list(bad)
+        same = (_same_words(words_g, words_e) and torch.equal(y1_g, self.y[1 - side])
+                and torch.equal(ep_g, self.epart[side]) and torch.equal(times_g, self.tbuf)
+                and _same_words(ctrl_g.tolist(), plan.ctrl_dev.tolist()))
+        self.probed = True
+        if not same:
+            self.refuse(s, "a replayed trial step did not reproduce the eagerly evaluated one bit for bit (func is not a "
+                           "pure function of t, y and its parameters)")
 
     def accepted(self, s) -> None:
         """The step just run was accepted: its end state becomes the next trial step's input pair."""
@@ -712,6 +871,10 @@ class RKAdaptiveStepsizeODESolver:
         # because a captured func runs in Python only while the graph is being built: per-evaluation Python side
         # effects (an evaluation counter, data-dependent branches) are not replayed — the user has to vouch for that
         wanted, auto = _graph_request(hip_graph)
+        self._graph_auto = auto
+        self._auto = None           # auto mode: this solve's policy ("now" / "later" / "never", _GraphStep.auto_policy)
+        self._auto_steps = 0
+        self._hold_pre = False      # auto mode: the eager step before the switch to replays enqueues no look-ahead stage
         self.hip_graph = wanted and device_ctrl and self._sync is None and y0.device.type == "cuda" \
             and hasattr(self.kernels, "stage_combine_dev") \
             and self.layout.total <= (_GRAPH_AUTO_MAX_ELEMENTS if auto else _GRAPH_MODE_MAX_ELEMENTS)
@@ -901,6 +1064,7 @@ class RKAdaptiveStepsizeODESolver:
         self._dense: Optional[_DenseRecord] = None
         self._t_end, self._pre = -math.inf, None    # event mode / direct stepping: no look-ahead
         self._g = None
+        self._auto, self._auto_steps, self._hold_pre = None, 0, False
         if self.first_step is not None:
             self._dt_shadow = None
 
@@ -994,7 +1158,7 @@ class RKAdaptiveStepsizeODESolver:
     def _trial_step(self) -> None:
         """One trial step by the path this solve runs on: a hipGraph replay (hip_graph mode, small states) or the
         eager launch sequence."""
-        if self.hip_graph and self._graph_step_ok():
+        if self.hip_graph and self._graph_step_ok() and self._graph_now():
             try:
                 self._graph_trial_step()
             except _CaptureFailed as exc:
@@ -1006,6 +1170,24 @@ class RKAdaptiveStepsizeODESolver:
                 self._adaptive_step()
         else:
             self._adaptive_step()
+
+    def _graph_now(self) -> bool:
+        """Whether THIS trial step goes through the captured-step path.  Always, once a solve is on it or when
+        `hip_graph=True` was asked for; under "auto" the first capture is put off as _GraphStep.auto_policy says."""
+        if self._g is not None or not self._graph_auto:
+            return True
+        if self._auto is None:
+            self._auto = _GraphStep.auto_policy(self)
+        if self._auto == "never":
+            self.hip_graph = False
+            return False
+        if self._auto == "later":
+            self._auto_steps += 1
+            if self._auto_steps <= _AUTO_CAPTURE_AFTER_STEPS:
+                # (the last eager step enqueues no look-ahead stage, so that the replays start from a clean state)
+                self._hold_pre = self._auto_steps == _AUTO_CAPTURE_AFTER_STEPS
+                return False
+        return self._pre is None
 
     def _advance(self, next_t: float, out: Optional[torch.Tensor], t_shadow=None) -> torch.Tensor:
         """Step until next_t is inside the last accepted step, then return y(next_t) (written into `out` if
@@ -1194,7 +1376,7 @@ class RKAdaptiveStepsizeODESolver:
         if err_partial is not None and lookahead:
             ctrl = self._ctrl
             ctrl.t0, ctrl.dt = t0, dt
-            tnext = torch.empty(ctrl.n_times, dtype=y0.dtype, device=y0.device)
+            tnext = torch.empty(ctrl.n_times, dtype=func.time_dtype, device=y0.device)
             if self._sync is None:
                 kern.error_norm_partial_ctrl(self.plan, err_partial, y0, y1, [k[j] for j in err_rem[0]],
                                              err_rem[1], dt_signed, ctrl, tnext)
@@ -1205,7 +1387,7 @@ class RKAdaptiveStepsizeODESolver:
                                         err_rem[1], dt_signed)
                 self._sync.reduce_device(self._plan_dev.out, self.plan.n_seg)
                 kern.step_controller(self.plan, self._plan_dev, self._plan_glob, ctrl, tnext, y0.dtype)
-            if t1 < self._t_end:
+            if t1 < self._t_end and not self._hold_pre:
                 # accepted or rejected, another trial step follows: enqueue its first stage and func evaluation now
                 yi_n = torch.empty_like(y0)
                 kern.stage_combine_sel(yi_n, y1, f1, y0, f0, row0.coef[0], self.plan)
@@ -1323,6 +1505,11 @@ class RKAdaptiveStepsizeODESolver:
             self.t0 = t0
             self.n_rejected += 1
         self.dt = dt_next
+        if g.refused is not None:
+            # auto mode: the step just taken stands (it was evaluated eagerly), the rest of the solve runs on the eager
+            # path from the state it left in g's buffers — which stay this solve's own (g is not handed back for reuse)
+            self.hip_graph = False
+            self._g = None
 
     def _user_norm_ratio(self, y0, y1, k, dt_signed):
         """User-supplied `norm` callable (misc.py:80-82 with a custom norm): the kernel materialises
@@ -1583,7 +1770,7 @@ class FixedGridODESolver(object):
         counter = torch.full((), -1, dtype=torch.int64, device=self.device)
         fracs, modes = [f for f, _ in self._graph_times], [m for _, m in self._graph_times]
         n_eval = len(fracs)
-        times = torch.empty(n_eval, dtype=self.dtype, device=self.device)
+        times = torch.empty(n_eval, dtype=func.time_dtype, device=self.device)
         # {unused, sign * dt}: the layout tdeq_stage_combine_dev reads its step size from (a norm plan's ctrl_dev)
         ctrl = _DtCell(torch.zeros(2, dtype=torch.float64, device=self.device))
         dt_dev = ctrl.ctrl_dev[1:]
@@ -1599,9 +1786,33 @@ class FixedGridODESolver(object):
         current = torch.cuda.current_stream(self.device)
         side = _side_stream(self.device)
         side.wait_stream(current)
+        auto = self._graph_auto
+        before = _side_effect_fingerprint(func.base_func, self.device) if auto else None
         with torch.cuda.stream(side):
             step()
         current.wait_stream(side)
+        if auto and n_t > 2:
+            # "auto": replay only what is safe and worth it — a func whose evaluation visibly changed its own state (a
+            # counter, a cache, random numbers) is not captured; nor is a grid too short to pay for the capture
+            base = func.base_func
+            reason = None
+            try:
+                reason = _GraphStep._refused.get(base)
+            except TypeError:
+                pass
+            if reason is None and _side_effect_fingerprint(base, self.device) != before:
+                reason = ("evaluating it changed its own attributes, buffers or the device's random-number state (an "
+                          "evaluation counter, a cache, dropout ...), which a replay would not repeat")
+                try:
+                    _GraphStep._refused[base] = reason
+                except TypeError:
+                    pass
+                warnings.warn("hip_graph='auto': {} is not captured into a hipGraph — {}; its solves run on the eager "
+                              "path (pass hip_graph=True to capture it regardless)".format(type(base).__name__, reason))
+            if reason is not None or n_t - 2 < _AUTO_MIN_GRID_STEPS:
+                for _ in range(n_t - 2):
+                    step()
+                return solution
         if n_t > 2:
             # ... the others are replays of one captured step
             graph = torch.cuda.CUDAGraph()
@@ -1635,7 +1846,7 @@ class FixedGridODESolver(object):
             "Event handling for fixed step solvers currently requires `step_size` to be provided in options."
         func, ops = self.func, self.ops
         scalar = func.np_dtype
-        time_tensor = lambda v: torch.tensor(float(v), dtype=self.dtype, device=self.device)
+        time_tensor = lambda v: torch.tensor(float(v), dtype=func.time_dtype, device=self.device)     # solvers.py:132
         start = t0 if (torch.is_grad_enabled() and torch.is_tensor(t0) and t0.requires_grad) else None
         t0 = scalar(float(t0.detach()))
         t_first = float(t0)
