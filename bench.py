@@ -538,13 +538,16 @@ def shard_regime_linear(device, steps=100, warmup=20):
     field = lambda t, y: y @ At
     out = {"state": f"{BATCH // 8} x {DIM} fp32 (1/8 of cfg2)", "steps_per_block": steps}
     for name, kw in (("host_driven", dict(lookahead=False)), ("lookahead", dict(lookahead=True)),
-                     ("hip_graph", dict(hip_graph=True))):
+                     ("hip_graph", dict(hip_graph=True)), ("auto", dict(hip_graph="auto"))):
         try:
             solver = make_stepper(field, y0, **kw)
-            blocks = time_steps(solver, steps, warmup, 1, device, n_blocks=3)
+            # ("auto": first sight of this func -> eager until solvers._AUTO_CAPTURE_AFTER_STEPS trial steps, then captured)
+            blocks = time_steps(solver, steps, warmup if name != "auto" else warmup + 110, 1, device, n_blocks=3)
             st = block_stats(blocks, steps)
             out[name] = {"ms_per_step": st["median"], "min": st["min"], "max": st["max"],
                          "stages_per_s_of_the_shard": 6e3 / st["median"]}
+            if name == "auto":
+                out[name]["replaying"] = solver._g is not None
             if name == "hip_graph":
                 solver = make_stepper(field, y0, **kw)
                 with torch.no_grad():
@@ -822,9 +825,10 @@ def cfg5_config(device):
                        "batch=32768 x dim=2, rtol=atol=1e-5"}
     for name, opts in (("eager", None), ("captured_steps", {"hip_graph": "auto"})):
         cnf = fs.ExampleCNF([z[f"p{i}"] for i in range(6)], trace="closed").to(device)
+        cnf.counting = opts is None         # "auto" refuses a func with an evaluation counter (it would stop counting)
         params = list(cnf.parameters())
         best = None
-        for rep in range(4):
+        for rep in range(5):                # (auto: pass 0 eager = first sight, pass 1 captures, passes 2.. replay)
             for p_ in params:
                 p_.grad = None
             x = z0.clone().requires_grad_(True)
@@ -837,11 +841,11 @@ def cfg5_config(device):
             loss.backward()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            if rep and (best is None or t2 - t0 < best[0] + best[1]):
+            if rep >= 2 and (best is None or t2 - t0 < best[0] + best[1]):
                 best = (t1 - t0, t2 - t1)
         gp = max(float((p_.grad.cpu() - torch.from_numpy(z[f"grad_p{i}"])).abs().max() /
                        torch.from_numpy(z[f"grad_p{i}"]).abs().max()) for i, p_ in enumerate(params))
-        out[name] = {"fwd_ms": 1e3 * best[0], "bwd_ms": 1e3 * best[1],
+        out[name] = {"options": opts, "fwd_ms": 1e3 * best[0], "bwd_ms": 1e3 * best[1],
                      "rel_err_z": fs.sample_rel_err(zt[-1][idx], z["z_end_rows"], z["z_end_absmax"]),
                      "rel_err_logp": fs.sample_rel_err(lp[-1][idx], z["logp_end_rows"], z["logp_end_absmax"]),
                      "rel_err_loss": abs(float(loss.detach()) - float(z["loss"])) / abs(float(z["loss"])),
@@ -861,7 +865,7 @@ def cfg1_config(device):
     ref = torch.from_numpy(z["cfg1_y"])
     out = {"workload": "BASELINE.json configs[0]: spiral ODE, rk4 fixed step, y0 in R^2, batch=1, fp32, 1000 output times"}
     for name, dev_, opts in (("gpu_eager", device, None), ("gpu_captured_step", device, {"hip_graph": True}),
-                             ("cpu_host_path", torch.device("cpu"), None)):
+                             ("gpu_auto", device, {"hip_graph": "auto"}), ("cpu_host_path", torch.device("cpu"), None)):
         try:
             A = torch.from_numpy(z["cfg1_A"]).to(dev_)
             y0 = torch.from_numpy(z["cfg1_y0"]).to(dev_)
@@ -952,6 +956,10 @@ def adjoint_pass(world, rank, device, rows_per_rank, steps, warmup, group_forced
     stats = {}
     group = torch.distributed.group.WORLD if (world > 1 or group_forced) else None
     extra = {"options": {"hip_graph": "auto"}} if graph else {}
+    if graph:
+        # "auto" replays only funcs without per-evaluation side effects (solvers._side_effect_fingerprint): the field's
+        # evaluation counter is switched off for this leg
+        field.counting = False
 
     def one():
         for p in params:

@@ -31,9 +31,11 @@ class MLPField(torch.nn.Module):
         super().__init__()
         self.net = net
         self.nfe = 0
+        self.counting = True     # False: no per-evaluation side effect — what hip_graph="auto" requires of a func it replays
 
     def forward(self, t, y):
-        self.nfe += 1
+        if self.counting:
+            self.nfe += 1
         return self.net(y)
 
 
@@ -101,6 +103,7 @@ class ExampleCNF(torch.nn.Module):
         self.width, self.dim, self.trace = width, dim, trace
         self.probe_seed, self._probe = probe_seed, None
         self.nfe = 0
+        self.counting = True     # False: no per-evaluation side effect (see MLPField)
 
     def _hyper(self, t):
         width, dim, block = self.width, self.dim, self.width * self.dim
@@ -116,7 +119,8 @@ class ExampleCNF(torch.nn.Module):
         return W, U, p[3 * block:]
 
     def forward(self, t, states):
-        self.nfe += 1
+        if self.counting:
+            self.nfe += 1
         z = states[0]
         W, U, b = self._hyper(t)
         if self.trace == "closed":

@@ -203,9 +203,7 @@ def test_complex_solves_on_the_kernels_equal_the_torch_op_path_and_the_reference
         ref = z[f"{tag}_{method}_{d}_y"]
         err = float((y.cpu() - T(ref)).abs().max() / np.abs(ref).max())
         assert err < (2e-5 if tag == "c64" else (1e-7 if method == "dopri8" else 1e-9)), err
-        if method == "rk4":
-            assert torch.equal(torch.view_as_real(y.cpu()), torch.view_as_real(T(ref)))
-        else:
+        if method != "rk4":     # (rk4: the solver's arithmetic is the reference's bit for bit, func's complex GEMM is the device's)
             assert nfe == int(z[f"{tag}_{method}_{d}_nfe"])
     # the torch-op path on the same device (r03's route for complex states)
     host = _fallback.HostKernels()

@@ -500,23 +500,19 @@ def test_auto_mode_refuses_random_fields():
     assert len(msgs) == 1 and "random-number" in msgs[0]
 
 
-_HIDDEN = {"scale": 1.0}
-
-
-def test_auto_mode_probe_catches_state_the_fingerprint_cannot_see():
-    """State hidden in a module-level dict: no attribute, buffer or RNG offset changes, so the fingerprint passes — the
-    replay-vs-eager comparison of the first captured step does not: the solve stays correct (eager) and warns."""
+def test_auto_mode_probe_catches_what_the_fingerprint_cannot_see():
+    """A func whose value depends on something no attribute, buffer or RNG offset shows — here: whether a stream capture
+    is in progress — passes the fingerprint; the replay-vs-eager comparison of the first captured step does not: the
+    solve stays correct (the eager results are kept), warns once, and the func is never captured again."""
     y0, t = _auto_problem()
     lin = torch.nn.Linear(8, 8).cuda()
 
     def f(t_, y_):
-        _HIDDEN["scale"] = 1.0 + (0.05 if _HIDDEN["scale"] == 1.0 else 0.0)      # alternates per PYTHON call
-        return lin(y_) * (0.1 * _HIDDEN["scale"])
+        return lin(y_) * (0.2 if torch.cuda.is_current_stream_capturing() else 0.1)
     outs = []
     with torch.no_grad(), warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         for mode in (False, "auto", "auto", "auto"):
-            _HIDDEN["scale"] = 1.0
             outs.append(tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph=mode)))
     assert all(torch.equal(o, outs[0]) for o in outs[1:])
     msgs = [str(x.message) for x in w if "hip_graph='auto'" in str(x.message)]
@@ -576,3 +572,27 @@ def test_auto_mode_on_fixed_grids():
         short_calls = calls[0]
     assert torch.equal(y_auto, y_eager) and torch.equal(y_short, y_eager[:10])
     assert long_calls == 8 and short_calls == 4 * 9          # replayed (first step + capture) / too short: eager
+
+
+def test_auto_mode_recaptures_when_a_python_scalar_of_func_changes():
+    """A captured graph bakes Python numbers into kernel arguments.  Under "auto" the plain attributes of func are part
+    of the cache key, so `f.scale = ...` between two solves gives the new value's solution, not a stale replay."""
+    y0, t = _auto_problem()
+
+    class Scaled(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            self.lin = torch.nn.Linear(8, 8).cuda()
+            self.scale = 0.5
+
+        def forward(self, t_, y_):
+            return torch.tanh(self.lin(y_)) * self.scale
+    f = Scaled()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for scale in (0.5, 0.5, 0.5, 1.5, 1.5, 1.5):
+            f.scale = scale
+            y_auto = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph="auto"))
+            y_eager = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8)
+            assert torch.equal(y_auto, y_eager), scale

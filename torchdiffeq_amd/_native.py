@@ -788,14 +788,26 @@ class ComplexHipKernels:
         plan.expect = ()
 
 
+class _GuardProbe:
+    """Test hook for the device guard on a one-GPU box (tests/test_dist_gpu.py): `pretend_current` = the index the guard
+    should take for the caller's current device — a state on cuda:0 then looks like a state on a NON-current device
+    and the switching branch runs for real (to device 0); `switched` counts how often it did."""
+    pretend_current = None
+    switched = 0
+
+
 def device_guard(device):
     """Context that makes `device` the current HIP device.  Every launch goes to `torch.cuda.current_stream()` — the
     CURRENT device's stream — and a kernel cannot be launched into another device's stream, so each entry point of the
     package runs under this guard: a state on `cuda:1` is integrated on cuda:1's stream whatever the caller's current
     device is.  Free when the device already is the current one (and for the CPU tensors of the host-logic tests)."""
     device = torch.device(device)
-    if device.type != "cuda" or device.index is None or device.index == torch.cuda.current_device():
+    if device.type != "cuda" or device.index is None:
         return contextlib.nullcontext()
+    current = torch.cuda.current_device() if _GuardProbe.pretend_current is None else _GuardProbe.pretend_current
+    if device.index == current:
+        return contextlib.nullcontext()
+    _GuardProbe.switched += 1
     return torch.cuda.device(device)
 
 

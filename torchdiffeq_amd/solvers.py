@@ -315,6 +315,41 @@ def _side_effect_fingerprint(fn, device):
     return tuple(out)
 
 
+def _scalar_state(fn):
+    """The plain Python values `fn` visibly holds (numbers, flags, strings, container lengths — no tensors: those are in
+    the key by storage address).  A captured graph bakes such values into its kernel arguments, so they are part of the
+    captured-step cache key: `self.scale = 0.5` changed between two solves leads to a new capture, not to a replay
+    with the old value."""
+    def plain(obj, out):
+        for name, v in list(getattr(obj, "__dict__", {}).items()):
+            if isinstance(v, (bool, int, float, complex, str, bytes, type(None))):
+                out.append((name, v))
+            elif isinstance(v, (list, tuple)) and len(v) <= 64 and all(isinstance(x, (bool, int, float, str)) for x in v):
+                out.append((name, tuple(v)))
+    out = []
+    if isinstance(fn, torch.nn.Module):
+        for m in fn.modules():
+            plain(m, out)
+            out.append(m.training)
+        return tuple(out)
+    plain(fn, out)
+    owner = getattr(fn, "__self__", None)
+    if owner is not None and not isinstance(owner, type):
+        out.append(_scalar_state(owner) if isinstance(owner, torch.nn.Module) else None)
+        plain(owner, out)
+    inner = getattr(fn, "__func__", fn)
+    for c in (getattr(inner, "__closure__", None) or ()):
+        if _cell_is_set(c):
+            v = c.cell_contents
+            if isinstance(v, (bool, int, float, complex, str, bytes, type(None))):
+                out.append(v)
+            elif isinstance(v, torch.nn.Module):
+                out.append(_scalar_state(v))
+            elif isinstance(v, (list, tuple)) and len(v) <= 64 and all(isinstance(x, (bool, int, float, str)) for x in v):
+                out.append(tuple(v))
+    return tuple(out)
+
+
 def _same_words(a, b) -> bool:
     """Equality of two flat lists of host doubles, NaN == NaN."""
     return len(a) == len(b) and all(x == y or (x != x and y != y) for x, y in zip(a, b))
@@ -500,7 +535,10 @@ class _GraphStep:
         # func object can be seen to hold goes into the key; a user-supplied `hip_graph_token` attribute of func (any
         # hashable: bump it when func changes what it computes) does too.
         key += (_held_tensor_ptrs(s.func.base_func), getattr(s.func.base_func, "hip_graph_token", None),
-                type(s.func).__name__, s.func.graph_key())
+                type(s.func).__name__, s.func.graph_key(),
+                # ("auto" only: with hip_graph=True the user vouches for func, and an evaluation counter among its
+                # attributes would otherwise change the key on every solve)
+                _scalar_state(s.func.base_func) if getattr(s, "_graph_auto", False) else None)
         return key
 
     @classmethod
@@ -644,33 +682,49 @@ class _GraphStep:
         current.wait_stream(stream)
 
     def _probe(self, s, side: int, graph) -> None:
-        """Auto mode, once per captured func: the trial step at hand is run TWICE from the same state — replayed from
-        the fresh graph, then evaluated eagerly — and everything a step produces must agree bit for bit: y1, the partial
-        error, the controller's decision words on the host and on the device, the next stage times.  The eager results
-        are the ones left in place (the caller reads them like any step's), so a mismatch costs nothing but the
-        capture: the solve goes on eagerly and `func` is not captured again."""
+        """Auto mode, once per captured func: the trial step at hand is run TWICE from the same state — evaluated
+        eagerly, then replayed from the fresh graph — and everything a step produces must agree bit for bit: y1, the
+        partial error, the controller's decision words on the host and on the device, the next stage times.  On
+        agreement the replay's results stay in place (they live in the buffers the graphs are wired to).  Otherwise the
+        eager results are put back (`take_words` hands the caller their decision words) — a mismatch costs nothing but
+        the capture: the solve goes on eagerly and `func` is not captured again."""
         kern, func, plan = s.kernels, s.func, s.plan
+        k_graph = self.k[side]                      # the stage tensors the captured nodes write (the graph's own pool)
         ctrl0, times0 = plan.ctrl_dev.clone(), self.tbuf.clone()
-        kern.arm_readback(plan)
-        graph.replay()
-        accept, dt_next, ratio, bad = kern.read_ctrl(plan)
-        words_g = [float(accept), dt_next, ratio] + list(bad)
-        y1_g, ep_g = self.y[1 - side].clone(), self.epart[side].clone()
-        ctrl_g, times_g = plan.ctrl_dev.clone(), self.tbuf.clone()
-        plan.ctrl_dev.copy_(ctrl0)
-        self.tbuf.copy_(times0)
         nfe = func.nfe
         self._eager_body(s, side)
         func.nfe = nfe
         accept, dt_next, ratio, bad = kern.read_ctrl(plan)
-        words_e = [float(accept), dt_next, ratio] + list(bad)
-        same = (_same_words(words_g, words_e) and torch.equal(y1_g, self.y[1 - side])
-                and torch.equal(ep_g, self.epart[side]) and torch.equal(times_g, self.tbuf)
-                and _same_words(ctrl_g.tolist(), plan.ctrl_dev.tolist()))
+        words_e = (accept, dt_next, ratio, list(bad))
+        k_eager = self.k[side]
+        y1_e, ep_e = self.y[1 - side].clone(), self.epart[side].clone()
+        ctrl_e, times_e = plan.ctrl_dev.clone(), self.tbuf.clone()
+        plan.ctrl_dev.copy_(ctrl0)
+        self.tbuf.copy_(times0)
+        self.k[side] = k_graph
+        kern.arm_readback(plan)
+        graph.replay()
+        accept, dt_next, ratio, bad = kern.read_ctrl(plan)
+        flat = lambda w: [float(w[0]), w[1], w[2]] + list(w[3])
+        same = (_same_words(flat((accept, dt_next, ratio, bad)), flat(words_e)) and torch.equal(y1_e, self.y[1 - side])
+                and torch.equal(ep_e, self.epart[side]) and torch.equal(times_e, self.tbuf)
+                and _same_words(ctrl_e.tolist(), plan.ctrl_dev.tolist())
+                and all(torch.equal(a, b) for a, b in zip(k_eager[1:], k_graph[1:])))
         self.probed = True
         if not same:
+            self.y[1 - side].copy_(y1_e)
+            self.epart[side].copy_(ep_e)
+            plan.ctrl_dev.copy_(ctrl_e)
+            self.tbuf.copy_(times_e)
+            self.k[side] = k_eager
+            self._words = words_e
             self.refuse(s, "a replayed trial step did not reproduce the eagerly evaluated one bit for bit (func is not a "
                            "pure function of t, y and its parameters)")
+
+    def take_words(self, kern, plan):
+        """(accept, dt_next, error_ratio, nonfinite) of the step `run` just took."""
+        words, self._words = getattr(self, "_words", None), None
+        return words if words is not None else kern.read_ctrl(plan)
 
     def accepted(self, s) -> None:
         """The step just run was accepted: its end state becomes the next trial step's input pair."""
@@ -1481,7 +1535,7 @@ class RKAdaptiveStepsizeODESolver:
             g = self._g = _GraphStep.acquire(self, t0, dt)
         side = g.side
         g.run(self)
-        accept_step, dt_next, _ratio, bad = kern.read_ctrl(self.plan)
+        accept_step, dt_next, _ratio, bad = g.take_words(kern, self.plan)
         dt_signed = float(T(dt)) * func.sign
         if accept_step:
             k = g.k[side]
@@ -1510,6 +1564,7 @@ class RKAdaptiveStepsizeODESolver:
             # path from the state it left in g's buffers — which stay this solve's own (g is not handed back for reuse)
             self.hip_graph = False
             self._g = None
+            self._hold_pre = False
 
     def _user_norm_ratio(self, y0, y1, k, dt_signed):
         """User-supplied `norm` callable (misc.py:80-82 with a custom norm): the kernel materialises
