@@ -1,6 +1,6 @@
 """Differential fuzzing against the reference (build container only: imports /root/reference).
 
-  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad|callbacks|hessian|vectol} [seed] [cases]
+  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad|callbacks|hessian|vectol|brow} [seed] [cases]
   (TDEQ_FUZZ_BACKEND=host: the product's torch-op host path for CPU states instead of the oracle test backend)
 
 Random states (0-dim .. 3-dim, tuples), dtypes, time grids (both directions), options and methods are solved by the
@@ -648,5 +648,58 @@ elif mode == "vectol":
             d=float((p-q).abs().max()/(p.abs().max()+1e-30))
             if not d<=tol: bad+=1; print('VALUE',desc,i,d); break
     print('done',n,'bad',bad)
+elif mode == "brow":
+    # r04: SURVEY.md §8(b) corners — the solver option `dtype`, states below fp32, func outputs of the wrong shape.  Runs on
+    # the package's torch-op host path (forced): bf16 / fp16 solves must equal the reference bit for bit with equal
+    # evaluation counts (or fail with the same assertion), fp32 / fp64 ones under a `dtype` option within the solve's
+    # own tolerance with equal counts in fp64.
+    warnings.simplefilter("ignore")
+    import importlib
+    importlib.reload(_native)           # undo the oracle substitution made above: states select their own backend
+    seed, n = int(sys.argv[1]), int(sys.argv[2]); rng = random.Random(seed); bad = 0
+    DT = [torch.bfloat16, torch.float16, torch.float32, torch.float64]
+    for case in range(n):
+        method = rng.choice(['dopri5', 'dopri8', 'bosh3', 'tsit5', 'adaptive_heun', 'fehlberg2', 'rk4', 'euler', 'midpoint'])
+        sdtype = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16, torch.float32, torch.float64])
+        shape = rng.choice([(3,), (2, 3), (4, 1, 2), (1,)]); is_tuple = rng.random() < 0.25; rev = rng.random() < 0.4
+        g = torch.Generator().manual_seed(rng.randrange(10**6))
+        y0 = torch.randn(shape, generator=g, dtype=torch.float64).to(sdtype); yb = torch.rand(2, generator=g, dtype=torch.float64).to(sdtype)
+        npts = rng.choice([2, 3, 5]); t = torch.sort(torch.rand(npts, generator=g, dtype=torch.float64) * 2).values
+        if float((t[1:] - t[:-1]).min()) < 0.05: continue
+        t = t.to(rng.choice([torch.float32, torch.float64]))
+        if rev: t = t.flip(0)
+        low = sdtype in (torch.bfloat16, torch.float16)
+        rtol, atol = (rng.choice([1e-2, 3e-2]), 1e-3) if low else (rng.choice([1e-4, 1e-6]), 1e-7)
+        opts = {}
+        fixed = method in ('rk4', 'euler', 'midpoint')
+        if not fixed:
+            if rng.random() < 0.6: opts['dtype'] = rng.choice(DT)
+            if rng.random() < 0.2: opts['first_step'] = 0.01
+            if rng.random() < 0.15: opts['max_step'] = 0.2
+            if rng.random() < 0.15: opts['safety'] = 0.8
+            if rng.random() < 0.15 and not rev: opts['step_t'] = torch.tensor([float(t.min()) + 0.013])
+        elif rng.random() < 0.4: opts['step_size'] = 0.0625
+        res = []
+        for L in (ref, tda):
+            nfe = [0]
+            def f(tt, y):
+                nfe[0] += 1
+                if is_tuple: return (-y[0] * (1 + 0.2 * tt) + 0.1 * torch.sin(y[0]), -0.4 * y[1])
+                return -y * (1 + 0.2 * tt) + 0.1 * torch.sin(y)
+            try:
+                with torch.no_grad(): out = L.odeint(f, (y0, yb) if is_tuple else y0, t, method=method, rtol=rtol, atol=atol, options=dict(opts))
+                res.append(('ok', out[0] if is_tuple else out, nfe[0]))
+            except Exception as e:
+                res.append(('err', type(e).__name__ + ': ' + str(e)[:60], 0))
+        a, b = res; desc = (case, method, str(sdtype)[6:], shape, is_tuple, rev, {k: (str(v)[6:] if k == 'dtype' else v) for k, v in opts.items()})
+        if a[0] != b[0] or (a[0] == 'err' and a[1] != b[1]): bad += 1; print('STATUS', desc, a[1] if a[0] == 'err' else 'ok', '|', b[1] if b[0] == 'err' else 'ok'); continue
+        if a[0] == 'err': continue
+        if low:
+            if a[2] != b[2] or not torch.equal(a[1], b[1]): bad += 1; print('LOWBITS', desc, a[2], b[2], float((a[1].float() - b[1].float()).abs().max()))
+            continue
+        if a[2] != b[2] and sdtype == torch.float64 and method != 'dopri8': bad += 1; print('NFE', desc, a[2], b[2]); continue
+        d = float((a[1] - b[1]).abs().max() / (a[1].abs().max() + 1e-30))
+        if not d <= (50 * rtol if sdtype == torch.float32 else (1e-6 if method == 'dopri8' else 1e-9)): bad += 1; print('VALUE', desc, d)
+    print('done', n, 'bad', bad)
 else:
-    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad | callbacks | hessian | vectol")
+    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad | callbacks | hessian | vectol | brow")

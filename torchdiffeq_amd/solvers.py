@@ -837,6 +837,11 @@ class RKAdaptiveStepsizeODESolver:
         self._W = scalar_type(self.dtype)
         self._wide = self._W is np.float64
         self.norm = rms_norm if norm is None else norm
+        if not self._wide:
+            # `torch.as_tensor(rtol, dtype=W)` (rk_common.py:186-187): the tolerances are W numbers before anything uses them
+            in_w = lambda tol: tol.to(self.dtype) if isinstance(tol, torch.Tensor) else (
+                type(tol)(in_w(v) for v in tol) if isinstance(tol, (list, tuple)) else self._w(float(tol)))
+            rtol, atol = in_w(rtol), in_w(atol)
         self.rtol, self.atol = rtol, atol
         # Per-element tolerances (a tensor / list broadcasting against the state — plain broadcasting in the reference,
         # misc.py:80-82): the kernels take one (rtol, atol) per segment, so they are asked for the RAW error and initial-
