@@ -28,6 +28,8 @@ def test_dtype_option_step_sequence(dev, state, method, kw, opt, direction):
     """Every time-like scalar lives in promote_types(dtype, y0.abs().dtype): with dtype=float32 (or float16, which
     promotes to it) on an fp32 state the accepted step sizes are fp32 numbers and must equal the reference's to an fp32
     ulp; NFE and accept / reject counts equal; solution within the tolerance the solve was asked for."""
+    if dev == "cuda" and (method != "dopri5" or opt == "o16"):
+        pytest.skip("host-side scalar arithmetic, identical on both devices: the cuda half keeps dopri5 x {fp32, fp64}")
     A, y0 = T(Z[f"dt_{state}_A"], dev), T(Z[f"dt_{state}_y0"], dev)
     t = torch.linspace(0.0, 1.5, 7, device=dev)
     if direction == "rev":
@@ -173,6 +175,8 @@ def test_low_precision_state_warns_and_selects_the_low_backend(monkeypatch):
 @pytest.mark.parametrize("case", list(FUNC_SHAPE_CASES))
 @pytest.mark.parametrize("method", [str(m) for m in Z["shape_methods"]])
 def test_func_output_shape_is_accepted_exactly_where_the_reference_accepts_it(dev, method, case):
+    if dev == "cuda" and method not in ("dopri5", "rk4"):
+        pytest.skip("host-side shape checks, identical on both devices: the cuda half keeps one adaptive and one fixed-grid method")
     i = list(Z["shape_methods"]).index(method)
     j = list(Z["shape_cases"]).index(case)
     shape, view = FUNC_SHAPE_CASES[case]
