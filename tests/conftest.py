@@ -43,9 +43,12 @@ def _poison_uninitialised_memory():
 # tolerances: hundreds of launch-bound steps of kernels the order-5 cases already exercise).
 _OUT_OF_SCOPE_METHODS = {"explicit_adams", "implicit_adams", "fixed_adams", "implicit_euler", "implicit_midpoint", "trapezoid",
                          "radauIIA3", "gl4", "radauIIA5", "gl6", "sdirk2", "trbdf2", "scipy_solver"}
-_SLOW_ON_GPU = ("test_seminorm_backward_evaluation_counts[cuda-adaptive_heun-f64]",
-                "test_solver_error_odeint[cuda-adaptive_heun-f32-rev]", "test_solver_error_odeint[cuda-adaptive_heun-f64-fwd]",
-                "test_solver_error_odeint[cuda-adaptive_heun-f64-rev]")
+# adaptive_heun (order 2: hundreds of launch-bound steps per solve at the suites' tolerances) exercises the same kernel
+# templates as every other pair with <= 2 terms per row; on the GPU box it runs where the METHOD is the subject
+# (tests/test_methods_golden.py, test_backprop_golden.py, test_lookahead.py, test_graph_mode_gpu.py, test_brow_golden.py)
+# and is left to the cpu half of the reference-suite / event / drop-in matrices.
+_GPU_ELSEWHERE_METHODS = {"adaptive_heun"}
+_GPU_ELSEWHERE_FILES = ("test_reference_suite.py", "test_events_golden.py", "test_dropin_golden.py", "test_detest_golden.py")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -56,8 +59,10 @@ def pytest_collection_modifyitems(config, items):
         cs = getattr(item, "callspec", None)
         if cs is None or cs.params.get("dev") != "cuda":
             continue
-        if any(item.nodeid.endswith(s) for s in _SLOW_ON_GPU):
-            item.add_marker(pytest.mark.skip(reason="slow on the GPU box without adding kernel coverage; runs on the cpu half"))
+        if item.fspath.basename in _GPU_ELSEWHERE_FILES and \
+                any(isinstance(v, str) and v in _GPU_ELSEWHERE_METHODS for v in cs.params.values()):
+            item.add_marker(pytest.mark.skip(reason="slow on the GPU box without adding kernel coverage: this method's cuda "
+                                                    "cases live in the method-level tests, the matrix on the cpu half"))
             continue
         out = sorted(v for v in cs.params.values() if isinstance(v, str) and v in _OUT_OF_SCOPE_METHODS)
         if not out:

@@ -1178,6 +1178,26 @@ def gen_brow():
                                rtol=1e-2, atol=1e-3, options=dict(dtype=torch.bfloat16))
         arrays[f"low_w16_{method}_y"] = y.float()
 
+    # bf16 through odeint_adjoint: forward rows, dL/dy0, dL/dW
+    for method in ("dopri5", "bosh3", "rk4"):
+        torch.manual_seed(1)
+        lin = torch.nn.Linear(4, 4).to(torch.bfloat16)
+        x = torch.randn(6, 4).to(torch.bfloat16).requires_grad_(True)
+        if method == "dopri5":
+            arrays["low_adj_W"], arrays["low_adj_b"], arrays["low_adj_y0"] = lin.weight.detach().float(), lin.bias.detach().float(), x.detach().float()
+
+        class LowField(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.lin = lin
+
+            def forward(self, t, y):
+                return torch.tanh(self.lin(y))
+        y = torchdiffeq.odeint_adjoint(LowField(), x, torch.tensor([0.0, 0.5, 1.0]), method=method, rtol=1e-2, atol=1e-3)
+        y[-1].float().pow(2).sum().backward()
+        arrays[f"low_adj_{method}_y"], arrays[f"low_adj_{method}_gy"] = y.detach().float(), x.grad.float()
+        arrays[f"low_adj_{method}_gW"] = lin.weight.grad.float()
+
     # ---- func outputs of the wrong shape: which (method, case) pairs the reference accepts ----
     table = np.zeros((len(FUNC_SHAPE_METHODS), len(FUNC_SHAPE_CASES)), dtype=np.int8)
     finals = np.zeros(table.shape, dtype=np.float64)

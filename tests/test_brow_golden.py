@@ -158,6 +158,33 @@ def test_low_precision_tuple_state_and_time_dtype(low_dev, method):
         assert rel_err(out[0].float(), Z[f"low_tuple_{method}_a"]) < 0.05 and rel_err(y.float(), Z[f"low_w16_{method}_y"]) < 0.05
 
 
+@pytest.mark.parametrize("method", ["dopri5", "bosh3", "rk4"])
+def test_low_precision_adjoint_gradients(low_dev, method):
+    """odeint_adjoint on a bf16 state and bf16 parameters: solution rows, dL/dy0 and dL/dW equal the reference's bit for
+    bit on the CPU (the augmented state, its segmented norm and the backward solve all run in bf16 there too)."""
+    lin = torch.nn.Linear(4, 4).to(torch.bfloat16).to(low_dev)
+    with torch.no_grad():
+        lin.weight.copy_(T(Z["low_adj_W"], low_dev))
+        lin.bias.copy_(T(Z["low_adj_b"], low_dev))
+    x = T(Z["low_adj_y0"], low_dev).to(torch.bfloat16).requires_grad_(True)
+
+    class LowField(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = lin
+
+        def forward(self, t, y):
+            return torch.tanh(self.lin(y))
+    y = tda.odeint_adjoint(LowField(), x, torch.tensor([0.0, 0.5, 1.0], device=low_dev), method=method, rtol=1e-2, atol=1e-3)
+    y[-1].float().pow(2).sum().backward()
+    got = (y.detach().float(), x.grad.float(), lin.weight.grad.float())
+    ref = tuple(T(Z[f"low_adj_{method}_{k}"]) for k in ("y", "gy", "gW"))
+    if low_dev == "cpu":
+        assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    else:
+        assert all(rel_err(a, b) < 0.1 for a, b in zip(got, ref))
+
+
 def test_low_precision_state_warns_and_selects_the_low_backend(monkeypatch):
     from torchdiffeq_amd import _native
     monkeypatch.setattr(_fallback, "_warned", False)

@@ -45,9 +45,9 @@ def _layout(n, chunk, n_seg):
 
 
 @pytest.mark.parametrize("tag", ["c64", "c128"])
-@pytest.mark.parametrize("n,chunk,n_seg,offset", [(1000, 1024, 1, 0), (4099, 1024, 1, 0), (4099, 1024, 1, 1), (1 << 20, 2048, 1, 0),
-                                                  (300000, 1024, 3, 0), (5000, 1024, 20, 0)])
-@pytest.mark.parametrize("nt", [1, 6, 9])
+@pytest.mark.parametrize("n,chunk,n_seg,offset,nt", [(1000, 1024, 1, 0, 1), (4099, 1024, 1, 0, 6), (4099, 1024, 1, 1, 6),
+                                                     (4099, 1024, 1, 1, 9), (1 << 20, 2048, 1, 0, 6), (300000, 1024, 3, 0, 9),
+                                                     (5000, 1024, 20, 0, 1), (5000, 1024, 20, 0, 9)])
 def test_complex_error_norm_kernel(tag, n, chunk, n_seg, offset, nt):
     dtype = CDT[tag]
     kern = _kern(dtype)
@@ -90,8 +90,7 @@ def test_complex_error_norm_kernel(tag, n, chunk, n_seg, offset, nt):
 
 
 @pytest.mark.parametrize("tag", ["c64", "c128"])
-@pytest.mark.parametrize("n,chunk,n_seg", [(4099, 1024, 1), (1 << 20, 2048, 1), (300000, 1024, 3)])
-@pytest.mark.parametrize("nt", [0, 1, 2])
+@pytest.mark.parametrize("n,chunk,n_seg,nt", [(4099, 1024, 1, 0), (4099, 1024, 1, 2), (1 << 20, 2048, 1, 1), (300000, 1024, 3, 2)])
 def test_complex_error_norm_partial_kernel(tag, n, chunk, n_seg, nt):
     dtype = CDT[tag]
     kern = _kern(dtype)

@@ -160,7 +160,8 @@ def odeint_dense(func, y0, t0, t1, *, rtol=1e-7, atol=1e-9, method=None, options
             raise IndexError("index {} is out of bounds for dimension 0 with size {}".format(idx, len(times)))
         ta, tb = times[idx - 1], times[idx]          # idx == 0 wraps to the last entry, as the reference's `times[idx - 1]` does
         assert ta <= ts <= tb, "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(ta, ts, tb)
-        x = np_dtype((ts - ta) / (tb - ta))
+        w = solver._w                       # time arithmetic in W = promote_types(options['dtype'], T), then cast to T (interp.py:39-40)
+        x = np_dtype(w(w(ts - ta) / w(tb - ta)))
         w, xp = [1.0, float(x)], x
         for _ in range(3):
             xp = np_dtype(xp * x)
