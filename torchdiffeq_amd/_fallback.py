@@ -121,12 +121,17 @@ class HostKernels:
         a = r.abs() if r.is_complex() else r
         return float(a.double().pow(2).sum())
 
+    # A tableau row's sum — the reference's `torch.sum(k * c, dim=-1)` (rk_common.py:79,89, 366) — as opposed to a chain
+    # of elementwise additions (`_lsum`: rk_common.py:110-157, solvers.py:166-181, fixed_adams.py).  The same thing in
+    # fp32 / fp64; states below fp32 round them differently (LowPrecisionHostKernels).
+    _rowsum = _lsum
+
     def make_plan(self, segments, total, chunk, device) -> HostPlan:
         return HostPlan(segments, total, chunk)
 
     # -- stage combines ------------------------------------------------------------------------------------
     def stage_combine(self, out, y0, ks, coefs, dt: float) -> None:
-        torch.add(y0, self._lsum(ks, self._coefs(y0, coefs, dt)), out=out)
+        torch.add(y0, self._rowsum(ks, self._coefs(y0, coefs, dt)), out=out)
 
     def stage_combine_fill(self, out, y0, ks, coefs, dt: float, fill_dst, fill_vals) -> None:
         self.stage_combine(out, y0, ks, coefs, dt)
@@ -134,13 +139,13 @@ class HostKernels:
 
     def stage_combine_err(self, out, err_out, y0, ks, coefs, err_coefs, dt: float) -> None:
         self.stage_combine(out, y0, ks, coefs, dt)
-        err_out.copy_(self._lsum(ks, self._coefs(y0, err_coefs, dt)))
+        err_out.copy_(self._rowsum(ks, self._coefs(y0, err_coefs, dt)))
 
     def stage_combine_multi(self, outs, rows, y0, acc_in, ks, dt: float, events=None) -> None:
         for o, (out, (coefs, mask, add_y0)) in enumerate(zip(outs, rows)):
             cs = self._coefs(y0, coefs, dt)
             take = [j for j in range(len(ks)) if (mask >> j) & 1]
-            s = self._lsum([ks[j] for j in take], [cs[j] for j in take], acc_in if o == 0 else None)
+            s = self._rowsum([ks[j] for j in take], [cs[j] for j in take], acc_in if o == 0 else None)
             if add_y0:
                 torch.add(y0, s, out=out)
             else:
@@ -166,10 +171,10 @@ class HostKernels:
             scaled_out[hi:].zero_()
 
     def error_norm(self, plan, y0, y1, ks, coefs, dt: float, scaled_out=None) -> None:
-        self._error_sums(plan, self._lsum(ks, self._coefs(y0, coefs, dt)), y0, y1, scaled_out)
+        self._error_sums(plan, self._rowsum(ks, self._coefs(y0, coefs, dt)), y0, y1, scaled_out)
 
     def error_norm_partial(self, plan, err_partial, y0, y1, ks, coefs, dt: float) -> None:
-        e = self._lsum(ks, self._coefs(y0, coefs, dt), err_partial) if len(ks) else err_partial
+        e = self._rowsum(ks, self._coefs(y0, coefs, dt), err_partial) if len(ks) else err_partial
         self._error_sums(plan, e, y0, y1, None)
 
     def error_scaled(self, plan, out, y0, y1, ks, coefs, dt: float) -> None:
@@ -209,7 +214,7 @@ class HostKernels:
     def _quartic(self, y0, y1, f0, f1, ks, coefs, dt: float):
         T = self._T(y0)
         dtT = float(T(dt))
-        ymid = y0 + self._lsum(ks, self._coefs(y0, coefs, dt))
+        ymid = y0 + self._rowsum(ks, self._coefs(y0, coefs, dt))
         two_dt = float(T(T(2) * T(dt)))
         qa = (two_dt * (f1 - f0) - 8 * (y1 + y0)) + 16 * ymid
         qb = ((dtT * (5 * f0 - 3 * f1) + 18 * y0) + 14 * y1) - 32 * ymid
@@ -343,8 +348,10 @@ class LowPrecisionHostKernels(HostKernels):
     name = "host-low"
 
     @staticmethod
-    def _lsum(ks, cs, start=None):
-        """round_T( start + sum_j float32(round_T(k_j * c_j)) ): products rounded to the state type, summed in float32."""
+    def _rowsum(ks, cs, start=None):
+        """round_T( start + sum_j float32(round_T(k_j * c_j)) ): products rounded to the state type, summed in float32 —
+        ATen's `torch.sum` of a reduced-precision row.  (Chains of elementwise additions — interpolation weights, the
+        rk2 / rk3 / rk4 step formulas, the Adams sums — round after every addition: the base class's `_lsum`.)"""
         acc = None if start is None else start.float()
         for k, c in zip(ks, cs):
             p = (k * c).float()

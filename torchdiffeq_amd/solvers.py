@@ -1139,6 +1139,9 @@ class RKAdaptiveStepsizeODESolver:
     def _select_initial_step(self, t0: float, y0: torch.Tensor, f0: torch.Tensor) -> float:
         """Hairer II.4 starting step (misc.py:36-77), scalars in the state precision T."""
         T = self.np_dtype
+        # per-element tolerances are fp64 tensors: the heuristic's norms and everything formed from them promote to fp64
+        # (misc.py:50-77 on tensors), only the constant 1e-6 floors stay in the state's type
+        S = np.float64 if self._vec_tol is not None else T
         kern, plan = self.kernels, self.plan
         order = self.order - 1   # the reference passes `self.order - 1` (rk_common.py:217)
         # Values come from the kernels on detached data; when the solve is differentiated, the SAME formulas are
@@ -1161,7 +1164,7 @@ class RKAdaptiveStepsizeODESolver:
                 vec_scale = self._vec_tol[1] + y0.abs() * self._vec_tol[0]      # misc.py:50, per element, fp64
                 q0, q1 = q0 / vec_scale, q1 / vec_scale
             with torch.no_grad():
-                d0, d1 = T(abs(float(self.norm(q0)))), T(abs(float(self.norm(q1))))
+                d0, d1 = S(abs(float(self.norm(q0)))), S(abs(float(self.norm(q1))))
         else:
             d0 = T(self._segment_norm(s0, bad))
             d1 = T(self._segment_norm(s1, bad))
@@ -1187,7 +1190,7 @@ class RKAdaptiveStepsizeODESolver:
             if self._vec_tol is not None:
                 q0 = q0 / vec_scale
             with torch.no_grad():
-                d2_num = T(abs(float(self.norm(q0))))
+                d2_num = S(abs(float(self.norm(q0))))
         else:
             kern.init_norms(plan, 1, f1, f0, y0)
             s2, _, bad = self._read_norms()
