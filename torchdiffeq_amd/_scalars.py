@@ -45,6 +45,8 @@ class _LowScalar(float):
     type.  `a op b` = round_low(float32(a) op float32(b)); a numpy scalar partner is a WIDER 0-dim tensor and wins the
     promotion (the operation is numpy's)."""
     __slots__ = ()
+    __array_ufunc__ = None      # numpy scalars defer their binary operators to this class (else `np.float32(2) * x` would take
+    #                             x for a Python float and hand back a float64 — 0-dim fp32 x 0-dim bf16 is fp32 in ATen)
     _round = staticmethod(_f32_to_bf16)
     torch_dtype = None
     eps_bits = 0            # explicit significand bits (for nextafter)

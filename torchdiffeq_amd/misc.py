@@ -503,7 +503,10 @@ def find_event(interp_fn, sign0, t0, t1, event_fn, tol: float, time_tensor, scal
     t0, t1 = scalar(t0), scalar(t1)
     with torch.no_grad():
         with np.errstate(all="ignore"):
-            nitrs = np.ceil(np.log(scalar(scalar(t1 - t0) / scalar(tol))) / scalar(math.log(2.0)))
+            width = scalar(scalar(t1 - t0) / scalar(tol))
+            # (a 16-bit time type has no numpy logarithm: ATen takes it in fp32 and rounds once)
+            log_w = np.log(width) if isinstance(width, np.floating) else scalar(np.log(np.float32(float(width))))
+            nitrs = np.ceil(np.float64(log_w / scalar(math.log(2.0))))
         if np.isinf(nitrs) and nitrs > 0:
             raise OverflowError("find_event: cannot bisect to a tolerance of 0 (atol must be positive)")
         nitrs = 0 if np.isnan(nitrs) else int(nitrs)
