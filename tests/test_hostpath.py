@@ -108,13 +108,10 @@ def test_complex_states_vs_reference_cpu(quiet, tag, method, d):
     y, nfe = _complex_case(z, tag, method, d, "cpu")
     ref = z[f"{tag}_{method}_{d}_y"]
     assert y.dtype == (torch.complex64 if tag == "c64" else torch.complex128) and tuple(y.shape) == ref.shape
-    err = float((y - T(ref)).abs().max() / np.abs(ref).max())
-    if method == "rk4":
-        assert torch.equal(y, T(ref))                 # no reduction anywhere: bit for bit
-    else:
-        # dopri8's first error estimate is rounding noise (a 9-term cancelling sum): its step sizes differ from the
-        # reference's in the last digits from the second step on, the solution within the tolerance
-        assert err < (2e-5 if tag == "c64" else (1e-7 if method == "dopri8" else 1e-9)), err
+    # r04: the host path hands row sums and norms to ATen as the reference does (_fallback.py) — every method, adaptive
+    # ones included, is the reference bit for bit on the CPU, with its evaluation count
+    assert torch.equal(torch.view_as_real(y), torch.view_as_real(T(ref)))
+    if method != "rk4":
         assert nfe == int(z[f"{tag}_{method}_{d}_nfe"])
 
 
@@ -183,11 +180,11 @@ def test_host_path_adaptive_solves_match_the_reference(quiet):
             return y_ @ A.T
         with torch.no_grad():
             y = tda.odeint(f, y0, t, rtol=rtol, atol=atol, method=method)
-        assert rel_err(y, z[f"{prefix}_y"]) < tol and nfe[0] == int(z[f"{prefix}_nfe"])
+        assert torch.equal(y, T(z[f"{prefix}_y"])) and nfe[0] == int(z[f"{prefix}_nfe"])      # r04: bit for bit
     A, y0, t = T(z["cfg4_A"]), T(z["cfg4_y0"]), T(z["cfg4_t"])
     with torch.no_grad():
         y = tda.odeint(lambda t_, y_: y_ @ A.T, y0, t, rtol=1e-9, atol=1e-11, method="dopri8")
-    assert rel_err(y, z["cfg4_y"]) < 1e-7
+    assert torch.equal(y, T(z["cfg4_y"]))
 
 
 def test_host_path_adjoint_and_tuple_state(quiet):

@@ -1,0 +1,118 @@
+"""Differential fuzzing of the COMPLEX path on the GPU box (r04): random complex64 / complex128 solves through the HIP
+kernels (`_native.ComplexHipKernels`: real kernels on the (re, im) view + complex norm kernels; look-ahead, host-driven
+and captured steps) against the package's torch-op path (`_fallback.HostKernels`) forced onto the same device.  Both
+evaluate the user's func with the same ATen kernels, so: fixed-grid solves bit-identical; adaptive solves equal
+evaluation counts and 1e-13 (complex128) / 2e-5 (complex64: a last-bit difference of a norm sum may move a step size);
+adjoint gradients 1e-9 / 1e-4.
+
+    python tools/fuzz_complex_gpu.py [seed] [cases]"""
+import os
+import random
+import sys
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torchdiffeq_amd as tda  # noqa: E402
+from torchdiffeq_amd import _fallback, _native  # noqa: E402
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+rng = random.Random(seed)
+warnings.simplefilter("ignore")
+DEV = "cuda"
+host = _fallback.HostKernels()
+orig_get = _native.get_kernels
+ADAPTIVE = ["dopri5", "dopri8", "tsit5", "bosh3", "fehlberg2", "adaptive_heun"]
+FIXED = ["euler", "midpoint", "heun2", "heun3", "rk4", "explicit_adams", "implicit_adams"]
+bad = 0
+for case in range(n_cases):
+    method = rng.choice(ADAPTIVE + ADAPTIVE + FIXED)
+    cdt = rng.choice([torch.complex64, torch.complex128])
+    rdt = torch.float32 if cdt == torch.complex64 else torch.float64
+    shape = rng.choice([(), (1,), (5,), (3, 4), (33, 7), (1025,), (2, 3, 5), (70000,)])
+    is_tuple = rng.random() < 0.3
+    rev = rng.random() < 0.4
+    npts = rng.choice([2, 3, 7, 40])
+    adjoint = rng.random() < 0.25 and method in ("dopri5", "rk4", "bosh3", "tsit5")
+    g = torch.Generator().manual_seed(rng.randrange(10 ** 6))
+    mk = lambda s: torch.complex(torch.randn(s, generator=g, dtype=torch.float64), torch.randn(s, generator=g, dtype=torch.float64)).to(cdt).to(DEV)
+    y0, yb = mk(shape), torch.randn(3, generator=g, dtype=torch.float64).to(rdt).to(DEV)       # second component REAL
+    w = mk(shape if shape else ()) * 0.3
+    t = torch.sort(torch.rand(npts, generator=g, dtype=torch.float64) * 2).values.to(rdt).to(DEV)
+    if float((t[1:] - t[:-1]).min()) < 1e-3:
+        continue
+    if rev:
+        t = t.flip(0)
+    opts = {}
+    if method in ADAPTIVE:
+        r = rng.random()
+        if r < 0.15:
+            opts["first_step"] = 0.01
+        elif r < 0.3:
+            opts["max_step"] = 0.2
+        elif r < 0.4 and not rev:
+            opts["step_t"] = torch.tensor([float(t.min()) + 0.0137], dtype=rdt)
+        if rng.random() < 0.3:
+            opts["hip_graph"] = True
+    else:
+        if rng.random() < 0.5:
+            opts["step_size"] = 0.05
+        if rng.random() < 0.3:
+            opts["interp"] = "cubic"
+        if rng.random() < 0.3:
+            opts["perturb"] = True
+    rtol, atol = (1e-5, 1e-7) if cdt == torch.complex64 else (1e-8, 1e-10)
+    lookahead = rng.random() < 0.7
+    res = []
+    for which in ("hip", "host"):
+        _native.get_kernels = orig_get if which == "hip" else (lambda device, dtype=None: host)
+        os.environ["TDEQ_LOOKAHEAD"] = "1" if (lookahead or which == "host") else "0"
+        nfe = [0]
+        wp = w.clone().requires_grad_(adjoint)
+
+        def f(tt, y):
+            nfe[0] += 1
+            if is_tuple:
+                return (-y[0] * wp * (1 + 0.2 * tt) + 0.1j * y[0] * y[0].abs(), -0.4 * y[1] * (1 + y[0].abs().mean().to(y[1].dtype)))
+            return -y * wp * (1 + 0.2 * tt) + 0.1j * y * y.abs()
+        x = y0.clone().requires_grad_(adjoint)
+        try:
+            if adjoint:
+                o = {k: v for k, v in opts.items() if k != "hip_graph"}
+                out = tda.odeint_adjoint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=o,
+                                         adjoint_params=(wp,))
+                y = out[0] if is_tuple else out
+                y[-1].abs().pow(2).sum().backward()
+                res.append(("ok", [y.detach(), x.grad, wp.grad], nfe[0]))
+            else:
+                with torch.no_grad():
+                    out = tda.odeint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=dict(opts))
+                res.append(("ok", [out[0] if is_tuple else out] + ([out[1]] if is_tuple else []), nfe[0]))
+        except Exception as e:
+            res.append(("err", type(e).__name__ + ": " + str(e)[:90], 0))
+    _native.get_kernels = orig_get
+    a, b = res
+    desc = (case, method, str(cdt)[6:], shape, is_tuple, adjoint, rev, lookahead, {k: (v if not torch.is_tensor(v) else "t") for k, v in opts.items()})
+    if a[0] != b[0]:
+        bad += 1
+        print("STATUS", desc, a[1] if a[0] == "err" else "ok", "|", b[1] if b[0] == "err" else "ok")
+        continue
+    if a[0] == "err":
+        continue
+    captured = opts.get("hip_graph")        # replays do not run func's Python body: counts differ by construction
+    if a[2] != b[2] and not captured and cdt == torch.complex128:
+        bad += 1
+        print("NFE", desc, a[2], b[2])
+        continue
+    exact = method in FIXED and method != "implicit_adams"
+    tol = (1e-9 if adjoint else 1e-12) if cdt == torch.complex128 else (2e-4 if adjoint else 3e-5)
+    for i, (p, q) in enumerate(zip(a[1], b[1])):
+        d = float((p - q).abs().max() / (q.abs().max() + 1e-30))
+        if (exact and not adjoint and d != 0.0) or not d <= tol:
+            bad += 1
+            print("VALUE", desc, i, d)
+            break
+print("done", n_cases, "bad", bad)

@@ -1,6 +1,6 @@
 """Differential fuzzing against the reference (build container only: imports /root/reference).
 
-  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad|callbacks|hessian|vectol|brow} [seed] [cases]
+  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_vs_reference.py {fixed|adaptive|adjoint|backprop|event|complex|tableau|eventgrad|callbacks|hessian|vectol|brow|hostexact} [seed] [cases]
   (TDEQ_FUZZ_BACKEND=host: the product's torch-op host path for CPU states instead of the oracle test backend)
 
 Random states (0-dim .. 3-dim, tuples), dtypes, time grids (both directions), options and methods are solved by the
@@ -701,5 +701,77 @@ elif mode == "brow":
         d = float((a[1] - b[1]).abs().max() / (a[1].abs().max() + 1e-30))
         if not d <= (50 * rtol if sdtype == torch.float32 else (1e-6 if method == 'dopri8' else 1e-9)): bad += 1; print('VALUE', desc, d)
     print('done', n, 'bad', bad)
+elif mode == "hostexact":
+    # r04: the torch-op host path hands every row sum and norm to ATen exactly as the reference does (_fallback.py), so on
+    # the CPU it must reproduce the reference BIT FOR BIT — every explicit method, fp32 / fp64 / complex / bf16, tuple
+    # states, both directions, the solver options, odeint_adjoint and backprop gradients — with equal evaluation counts.
+    warnings.simplefilter("ignore")
+    import importlib
+    importlib.reload(_native)
+    seed, n = int(sys.argv[1]), int(sys.argv[2]); rng = random.Random(seed); bad = 0
+    ADAPT = ['dopri5', 'dopri8', 'bosh3', 'tsit5', 'adaptive_heun', 'fehlberg2']; FIX = ['rk4', 'euler', 'midpoint', 'heun2', 'heun3']
+    for case in range(n):
+        method = rng.choice(ADAPT + ADAPT + FIX)
+        dtype = rng.choice([torch.float32, torch.float64, torch.float64, torch.complex64, torch.complex128, torch.bfloat16])
+        rdt = {torch.complex64: torch.float32, torch.complex128: torch.float64}.get(dtype, dtype)
+        shape = rng.choice([(3,), (2, 3), (4, 1, 2), (1,), (17,)]); is_tuple = rng.random() < 0.3; rev = rng.random() < 0.4
+        grad = rng.choice([None, None, 'adjoint', 'backprop']) if dtype in (torch.float32, torch.float64) else None
+        g = torch.Generator().manual_seed(rng.randrange(10**6))
+        mk = lambda s: (torch.complex(torch.randn(s, generator=g, dtype=torch.float64), torch.randn(s, generator=g, dtype=torch.float64))
+                        if dtype.is_complex else torch.randn(s, generator=g, dtype=torch.float64)).to(dtype)
+        y0, yb, w0 = mk(shape), torch.rand(2, generator=g, dtype=torch.float64).to(rdt), mk(shape) * 0.3
+        npts = rng.choice([2, 3, 5]); t = torch.sort(torch.rand(npts, generator=g, dtype=torch.float64) * 2).values
+        if float((t[1:] - t[:-1]).min()) < 0.05: continue
+        t = t.to(rng.choice([torch.float32, torch.float64]) if rdt != torch.float64 else torch.float64)
+        if rev: t = t.flip(0)
+        low = dtype == torch.bfloat16
+        rtol, atol = (2e-2, 1e-3) if low else ((1e-4, 1e-6) if method in ('adaptive_heun', 'fehlberg2') or rdt == torch.float32 else (1e-7, 1e-9))
+        opts = {}
+        if method in ADAPT:
+            r = rng.random()
+            if r < 0.15: opts['first_step'] = 0.01
+            elif r < 0.3: opts['max_step'] = 0.2
+            elif r < 0.4: opts['safety'] = 0.8
+            elif r < 0.5 and not rev: opts['step_t'] = torch.tensor([float(t.min()) + 0.013])
+            elif r < 0.6 and not rev: opts['jump_t'] = torch.tensor([float(t.min()) + 0.021])
+            if rng.random() < 0.25: opts['dtype'] = rng.choice([torch.float32, torch.float64])
+        else:
+            if rng.random() < 0.5: opts['step_size'] = 0.0625
+            if rng.random() < 0.3: opts['interp'] = 'cubic'
+            if rng.random() < 0.3: opts['perturb'] = True
+        res = []
+        for L in (ref, tda):
+            nfe = [0]
+            w = w0.clone().requires_grad_(grad is not None)
+            def f(tt, y):
+                nfe[0] += 1
+                if is_tuple: return (-y[0] * w * (1 + 0.2 * tt) + 0.1 * torch.sin(y[0]), -0.4 * y[1] * (1 + y[0].abs().mean().to(y[1].dtype)))
+                return -y * w * (1 + 0.2 * tt) + 0.1 * torch.sin(y)
+            x = y0.clone().requires_grad_(grad is not None)
+            try:
+                if grad == 'adjoint':
+                    out = L.odeint_adjoint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=dict(opts), adjoint_params=(w,))
+                elif grad == 'backprop':
+                    out = L.odeint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=dict(opts))
+                else:
+                    with torch.no_grad(): out = L.odeint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=dict(opts))
+                o = out[0] if is_tuple else out
+                vals = [o.detach()] + ([out[1].detach()] if is_tuple else [])
+                if grad:
+                    o[-1].pow(2).sum().backward(); vals += [x.grad, w.grad]
+                res.append(('ok', vals, nfe[0]))
+            except Exception as e:
+                res.append(('err', type(e).__name__ + ': ' + str(e)[:60], 0))
+        a, b = res; desc = (case, method, str(dtype)[6:], shape, is_tuple, rev, grad, {k: (str(v)[6:] if k == 'dtype' else ('t' if torch.is_tensor(v) else v)) for k, v in opts.items()})
+        if a[0] != b[0] or (a[0] == 'err' and a[1] != b[1]): bad += 1; print('STATUS', desc, a[1] if a[0] == 'err' else 'ok', '|', b[1] if b[0] == 'err' else 'ok'); continue
+        if a[0] == 'err': continue
+        n_fwd = 2 if is_tuple else 1            # backprop gradients come from a hand-written backward (autodiff._LinearOp): same
+        cmp = a[1] if grad != 'backprop' else a[1][:n_fwd]      # values to rounding, a different accumulation order of the cotangents
+        exact = all(torch.equal(torch.view_as_real(p) if p.is_complex() else p, torch.view_as_real(q) if q.is_complex() else q) for p, q in zip(cmp, b[1]))
+        if exact and grad == 'backprop':
+            exact = all(float((p - q).abs().max()) <= (1e-5 if rdt == torch.float32 else 1e-12) * float(p.abs().max() + 1e-30) for p, q in zip(a[1][n_fwd:], b[1][n_fwd:]))
+        if a[2] != b[2] or not exact:
+            bad += 1; print('BITS', desc, a[2], b[2], [float((p - q).abs().max() / (p.abs().max() + 1e-30)) for p, q in zip(a[1], b[1])])
+    print('done', n, 'bad', bad)
 else:
-    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad | callbacks | hessian | vectol | brow")
+    raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad | callbacks | hessian | vectol | brow | hostexact")

@@ -9,11 +9,18 @@ Selection is by the STATE alone (`_native.get_kernels`): a real fp32 / fp64 stat
 HIP kernels and fails loudly if libtdeq_hip.so is missing — it never lands here.  This module never imports `oracle/`
 (tests/test_abi.py::test_product_never_imports_oracle); the first use warns once (`HostPathWarning`).
 
-Arithmetic: the same rounding sequence as the kernels (include/tdeq_hip.h) — coefficients
-fl_T(fl_T(coef) * fl_T(dt)), products and sums rounded separately, left to right over the non-zero tableau entries
-(rk_common.py:79,89,201-205), the operation order of interp.py:17-21,42-47 and rk_common.py:110-157 — so the fixed-grid
-methods equal the reference bit for bit here as they do on the GPU; the norm sums are accumulated in fp64 like the
-kernels' (DESIGN.md §8).  T = the REAL dtype of the state (`y0.abs().dtype`), also for complex states.
+Arithmetic (r04): the REFERENCE's, literally.  Where the HIP kernels have to pick an order ATen leaves open — the sum
+over a tableau row, the accumulation of a norm — this path does not pick: it hands ATen the same expression the reference
+evaluates.  A row sum is `torch.sum` over a dense [N, row length] product tensor with the products at their tableau
+positions (`_rowsum`: ATen adds ≤ 7 columns as four interleaved partial sums, more through vector lanes — the result
+depends on the positions); a norm is `x.abs().pow(2).mean().sqrt()` in the state's type per component
+(`HostPlan.rms0 / rms1`, misc.py:22-33), the fp64 sums the kernel interface reports are kept beside it.  Everything else
+follows the operation order of interp.py:17-21,42-47 and rk_common.py:110-157 with coefficients fl_T(fl_T(coef) *
+fl_T(dt)) (rk_common.py:79,89,201-205), and the host scalars round like 0-dim tensors (`_scalars.py`).  Consequence: on
+the CPU every explicit method — adaptive and fixed-grid, fp32 / fp64 / complex / bf16, adjoint included — reproduces the
+reference BIT FOR BIT (tests/test_hostpath.py, tests/test_brow_golden.py, `tools/fuzz_vs_reference.py` with
+TDEQ_FUZZ_BACKEND=host); the solver drivers switch off the fused error split and the carried partial sums here (both
+re-associate a row).  T = the REAL dtype of the state (`y0.abs().dtype`), also for complex states.
 """
 from __future__ import annotations
 
@@ -62,6 +69,10 @@ class HostPlan:
         self.sums0 = [0.0] * self.n_seg
         self.sums1 = [0.0] * self.n_seg
         self.bad = [0.0] * self.n_seg
+        # the reference's own norm of the same quotients, per segment: sqrt(mean(|x|^2)) evaluated by ATen in the state's
+        # type (what the solver drivers use on this path — `literal_norms`)
+        self.rms0 = [0.0] * self.n_seg
+        self.rms1 = [0.0] * self.n_seg
 
 
 def _nonfinite(*xs: torch.Tensor) -> float:
@@ -94,6 +105,8 @@ class HostKernels:
 
     name = "host"
     device_controller = False
+    literal_row_sums = True      # no fused error split / carried partial sums on this path (solvers.py)
+    literal_norms = True         # HostPlan.rms0 / rms1 hold the reference's norm values
 
     # -- helpers -----------------------------------------------------------------------------------------
     @staticmethod
@@ -121,17 +134,34 @@ class HostKernels:
         a = r.abs() if r.is_complex() else r
         return float(a.double().pow(2).sum())
 
-    # A tableau row's sum — the reference's `torch.sum(k * c, dim=-1)` (rk_common.py:79,89, 366) — as opposed to a chain
-    # of elementwise additions (`_lsum`: rk_common.py:110-157, solvers.py:166-181, fixed_adams.py).  The same thing in
-    # fp32 / fp64; states below fp32 round them differently (LowPrecisionHostKernels).
-    _rowsum = _lsum
+    @staticmethod
+    def _rowsum(ks, cs, start=None, row=None):
+        """A tableau row's sum — the reference's `torch.sum(k[..., :n] * c, dim=-1)` (rk_common.py:79,89,366) — as opposed
+        to a chain of elementwise additions (`_lsum`: rk_common.py:110-157, solvers.py:166-181, fixed_adams.py).  `row`
+        = the row's `tableaus.RowCoefs` (positions `idx` of the non-zero weights in a dense row of `width` columns): the
+        products go to their columns of a zero-filled [N, width] tensor (a zero weight contributes +0, but its position
+        decides which of ATen's partial sums the others land in) and ATen sums it — for every dtype its own way (bf16 /
+        fp16: products rounded to the state type, accumulated in fp32, rounded once).  Without `row` (user-supplied
+        weights, continued partial sums): the chain."""
+        width = getattr(row, "width", None)
+        if start is not None or width is None or len(ks) == 0:
+            return HostKernels._lsum(ks, cs, start)
+        prod = ks[0].new_zeros((ks[0].numel(), width))
+        for k, c, j in zip(ks, cs, row.idx):
+            torch.mul(k.reshape(-1), c, out=prod[:, j])
+        return prod.sum(dim=-1).view_as(ks[0])
+
+    @staticmethod
+    def _rms(r: torch.Tensor) -> float:
+        """misc.py:22-23, literally (NaN for an empty component, as there)."""
+        return float(r.abs().pow(2).mean().sqrt()) if r.numel() else float("nan")
 
     def make_plan(self, segments, total, chunk, device) -> HostPlan:
         return HostPlan(segments, total, chunk)
 
     # -- stage combines ------------------------------------------------------------------------------------
     def stage_combine(self, out, y0, ks, coefs, dt: float) -> None:
-        torch.add(y0, self._rowsum(ks, self._coefs(y0, coefs, dt)), out=out)
+        torch.add(y0, self._rowsum(ks, self._coefs(y0, coefs, dt), None, coefs), out=out)
 
     def stage_combine_fill(self, out, y0, ks, coefs, dt: float, fill_dst, fill_vals) -> None:
         self.stage_combine(out, y0, ks, coefs, dt)
@@ -159,6 +189,7 @@ class HostKernels:
             tol = torch.fmax(y0[sl].abs(), y1[sl].abs()) * float(T(rtol)) + float(T(atol))
             r = e[sl] / tol
             plan.sums0[s] = self._sumsq(r)
+            plan.rms0[s] = self._rms(r)
             plan.bad[s] = _nonfinite(y0[sl], y1[sl])
             if scaled_out is not None:
                 scaled_out[sl] = r
@@ -171,7 +202,7 @@ class HostKernels:
             scaled_out[hi:].zero_()
 
     def error_norm(self, plan, y0, y1, ks, coefs, dt: float, scaled_out=None) -> None:
-        self._error_sums(plan, self._rowsum(ks, self._coefs(y0, coefs, dt)), y0, y1, scaled_out)
+        self._error_sums(plan, self._rowsum(ks, self._coefs(y0, coefs, dt), None, coefs), y0, y1, scaled_out)
 
     def error_norm_partial(self, plan, err_partial, y0, y1, ks, coefs, dt: float) -> None:
         e = self._rowsum(ks, self._coefs(y0, coefs, dt), err_partial) if len(ks) else err_partial
@@ -192,9 +223,9 @@ class HostKernels:
 
     def init_norms(self, plan, mode: int, a, b, yscale) -> None:
         for s, sl, q0, q1 in self._init_quotients(plan, mode, a, b, yscale):
-            plan.sums0[s] = self._sumsq(q0)
+            plan.sums0[s], plan.rms0[s] = self._sumsq(q0), self._rms(q0)
             if q1 is not None:
-                plan.sums1[s] = self._sumsq(q1)
+                plan.sums1[s], plan.rms1[s] = self._sumsq(q1), self._rms(q1)
             plan.bad[s] = _nonfinite(yscale[sl])
 
     def init_scaled(self, plan, mode: int, a, b, yscale, out0, out1=None) -> None:
@@ -214,7 +245,7 @@ class HostKernels:
     def _quartic(self, y0, y1, f0, f1, ks, coefs, dt: float):
         T = self._T(y0)
         dtT = float(T(dt))
-        ymid = y0 + self._rowsum(ks, self._coefs(y0, coefs, dt))
+        ymid = y0 + self._rowsum(ks, self._coefs(y0, coefs, dt), None, coefs)
         two_dt = float(T(T(2) * T(dt)))
         qa = (two_dt * (f1 - f0) - 8 * (y1 + y0)) + 16 * ymid
         qb = ((dtT * (5 * f0 - 3 * f1) + 18 * y0) + 14 * y1) - 32 * ymid
@@ -248,16 +279,19 @@ class HostKernels:
 
     # -- fixed-grid steps (rk_common.py:110-157, solvers.py:166-181) ------------------------------------------------
     def rk4_stage(self, stage: int, out, y0, k1, k2, k3, k4, dt: float) -> None:
+        # rk_common.py:110-118 with dt a 0-dim tensor: `dt * k` rounds dt to the state type first, `k * dt` and
+        # `... * _one_third` take the scalar as ATen takes a second operand (`_scalars.operand`: the state type for
+        # fp32 / fp64 — the same number —, fp32 for the 16-bit types)
         T = self._T(y0)
-        dtT, third = float(T(dt)), float(T(1.0 / 3.0))
+        dt_first, dt_second, third = float(T(dt)), operand(T, dt), operand(T, 1.0 / 3.0)
         if stage == 1:
-            r = y0 + (dtT * k1) * third
+            r = y0 + (dt_first * k1) * third
         elif stage == 2:
-            r = y0 + dtT * (k2 - k1 * third)
+            r = y0 + dt_first * (k2 - k1 * third)
         elif stage == 3:
-            r = y0 + dtT * ((k1 - k2) + k3)
+            r = y0 + dt_first * ((k1 - k2) + k3)
         else:
-            r = y0 + (((k1 + 3 * (k2 + k3)) + k4) * dtT) * 0.125
+            r = y0 + (((k1 + 3 * (k2 + k3)) + k4) * dt_second) * 0.125
         out.copy_(r)
 
     def lerp(self, out, y0, y1, slope: float) -> None:
@@ -335,47 +369,11 @@ class HostKernels:
 @_no_grad_methods
 class LowPrecisionHostKernels(HostKernels):
     """bfloat16 / float16 states: the reference integrates them in their own precision (misc.py:185-187,
-    rk_common.py:61-65 — every time-like scalar is cast to `y0.abs().dtype`), and so does this backend.  What differs
-    from the fp32 / fp64 arithmetic is how ATen rounds reduced-precision work (measured, tools/lowfloat_semantics.py):
-    elementwise operations compute in float32 and round once; `torch.sum` accumulates a row in float32 and rounds
-    ONCE (so a tableau row is not a chain of separately rounded additions); a Python number after `*` is taken at
-    float32 precision.  The norm is the reference's literal `x.abs().pow(2).mean().sqrt()` in the state's type, handed
-    back through the sums interface as rms^2 * n (exact in fp64: the host's sqrt(sum / n) returns rms bit for bit).
-    The solver drivers switch off the fused error combine and the carried partial sums for these states (both split a
-    row's sum).  Exact for the adaptive methods and rk4; the other fixed-grid methods follow the fp32 / fp64 operation
-    order, which is close but not bit-faithful in 16 bits."""
+    rk_common.py:61-65 — every time-like scalar is cast to `y0.abs().dtype`), and so does this backend, on whatever
+    device the state lives.  The arithmetic is HostKernels' — ATen itself rounds a reduced-precision `torch.sum`
+    (products in the state type, fp32 accumulation, one rounding) and `mean()` its own way, and `_scalars.operand` /
+    `BFloat16Scalar` / `Float16Scalar` reproduce how it takes Python numbers and 0-dim partners next to a 16-bit tensor
+    (tools/lowfloat_semantics.py).  A class of its own only so that the selection (`_native.get_kernels`) and the
+    warning say what runs: no HIP kernels exist for these element types."""
 
     name = "host-low"
-
-    @staticmethod
-    def _rowsum(ks, cs, start=None):
-        """round_T( start + sum_j float32(round_T(k_j * c_j)) ): products rounded to the state type, summed in float32 —
-        ATen's `torch.sum` of a reduced-precision row.  (Chains of elementwise additions — interpolation weights, the
-        rk2 / rk3 / rk4 step formulas, the Adams sums — round after every addition: the base class's `_lsum`.)"""
-        acc = None if start is None else start.float()
-        for k, c in zip(ks, cs):
-            p = (k * c).float()
-            acc = p if acc is None else acc + p
-        return acc.to(ks[0].dtype)
-
-    @staticmethod
-    def _sumsq(r: torch.Tensor) -> float:
-        if r.numel() == 0:
-            return 0.0
-        rms = float(r.abs().pow(2).mean().sqrt())
-        return rms * rms * r.numel()
-
-    def rk4_stage(self, stage: int, out, y0, k1, k2, k3, k4, dt: float) -> None:
-        # rk_common.py:110-118 with dt a 0-dim tensor: `dt * k` rounds dt to the state type first, `k * dt` and
-        # `... * _one_third` take the scalar at float32
-        T = self._T(y0)
-        dt_first, dt_second, third = float(T(dt)), operand(T, dt), operand(T, 1.0 / 3.0)
-        if stage == 1:
-            r = y0 + (dt_first * k1) * third
-        elif stage == 2:
-            r = y0 + dt_first * (k2 - k1 * third)
-        elif stage == 3:
-            r = y0 + dt_first * ((k1 - k2) + k3)
-        else:
-            r = y0 + (((k1 + 3 * (k2 + k3)) + k4) * dt_second) * 0.125
-        out.copy_(r)

@@ -333,7 +333,7 @@ class HipKernels:
             ptrs = arrays[n]
             for j in range(n):
                 ptrs[j] = ks[j].data_ptr()
-        if type(coefs) is tuple:
+        if isinstance(coefs, tuple):        # (a tableau row's RowCoefs included)
             cf = cls._COEF_ARRAYS.get(coefs)
             if cf is None:
                 if len(cls._COEF_ARRAYS) > 4096:      # not a tableau row cache any more: start over

@@ -889,9 +889,10 @@ class RKAdaptiveStepsizeODESolver:
         last = self._beta[-1] if tab.fsal_solution else self._c_sol
         n_lead = len(last.idx)
         self._fuse = None
-        # (not for bf16 / fp16 states: ATen sums a reduced-precision row in float32 and rounds ONCE — splitting the
-        # error sum in two would round twice)
-        if self._c_err.idx[:n_lead] == last.idx and len(self._c_err.idx) - n_lead <= 2 and not is_low(self.np_dtype):
+        # (not on the torch-op host path, which hands every row to ATen's `torch.sum` whole — `literal_row_sums`,
+        # _fallback.py: splitting a row re-associates it, and for bf16 / fp16 states would round it twice)
+        if self._c_err.idx[:n_lead] == last.idx and len(self._c_err.idx) - n_lead <= 2 \
+                and not getattr(self.kernels, "literal_row_sums", False):
             self._fuse = (self._c_err.coef[:n_lead], self._c_err.idx[n_lead:], self._c_err.coef[n_lead:])
         # Carried partial sums (tableaus.carry_plan / tdeq_stage_combine_multi): fewer bytes per step for the same bits.
         # TDEQ_CARRY: unset / "auto" = the tableaus where it is a measured gain (CARRY_DEFAULT_ON); "1" = every
@@ -970,17 +971,23 @@ class RKAdaptiveStepsizeODESolver:
         return {"callback_step", "callback_accept_step", "callback_reject_step"}
 
     # -- norms -------------------------------------------------------------------------------------
-    def _segment_norm(self, sumsq: Sequence[float], bad: Sequence[float]):
-        """max over the selected segments of sqrt(mean), rounded to the state dtype (misc.py:22-33)."""
+    def _segment_norm(self, sumsq: Sequence[float], bad: Sequence[float], which: int = 0):
+        """max over the selected segments of sqrt(mean), rounded to the state dtype (misc.py:22-33).  `which`: the first /
+        second sum of the last norm launch — only needed on the torch-op host path, whose plan also holds the
+        reference's own norm values (`literal_norms`: ATen's `abs().pow(2).mean().sqrt()` per segment) and they are the
+        ones used there."""
         numels = self._numels
         n = len(numels)
         if isinstance(self.norm, BuiltinNorm) and self.norm.n_skip_tail:
             n -= self.norm.n_skip_tail
+        literal = None
+        if self._sync is None and getattr(self.kernels, "literal_norms", False):
+            literal = self.plan.rms1 if which else self.plan.rms0
         val = 0.0
         for s in range(n):
             if numels[s] == 0:
                 continue
-            val = _nan_max(val, math.sqrt(sumsq[s] / numels[s]))
+            val = _nan_max(val, literal[s] if literal is not None else math.sqrt(sumsq[s] / numels[s]))
         with np.errstate(over="ignore"):
             return float(self.np_dtype(val))
 
@@ -1167,7 +1174,7 @@ class RKAdaptiveStepsizeODESolver:
                 d0, d1 = S(abs(float(self.norm(q0)))), S(abs(float(self.norm(q1))))
         else:
             d0 = T(self._segment_norm(s0, bad))
-            d1 = T(self._segment_norm(s1, bad))
+            d1 = T(self._segment_norm(s1, bad, which=1))
         # Scalar arithmetic below: each operation as ATen rounds it for 0-dim tensors of type T with Python numbers
         # mixed in (_scalars.py) — `0.01 / x` is reciprocal-then-multiply, `x ** e` is raised in double for fp32.
         if d0 < 1e-5 or d1 < 1e-5:

@@ -33,10 +33,23 @@ def _row(text: str) -> List[float]:
     return [_ratio(tok) for tok in text.split()]
 
 
+class RowCoefs(tuple):
+    """The non-zero weights of a tableau row — a plain tuple to everything that only multiplies (the HIP kernels take the
+    values; equality and hashing are the tuple's) — that also remembers WHERE in the dense row they sit (`idx`) and how
+    long that row is (`width`).  The torch-op host path needs both: ATen's `torch.sum` over the stage dimension adds the
+    products in an order that depends on their positions (four interleaved partial sums, vector lanes from 8 columns on;
+    DESIGN.md §8), and reproducing the reference bit for bit there means handing ATen the same dense row."""
+
+    def __new__(cls, values, idx, width):
+        self = super().__new__(cls, values)
+        self.idx, self.width = tuple(idx), int(width)
+        return self
+
+
 @dataclasses.dataclass(frozen=True)
 class SparseRow:
     idx: Tuple[int, ...]      # stage slots with a non-zero weight
-    coef: Tuple[float, ...]   # fp64 weights (cast to the state dtype by the kernel)
+    coef: "RowCoefs"          # fp64 weights (cast to the state dtype by the kernel), a tuple that knows its row
 
     @staticmethod
     def from_dense(values: Sequence[float]) -> "SparseRow":
@@ -53,7 +66,8 @@ def _sparse_row(values: Tuple[float, ...]) -> SparseRow:
         # the kernels take >= 1 term, so keep one explicit zero — 0 * k_0, which is also what the reference's dense
         # sum computes (rk_common.py:79, :88), non-finite k_0 included
         nz = [(0, 0.0)]
-    return SparseRow(tuple(i for i, _ in nz), tuple(v for _, v in nz))
+    idx = tuple(i for i, _ in nz)
+    return SparseRow(idx, RowCoefs((v for _, v in nz), idx, len(values)))
 
 
 @dataclasses.dataclass(frozen=True)
