@@ -138,7 +138,7 @@ def test_linear_operations_on_the_real_view_equal_the_torch_op_path(tag):
     """stage combine / dense output / rk4 / lerp / pack through ComplexHipKernels vs `_fallback.HostKernels` (torch ops on
     complex tensors) on the same device: bit-identical."""
     dtype = CDT[tag]
-    kern, host = _kern(dtype), _fallback.HostKernels()
+    kern, host = _kern(dtype), _fallback.KernelOrderHostKernels()
     n = 5000
     y0, y1 = _z(n, dtype, 1), _z(n, dtype, 2)
     ks = [_z(n, dtype, 10 + j) for j in range(7)]
@@ -205,7 +205,7 @@ def test_complex_solves_on_the_kernels_equal_the_torch_op_path_and_the_reference
         if method != "rk4":     # (rk4: the solver's arithmetic is the reference's bit for bit, func's complex GEMM is the device's)
             assert nfe == int(z[f"{tag}_{method}_{d}_nfe"])
     # the torch-op path on the same device (r03's route for complex states)
-    host = _fallback.HostKernels()
+    host = _fallback.KernelOrderHostKernels()
     monkeypatch.setattr(_native, "get_kernels", lambda device, dtype=None: host)
     y_host, nfe_host = _solve(z, tag, method, d)
     monkeypatch.undo()

@@ -23,7 +23,7 @@ n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 rng = random.Random(seed)
 warnings.simplefilter("ignore")
 DEV = "cuda"
-host = _fallback.HostKernels()
+host = _fallback.KernelOrderHostKernels()
 orig_get = _native.get_kernels
 ADAPTIVE = ["dopri5", "dopri8", "tsit5", "bosh3", "fehlberg2", "adaptive_heun"]
 FIXED = ["euler", "midpoint", "heun2", "heun3", "rk4", "explicit_adams", "implicit_adams"]

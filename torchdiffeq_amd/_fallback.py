@@ -377,3 +377,20 @@ class LowPrecisionHostKernels(HostKernels):
     warning say what runs: no HIP kernels exist for these element types."""
 
     name = "host-low"
+
+
+@_no_grad_methods
+class KernelOrderHostKernels(HostKernels):
+    """The HIP kernels' arithmetic restated in torch ops: tableau rows summed LEFT TO RIGHT over the non-zero entries
+    (the order the kernels and the C oracle use, and what makes the fused error split and the carried partial sums
+    possible), norms from the fp64 sums.  Not selected for any state — it exists so that the GPU tests and
+    tools/fuzz_complex_gpu.py can compare a HIP solve with the same algorithm evaluated by ATen on the same device
+    (test infrastructure; r03's host path did this for every state)."""
+
+    name = "host-kernel-order"
+    literal_row_sums = False
+    literal_norms = False
+
+    @staticmethod
+    def _rowsum(ks, cs, start=None, row=None):
+        return HostKernels._lsum(ks, cs, start)
