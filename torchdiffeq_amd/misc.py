@@ -259,8 +259,9 @@ def vector_tolerances(rtol, atol, layout: "StateLayout", device):
         v = torch.full((layout.total,), pad, dtype=torch.float64, device=device)
         for i, (off, n) in enumerate(zip(layout.offsets, layout.numels)):
             e = ent[i] if ent is not None else tol
-            v[off:off + n] = torch.as_tensor(e, device=device).to(torch.float64).reshape(-1).expand(n) \
-                if torch.as_tensor(e).numel() in (1, n) else torch.as_tensor(e, device=device).to(torch.float64).reshape(-1)
+            # `torch.as_tensor(tol_).expand(shape.numel())` (misc.py:115-123): a 0-dim / [1] / [n] entry; anything else —
+            # e.g. an entry shaped like its component — raises there, and therefore here
+            v[off:off + n] = torch.as_tensor(e, device=device).to(torch.float64).expand(n)
         flat.append(v)
     return flat[0], flat[1]
 
