@@ -59,6 +59,11 @@ Extra objects in the JSON line (linear workload):
   reference_style_eager_gpu   the reference's eager op sequence restated in stock PyTorch on the same GPU
                 (oracle/eager_torch_port.py — pinned op for op to the reference's step sequences,
                 tests/test_oracle_golden.py::test_eager_torch_port_is_the_reference_op_for_op).
+  same_device_reference, adjoint_same_device_reference, configs.cfg4.same_device_reference   (N = 1) the same solves
+                once more on this GPU with the REFERENCE's arithmetic — the package's torch-op host path (the reference's own
+                expressions evaluated by ATen; bit-identical to the reference on the CPU, tools/fuzz_vs_reference.py
+                hostexact) forced onto the cuda state: evaluation counts of both, step-size differences, rel-err over ALL rows
+                / gradients.  "max rel-err vs reference odeint" with the field's arithmetic equal on both sides.
   cpu_baseline  the CPU oracle (a port: the reference itself cannot travel to the GPU box) on a bounded sample, on
                 rank 0 at N = 1, with BASELINE.md's figure for the real reference on 8 cores beside it.
 """
@@ -274,6 +279,68 @@ def eager_gpu_baseline(field, y0, first_step, steps=12):
 # ---------------------------------------------------------------------------------------------------
 # linear workload (cfg2)
 # ---------------------------------------------------------------------------------------------------
+class reference_arithmetic:
+    """Context: every solve inside runs on the package's torch-op host path — the reference's own expressions evaluated by
+    ATen (bit-identical to the reference on the CPU) — whatever device the state lives on.  For the same-device
+    comparisons of the bench line only (the product selects its backend by the state alone)."""
+
+    def __enter__(self):
+        from torchdiffeq_amd import _fallback, _native
+        self._native, self._orig = _native, _native.get_kernels
+        host = _fallback.HostKernels()
+        _native.get_kernels = lambda d, dt=None: host
+        return self
+
+    def __exit__(self, *exc):
+        self._native.get_kernels = self._orig
+
+
+def same_device_reference(field, y0, device):
+    """BASELINE.json's "max rel-err vs reference odeint" with the reference's arithmetic ON THE SAME GPU.  The reference
+    itself is a Python package that does not exist on the GPU box; the package's torch-op host path evaluates the
+    reference's own expressions with ATen — `torch.sum` over the dense tableau row, `abs().pow(2).mean().sqrt()` — and is
+    bit-identical to the reference wherever the two can be run side by side (the CPU: tools/fuzz_vs_reference.py hostexact,
+    750 cases).  Forced onto the cuda state it is what `torchdiffeq.odeint(..., device='cuda')` computes: same func (the
+    same hipBLASLt GEMM), ATen's GPU reductions instead of the HIP kernels.  Reported: both solves' evaluation counts and
+    accepted step sizes, and max|y - y_ref| / max|y_ref| over ALL rows."""
+    import torchdiffeq_amd as tda
+    from torchdiffeq_amd import _fallback, _native
+    t = torch.tensor([0.0, 1.0], device=device)
+    runs = {}
+    for name in ("hip", "reference_arithmetic"):
+        steps, nfe = [], [0]
+
+        class F(torch.nn.Module):
+            def forward(self, t_, y_):
+                nfe[0] += 1
+                return field(t_, y_)
+
+            def callback_accept_step(self, t0, y, dt):
+                steps.append(float(dt))
+        orig = _native.get_kernels
+        if name != "hip":
+            host = _fallback.HostKernels()
+            _native.get_kernels = lambda d, dt=None: host
+        try:
+            with torch.no_grad():
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                y = tda.odeint(F(), y0, t, rtol=RTOL, atol=ATOL, method="dopri5")[-1]
+                torch.cuda.synchronize()
+                runs[name] = (y, nfe[0], steps, time.perf_counter() - t0)
+        finally:
+            _native.get_kernels = orig
+    (y, nfe, st, wall), (yr, nfe_r, st_r, wall_r) = runs["hip"], runs["reference_arithmetic"]
+    n = min(len(st), len(st_r))
+    return {"what": "odeint(t=[0,1]) of this workload twice on this GPU: HIP kernels vs the reference's own torch expressions "
+                    "(torchdiffeq_amd._fallback.HostKernels forced onto the cuda state; bit-identical to the reference on the CPU)",
+            "rel_err_all_rows": float((y - yr).abs().max() / yr.abs().max()),
+            "nfe": nfe, "reference_arithmetic_nfe": nfe_r, "accepted": len(st), "reference_arithmetic_accepted": len(st_r),
+            "max_rel_step_size_difference": max((abs(a - b) / b for a, b in zip(st[:n], st_r[:n])), default=None),
+            "wall_s": wall, "reference_arithmetic_wall_s": wall_r,
+            "note": "the HIP solve runs with callbacks here (host-driven loop), like its twin"}
+
+
 def make_stepper(field, y0, hip_graph=False, lookahead=None, dist_sync=None):
     """A Dopri5Solver in the middle of a long solve (no output time ahead — where the look-ahead first stage
     applies), ready for `_trial_step()` calls."""
@@ -775,8 +842,16 @@ def cfg4_config(device):
             tda.odeint(field, y0, t, rtol=rtol, atol=atol, method="dopri8")
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / 3
+    with torch.no_grad(), reference_arithmetic():
+        nfe[0] = 0
+        y_same = tda.odeint(field, y0, t, rtol=rtol, atol=atol, method="dopri8")[-1]
+        nfe_same, nfe[0] = nfe[0], 0
+    same = {"rel_err_all_rows": float((y_end - y_same).abs().max() / y_same.abs().max()), "reference_arithmetic_nfe": nfe_same,
+            "what": "the reference's own torch expressions on this GPU (see `same_device_reference` of the line)"}
+    del y_same
     rows = torch.from_numpy(z["rows"]).to(device)
     out = {"workload": "BASELINE.json configs[3]: dopri8 fp64, batch=16384 x dim=512, rtol=1e-9 atol=1e-11",
+           "same_device_reference": same,
            "odeint_t01_ms": ms, "nfe": n_eval, "reference_nfe": int(z["nfe"]),
            "rk_stages_per_s": (n_eval - 2) / (ms * 1e-3),
            "rel_err_vs_reference": fs.sample_rel_err(y_end[rows], z["y_end_rows"], z["y_end_absmax"]),
@@ -1029,6 +1104,39 @@ def adjoint_pass(world, rank, device, rows_per_rank, steps, warmup, group_forced
                           "what": "parameter adjoints: the contiguous tail of the flat augmented state, one call "
                                   "(reference: adj_params = aug_state[3:], adjoint.py:150-153)"},
             "param_grad_l2": grad_norm, "breakdown": breakdown}
+
+
+def adjoint_same_device_reference(device):
+    """cfg3 at full size twice on this GPU — HIP kernels vs the reference's own torch expressions (`reference_arithmetic`)
+    — with the SAME field arithmetic (hipBLASLt GEMMs, device tanh) on both sides: evaluation counts of the forward and
+    backward solve, and how far the gradients are apart.  Answers whether the backward solve's +12 evaluations over the
+    reference's CPU run (74 -> 86) come from the solver or from the device's field arithmetic."""
+    import contextlib
+    import _fullsize as fs
+    import torchdiffeq_amd as tda
+    field, y0 = fs.cfg3_problem()
+    field, y0 = field.to(device), y0.to(device)
+    t = torch.tensor([0.0, 1.0], device=device)
+    params = list(field.parameters())
+    runs = {}
+    for name, ctx in (("hip", contextlib.nullcontext()), ("reference_arithmetic", reference_arithmetic())):
+        for p in params:
+            p.grad = None
+        x = y0.clone().requires_grad_(True)
+        with ctx:
+            field.nfe = 0
+            y = tda.odeint_adjoint(field, x, t, rtol=1e-5, atol=1e-7, method="dopri5")
+            nfe_fwd, field.nfe = field.nfe, 0
+            y[-1].pow(2).sum().backward()
+        runs[name] = (nfe_fwd, field.nfe, y[-1].detach(), x.grad.clone(), [p.grad.clone() for p in params])
+    a, b = runs["hip"], runs["reference_arithmetic"]
+    rel = lambda p, q: float((p - q).abs().max() / q.abs().max())
+    return {"what": "cfg3 (odeint_adjoint, MLP 64-256-256-64, 65536 x 64 fp32) on this GPU: HIP kernels vs the reference's own "
+                    "torch expressions, same field arithmetic on both sides",
+            "nfe_fwd": a[0], "nfe_bwd": a[1], "reference_arithmetic_nfe_fwd": b[0], "reference_arithmetic_nfe_bwd": b[1],
+            "reference_on_cpu_nfe": [20, 74],
+            "rel_err_y_end": rel(a[2], b[2]), "rel_err_grad_y0": rel(a[3], b[3]),
+            "max_rel_err_param_grads": max(rel(p, q) for p, q in zip(a[4], b[4]))}
 
 
 def run_adjoint(args, rank, world, device):
@@ -1312,6 +1420,8 @@ def main():
                 with torch.no_grad():
                     return eager_gpu_baseline(field, y0, 0.05)
             ex.run("reference_style_eager_gpu", eager)
+            ex.run("same_device_reference", lambda: same_device_reference(field, y0, device))
+            ex.run("adjoint_same_device_reference", lambda: adjoint_same_device_reference(device))
             watchdog.cancel()           # the CPU leg is bounded by its own clock
             out["cpu_baseline"] = cpu_baseline()
         watchdog.cancel()
