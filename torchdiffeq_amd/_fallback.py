@@ -188,8 +188,8 @@ class HostKernels:
             sl = slice(off, off + n)
             tol = torch.fmax(y0[sl].abs(), y1[sl].abs()) * float(T(rtol)) + float(T(atol))
             r = e[sl] / tol
-            plan.sums0[s] = self._sumsq(r)
-            plan.rms0[s] = self._rms(r)
+            plan.rms0[s] = rms = self._rms(r)
+            plan.sums0[s] = self._sumsq(r) if not self.literal_norms else rms * rms * n     # (interface; unused on this path)
             plan.bad[s] = _nonfinite(y0[sl], y1[sl])
             if scaled_out is not None:
                 scaled_out[sl] = r
@@ -223,9 +223,12 @@ class HostKernels:
 
     def init_norms(self, plan, mode: int, a, b, yscale) -> None:
         for s, sl, q0, q1 in self._init_quotients(plan, mode, a, b, yscale):
-            plan.sums0[s], plan.rms0[s] = self._sumsq(q0), self._rms(q0)
+            n = q0.numel()
+            plan.rms0[s] = rms = self._rms(q0)
+            plan.sums0[s] = self._sumsq(q0) if not self.literal_norms else rms * rms * n
             if q1 is not None:
-                plan.sums1[s], plan.rms1[s] = self._sumsq(q1), self._rms(q1)
+                plan.rms1[s] = rms = self._rms(q1)
+                plan.sums1[s] = self._sumsq(q1) if not self.literal_norms else rms * rms * n
             plan.bad[s] = _nonfinite(yscale[sl])
 
     def init_scaled(self, plan, mode: int, a, b, yscale, out0, out1=None) -> None:
