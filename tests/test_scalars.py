@@ -63,8 +63,9 @@ def test_rdiv_and_power_are_atens_operations():
 
 @pytest.mark.parametrize("dtype", [torch.complex64, torch.complex128])
 def test_complex_norm_oracle_equals_the_torch_op_host_kernels(dtype):
-    """oracle/complex_norms.py (the checker of the complex HIP kernels) and `_fallback.HostKernels` are two
-    restatements of misc.py:80-82 / 50-56 for complex states; on the CPU they must agree bit for bit."""
+    """oracle/complex_norms.py (the checker of the complex HIP kernels) and `_fallback.KernelOrderHostKernels` (the
+    kernels' left-to-right arithmetic in torch ops) are two restatements of misc.py:80-82 / 50-56 for complex states in
+    the kernels' order; on the CPU they must agree bit for bit."""
     from oracle import complex_norms as cn
     g = torch.Generator().manual_seed(0)
     z = lambda n: torch.complex(torch.randn(n, generator=g, dtype=torch.float64), torch.randn(n, generator=g, dtype=torch.float64)).to(dtype)
@@ -73,7 +74,7 @@ def test_complex_norm_oracle_equals_the_torch_op_host_kernels(dtype):
     y0, y1, part = z(n), z(n), z(n)
     ks = [z(n) for _ in range(4)]
     coefs = [0.1, -0.25, 0.3, 0.05]
-    hk = _fallback.HostKernels()
+    hk = _fallback.KernelOrderHostKernels()
     plan = hk.make_plan([(off, m, 1e-3, 1e-6) for off, m in segs], n, chunk, "cpu")
     hk.error_norm(plan, y0, y1, ks, coefs, 0.05)
     r, _ = cn.error_ratio_parts(cn.error_estimate(ks, coefs, 0.05), y0, y1, 1e-3, 1e-6)

@@ -55,12 +55,23 @@ def loop(name, make_loss):
     return out
 
 
+def _nograd(fn):
+    with torch.no_grad():
+        return fn()
+
+
 t = torch.tensor([0.0, 0.5, 1.0], device=dev)
 res = {
     "odeint_backprop": loop("odeint_backprop", lambda f, x: tda.odeint(f, x, t, rtol=1e-4, atol=1e-6)[-1].pow(2).mean()),
     "odeint_backprop_rk4": loop("odeint_backprop_rk4", lambda f, x: tda.odeint(f, x, t, method="rk4", options=dict(step_size=0.1))[-1].pow(2).mean()),
     "adjoint_eager": loop("adjoint_eager", lambda f, x: tda.odeint_adjoint(f, x, t, rtol=1e-4, atol=1e-6)[-1].pow(2).mean()),
     "adjoint_hip_graph": loop("adjoint_hip_graph", lambda f, x: tda.odeint_adjoint(f, x, t, rtol=1e-4, atol=1e-6, options=dict(hip_graph=True))[-1].pow(2).mean()),
+    # r04: "auto" (lazy capture, side-effect fingerprint, replay-vs-eager probe) in a training loop, and complex states
+    "adjoint_hip_graph_auto": loop("adjoint_hip_graph_auto", lambda f, x: tda.odeint_adjoint(f, x, t, rtol=1e-4, atol=1e-6, options=dict(hip_graph="auto"))[-1].pow(2).mean()),
+    "odeint_nograd_auto": loop("odeint_nograd_auto", lambda f, x: (lambda y: f.net(y.detach()).pow(2).mean())(
+        _nograd(lambda: tda.odeint(f, x, t, rtol=1e-4, atol=1e-6, options=dict(hip_graph="auto"))[-1]))),
+    "complex_odeint": loop("complex_odeint", lambda f, x: (lambda y: f.net(y.real).pow(2).mean())(_nograd(lambda: tda.odeint(
+        lambda t_, z: torch.complex(f.net(z.real), f.net(z.imag)) * 0.5, torch.complex(x, x.flip(1)), t, rtol=1e-4, atol=1e-6)[-1]))),
     "adjoint_tuple": loop("adjoint_tuple", lambda f, x: tda.odeint_adjoint(f, (x, torch.ones(8, device=dev)), t, rtol=1e-4, atol=1e-6)[0][-1].pow(2).mean()),
     "event": loop("event", lambda f, x: (lambda et, ys: et + ys[-1].pow(2).mean())(*tda.odeint_event(
         f, x, torch.tensor(0.0, device=dev), event_fn=lambda t_, y: 0.7 - t_ + 0.0 * y.sum(), rtol=1e-4, atol=1e-6))),
