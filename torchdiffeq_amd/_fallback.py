@@ -297,6 +297,11 @@ class HostKernels:
             r = y0 + (((k1 + 3 * (k2 + k3)) + k4) * dt_second) * 0.125
         out.copy_(r)
 
+    def scaled_add(self, out, y0, k, scalar: float) -> None:
+        """y0 + k * s with the 0-dim scalar as the SECOND operand (fixed_grid.py:18, `y0 + f0 * half_dt`): the state type
+        for fp32 / fp64 — where it equals the generic stage combine —, fp32 for the 16-bit types (`_scalars.operand`)."""
+        out.copy_(y0 + k * operand(self._T(y0), scalar))
+
     def lerp(self, out, y0, y1, slope: float) -> None:
         out.copy_(y0 + float(self._T(y0)(slope)) * (y1 - y0))
 

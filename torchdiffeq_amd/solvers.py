@@ -2081,7 +2081,12 @@ class Midpoint(FixedGridODESolver):
         dts = float(dt) * func.sign
         half_dt = self._tmul(scalar, dt, 0.5)
         f0 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
-        y_mid = ops.combine(y0, [f0], [0.5], dts, sh.dt_signed())
+        if is_low(func.np_dtype) and not (torch.is_grad_enabled() and (y0.requires_grad or f0.requires_grad)):
+            # 16-bit states: `f0 * half_dt` takes the scalar at fp32 (ATen's second-operand rule), not rounded to the state
+            y_mid = torch.empty_like(y0)
+            self.kernels.scaled_add(y_mid, y0, f0, float(half_dt) * func.sign)
+        else:
+            y_mid = ops.combine(y0, [f0], [0.5], dts, sh.dt_signed())
         k2 = func.eval(scalar(t0 + half_dt), y_mid, shadow=sh.time(0.5))
         y1 = ops.combine(y0, [k2], [1.0], dts, sh.dt_signed(), out=y1_out)
         return y1, f0
