@@ -36,8 +36,13 @@ def error_ratio_parts(err, y0, y1, rtol: float, atol: float) -> Tuple[torch.Tens
 
 
 def segment_sums(r: torch.Tensor, segs: Sequence[Tuple[int, int]]) -> List[float]:
-    """sum |r|^2 per segment (element offset, numel), |r| rounded to T first (misc.py:22: `abs().pow(2)`), summed in fp64."""
-    return [float(r[off:off + n].abs().double().pow(2).sum()) for off, n in segs]
+    """sum |r|^2 per segment (element offset, numel) in fp64, |r|^2 = re^2 + im^2 formed in double (misc.py:22 squares the
+    rounded modulus and accumulates in T; the kernels' fp64 accumulation takes the components — DESIGN.md §8)."""
+    out = []
+    for off, n in segs:
+        v = torch.view_as_real(r[off:off + n]).double()
+        out.append(float((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]).sum()))
+    return out
 
 
 def init_quotients(mode: int, a, b, y, rtol: float, atol: float):

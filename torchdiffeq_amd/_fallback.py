@@ -131,8 +131,10 @@ class HostKernels:
     @staticmethod
     def _sumsq(r: torch.Tensor) -> float:
         """Sum of |r|^2 in fp64 — what the norm kernels hand back per segment (the host forms sqrt(sum / n))."""
-        a = r.abs() if r.is_complex() else r
-        return float(a.double().pow(2).sum())
+        if r.is_complex():          # re^2 + im^2 in double, like the complex norm kernels (not the square of a rounded modulus)
+            v = torch.view_as_real(r).double()
+            return float((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]).sum())
+        return float(r.double().pow(2).sum())
 
     @staticmethod
     def _rowsum(ks, cs, start=None, row=None):

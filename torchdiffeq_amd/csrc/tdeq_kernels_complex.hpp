@@ -10,7 +10,8 @@
 // ATen forms them as (measured on the MI355X and on the CPU, profiles/r04_complex_abs_probe.json, 2^20 values each):
 //     |z|  = hypot(re, im)                    — the device libm's hypot, bit for bit (NOT sqrt(re*re + im*im))
 //     z / real = (re * (1/real), im * (1/real)) — multiplication by the rounded reciprocal
-// and so do these kernels, in T = the real type of the state; |r|^2 is accumulated in fp64 like the real kernels' r^2.
+// and so do these kernels, in T = the real type of the state; what is accumulated (in fp64, like the real kernels' r^2) is
+// re(r)^2 + im(r)^2 formed in double, not the square of a rounded modulus.
 // Layout: the segment table counts COMPLEX elements; a chunk of `chunk` elements is 2*chunk reals.  16 B per lane
 // (two complex64 or one complex128) when every stream is 16-byte aligned, one element per lane otherwise.
 #pragma once
@@ -21,6 +22,11 @@ namespace tdeq {
 
 __device__ __forceinline__ float chyp(float re, float im) { return hypotf(re, im); }
 __device__ __forceinline__ double chyp(double re, double im) { return hypot(re, im); }
+
+// |r|^2 for the fp64 accumulation: re^2 + im^2 formed in double — exact for float components, one rounding for double
+// ones — instead of squaring a rounded modulus (the reference squares fl_T(|r|) and accumulates in T: both lose more)
+template <typename T>
+__device__ __forceinline__ double cabs2(T re, T im) { return (double)re * (double)re + (double)im * (double)im; }
 
 template <typename T>
 __device__ __forceinline__ bool cfinite(T re, T im) { return __builtin_isfinite(re) && __builtin_isfinite(im); }
@@ -33,8 +39,7 @@ __device__ __forceinline__ void cplx_tol_accumulate(T e_re, T e_im, T y0r, T y0i
     const T inv = (T)1 / tol;
     r_re = e_re * inv;
     r_im = e_im * inv;
-    const T h = chyp(r_re, r_im);
-    acc += (double)h * (double)h;
+    acc += cabs2(r_re, r_im);
     bad += (cfinite(y0r, y0i) && cfinite(y1r, y1i)) ? 0.0 : 1.0;
 }
 
@@ -175,8 +180,7 @@ __global__ __launch_bounds__(kBlock) void cplx_init_norms_kernel(const CplxInitA
             q0r = a.a[base + t] * inv;
             q0i = a.a[base + t + 1] * inv;
             const T q1r = a.b[base + t] * inv, q1i = a.b[base + t + 1] * inv;
-            const T h1 = chyp(q1r, q1i);
-            acc[1] += (double)h1 * (double)h1;
+            acc[1] += cabs2(q1r, q1i);
             if (OUT) {
                 a.out1[base + t] = q1r;
                 a.out1[base + t + 1] = q1i;
@@ -185,8 +189,7 @@ __global__ __launch_bounds__(kBlock) void cplx_init_norms_kernel(const CplxInitA
             q0r = (a.a[base + t] - a.b[base + t]) * inv;
             q0i = (a.a[base + t + 1] - a.b[base + t + 1]) * inv;
         }
-        const T h0 = chyp(q0r, q0i);
-        acc[0] += (double)h0 * (double)h0;
+        acc[0] += cabs2(q0r, q0i);
         acc[2] += cfinite(yr, yi) ? 0.0 : 1.0;
         if (OUT) {
             a.out0[base + t] = q0r;
