@@ -629,6 +629,30 @@ def shard_regime_linear(device, steps=100, warmup=20):
     return out
 
 
+def strong_scaling_prediction(device, full_ms, steps=100, warmup=20):
+    """What ONE GPU does on the shard an N-GPU strong-scaling run of cfg2 gives it (N = 2, 4, 8: 32768 / 16384 / 8192 rows),
+    on the step path `bench.py --gpus N` takes for that shard (captured steps up to 2^21 elements, the look-ahead path
+    above).  No data-path collective exists, so the run's step time is the slowest shard's: 6 / this = the predicted
+    `value`, full-size step / this = the predicted speed-up over N = 1 — the curve the 8-GPU node will be measured against."""
+    out = {}
+    for n_gpus in (2, 4, 8):
+        rows = BATCH // n_gpus
+        A, y0 = make_problem(device, rows=slice(0, rows))
+        At = A.T.contiguous()
+        graph = y0.numel() <= (1 << 21)
+        try:
+            solver = make_stepper(lambda t, y: y @ At, y0, hip_graph=graph)
+            st = block_stats(time_steps(solver, steps, warmup, 1, device, n_blocks=3), steps)
+            out[str(n_gpus)] = {"rows_per_gpu": rows, "elements": y0.numel(), "step_path": "hip_graph" if graph else "lookahead",
+                                "ms_per_step": st["median"], "predicted_value_RK_stages_per_s": 6e3 / st["median"],
+                                "predicted_speedup_over_n1": full_ms / st["median"]}
+        except Exception as exc:
+            out[str(n_gpus)] = {"error": repr(exc)}
+        del solver
+        torch.cuda.empty_cache()
+    return out
+
+
 def run_linear(args, rank, world, device, parity=True):
     import torchdiffeq_amd as tda
     strong = args.scaling == "strong" and world > 1
@@ -1402,6 +1426,7 @@ def main():
         if extras and world == 1 and rank == 0:
             def shard_regime():
                 r = {"linear": shard_regime_linear(device),
+                     "strong_scaling_prediction": strong_scaling_prediction(device, out["ms_per_step"]),
                      "adjoint": adjoint_pass(1, 0, device, ADJ_BATCH // 8, 3, 1),
                      "adjoint_hip_graph_auto": adjoint_pass(1, 0, device, ADJ_BATCH // 8, 3, 2, graph=True)}
                 full = out["ms_per_step"]
@@ -1413,7 +1438,21 @@ def main():
                              "6x at 8 GPUs holds for a fixed global batch"
                 return r
             ex.run("shard_regime", shard_regime)
-            ex.run("adjoint_full", lambda: adjoint_pass(1, 0, device, ADJ_BATCH, 3, 1))
+            full = ex.run("adjoint_full", lambda: adjoint_pass(1, 0, device, ADJ_BATCH, 3, 1))
+
+            def adjoint_prediction():
+                # one GPU on the shard an N-GPU strong-scaling run of cfg3 gives it (the all-reduce of 0.4 MB excluded)
+                pred = {}
+                for n_gpus in (2, 4, 8):
+                    r = adjoint_pass(1, 0, device, ADJ_BATCH // n_gpus, 3, 1)
+                    pred[str(n_gpus)] = {"rows_per_gpu": ADJ_BATCH // n_gpus, "ms_per_pass": r["ms_per_pass"],
+                                         "nfe_fwd": r["nfe_fwd"], "nfe_bwd": r["nfe_bwd"],
+                                         "predicted_speedup_over_n1": (full["ms_per_pass"] / r["ms_per_pass"])
+                                         if isinstance(full, dict) and "ms_per_pass" in full else None,
+                                         "func_floor_ms": r["breakdown"].get("func_floor_ms"),
+                                         "solver_floor_ms": r["breakdown"].get("solver_floor_ms")}
+                return pred
+            ex.run("adjoint_strong_scaling_prediction", adjoint_prediction)
             ex.run("configs", lambda: other_configs(device))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             def eager():
