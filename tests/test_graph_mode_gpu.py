@@ -13,6 +13,14 @@ from torchdiffeq_amd.odeint import SOLVERS
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _no_process_wide_graph_default(monkeypatch):
+    """These tests choose the step path per call (`options={'hip_graph': ...}`) and assert on cache entries and Python
+    call counts: a process-wide TDEQ_HIP_GRAPH default (the suite is also run under TDEQ_HIP_GRAPH=auto) must not turn
+    their eager baselines into captured solves."""
+    monkeypatch.delenv("TDEQ_HIP_GRAPH", raising=False)
+
+
 def _spiral():
     A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], device="cuda")
     return (lambda t, y: (y ** 3) @ A), torch.tensor([[2.0, 0.0]], device="cuda")
@@ -596,3 +604,28 @@ def test_auto_mode_recaptures_when_a_python_scalar_of_func_changes():
             y_auto = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph="auto"))
             y_eager = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8)
             assert torch.equal(y_auto, y_eager), scale
+
+
+def test_auto_mode_never_adds_evaluations_a_counting_func_could_see():
+    """`odeint_adjoint(..., options={'hip_graph': 'auto'})` with a field that counts its evaluations (every example of the
+    reference does): forward and backward counts of every iteration of a training loop equal the eager ones — in
+    particular the backward solve's proxy check (two evaluations of func, adjoint._AugmentedDynamics.proxy_is_faithful)
+    is not run while nothing can be captured (first sight / refused func)."""
+    y0, t = _auto_problem()
+    f = _CountingField()
+
+    def one(options):
+        x = y0.clone().requires_grad_(True)
+        f.zero_grad()
+        f.nfe = 0
+        y = tda.odeint_adjoint(f, x, t, method="dopri5", rtol=1e-6, atol=1e-8, options=options)
+        fwd, f.nfe = f.nfe, 0
+        y[-1].pow(2).sum().backward()
+        return fwd, f.nfe, x.grad.clone(), f.lin.weight.grad.clone()
+    ref = one(None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(4):
+            got = one(dict(hip_graph="auto"))
+            assert got[:2] == ref[:2], (got[:2], ref[:2])
+            assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])

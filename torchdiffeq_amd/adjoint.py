@@ -31,6 +31,26 @@ from .odeint import SOLVERS
 import weakref
 
 _PROXY_CHECKED = weakref.WeakKeyDictionary()      # func -> (parameter storages, functional_call VJPs verified)
+_AUTO_BACKWARD_SEEN = weakref.WeakSet()           # funcs whose backward solve has run once under hip_graph="auto"
+
+
+def _auto_backward_due(base_func, total: int) -> bool:
+    """`hip_graph="auto"` on the adjoint's backward solve: whether capturing is on the table at all for THIS solve — the
+    augmented state is small enough, func has not been refused (solvers._GraphStep.refuse) and this is not the first
+    backward solve of func (first solves run eagerly under "auto", like the forward one's).  Only then is the proxy
+    check worth its two evaluations of func — which a func that counts its evaluations would see."""
+    from .solvers import _GRAPH_AUTO_MAX_ELEMENTS, _GraphStep
+    if total > _GRAPH_AUTO_MAX_ELEMENTS:
+        return False
+    try:
+        if base_func in _GraphStep._refused:
+            return False
+        if base_func not in _AUTO_BACKWARD_SEEN:
+            _AUTO_BACKWARD_SEEN.add(base_func)
+            return False
+    except TypeError:           # not weakly referenceable: never captured across solves anyway
+        return False
+    return True
 
 
 class _AugmentedDynamics(OdeFunc):
@@ -264,6 +284,10 @@ class OdeintAdjointMethod(torch.autograd.Function):
                 if not auto and "hip_graph" in ctx.adjoint_options:
                     warnings.warn("hip_graph: the adjoint's backward solve can only be captured when func is an "
                                   "nn.Module and every adjoint parameter is one of its parameters; running it eagerly")
+                options["hip_graph"] = False
+            elif wanted and auto and not _auto_backward_due(fwd.base_func, aug_layout.total):
+                # "auto": nothing would be captured in this backward solve (state too large, func refused, or first sight
+                # of func — first solves are eager) — so func is not evaluated for the proxy check either
                 options["hip_graph"] = False
             elif wanted:
                 # parameter VJPs through leaf aliases (functional_call) only if they are the real ones: checked by one
