@@ -629,3 +629,30 @@ def test_auto_mode_never_adds_evaluations_a_counting_func_could_see():
             got = one(dict(hip_graph="auto"))
             assert got[:2] == ref[:2], (got[:2], ref[:2])
             assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
+
+
+def test_auto_mode_adjoint_loop_backward_is_captured_at_its_second_sight():
+    """Iteration 1 of a training loop: forward and backward eager (Python calls = the eager count).  Iteration 2: both
+    captured (adjoint: proxy check + capture).  Iteration 3: replays only — a handful of Python calls; gradients agree
+    with the eager ones to the last bit in every iteration."""
+    y0, t = _auto_problem()
+    f = _PureField()
+    calls = f.calls()
+
+    def one(options):
+        x = y0.clone().requires_grad_(True)
+        f.zero_grad()
+        calls[0] = 0
+        y = tda.odeint_adjoint(f, x, t, method="dopri5", rtol=1e-6, atol=1e-8, options=options)
+        y[-1].pow(2).sum().backward()
+        return calls[0], x.grad.clone(), f.lin.weight.grad.clone()
+    n_eager, gx, gw = one(None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        counts = []
+        for _ in range(4):
+            n, gx_a, gw_a = one(dict(hip_graph="auto"))
+            counts.append(n)
+            assert torch.equal(gx_a, gx) and torch.equal(gw_a, gw)
+    assert counts[0] == n_eager, (counts, n_eager)
+    assert counts[2] < n_eager // 2 and counts[3] <= counts[2], (counts, n_eager)

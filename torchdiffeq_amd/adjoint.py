@@ -280,6 +280,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
                 options["hip_graph"] = False
             from .solvers import _graph_request
             wanted, auto = _graph_request(options.get("hip_graph"))
+            auto_second_sight = False
             if wanted and aug_func.proxy_names is None:
                 if not auto and "hip_graph" in ctx.adjoint_options:
                     warnings.warn("hip_graph: the adjoint's backward solve can only be captured when func is an "
@@ -297,6 +298,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
                 t_end_user = torch.full((), float(fwd.np_dtype(float(t[-1]))), dtype=fwd.time_dtype, device=device)
                 if aug_func.proxy_is_faithful(t_end_user, aug):
                     aug_func.use_proxy = True
+                    auto_second_sight = auto    # (the first backward solve of func ran with the option off)
                 else:
                     warnings.warn("hip_graph: func reaches some of its parameters other than by attribute lookup on the "
                                   "module (torch.func.functional_call cannot re-route them), so the backward solve "
@@ -340,6 +342,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
                     bwd_cls, aug_layout, options, _adjoint_tolerance(ctx.adjoint_rtol, n_y, len(adjoint_params), "rtol"),
                     _adjoint_tolerance(ctx.adjoint_atol, n_y, len(adjoint_params), "atol"), device)
                 solver = bwd_cls(func=aug_func, y0=aug, rtol=bwd_rtol, atol=bwd_atol, **bwd_options)
+                if auto_second_sight:
+                    solver._auto_seen_before = True     # -> _GraphStep.auto_policy: capture at this solve's first step
                 if aug_func.use_proxy and not getattr(solver, "hip_graph", False):
                     aug_func.use_proxy = False      # the solver runs eagerly after all (state too large, user norm ...):
                                                     # differentiate func directly, as without the option

@@ -482,11 +482,13 @@ class _GraphStep:
     _refused = weakref.WeakKeyDictionary()      # auto mode: func -> why it is never captured
 
     @classmethod
-    def auto_policy(cls, s) -> str:
+    def auto_policy(cls, s, seen_before: bool = False) -> str:
         """`hip_graph="auto"`, asked at the first trial step of a solve: "now" — a captured step for this (func, layout)
         is cached or the pair has been solved before (second call of a training loop): capture / replay from the first
         step; "later" — first sight: eager, captured only if this one solve turns out long
-        (_AUTO_CAPTURE_AFTER_STEPS); "never" — func was found to have per-evaluation side effects."""
+        (_AUTO_CAPTURE_AFTER_STEPS); "never" — func was found to have per-evaluation side effects.
+        `seen_before`: the caller has solved this pair once already without asking (the adjoint's first backward solve
+        runs with the option off, adjoint._auto_backward_due)."""
         base = s.func.base_func
         try:
             if base in cls._refused:
@@ -500,7 +502,8 @@ class _GraphStep:
             seen = cls._seen.get(base)
             if seen is None:
                 seen = cls._seen[base] = set()
-            if key in seen:
+            if key in seen or seen_before:
+                seen.add(key)
                 return "now"
             seen.add(key)
         except TypeError:               # func object cannot be weakly referenced / hashed
@@ -1246,7 +1249,7 @@ class RKAdaptiveStepsizeODESolver:
         if self._g is not None or not self._graph_auto:
             return True
         if self._auto is None:
-            self._auto = _GraphStep.auto_policy(self)
+            self._auto = _GraphStep.auto_policy(self, getattr(self, "_auto_seen_before", False))
         if self._auto == "never":
             self.hip_graph = False
             return False
