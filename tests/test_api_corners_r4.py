@@ -1,0 +1,89 @@
+"""Corners of the drop-in surface found by a differential run against the imported reference (round 4, build container:
+75 API / error cases, same exception classes and results after these fixes).  No GPU and no reference needed here: each
+test pins what the reference does, cited."""
+import warnings
+
+import pytest
+import torch
+
+import torchdiffeq_amd as tda
+
+
+class _Field(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.lin = torch.nn.Linear(3, 3)
+
+    def forward(self, t, y):
+        return torch.tanh(self.lin(y)) * torch.cos(t)
+
+
+Y0 = torch.tensor([[0.3, -0.2, 0.5], [1.0, 0.1, -0.7]])
+T = torch.linspace(0, 1, 5)
+
+
+@pytest.fixture(autouse=True)
+def _quiet_host_path():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", tda.HostPathWarning)
+        yield
+
+
+def test_step_size_zero_is_torchs_range_error():
+    # solvers.py:86-96: torch.arange(0, inf) -> RuntimeError
+    with pytest.raises(RuntimeError, match="unsupported range"):
+        tda.odeint(_Field(), Y0, T, method="rk4", options=dict(step_size=0.0))
+
+
+def test_norm_returning_more_than_one_element_is_a_runtime_error():
+    # misc.py:60 `if d0 < 1e-5 or d1 < 1e-5` on a vector
+    with pytest.raises(RuntimeError, match="more than one value"):
+        tda.odeint(_Field(), Y0, T, method="dopri5", options=dict(norm=lambda x: x))
+
+
+def test_unknown_adjoint_norm_string_fails_in_the_backward_solve_not_before():
+    # adjoint.py:271-288: everything but "seminorm" is taken for a callable
+    f = _Field()
+    y = tda.odeint_adjoint(f, Y0.clone().requires_grad_(True), T, adjoint_options=dict(norm="semi"))
+    with pytest.raises(TypeError, match="not callable"):
+        y[-1].sum().backward()
+
+
+def test_tuple_state_of_mixed_dtypes_is_promoted_as_a_whole():
+    # misc.py:206-207: the components are concatenated -> one dtype for func's inputs and for every output
+    seen = []
+
+    def f(t, y):
+        seen.append(tuple(c.dtype for c in y))
+        return (-y[0], -0.5 * y[1])
+    a, b = tda.odeint(f, (Y0, Y0.double()), T, method="dopri5")
+    assert a.dtype == b.dtype == torch.float64 and set(seen) == {(torch.float64, torch.float64)}
+    a64, b64 = tda.odeint(lambda t, y: (-y[0], -0.5 * y[1]), (Y0.double(), Y0.double()), T, method="dopri5")
+    assert torch.equal(a, a64) and torch.equal(b, b64)
+    z, w = tda.odeint(lambda t, y: (-y[0], 1j * y[1]), (Y0, Y0.to(torch.complex64)), T, method="rk4")
+    assert z.dtype == w.dtype == torch.complex64
+
+
+def test_func_returning_a_python_number():
+    # fixed_grid.py: `y0 + dt * 1.0` broadcasts; rk_common.py:69 needs `.shape` -> AttributeError
+    y = tda.odeint(lambda t, y: 1.0, Y0, T, method="rk4")
+    assert torch.allclose(y[-1], Y0 + 1.0, atol=1e-6)
+    with pytest.raises(AttributeError) as exc:
+        tda.odeint(lambda t, y: 1.0, Y0, T, method="dopri5")
+    assert isinstance(exc.value, TypeError)          # (what this package has raised so far)
+
+
+def test_integer_state_is_refused_with_the_references_exception_class():
+    # misc.py:185-196: nextafter is not implemented for integers
+    with pytest.raises(NotImplementedError) as exc:
+        tda.odeint(lambda t, y: y, torch.tensor([1, 2]), T, method="dopri5")
+    assert isinstance(exc.value, TypeError)
+
+
+def test_zero_tolerances_fail_like_the_reference_without_numpy_warnings():
+    # rtol = atol = 0: the heuristic divides 0 by 0 — 0-dim tensors do that silently, so do the host scalars
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        with pytest.raises(AssertionError):
+            tda.odeint(_Field(), Y0, T, rtol=0.0, atol=0.0, method="dopri5", options=dict(max_num_steps=50))

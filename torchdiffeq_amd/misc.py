@@ -12,6 +12,7 @@ organised for the HIP path instead of a stack of `nn.Module` wrappers:
 """
 from __future__ import annotations
 
+import functools
 import math
 import os
 import warnings
@@ -79,6 +80,14 @@ mixed_norm = BuiltinNorm(name="mixed")    # default for tuple states (misc.py:24
 # ---------------------------------------------------------------------------------------------------
 # State layout
 # ---------------------------------------------------------------------------------------------------
+class FuncOutputTypeError(TypeError, AttributeError):
+    """func returned something that is not a Tensor (the reference: AttributeError from `f.shape`, rk_common.py:69)."""
+
+
+class UnsupportedStateDtype(TypeError, NotImplementedError):
+    """An integer / bool state (the reference: NotImplementedError from `nextafter`, misc.py:185-196)."""
+
+
 class StateLayout:
     """Flat layout of a (tuple) state: segment s occupies [offset[s], offset[s]+numel[s]) and every
     offset is a multiple of `chunk` elements, so all segments are 16-byte aligned for the vector path
@@ -399,7 +408,10 @@ class OdeFunc:
         Everything else raises RuntimeError here (the reference: a broadcasting / view error from inside the step)
         instead of being read out of bounds by a kernel."""
         if not isinstance(f, torch.Tensor):
-            raise TypeError("func must return a Tensor{}; got {}".format(what, type(f).__name__))
+            if isinstance(f, (int, float)) and not isinstance(f, bool) and not self.strict_numel and not what:
+                f = torch.tensor(f, dtype=self.dtype, device=self.device)   # `y0 + dt * 1.0` is fine in fixed_grid.py
+            else:
+                raise FuncOutputTypeError("func must return a Tensor{}; got {}".format(what, type(f).__name__))
         if f.device != self.device and f.dim() == 0:
             f = f.to(self.device)       # `y0 + dt * f` accepts a 0-dim tensor from another device (rk_common.py:79)
         if f.device != self.device:
@@ -545,16 +557,19 @@ def check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS) ->
             assert isinstance(y0_, torch.Tensor), "y0 must be either a torch.Tensor or a tuple"
         shapes = [y0_.shape for y0_ in y0]
         first = y0[0]
+        # components of different dtypes: the reference concatenates them (misc.py:206-207), i.e. the whole state —
+        # what func is given and what is returned — has the promoted dtype
+        dtype = functools.reduce(torch.promote_types, [y0_.dtype for y0_ in y0]) if len(y0) else None
     else:
         shapes = [y0.shape]
         first = y0
-    dtype = first.dtype
+        dtype = first.dtype
     device = first.device
     # float32 / float64 (and complex64 / complex128 through their real views) run on the HIP kernels; bfloat16 / float16
     # states are integrated in their own precision on the host path, as the reference does (misc.py:185-187)
     if dtype not in SUPPORTED_STATE_DTYPES:
-        raise TypeError("torchdiffeq_amd supports float32 / float64 / complex64 / complex128 states (and bfloat16 / "
-                        f"float16 on the torch-op host path), got {dtype}")
+        raise UnsupportedStateDtype("torchdiffeq_amd supports float32 / float64 / complex64 / complex128 states (and "
+                                    f"bfloat16 / float16 on the torch-op host path), got {dtype}")
 
     if options is None:
         options = {}

@@ -61,6 +61,15 @@ def _clamp(x: float, lo: float, hi: float) -> float:
     return min(max(x, lo), hi)
 
 
+def _norm_value(x) -> float:
+    """|value| of what a user's `norm` callable returned.  More than one element is the reference's error: its next
+    statement compares the result (`d0 < 1e-5`, `error_ratio <= 1`: misc.py:60, rk_common.py:303)."""
+    if isinstance(x, torch.Tensor) and x.numel() != 1:
+        raise RuntimeError("Boolean value of Tensor with more than one value is ambiguous (the `norm` callable must "
+                           "return a scalar)")
+    return abs(float(x))
+
+
 def _as_float(x) -> float:
     if isinstance(x, torch.Tensor):
         return float(x.item())
@@ -83,6 +92,7 @@ def optimal_step_size(last_step: float, error_ratio: float, safety: float, ifact
     return last_step * factor
 
 
+@np.errstate(all="ignore")     # host scalars follow IEEE silently, as 0-dim tensors do
 def optimal_step_size_in(W, last_step, error_ratio, safety, ifactor, dfactor, order) -> float:
     """The same controller with every operation rounded in the host scalar type W (misc.py:85-95 on 0-dim tensors of
     the solver option `dtype`, rk_common.py:176-194) — for W other than fp64."""
@@ -974,6 +984,7 @@ class RKAdaptiveStepsizeODESolver:
         return {"callback_step", "callback_accept_step", "callback_reject_step"}
 
     # -- norms -------------------------------------------------------------------------------------
+    @np.errstate(all="ignore")     # host scalars follow IEEE silently, as 0-dim tensors do
     def _segment_norm(self, sumsq: Sequence[float], bad: Sequence[float], which: int = 0):
         """max over the selected segments of sqrt(mean), rounded to the state dtype (misc.py:22-33).  `which`: the first /
         second sum of the last norm launch — only needed on the torch-op host path, whose plan also holds the
@@ -1146,6 +1157,7 @@ class RKAdaptiveStepsizeODESolver:
         self.next_step_index = min(bisect.bisect(step_t, t0), len(step_t) - 1)
         self.next_jump_index = min(bisect.bisect(jump_t, t0), len(jump_t) - 1)
 
+    @np.errstate(all="ignore")     # host scalars follow IEEE silently, as 0-dim tensors do
     def _select_initial_step(self, t0: float, y0: torch.Tensor, f0: torch.Tensor) -> float:
         """Hairer II.4 starting step (misc.py:36-77), scalars in the state precision T."""
         T = self.np_dtype
@@ -1174,7 +1186,7 @@ class RKAdaptiveStepsizeODESolver:
                 vec_scale = self._vec_tol[1] + y0.abs() * self._vec_tol[0]      # misc.py:50, per element, fp64
                 q0, q1 = q0 / vec_scale, q1 / vec_scale
             with torch.no_grad():
-                d0, d1 = S(abs(float(self.norm(q0)))), S(abs(float(self.norm(q1))))
+                d0, d1 = S(_norm_value(self.norm(q0))), S(_norm_value(self.norm(q1)))
         else:
             d0 = T(self._segment_norm(s0, bad))
             d1 = T(self._segment_norm(s1, bad, which=1))
@@ -1200,7 +1212,7 @@ class RKAdaptiveStepsizeODESolver:
             if self._vec_tol is not None:
                 q0 = q0 / vec_scale
             with torch.no_grad():
-                d2_num = S(abs(float(self.norm(q0))))
+                d2_num = S(_norm_value(self.norm(q0)))
         else:
             kern.init_norms(plan, 1, f1, f0, y0)
             s2, _, bad = self._read_norms()
@@ -1267,6 +1279,7 @@ class RKAdaptiveStepsizeODESolver:
         self._step_until(next_t)
         return self._interp_evaluate(next_t, out, t_shadow)
 
+    @np.errstate(all="ignore")     # host scalars follow IEEE silently, as 0-dim tensors do
     def _interp_fraction(self, rec, t: float) -> float:
         """x = (t - t0) / (t1 - t0) formed in W, then cast to T (interp.py:39-40)."""
         w = self._w
@@ -1596,7 +1609,7 @@ class RKAdaptiveStepsizeODESolver:
             if self._vec_tol is not None:       # `scaled` is the raw error estimate here (segment tolerances 0 / 1)
                 scaled = scaled / (self._vec_tol[1] + self._vec_tol[0] * torch.maximum(y0.abs(), y1.abs()))
             ratio = self.norm(scaled)
-        ratio = abs(float(ratio))
+        ratio = _norm_value(ratio)
         return ratio, any(b != 0 for b in bad)
 
 
@@ -1645,7 +1658,10 @@ def _uniform_grid(t: torch.Tensor, step_size) -> torch.Tensor:
     the reference's do (solvers.py:86-96; on a ROCm device a tensor divided by a host scalar is a multiplication by
     its reciprocal, which host arithmetic would not reproduce), and the grid keeps the autograd graph of `t`."""
     first, last = t[0], t[-1]
-    count = int(torch.ceil((last - first) / step_size + 1))
+    count = float(torch.ceil((last - first) / step_size + 1))
+    if not math.isfinite(count):
+        torch.arange(0, count)          # step_size 0 / nan: torch's own RuntimeError ("unsupported range: 0 -> inf")
+    count = int(count)
     grid = torch.arange(count, dtype=t.dtype, device=t.device) * step_size + first
     grid[-1] = last
     return grid
