@@ -87,3 +87,19 @@ def test_zero_tolerances_fail_like_the_reference_without_numpy_warnings():
         warnings.simplefilter("error", RuntimeWarning)
         with pytest.raises(AssertionError):
             tda.odeint(_Field(), Y0, T, rtol=0.0, atol=0.0, method="dopri5", options=dict(max_num_steps=50))
+
+
+def test_dense_output_takes_one_time_per_call():
+    # odeint.py:151-156: a vector of query times indexes the coefficient stack out of bounds -> IndexError
+    dense = tda.odeint_dense(lambda t, y: -y, Y0, torch.tensor(0.0), torch.tensor(1.0))
+    assert torch.allclose(dense(torch.tensor(0.5)), Y0 * torch.exp(torch.tensor(-0.5)), atol=1e-6)
+    with pytest.raises(IndexError):
+        dense(torch.tensor([0.25, 0.5]))
+
+
+def test_nonfinite_state_message_shows_the_state_without_alignment_padding():
+    # rk_common.py:280: the assertion prints the flat state; a tuple state's flat vector here is padded per component
+    with pytest.raises(AssertionError, match="non-finite values in state") as exc:
+        tda.odeint(lambda t, y: (-y[0], -y[1]), (torch.tensor([float("inf"), 1.0]), torch.ones(3)), T, method="dopri5",
+                   options=dict(first_step=0.1))
+    assert "tensor([inf, 1., 1., 1., 1.])" in str(exc.value)          # 5 values, not a chunk-padded vector

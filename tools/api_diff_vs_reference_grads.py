@@ -1,0 +1,112 @@
+import sys, torch, warnings, math
+sys.path.insert(0,'/root/reference'); import torchdiffeq as ref
+sys.path.insert(0,'/root/repo'); import torchdiffeq_amd as tda
+class F(torch.nn.Module):
+    def __init__(s):
+        super().__init__(); torch.manual_seed(0); s.lin=torch.nn.Linear(3,3); s.p=torch.nn.Parameter(torch.tensor(0.7)); s.unused=torch.nn.Parameter(torch.ones(2))
+    def forward(s,t,y): return torch.tanh(s.lin(y))*torch.cos(s.p*t)
+y0=torch.tensor([[0.3,-0.2,0.5],[1.0,0.1,-0.7]])
+t=torch.linspace(0,1,5)
+def grads(lib, method='dopri5', adjoint=True, tgrad=False, tup=False, **kw):
+    f=F()
+    x=y0.clone().requires_grad_(True)
+    tt=t.clone().requires_grad_(tgrad)
+    fn = lib.odeint_adjoint if adjoint else lib.odeint
+    if tup:
+        func=lambda t_,y: (f(t_,y[0]), -y[1]*f.p)
+        if adjoint:
+            class W(torch.nn.Module):
+                def __init__(s): super().__init__(); s.f=f
+                def forward(s,t_,y): return (s.f(t_,y[0]), -y[1]*s.f.p)
+            func=W()
+        out=fn(func,(x,x*2),tt,method=method,**kw)
+        loss=out[0][-1].pow(2).sum()+out[1][-1].sum()+out[0][2].sum()
+    else:
+        out=fn(f,x,tt,method=method,**kw)
+        loss=out[-1].pow(2).sum()+out[2].sum()
+    loss.backward()
+    res=[loss.detach(), x.grad]
+    if tgrad: res.append(tt.grad)
+    for n,p in f.named_parameters(): res.append(p.grad if p.grad is not None else torch.tensor(float('nan')))
+    return tuple(res)
+class CB(torch.nn.Module):
+    def __init__(s): super().__init__(); s.f=F(); s.log=[]
+    def forward(s,t,y): return s.f(t,y)
+    def callback_step(s,t0,y0,dt): s.log.append(('s',float(t0),float(dt)))
+    def callback_accept_step(s,t0,y0,dt): s.log.append(('a',float(t0),float(dt)))
+    def callback_reject_step(s,t0,y0,dt): s.log.append(('r',float(t0),float(dt)))
+    def callback_step_adjoint(s,t0,y0,dt): s.log.append(('sa',float(t0),float(dt)))
+    def callback_accept_step_adjoint(s,t0,y0,dt): s.log.append(('aa',float(t0),float(dt)))
+def cb(lib, method, adjoint=False, **kw):
+    f=CB(); x=y0.clone().requires_grad_(adjoint)
+    fn = lib.odeint_adjoint if adjoint else lib.odeint
+    out=fn(f,x,t,method=method,**kw)
+    if adjoint: out[-1].sum().backward()
+    return (torch.tensor([len(f.log)]), torch.tensor([hash(tuple(a for a,_,_ in f.log))%100000]), torch.tensor([v for _,v,_ in f.log]+[0.]), torch.tensor([v for _,_,v in f.log]+[0.]))
+def ev(lib, adjoint=False, method='dopri5', rev=False, **kw):
+    g=torch.nn.Parameter(torch.tensor(9.8)); 
+    class B(torch.nn.Module):
+        def __init__(s): super().__init__(); s.g=g
+        def forward(s,t,st): pos,vel=st; return vel, -s.g*torch.ones_like(vel)
+    b=B()
+    pos=torch.tensor([10.0],requires_grad=True); vel=torch.tensor([0.0 if not rev else 1.0])
+    t0=torch.tensor(0.0, requires_grad=True)
+    fn=lib.odeint_event
+    et,sol=fn(b,(pos,vel),t0,event_fn=lambda t,st: st[0] if not rev else st[0]-10.02,reverse_time=rev,odeint_interface=lib.odeint_adjoint if adjoint else lib.odeint,method=method,atol=1e-8,rtol=1e-8,**kw)
+    L=et+sol[1][-1].sum()
+    L.backward()
+    return (et.detach(), sol[0][-1].detach(), sol[1][-1].detach(), pos.grad, g.grad, t0.grad if t0.grad is not None else torch.tensor(float('nan')))
+def run(lib,call):
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        try:
+            r=call(lib)
+            return ('ok',r,[str(x.message)[:80] for x in w if 'host path' not in str(x.message) and 'lives on' not in str(x.message)])
+        except Exception as e:
+            import traceback
+            return (type(e).__name__, str(e)[:100],[])
+cases={
+ 'adj_dopri5': lambda L: grads(L),
+ 'adj_dopri5_tgrad': lambda L: grads(L,tgrad=True),
+ 'adj_dopri8_tgrad': lambda L: grads(L,method='dopri8',tgrad=True),
+ 'adj_rk4_tgrad': lambda L: grads(L,method='rk4',tgrad=True,options=dict(step_size=0.1)),
+ 'adj_tuple_tgrad': lambda L: grads(L,tgrad=True,tup=True),
+ 'adj_seminorm': lambda L: grads(L,adjoint_options=dict(norm='seminorm')),
+ 'adj_tight': lambda L: grads(L,rtol=1e-9,atol=1e-10,adjoint_rtol=1e-5,adjoint_atol=1e-7),
+ 'adj_method_bosh3': lambda L: grads(L,adjoint_method='bosh3'),
+ 'adj_method_euler': lambda L: grads(L,adjoint_method='euler',adjoint_options=dict(step_size=0.05)),
+ 'adj_adams': lambda L: grads(L,method='implicit_adams',tgrad=True,options=dict(step_size=0.1)),
+ 'bp_dopri5_tgrad': lambda L: grads(L,adjoint=False,tgrad=True),
+ 'bp_tsit5': lambda L: grads(L,adjoint=False,method='tsit5'),
+ 'bp_heun3_tgrad': lambda L: grads(L,adjoint=False,method='heun3',tgrad=True,options=dict(step_size=0.13)),
+ 'bp_tuple': lambda L: grads(L,adjoint=False,tup=True,tgrad=True),
+ 'bp_midpoint_cubic': lambda L: grads(L,adjoint=False,method='midpoint',options=dict(step_size=0.3,interp='cubic')),
+ 'cb_dopri5': lambda L: cb(L,'dopri5'),
+ 'cb_dopri5_tight': lambda L: cb(L,'dopri5',rtol=1e-10,atol=1e-12),
+ 'cb_rk4': lambda L: cb(L,'rk4',options=dict(step_size=0.1)),
+ 'cb_adj': lambda L: cb(L,'dopri5',adjoint=True),
+ 'cb_adams': lambda L: cb(L,'implicit_adams',options=dict(step_size=0.1)),
+ 'ev_plain': lambda L: ev(L),
+ 'ev_adj': lambda L: ev(L,adjoint=True),
+ 'ev_rk4': lambda L: ev(L,method='rk4',options=dict(step_size=0.01)),
+ 'ev_dopri8': lambda L: ev(L,method='dopri8'),
+ 'ev_rev': lambda L: ev(L,rev=True),
+ 'ev_rev_adj': lambda L: ev(L,rev=True,adjoint=True),
+}
+nd=0
+for name,call in cases.items():
+    a=run(ref,call); b=run(tda,call)
+    same=a[0]==b[0]; detail=''
+    if same and a[0]=='ok':
+        for i,(x,y) in enumerate(zip(a[1],b[1])):
+            if x.shape!=y.shape or x.dtype!=y.dtype: same=False; detail+=f' [{i}] shape/dtype {tuple(x.shape)}{x.dtype} vs {tuple(y.shape)}{y.dtype}'; continue
+            nanmis=bool((torch.isnan(x)!=torch.isnan(y)).any())
+            d=((x.double()-y.double()).abs().nan_to_num(0).max()/(x.double().abs().nan_to_num(0).max()+1e-30)).item() if x.numel() else 0.
+            if nanmis or d>2e-5: same=False
+            detail+=f' {d:.0e}'+('N' if nanmis else '')
+    else:
+        detail=f'REF={a[1]} || OURS={b[1]}'
+    wd='' if [x[:40] for x in a[2]]==[x[:40] for x in b[2]] else f' WARN {a[2]} vs {b[2]}'
+    if not same or wd: nd+=1
+    print(('SAME' if same else 'DIFF'), name, a[0], b[0], detail, wd)
+print('non-same',nd)

@@ -154,6 +154,10 @@ def odeint_dense(func, y0, t0, t1, *, rtol=1e-7, atol=1e-9, method=None, options
     import bisect
 
     def dense_output_fn(t_eval):
+        if isinstance(t_eval, torch.Tensor) and t_eval.numel() != 1:
+            # (the reference's closure indexes its coefficient stack with the whole `searchsorted` result: odeint.py:151-156)
+            raise IndexError("odeint_dense: the dense output is evaluated at one time per call, got {} times"
+                             .format(t_eval.numel()))
         ts = sign * float(t_eval)
         idx = bisect.bisect_right(times, ts)
         if idx >= len(times):

@@ -1255,6 +1255,12 @@ class RKAdaptiveStepsizeODESolver:
         else:
             self._adaptive_step()
 
+    def _unpadded(self, flat: torch.Tensor) -> torch.Tensor:
+        """The state as the reference's flat vector (components back to back, no alignment padding) — error messages."""
+        if self.layout.n_seg == 1:
+            return flat
+        return torch.cat([c.reshape(-1) for c in self.layout.unpack(flat)])
+
     def _graph_now(self) -> bool:
         """Whether THIS trial step goes through the captured-step path.  Always, once a solve is on it or when
         `hip_graph=True` was asked for; under "auto" the first capture is put off as _GraphStep.auto_policy says."""
@@ -1337,7 +1343,7 @@ class RKAdaptiveStepsizeODESolver:
         w = self._w
         t1 = w(t0 + dt)
         assert t1 > t0, "underflow in dt {}".format(dt)
-        assert not self._y_nonfinite, "non-finite values in state `y`: {}".format(y0)
+        assert not self._y_nonfinite, "non-finite values in state `y`: {}".format(self._unpadded(y0))
 
         on_step_t = False
         if len(self._step_t):
@@ -1560,7 +1566,7 @@ class RKAdaptiveStepsizeODESolver:
         dt = _clamp(dt, self.min_step, self.max_step)
         t1 = t0 + dt
         assert t0 + dt > t0, "underflow in dt {}".format(dt)
-        assert not self._y_nonfinite, "non-finite values in state `y`: {}".format(self.y1)
+        assert not self._y_nonfinite, "non-finite values in state `y`: {}".format(self._unpadded(self.y1))
         g = self._g
         if g is None:
             g = self._g = _GraphStep.acquire(self, t0, dt)
@@ -1658,7 +1664,7 @@ def _uniform_grid(t: torch.Tensor, step_size) -> torch.Tensor:
     the reference's do (solvers.py:86-96; on a ROCm device a tensor divided by a host scalar is a multiplication by
     its reciprocal, which host arithmetic would not reproduce), and the grid keeps the autograd graph of `t`."""
     first, last = t[0], t[-1]
-    count = float(torch.ceil((last - first) / step_size + 1))
+    count = float(torch.ceil((last - first) / step_size + 1).detach())
     if not math.isfinite(count):
         torch.arange(0, count)          # step_size 0 / nan: torch's own RuntimeError ("unsupported range: 0 -> inf")
     count = int(count)
