@@ -1,3 +1,5 @@
+"""Differential batch against the imported reference (build container; see api_diff_vs_reference.py): prints SAME / DIFF
+per case — exception class, shapes, dtypes, values, gradients."""
 import sys, torch, warnings, math
 sys.path.insert(0,'/root/reference'); import torchdiffeq as ref
 sys.path.insert(0,'/root/repo'); import torchdiffeq_amd as tda
