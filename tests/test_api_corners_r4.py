@@ -19,30 +19,36 @@ class _Field(torch.nn.Module):
         return torch.tanh(self.lin(y)) * torch.cos(t)
 
 
-Y0 = torch.tensor([[0.3, -0.2, 0.5], [1.0, 0.1, -0.7]])
-T = torch.linspace(0, 1, 5)
+_Y0 = torch.tensor([[0.3, -0.2, 0.5], [1.0, 0.1, -0.7]])
+_T = torch.linspace(0, 1, 5)
 
 
-@pytest.fixture(autouse=True)
-def _quiet_host_path():
+@pytest.fixture(params=["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def on(request):
+    """The device of the state: the torch-op host path ("cpu") or the HIP kernels ("cuda") — same behaviour on both."""
+    global Y0, T
+    Y0, T = _Y0.to(request.param), _T.to(request.param)
+    prev = torch.get_default_device()
+    torch.set_default_device(request.param)
     with warnings.catch_warnings():
-        warnings.simplefilter("ignore", tda.HostPathWarning)
-        yield
+        warnings.simplefilter("ignore" if request.param == "cpu" else "error", tda.HostPathWarning)
+        yield request.param
+    torch.set_default_device(prev)
 
 
-def test_step_size_zero_is_torchs_range_error():
+def test_step_size_zero_is_torchs_range_error(on):
     # solvers.py:86-96: torch.arange(0, inf) -> RuntimeError
     with pytest.raises(RuntimeError, match="unsupported range"):
         tda.odeint(_Field(), Y0, T, method="rk4", options=dict(step_size=0.0))
 
 
-def test_norm_returning_more_than_one_element_is_a_runtime_error():
+def test_norm_returning_more_than_one_element_is_a_runtime_error(on):
     # misc.py:60 `if d0 < 1e-5 or d1 < 1e-5` on a vector
     with pytest.raises(RuntimeError, match="more than one value"):
         tda.odeint(_Field(), Y0, T, method="dopri5", options=dict(norm=lambda x: x))
 
 
-def test_unknown_adjoint_norm_string_fails_in_the_backward_solve_not_before():
+def test_unknown_adjoint_norm_string_fails_in_the_backward_solve_not_before(on):
     # adjoint.py:271-288: everything but "seminorm" is taken for a callable
     f = _Field()
     y = tda.odeint_adjoint(f, Y0.clone().requires_grad_(True), T, adjoint_options=dict(norm="semi"))
@@ -50,7 +56,7 @@ def test_unknown_adjoint_norm_string_fails_in_the_backward_solve_not_before():
         y[-1].sum().backward()
 
 
-def test_tuple_state_of_mixed_dtypes_is_promoted_as_a_whole():
+def test_tuple_state_of_mixed_dtypes_is_promoted_as_a_whole(on):
     # misc.py:206-207: the components are concatenated -> one dtype for func's inputs and for every output
     seen = []
 
@@ -65,7 +71,7 @@ def test_tuple_state_of_mixed_dtypes_is_promoted_as_a_whole():
     assert z.dtype == w.dtype == torch.complex64
 
 
-def test_func_returning_a_python_number():
+def test_func_returning_a_python_number(on):
     # fixed_grid.py: `y0 + dt * 1.0` broadcasts; rk_common.py:69 needs `.shape` -> AttributeError
     y = tda.odeint(lambda t, y: 1.0, Y0, T, method="rk4")
     assert torch.allclose(y[-1], Y0 + 1.0, atol=1e-6)
@@ -74,14 +80,14 @@ def test_func_returning_a_python_number():
     assert isinstance(exc.value, TypeError)          # (what this package has raised so far)
 
 
-def test_integer_state_is_refused_with_the_references_exception_class():
+def test_integer_state_is_refused_with_the_references_exception_class(on):
     # misc.py:185-196: nextafter is not implemented for integers
     with pytest.raises(NotImplementedError) as exc:
         tda.odeint(lambda t, y: y, torch.tensor([1, 2]), T, method="dopri5")
     assert isinstance(exc.value, TypeError)
 
 
-def test_zero_tolerances_fail_like_the_reference_without_numpy_warnings():
+def test_zero_tolerances_fail_like_the_reference_without_numpy_warnings(on):
     # rtol = atol = 0: the heuristic divides 0 by 0 — 0-dim tensors do that silently, so do the host scalars
     with warnings.catch_warnings():
         warnings.simplefilter("error", RuntimeWarning)
@@ -89,7 +95,7 @@ def test_zero_tolerances_fail_like_the_reference_without_numpy_warnings():
             tda.odeint(_Field(), Y0, T, rtol=0.0, atol=0.0, method="dopri5", options=dict(max_num_steps=50))
 
 
-def test_dense_output_takes_one_time_per_call():
+def test_dense_output_takes_one_time_per_call(on):
     # odeint.py:151-156: a vector of query times indexes the coefficient stack out of bounds -> IndexError
     dense = tda.odeint_dense(lambda t, y: -y, Y0, torch.tensor(0.0), torch.tensor(1.0))
     assert torch.allclose(dense(torch.tensor(0.5)), Y0 * torch.exp(torch.tensor(-0.5)), atol=1e-6)
@@ -97,7 +103,7 @@ def test_dense_output_takes_one_time_per_call():
         dense(torch.tensor([0.25, 0.5]))
 
 
-def test_nonfinite_state_message_shows_the_state_without_alignment_padding():
+def test_nonfinite_state_message_shows_the_state_without_alignment_padding(on):
     # rk_common.py:280: the assertion prints the flat state; a tuple state's flat vector here is padded per component
     with pytest.raises(AssertionError, match="non-finite values in state") as exc:
         tda.odeint(lambda t, y: (-y[0], -y[1]), (torch.tensor([float("inf"), 1.0]), torch.ones(3)), T, method="dopri5",
