@@ -108,4 +108,4 @@ def test_nonfinite_state_message_shows_the_state_without_alignment_padding(on):
     with pytest.raises(AssertionError, match="non-finite values in state") as exc:
         tda.odeint(lambda t, y: (-y[0], -y[1]), (torch.tensor([float("inf"), 1.0]), torch.ones(3)), T, method="dopri5",
                    options=dict(first_step=0.1))
-    assert "tensor([inf, 1., 1., 1., 1.])" in str(exc.value)          # 5 values, not a chunk-padded vector
+    assert "tensor([inf, 1., 1., 1., 1.]" in str(exc.value)          # 5 values, not a chunk-padded vector
