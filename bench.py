@@ -1082,7 +1082,7 @@ def adjoint_pass(world, rank, device, rows_per_rank, steps, warmup, group_forced
     group = torch.distributed.group.WORLD if (world > 1 or group_forced) else None
     extra = {"options": {"hip_graph": "auto"}} if graph else {}
     if graph:
-        # "auto" replays only funcs without per-evaluation side effects (solvers._side_effect_fingerprint): the field's
+        # "auto" replays only funcs without per-evaluation side effects (_graph._side_effect_fingerprint): the field's
         # evaluation counter is switched off for this leg
         field.counting = False
 

@@ -95,7 +95,7 @@ def main():
     assert calls["n"] > n0
     assert torch.allclose(y_plain, y_lock, rtol=1e-5, atol=1e-6)
     # (4) captured trial steps in a process that HAS a live RCCL communicator: its watchdog thread issues HIP calls of
-    #     its own, which a "global" capture would be invalidated by (solvers._capture uses thread_local); a failed
+    #     its own, which a "global" capture would be invalidated by (_graph._capture uses thread_local); a failed
     #     capture would fall back to the eager path with a warning — turned into an error here
     import warnings
     with torch.no_grad(), warnings.catch_warnings():

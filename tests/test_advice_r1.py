@@ -116,7 +116,7 @@ def test_sharded_adjoint_keeps_option_validation(cpu_backend):
 
 
 def test_captured_step_cache_key_sees_every_tensor_a_func_holds():
-    """solvers._held_tensor_ptrs (part of the captured-step cache key): parameters, buffers and PLAIN tensor attributes
+    """_graph._held_tensor_ptrs (part of the captured-step cache key): parameters, buffers and PLAIN tensor attributes
     of a Module (all submodules), closure cells, defaults, module-level tensors named by a function body, the owner of
     a bound method, functools.partial arguments — so re-binding any of them to new storage forces a new capture."""
     import functools

@@ -1,0 +1,626 @@
+"""Captured trial steps: hipGraph capture, the ping-pong step graphs of the adaptive solvers, their reuse across solves
+and the `hip_graph="auto"` safety machinery (split out of solvers.py).
+
+  _graph_request                     the `hip_graph` option / TDEQ_HIP_GRAPH -> (wanted, auto)
+  _held_tensor_ptrs, _scalar_state   what a captured graph of `func` depends on -> the cache key (_GraphStep._key)
+  _side_effect_fingerprint           "auto": visible per-evaluation side effects of func (refused if any)
+  _capture, _side_stream             stream capture without device synchronisation, one side stream per thread
+  _GraphStep                         static buffers + two graphs (one per state side) of ONE adaptive trial step
+                                     (reference semantics: rk_common.py:266-361), probe of the first replay, cache
+The solvers (`solvers.py`) drive these; nothing here decides accept / reject.
+"""
+from __future__ import annotations
+
+import collections
+import contextlib
+import functools
+import gc
+import os
+import threading
+import warnings
+import weakref
+from typing import List, Optional
+
+import torch
+
+from .misc import Perturb
+
+# hipGraph mode targets launch-latency-bound states; its stage kernel (run-time term count, scalar loads) is not the
+# bandwidth-tuned one, so beyond this size the eager path is used
+_GRAPH_MODE_MAX_ELEMENTS = 1 << 22
+
+
+# `hip_graph="auto"`: capture only where a trial step costs launch latency rather than bandwidth (measured on the
+# MI355X, profiles/r02_shard_regime.json: the captured step wins up to ~2M elements and loses beyond)
+_GRAPH_AUTO_MAX_ELEMENTS = 1 << 21
+
+
+def _graph_request(hip_graph):
+    """(wanted, auto) from the `hip_graph` solver option: True / False, "auto", or None = the process-wide default
+    taken from the environment variable TDEQ_HIP_GRAPH ("0" — the default —, "1" or "auto")."""
+    if hip_graph is None:
+        hip_graph = {"0": False, "": False, "1": True, "auto": "auto"}.get(os.environ.get("TDEQ_HIP_GRAPH", "0").lower())
+        if hip_graph is None:
+            raise ValueError("TDEQ_HIP_GRAPH must be 0, 1 or auto")
+    if isinstance(hip_graph, str):
+        if hip_graph.lower() != "auto":
+            raise ValueError("hip_graph must be True, False or 'auto'")
+        return True, True
+    return bool(hip_graph), False
+
+
+def _tensors_in(value, _level=0):
+    """Tensors directly in `value` or one container level down (list / tuple / dict / set attribute values)."""
+    if isinstance(value, torch.Tensor):
+        return [value]
+    if _level == 0 and isinstance(value, (list, tuple, set, frozenset)):
+        return [t for v in value for t in _tensors_in(v, 1)]
+    if _level == 0 and isinstance(value, dict):
+        return [t for v in value.values() for t in _tensors_in(v, 1)]
+    return []
+
+
+def _object_tensor_ptrs(obj):
+    """Storage addresses of the tensors an object's attributes hold (directly or inside a list / tuple / dict)."""
+    return [t.data_ptr() for v in getattr(obj, "__dict__", {}).values() for t in _tensors_in(v)]
+
+
+def _held_tensor_ptrs(fn, _depth=0):
+    """Storage addresses of the tensors a func object visibly holds: an nn.Module's parameters, buffers and plain
+    tensor attributes (all submodules, also inside list / tuple / dict attributes); a function's closure cells,
+    defaults and the module-level tensors its body names; a bound method's owner; an instance with `__call__` (its
+    attributes and what its `__call__` closes over); a functools.partial's arguments.  Part of the captured-step cache
+    key (see _GraphStep._key)."""
+    ptrs = []
+    if isinstance(fn, torch.nn.Module):
+        ptrs += [p.data_ptr() for p in fn.parameters()] + [b.data_ptr() for b in fn.buffers()]
+        for m in fn.modules():
+            ptrs += _object_tensor_ptrs(m)
+        return tuple(ptrs)
+    if _depth > 2:
+        return ()
+    owner = getattr(fn, "__self__", None)
+    if owner is not None and not isinstance(owner, type):
+        ptrs += _held_tensor_ptrs(owner, _depth + 1) if isinstance(owner, torch.nn.Module) else \
+            _object_tensor_ptrs(owner)
+    is_function = hasattr(fn, "__code__") or hasattr(getattr(fn, "__func__", None), "__code__")
+    if not is_function and not isinstance(fn, type) and hasattr(type(fn), "__call__") \
+            and not isinstance(fn, functools.partial) and getattr(fn, "__dict__", None) is not None:
+        # a callable INSTANCE (class with __call__): what it stores, and what its __call__ is written over
+        ptrs += _object_tensor_ptrs(fn)
+        call = getattr(type(fn), "__call__", None)
+        if call is not None and hasattr(call, "__code__"):
+            ptrs += _held_tensor_ptrs(call, _depth + 1)
+    inner = getattr(fn, "__func__", fn)
+    held = [c.cell_contents for c in (getattr(inner, "__closure__", None) or ()) if _cell_is_set(c)]
+    held += list(getattr(inner, "__defaults__", None) or ())
+    code, glob = getattr(inner, "__code__", None), getattr(inner, "__globals__", None)
+    if code is not None and glob is not None:        # module-level tensors / modules the body names
+        held += [glob[n] for n in code.co_names if isinstance(glob.get(n), (torch.Tensor, torch.nn.Module))]
+    held += list(getattr(fn, "args", ())) + list((getattr(fn, "keywords", None) or {}).values())     # functools.partial
+    if getattr(fn, "func", None) is not None and callable(fn.func):
+        held.append(fn.func)
+    for v in held:
+        if isinstance(v, torch.nn.Module) or (callable(v) and not isinstance(v, torch.Tensor)):
+            ptrs += _held_tensor_ptrs(v, _depth + 1)
+        else:
+            ptrs += [t.data_ptr() for t in _tensors_in(v)]
+    return tuple(ptrs)
+
+
+def _reusable_across_solves(fn) -> bool:
+    """Whether a captured step of `fn` may be kept for the NEXT solve.  The cache key must change when fn is re-bound
+    to new storage; for a plain function / lambda / partial / Module the discovery above sees what it holds.  An
+    arbitrary callable object in which NO tensor could be found (state hidden behind properties, __slots__, nested
+    objects ...) gives an empty key that cannot notice a re-binding — such a func is captured per solve, unless it
+    carries a `hip_graph_token`."""
+    if isinstance(fn, torch.nn.Module) or getattr(fn, "hip_graph_token", None) is not None:
+        return True
+    if hasattr(fn, "__code__") or hasattr(getattr(fn, "__func__", None), "__code__") or isinstance(fn, functools.partial):
+        return True
+    if type(fn).__module__ in ("builtins", "torch") or isinstance(fn, type(torch.tanh)):
+        return True         # a builtin / torch op: holds nothing
+    return len(_held_tensor_ptrs(fn)) > 0
+
+
+def _cell_is_set(cell) -> bool:
+    try:
+        cell.cell_contents
+        return True
+    except ValueError:
+        return False
+
+
+# `hip_graph="auto"`: a first capture costs about as much as a hundred eager trial steps of a small state (≈12 ms
+# against 0.2 -> 0.08 ms per step, profiles/r03_config_times.json), so a (func, layout) seen for the FIRST time runs
+# eagerly and is captured only once its solve has taken this many trial steps — or at the first step of the NEXT solve
+# with the same key (a training loop), whichever comes first
+_AUTO_CAPTURE_AFTER_STEPS = 96
+_AUTO_MIN_GRID_STEPS = 24           # fixed grids: intervals below which "auto" does not capture (one capture ≈ 1 ms there)
+
+
+def _visible_state(obj, out, depth=0):
+    """Cheap identity of what `obj` visibly holds — plain numbers, flags, strings, container lengths, tensor storages
+    with their in-place version counters — appended to `out`."""
+    for name, v in list(getattr(obj, "__dict__", {}).items()):
+        if isinstance(v, torch.Tensor):
+            out.append((name, v.data_ptr(), v._version))
+        elif isinstance(v, (bool, int, float, complex, str, bytes, type(None))):
+            out.append((name, v))
+        elif isinstance(v, (list, tuple, set, frozenset, collections.deque)):
+            out.append((name, len(v), tuple((t.data_ptr(), t._version) for t in v if isinstance(t, torch.Tensor))))
+        elif isinstance(v, dict) and name not in ("_parameters", "_buffers", "_modules"):
+            out.append((name, len(v), tuple((t.data_ptr(), t._version) for t in v.values() if isinstance(t, torch.Tensor))))
+
+
+def _side_effect_fingerprint(fn, device):
+    """What an evaluation of `fn` could change OUTSIDE its return value, as far as it can be seen from here: the
+    attributes of the callable (all submodules of an nn.Module; the objects a function closes over / is bound to),
+    parameter and buffer version counters, and the device's random-number offset.  Equal before and after an eager
+    evaluation = no visible per-evaluation side effect — the premise of replaying `fn` from a captured hipGraph, where
+    its Python body does not run at all."""
+    out = []
+    if isinstance(fn, torch.nn.Module):
+        for m in fn.modules():
+            _visible_state(m, out)
+        out += [(n, t.data_ptr(), t._version) for n, t in fn.named_parameters()]
+        out += [(n, t.data_ptr(), t._version) for n, t in fn.named_buffers()]
+    else:
+        _visible_state(fn, out)
+        owner = getattr(fn, "__self__", None)
+        if owner is not None and not isinstance(owner, type):
+            out.append(_side_effect_fingerprint(owner, None) if isinstance(owner, torch.nn.Module) else None)
+            _visible_state(owner, out)
+        inner = getattr(fn, "__func__", fn)
+        for c in (getattr(inner, "__closure__", None) or ()):
+            if _cell_is_set(c):
+                v = c.cell_contents
+                if isinstance(v, torch.nn.Module):
+                    out.append(_side_effect_fingerprint(v, None))
+                elif isinstance(v, torch.Tensor):
+                    out.append((v.data_ptr(), v._version))
+                elif isinstance(v, (bool, int, float, str, type(None))):
+                    out.append(v)
+                elif isinstance(v, (list, dict, set)):
+                    out.append(len(v))      # e.g. `nfe = [0]` / a log list a lambda appends to
+                    if isinstance(v, list):
+                        out.append(tuple(x for x in v if isinstance(x, (bool, int, float))))
+                elif hasattr(v, "__dict__") and not callable(v):
+                    _visible_state(v, out)
+    if device is not None and torch.device(device).type == "cuda":
+        try:
+            idx = torch.device(device).index
+            gen = torch.cuda.default_generators[torch.cuda.current_device() if idx is None else idx]
+            out.append(("rng", gen.initial_seed(), gen.get_offset()))
+        except Exception:      # a build without generator offsets: the attribute checks still stand
+            pass
+    return tuple(out)
+
+
+def _scalar_state(fn):
+    """The plain Python values `fn` visibly holds (numbers, flags, strings, container lengths — no tensors: those are in
+    the key by storage address).  A captured graph bakes such values into its kernel arguments, so they are part of the
+    captured-step cache key: `self.scale = 0.5` changed between two solves leads to a new capture, not to a replay
+    with the old value."""
+    def plain(obj, out):
+        for name, v in list(getattr(obj, "__dict__", {}).items()):
+            if isinstance(v, (bool, int, float, complex, str, bytes, type(None))):
+                out.append((name, v))
+            elif isinstance(v, (list, tuple)) and len(v) <= 64 and all(isinstance(x, (bool, int, float, str)) for x in v):
+                out.append((name, tuple(v)))
+    out = []
+    if isinstance(fn, torch.nn.Module):
+        for m in fn.modules():
+            plain(m, out)
+            out.append(m.training)
+        return tuple(out)
+    plain(fn, out)
+    owner = getattr(fn, "__self__", None)
+    if owner is not None and not isinstance(owner, type):
+        out.append(_scalar_state(owner) if isinstance(owner, torch.nn.Module) else None)
+        plain(owner, out)
+    inner = getattr(fn, "__func__", fn)
+    for c in (getattr(inner, "__closure__", None) or ()):
+        if _cell_is_set(c):
+            v = c.cell_contents
+            if isinstance(v, (bool, int, float, complex, str, bytes, type(None))):
+                out.append(v)
+            elif isinstance(v, torch.nn.Module):
+                out.append(_scalar_state(v))
+            elif isinstance(v, (list, tuple)) and len(v) <= 64 and all(isinstance(x, (bool, int, float, str)) for x in v):
+                out.append(tuple(v))
+    return tuple(out)
+
+
+def _same_words(a, b) -> bool:
+    """Equality of two flat lists of host doubles, NaN == NaN."""
+    return len(a) == len(b) and all(x == y or (x != x and y != y) for x, y in zip(a, b))
+
+
+class _DtCell:
+    """A two-double device buffer shaped like a norm plan's `ctrl_dev` ({accept, sign*dt, ...}): lets the fixed-grid
+    graph mode reuse tdeq_stage_combine_dev, which reads its step size from word 1."""
+    __slots__ = ("ctrl_dev",)
+
+    def __init__(self, buf):
+        self.ctrl_dev = buf
+
+
+class _CaptureFailed(RuntimeError):
+    """The step body could not be captured into a hipGraph; no kernel of it has run."""
+
+
+_SIDE_STREAMS = threading.local()
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    """The side stream of warm-up steps and stream captures: ONE per thread and device, reused.  PyTorch keeps a BLAS
+    workspace (128 MiB on ROCm) per (handle, stream) that has ever run a GEMM and never returns it; a fresh
+    `torch.cuda.Stream` per capture grew the process by that much for every newly captured func (measured:
+    `tools/soak_training.py`, +478 MB after one captured adjoint loop), up to PyTorch's pool of 32 streams.  Per thread
+    because a stream can be in one capture at a time."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    streams = getattr(_SIDE_STREAMS, "by_device", None)
+    if streams is None:
+        streams = _SIDE_STREAMS.by_device = {}
+    stream = streams.get(key)
+    if stream is None:
+        stream = streams[key] = torch.cuda.Stream(torch.device("cuda", key))
+    return stream
+
+
+@contextlib.contextmanager
+def _capture(graph, pool=None):
+    """Stream capture of a step body into `graph`.  Unlike the `torch.cuda.graph` context this neither synchronises
+    the device nor empties the caching allocator (both cost milliseconds — more than a short solve), and it pauses
+    the cyclic garbage collector: a collection in the middle of a capture may finalize unrelated objects that own HIP
+    resources (pinned buffers, events, other graphs), whose release calls are illegal while a stream is capturing."""
+    current = torch.cuda.current_stream()
+    side = _side_stream(current.device)
+    side.wait_stream(current)
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.stream(side):
+            # capture_error_mode "thread_local": only THIS thread's calls are held to the capture rules.  Under the
+            # default ("global") a HIP call from any other thread during the capture is an error that invalidates it —
+            # and a process with an RCCL process group has such a thread (the communicator's watchdog polls events):
+            # every rank of a multi-GPU run would lose its capture at random.
+            kw = {"capture_error_mode": "thread_local"}
+            if pool is not None:
+                kw["pool"] = pool                   # same private memory pool as a graph that never runs concurrently
+            graph.capture_begin(**kw)
+            try:
+                yield
+            finally:
+                graph.capture_end()
+    finally:
+        if was_enabled:
+            gc.enable()
+    current.wait_stream(side)
+
+
+class _GraphStep:
+    """Static buffers + the captured hipGraphs of one adaptive trial step (RKAdaptiveStepsizeODESolver._graph_trial_step).
+
+    r03: TWO graphs over ping-pong state buffers instead of one graph + a commit kernel.  The host reads the
+    controller's decision after every replay anyway, so it — not a device-side select — knows which state pair the
+    next trial step starts from:
+        side 0   reads (y[0], f0),            writes y1 into y[1]; its last evaluation k0[-1] = f(t1, y[1]) IS side 1's f
+        side 1   reads (y[1], k0[-1]),        writes y1 into y[0]; its last evaluation is copied into f0 (one N-word
+                                              copy inside the graph: func's output buffer cannot be chosen)
+    An accepted step flips the side, a rejected one replays the same graph (its input pair is untouched).  The r02
+    `tdeq_step_commit` (4 reads + 4 writes per element and step, one dispatch) is gone: per accepted step 0 or 2 words
+    move instead of 8.  The pair a step started from stays intact until the next replay, which is what the lazy dense
+    output of the last accepted step reads.
+    The first trial step runs the body eagerly on a side stream (library / allocator warm-up), the second call
+    captures side 0, side 1 is captured when first needed; every later call is a replay.  Holds no reference to the
+    solver (no reference cycle: the graphs and their memory pool are released by reference counting)."""
+
+    def __init__(self, s, t0: float, dt: float):
+        dev = s.y0.device
+        self.y = [torch.empty_like(s.y1), torch.empty_like(s.y1)]
+        self.f0 = torch.empty_like(s.y1)
+        self.epart = [torch.empty_like(s.y1), torch.empty_like(s.y1)]
+        self.tbuf = torch.empty(len(s._beta), dtype=s.func.time_dtype, device=dev)      # stage times: real, also for complex states
+        self.ts = self.tbuf.unbind(0)
+        self.k: List[Optional[List[torch.Tensor]]] = [None, None]
+        self.graphs = [None, None]
+        self.side = 0
+        self.calls = 0
+        self.plan = s.plan          # the graphs' norm kernels write into THIS plan's buffers
+        self.in_use = True
+        self.auto = bool(getattr(s, "_graph_auto", False))    # `hip_graph="auto"`: verify before trusting replays
+        self.probed = False         # a replayed step has reproduced an eager one bit for bit
+        self.refused = None         # why this func must not be replayed (auto mode)
+        self.reset(s, t0, dt)
+
+    # -- the current pair ----------------------------------------------------------------------------------
+    def f_in(self, side: int) -> torch.Tensor:
+        return self.f0 if side == 0 else self.k[0][-1]
+
+    def reset(self, s, t0: float, dt: float) -> None:
+        """Load a solve's current state into side 0's input pair: y, f(t0, y), the device-resident step state
+        {accept, sign*T(dt), t0, dt} and the first trial's stage times."""
+        func, kern, T = s.func, s.kernels, s.np_dtype
+        self.side = 0
+        self.y[0].copy_(s.y1.detach())
+        self.f0.copy_(s.f1.detach())
+        t0_T, dt_T, t1_T = T(t0), T(dt), T(t0 + dt)
+        self.plan.ctrl_dev.copy_(torch.tensor([0.0, float(dt_T) * func.sign, t0, dt], dtype=torch.float64))
+        times = [(t1_T, Perturb.PREV) if s._alpha_is_one[i] else (t0_T + s._alpha[i] * dt_T, Perturb.NONE)
+                 for i in range(len(s._beta))]
+        kern.fill_scalars(self.tbuf, [func.user_time(t, p) for t, p in times])
+
+    # -- reuse across solves ---------------------------------------------------------------------------------
+    # A training loop calls odeint with the same func and state layout over and over; capturing (≈1 ms) and the eager
+    # warm-up step would be paid per call.  Captured steps are therefore kept per `func` object (weakly: they go
+    # away with it) and re-armed with the next solve's state.  Valid as long as func computes the same kernels on the
+    # same parameter storages — what a captured graph requires anyway; `clear_graph_cache()` drops them.
+    _cache = weakref.WeakKeyDictionary()
+    _MAX_PER_FUNC = 4
+    _seen = weakref.WeakKeyDictionary()         # auto mode: func -> keys that have been solved (eagerly) once already
+    _refused = weakref.WeakKeyDictionary()      # auto mode: func -> why it is never captured
+
+    @classmethod
+    def auto_policy(cls, s, seen_before: bool = False) -> str:
+        """`hip_graph="auto"`, asked at the first trial step of a solve: "now" — a captured step for this (func, layout)
+        is cached or the pair has been solved before (second call of a training loop): capture / replay from the first
+        step; "later" — first sight: eager, captured only if this one solve turns out long
+        (_AUTO_CAPTURE_AFTER_STEPS); "never" — func was found to have per-evaluation side effects.
+        `seen_before`: the caller has solved this pair once already without asking (the adjoint's first backward solve
+        runs with the option off, adjoint._auto_backward_due)."""
+        base = s.func.base_func
+        try:
+            if base in cls._refused:
+                return "never"
+            if not _reusable_across_solves(base):
+                return "later"
+            key = cls._key(s)
+            per_func = cls._cache.get(base)
+            if per_func is not None and key in per_func:
+                return "now"
+            seen = cls._seen.get(base)
+            if seen is None:
+                seen = cls._seen[base] = set()
+            if key in seen or seen_before:
+                seen.add(key)
+                return "now"
+            seen.add(key)
+        except TypeError:               # func object cannot be weakly referenced / hashed
+            pass
+        return "later"
+
+    def refuse(self, s, reason: str) -> None:
+        """Auto mode found `func` unfit for replay: remember it (per func object), drop the cached graphs, say so once."""
+        self.refused = reason
+        base = s.func.base_func
+        try:
+            first = base not in self._refused
+            self._refused[base] = reason
+            per_func = self._cache.get(base)
+            if per_func is not None:
+                for k in [k for k, g in per_func.items() if g is self]:
+                    del per_func[k]
+        except TypeError:
+            first = True
+        if first:
+            warnings.warn("hip_graph='auto': {} is not captured into a hipGraph — {}; its solves run on the eager "
+                          "path (pass hip_graph=True to capture it regardless)".format(type(base).__name__, reason))
+
+    @staticmethod
+    def _key(s):
+        c = s._ctrl
+        segs = tuple((int(sg.chunk_start), int(sg.numel), float(sg.rtol), float(sg.atol)) for sg in s.plan.segs)
+        key = (type(s).__name__, str(s.y0.dtype), str(s.y0.device), int(s.layout.total), int(s.plan.chunk), segs,
+               c.safety, c.ifactor, c.dfactor, c.exponent, c.min_step, c.max_step, c.time_sign, int(c.n_norm_seg))
+        # A captured graph reads the STORAGES it saw: in-place updates are fine, anything re-allocated (module.to(...),
+        # a re-built layer, a closure variable bound to a new tensor) must lead to a new capture — so every tensor the
+        # func object can be seen to hold goes into the key; a user-supplied `hip_graph_token` attribute of func (any
+        # hashable: bump it when func changes what it computes) does too.
+        key += (_held_tensor_ptrs(s.func.base_func), getattr(s.func.base_func, "hip_graph_token", None),
+                type(s.func).__name__, s.func.graph_key(),
+                # ("auto" only: with hip_graph=True the user vouches for func, and an evaluation counter among its
+                # attributes would otherwise change the key on every solve)
+                _scalar_state(s.func.base_func) if getattr(s, "_graph_auto", False) else None)
+        return key
+
+    @classmethod
+    def acquire(cls, s, t0: float, dt: float) -> "_GraphStep":
+        if not _reusable_across_solves(s.func.base_func):
+            return cls(s, t0, dt)   # nothing in the key would notice a re-bound tensor: capture per solve
+        try:
+            per_func = cls._cache.get(s.func.base_func)
+        except TypeError:           # func object cannot be weakly referenced: no reuse
+            return cls(s, t0, dt)
+        key = cls._key(s)
+        g = per_func.get(key) if per_func is not None else None
+        if g is not None and not g.in_use:
+            g.in_use = True
+            s.plan = g.plan         # read-backs must poll the buffers the captured kernels write
+            g.reset(s, t0, dt)
+            return g
+        g = cls(s, t0, dt)
+        if per_func is None:
+            try:
+                per_func = cls._cache[s.func.base_func] = {}
+            except TypeError:
+                return g
+        if key not in per_func:
+            if len(per_func) >= cls._MAX_PER_FUNC:       # evict the oldest entry that no running solve holds
+                for old_key, old in list(per_func.items()):
+                    if not old.in_use:
+                        del per_func[old_key]
+                        break
+            if len(per_func) < cls._MAX_PER_FUNC:
+                per_func[key] = g
+        return g
+
+    def release(self) -> None:
+        self.in_use = False
+
+    def body(self, s, side: int) -> None:
+        func, kern, plan = s.func, s.kernels, s.plan
+        beta, fuse, fsal = s._beta, s._fuse, s.tableau.fsal_solution
+        y_cur, f_cur, y1, epart = self.y[side], self.f_in(side), self.y[1 - side], self.epart[side]
+        k = [f_cur]
+        yi = torch.empty_like(y_cur)
+        kern.stage_combine_dev(yi, None, y_cur, [f_cur], beta[0].coef, None, plan)
+        k.append(func.eval_at(self.ts[0], yi))
+        n_rows = len(beta)
+        carry = s._carry if hasattr(kern, "stage_combine_multi_dev") else None
+        if carry is not None:
+            # planned launches (tableaus.carry_plan) with the step size read on the device: same stage inputs, fewer
+            # bytes and — dopri8 — one node fewer per captured step
+            held, R = {}, len(carry.ops)
+            for i in range(1, R):
+                op = carry.ops[i]
+                row = beta[i] if i < n_rows else s._c_sol
+                if op is None:
+                    yi = held.pop(i)
+                elif len(op.targets) == 1 and not op.continues:
+                    yi = y1 if i == R - 1 else torch.empty_like(y_cur)
+                    kern.stage_combine_dev(yi, None, y_cur, [k[j] for j in row.idx], row.coef, None, plan)
+                elif op.targets == (i, R) and i == R - 1 and not op.continues and op.idx == row.idx:
+                    yi, held[R] = y1, epart
+                    kern.stage_combine_dev(yi, epart, y_cur, [k[j] for j in row.idx], row.coef, fuse[0], plan)
+                else:
+                    # the step's solution (launch row R - 1) and the partial error go to the static buffers
+                    outs = [y1 if t == R - 1 else (epart if t == R else torch.empty_like(y_cur)) for t in op.targets]
+                    kern.stage_combine_multi_dev(outs, op.spec, y_cur, held.pop(i) if op.continues else None,
+                                                 [k[j] for j in op.idx], plan)
+                    yi = outs[0]
+                    for tgt, buf in zip(op.targets[1:], outs[1:]):
+                        held[tgt] = buf
+                if i < n_rows:
+                    k.append(func.eval_at(self.ts[i], yi))
+            assert held.pop(R) is epart and not held
+            kern.error_norm_partial_ctrl(plan, epart, y_cur, y1, [k[j] for j in carry.err_idx], carry.err_coef, 0.0,
+                                         s._ctrl, self.tbuf, state_in_dev=True)
+            if side == 1:
+                self.f0.copy_(k[-1])
+            self.k[side] = k
+            return
+        for i in range(1, n_rows):
+            row = beta[i]
+            ks = [k[j] for j in row.idx]
+            if i == n_rows - 1 and fsal:
+                yi = y1
+                kern.stage_combine_dev(yi, epart, y_cur, ks, row.coef, fuse[0], plan)
+            else:
+                yi = torch.empty_like(y_cur)
+                kern.stage_combine_dev(yi, None, y_cur, ks, row.coef, None, plan)
+            k.append(func.eval_at(self.ts[i], yi))
+        if not fsal:
+            sol = s._c_sol
+            kern.stage_combine_dev(y1, epart, y_cur, [k[j] for j in sol.idx], sol.coef, fuse[0], plan)
+        kern.error_norm_partial_ctrl(plan, epart, y_cur, y1, [k[j] for j in fuse[1]], fuse[2], 0.0,
+                                     s._ctrl, self.tbuf, state_in_dev=True)
+        if side == 1:
+            self.f0.copy_(k[-1])          # side 0 reads its derivative from a buffer of its own (see the class text)
+        self.k[side] = k
+
+    def run(self, s) -> None:
+        """One trial step from the current side's pair.  The caller flips `side` when the step was accepted."""
+        kern, func = s.kernels, s.func
+        self.calls += 1
+        side = self.side
+        if self.calls == 1:
+            before = _side_effect_fingerprint(func.base_func, s.y0.device) if self.auto else None
+            self._eager_body(s, 0)
+            self.eager = True
+            if self.auto and _side_effect_fingerprint(func.base_func, s.y0.device) != before:
+                self.refuse(s, "evaluating it changed its own attributes, buffers or the device's random-number state "
+                               "(an evaluation counter, a cache, dropout ...), which a replay would not repeat")
+            return
+        self.eager = False
+        if self.graphs[side] is None:
+            graph = torch.cuda.CUDAGraph()
+            nfe = func.nfe
+            # the two sides never run concurrently and keep their own results alive (self.k): one memory pool serves
+            # both captures — the second one reuses the blocks the first one's freed intermediates left behind instead
+            # of paying for fresh device allocations
+            other = self.graphs[1 - side]
+            try:
+                with _capture(graph, pool=None if other is None else other.pool()):
+                    self.body(s, side)
+            except Exception as exc:       # func is not capturable (host sync, unsupported op ...): nothing has run
+                func.nfe = nfe
+                raise _CaptureFailed(repr(exc)) from exc
+            func.nfe = nfe
+            self.graphs[side] = graph
+            if self.auto and not self.probed:
+                self._probe(s, side, graph)
+                func.nfe += len(s._beta)
+                return
+        kern.arm_readback(s.plan)
+        self.graphs[side].replay()
+        func.nfe += len(s._beta)
+
+    def _eager_body(self, s, side: int) -> None:
+        current = torch.cuda.current_stream(s.y0.device)
+        stream = _side_stream(s.y0.device)
+        stream.wait_stream(current)
+        with torch.cuda.stream(stream):
+            self.body(s, side)
+        current.wait_stream(stream)
+
+    def _probe(self, s, side: int, graph) -> None:
+        """Auto mode, once per captured func: the trial step at hand is run TWICE from the same state — evaluated
+        eagerly, then replayed from the fresh graph — and everything a step produces must agree bit for bit: y1, the
+        partial error, the controller's decision words on the host and on the device, the next stage times.  On
+        agreement the replay's results stay in place (they live in the buffers the graphs are wired to).  Otherwise the
+        eager results are put back (`take_words` hands the caller their decision words) — a mismatch costs nothing but
+        the capture: the solve goes on eagerly and `func` is not captured again."""
+        kern, func, plan = s.kernels, s.func, s.plan
+        k_graph = self.k[side]                      # the stage tensors the captured nodes write (the graph's own pool)
+        ctrl0, times0 = plan.ctrl_dev.clone(), self.tbuf.clone()
+        nfe = func.nfe
+        self._eager_body(s, side)
+        func.nfe = nfe
+        accept, dt_next, ratio, bad = kern.read_ctrl(plan)
+        words_e = (accept, dt_next, ratio, list(bad))
+        k_eager = self.k[side]
+        y1_e, ep_e = self.y[1 - side].clone(), self.epart[side].clone()
+        ctrl_e, times_e = plan.ctrl_dev.clone(), self.tbuf.clone()
+        plan.ctrl_dev.copy_(ctrl0)
+        self.tbuf.copy_(times0)
+        self.k[side] = k_graph
+        kern.arm_readback(plan)
+        graph.replay()
+        accept, dt_next, ratio, bad = kern.read_ctrl(plan)
+        flat = lambda w: [float(w[0]), w[1], w[2]] + list(w[3])
+        same = (_same_words(flat((accept, dt_next, ratio, bad)), flat(words_e)) and torch.equal(y1_e, self.y[1 - side])
+                and torch.equal(ep_e, self.epart[side]) and torch.equal(times_e, self.tbuf)
+                and _same_words(ctrl_e.tolist(), plan.ctrl_dev.tolist())
+                and all(torch.equal(a, b) for a, b in zip(k_eager[1:], k_graph[1:])))
+        self.probed = True
+        if not same:
+            self.y[1 - side].copy_(y1_e)
+            self.epart[side].copy_(ep_e)
+            plan.ctrl_dev.copy_(ctrl_e)
+            self.tbuf.copy_(times_e)
+            self.k[side] = k_eager
+            self._words = words_e
+            self.refuse(s, "a replayed trial step did not reproduce the eagerly evaluated one bit for bit (func is not a "
+                           "pure function of t, y and its parameters)")
+
+    def take_words(self, kern, plan):
+        """(accept, dt_next, error_ratio, nonfinite) of the step `run` just took."""
+        words, self._words = getattr(self, "_words", None), None
+        return words if words is not None else kern.read_ctrl(plan)
+
+    def accepted(self, s) -> None:
+        """The step just run was accepted: its end state becomes the next trial step's input pair."""
+        if self.eager:
+            # the warm-up step ran on transient buffers: move its end state into side 0's pair (once per capture)
+            self.y[0].copy_(self.y[1])
+            self.f0.copy_(self.k[0][-1])
+            return
+        self.side = 1 - self.side
+
+
+def clear_graph_cache() -> None:
+    """Drop every captured trial-step graph kept for reuse (options={'hip_graph': True})."""
+    _GraphStep._cache.clear()

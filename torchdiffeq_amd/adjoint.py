@@ -36,7 +36,7 @@ _AUTO_BACKWARD_SEEN = weakref.WeakSet()           # funcs whose backward solve h
 
 def _auto_backward_due(base_func, total: int) -> bool:
     """`hip_graph="auto"` on the adjoint's backward solve: whether capturing is on the table at all for THIS solve — the
-    augmented state is small enough, func has not been refused (solvers._GraphStep.refuse) and this is not the first
+    augmented state is small enough, func has not been refused (_graph._GraphStep.refuse) and this is not the first
     backward solve of func (first solves run eagerly under "auto", like the forward one's).  Only then is the proxy
     check worth its two evaluations of func — which a func that counts its evaluations would see."""
     from .solvers import _GRAPH_AUTO_MAX_ELEMENTS, _GraphStep
@@ -86,7 +86,7 @@ class _AugmentedDynamics(OdeFunc):
                 self.proxy_names = [by_id[id(p)] for p in self.params]
 
     def graph_key(self):
-        """What a captured trial step of these dynamics depends on beyond the user's func (solvers._GraphStep._key)."""
+        """What a captured trial step of these dynamics depends on beyond the user's func (_graph._GraphStep._key)."""
         return ("adjoint", self.fwd.sign, tuple(p.data_ptr() for p in self.params),
                 tuple(tuple(sh) for sh in self.fwd.layout.shapes))
 
