@@ -83,7 +83,7 @@ def test_double_backward_through_the_solver_works(dev):
         vp, vm = [0.3, -0.7], [0.3, -0.7]
         vp[i] += eps
         vm[i] -= eps
-        fd = (grad_at(vp)[1].sum() - grad_at(vm)[1].sum()) / (2 * eps)
+        fd = ((grad_at(vp)[1].sum() - grad_at(vm)[1].sum()) / (2 * eps)).detach()
         assert abs(float(h[i]) - float(fd)) < 1e-6 * max(1.0, abs(float(fd))), (i, float(h[i]), float(fd))
 
 
