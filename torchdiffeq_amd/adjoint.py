@@ -31,7 +31,7 @@ from .odeint import SOLVERS
 import weakref
 
 _PROXY_CHECKED = weakref.WeakKeyDictionary()      # func -> (parameter storages, functional_call VJPs verified)
-_AUTO_BACKWARD_SEEN = weakref.WeakSet()           # funcs whose backward solve has run once under hip_graph="auto"
+_AUTO_BACKWARD_SEEN = weakref.WeakKeyDictionary() # func -> sizes of the augmented states solved once under hip_graph="auto"
 
 
 def _auto_backward_due(base_func, total: int) -> bool:
@@ -45,8 +45,9 @@ def _auto_backward_due(base_func, total: int) -> bool:
     try:
         if base_func in _GraphStep._refused:
             return False
-        if base_func not in _AUTO_BACKWARD_SEEN:
-            _AUTO_BACKWARD_SEEN.add(base_func)
+        seen = _AUTO_BACKWARD_SEEN.setdefault(base_func, set())
+        if total not in seen:           # (per state size: another batch size is a first sight again)
+            seen.add(total)
             return False
     except TypeError:           # not weakly referenceable: never captured across solves anyway
         return False
