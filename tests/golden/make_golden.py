@@ -495,7 +495,14 @@ def gen_backprop():
              ("midpoint_step", "midpoint", [0.0, 0.33, 1.0], dict(step_size=0.1), False),
              ("heun2_perturb", "heun2", [0.0, 0.33, 1.0], dict(step_size=0.1, perturb=True), False),
              ("heun3_cubic", "heun3", [0.0, 0.33, 1.0], dict(step_size=0.1, interp="cubic"), False),
-             ("rk4_cubic_rev", "rk4", [1.0, 0.45, 0.0], dict(step_size=0.125, interp="cubic"), False)]
+             ("rk4_cubic_rev", "rk4", [1.0, 0.45, 0.0], dict(step_size=0.125, interp="cubic"), False),
+             # r04: steps cut short at prescribed points — dt = t_point - t0 moves against t0, t1 = t_point with nothing
+             # (rk_common.py:296-309): the first-step heuristic's / t[0]'s gradient ends there
+             ("dopri5_step_t_first", "dopri5", [0.0, 0.4, 1.0], dict(step_t=[0.013]), False),
+             ("dopri5_step_t_mid", "dopri5", [0.0, 0.4, 1.0], dict(step_t=[0.55]), False),
+             ("bosh3_jump_t_mid", "bosh3", [0.0, 0.4, 1.0], dict(jump_t=[0.55]), False),
+             ("tsit5_tuple_step_jump", "tsit5", [0.0, 0.4, 1.0], dict(step_t=[0.2, 0.8], jump_t=[0.5]), True),
+             ("dopri5_rev_step_t", "dopri5", [1.0, 0.3, 0.0], dict(step_t=[0.6]), False)]
     for tag, method, tt, opts, tup in cases:
         tol = dict(rtol=1e-4, atol=1e-6) if method in ("fehlberg2", "adaptive_heun") else {}
         out = run(method, tt, opts, tup, **tol)

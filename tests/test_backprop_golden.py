@@ -25,7 +25,13 @@ CASES = [("dopri5", "dopri5", None, False, 1e-8), ("dopri8", "dopri8", None, Fal
          ("midpoint_step", "midpoint", dict(step_size=0.1), False, 1e-9),
          ("heun2_perturb", "heun2", dict(step_size=0.1, perturb=True), False, 1e-9),
          ("heun3_cubic", "heun3", dict(step_size=0.1, interp="cubic"), False, 1e-9),
-         ("rk4_cubic_rev", "rk4", dict(step_size=0.125, interp="cubic"), False, 1e-9)]
+         ("rk4_cubic_rev", "rk4", dict(step_size=0.125, interp="cubic"), False, 1e-9),
+         # r04 (found by `tools/fuzz_vs_reference.py hostexact`): a step that ends on a `step_t` / `jump_t` point
+         ("dopri5_step_t_first", "dopri5", dict(step_t=[0.013]), False, 1e-9),
+         ("dopri5_step_t_mid", "dopri5", dict(step_t=[0.55]), False, 1e-9),
+         ("bosh3_jump_t_mid", "bosh3", dict(jump_t=[0.55]), False, 1e-9),
+         ("tsit5_tuple_step_jump", "tsit5", dict(step_t=[0.2, 0.8], jump_t=[0.5]), True, 1e-9),
+         ("dopri5_rev_step_t", "dopri5", dict(step_t=[0.6]), False, 1e-9)]
 
 
 def _problem(z, dev):

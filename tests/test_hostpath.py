@@ -228,3 +228,28 @@ def test_second_order_gradients_with_times_in_the_graph(dev, method, kw):
     tol = 1e-8 if method == "rk4" else 1e-5
     for got, key in ((hx, "hx"), (ht, "ht"), (hW, "hW")):
         assert rel_err(got, z[f"hesst_{method}_{key}"]) < tol, (key, rel_err(got, z[f"hesst_{method}_{key}"]))
+
+
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+@pytest.mark.parametrize("tag", ["fwd", "rev"])
+def test_host_path_tuple_tolerances_are_the_references_flat_vectors(quiet, dname, tag):
+    """misc.py:115-123: a tupled rtol / atol becomes ONE flat vector of the time dtype, so the reference's error ratio
+    of an fp32 state is an fp64 number there (the HIP kernels take the entries per segment, in fp32: rounding-level
+    agreement, tests/test_parity_golden.py).  The host path keeps the reference's forms — a 0-dim tensor or a vector per
+    tolerance, `misc.vector_tolerances` — and reproduces tests/golden/tuple_tol.npz bit for bit, evaluation counts
+    included.  (Found by `tools/fuzz_vs_reference.py vectol` under TDEQ_FUZZ_BACKEND=host, r04.)"""
+    z = load("tuple_tol.npz")
+    A, ya, yb = (T(z[f"tt_{dname}_{k}"]) for k in ("A", "y0a", "y0b"))
+    t = torch.tensor([0.0, 0.7, 2.0], dtype=torch.float64)
+    if tag == "rev":
+        t = t.flip(0)
+    count = [0]
+
+    def f(t_, y_):
+        count[0] += 1
+        return y_[0] @ A.T * torch.cos(t_), -y_[1] * 0.5
+
+    with torch.no_grad():
+        sa, sb = tda.odeint(f, (ya, yb), t, rtol=(1e-5, 1e-3), atol=(1e-7, 1e-4), method="dopri5")
+    assert count[0] == int(z[f"tt_{dname}_{tag}_nfe"])
+    assert torch.equal(sa, T(z[f"tt_{dname}_{tag}_ya"])) and torch.equal(sb, T(z[f"tt_{dname}_{tag}_yb"]))

@@ -644,9 +644,10 @@ elif mode == "vectol":
         if a[0]=='err': continue
         tol=(1e-9 if method!='dopri8' else 1e-6) if dtype==torch.float64 else 2e-5
         if a[2]!=b[2] and dtype==torch.float64 and method!='dopri8': bad+=1; print('NFE',desc,a[2],b[2]); continue
+        exact = os.environ.get("TDEQ_FUZZ_BACKEND") == "host" and not adj    # r04: the host path is the reference's arithmetic
         for i,(p,q) in enumerate(zip(a[1],b[1])):
             d=float((p-q).abs().max()/(p.abs().max()+1e-30))
-            if not d<=tol: bad+=1; print('VALUE',desc,i,d); break
+            if not d<=tol or (exact and (d != 0.0 or a[2] != b[2])): bad+=1; print('VALUE' if not d<=tol else 'BITS',desc,i,d,a[2],b[2]); break
     print('done',n,'bad',bad)
 elif mode == "brow":
     # r04: SURVEY.md §8(b) corners — the solver option `dtype`, states below fp32, func outputs of the wrong shape.  Runs on

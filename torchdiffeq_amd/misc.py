@@ -229,50 +229,56 @@ def component_norm(layout: "StateLayout", n_skip_tail: int = 0):
     return _norm
 
 
-def vector_tolerances(rtol, atol, layout: "StateLayout", device):
-    """`(rtol, atol)` as fp64 tensors over the flat (padded) state when a tolerance is given PER ELEMENT — a tensor /
-    list that broadcasts against a tensor state, or tuple entries that are vectors over their component — else None.
-    The reference needs no code for this: `atol + rtol * max(|y0|, |y1|)` simply broadcasts (misc.py:80-82, the
-    tolerances having become fp64 tensors in rk_common.py:186-187; tuple entries are expanded by misc.py:115-123), and the
-    quotient, the norm and the error ratio are then fp64.  Padding gets (0, 1): quotients there stay finite."""
-    def per_element(tol, shape):
-        t = torch.as_tensor(tol, dtype=torch.float64, device=device)
-        return torch.broadcast_to(t, shape).reshape(-1) if t.numel() > 1 else None
+def vector_tolerances(rtol, atol, layout: "StateLayout", device, dtype=torch.float64, tuple_entries_too=False):
+    """`(rtol, atol)` in the forms the reference's arithmetic sees when a tolerance is given PER ELEMENT — a tensor / list
+    that broadcasts against a tensor state, or tuple entries that are vectors over their component — else None.
+    The reference needs no code for this: `atol + rtol * max(|y0|, |y1|)` simply broadcasts (misc.py:80-82), the
+    tolerances having become tensors of the time dtype W in rk_common.py:186-187 (tuple tolerances: one flat vector,
+    misc.py:115-123).  What type promotion then does depends on WHICH of the two is dimensioned — a 0-dim W tensor
+    times the fp32 state is an fp32 product, a W vector times it a W product — so each tolerance comes back as it is
+    there: a 0-dim tensor, or a vector over the flat (padded) state; the padding gets (0, 1): quotients stay finite.
+    `tuple_entries_too`: also for a tuple of SCALAR entries (the literal host path: the reference's tolerance is a flat
+    W vector then, its error ratio a W number; the HIP kernels take such entries per segment, in the state's type)."""
+    def scalar(tol):
+        return torch.as_tensor(tol, dtype=dtype, device=device).reshape(())      # rk_common.py:186-187
 
-    def is_vector(tol):
-        if isinstance(tol, torch.Tensor):
-            return tol.numel() > 1
-        return isinstance(tol, (list, tuple))
     if not layout.is_tuple:
-        if not (is_vector(rtol) or is_vector(atol)):
+        def form(tol):
+            if isinstance(tol, torch.Tensor):
+                return tol.dim() > 0
+            return isinstance(tol, (list, tuple))
+        if not (form(rtol) or form(atol)):
             return None
         shape = layout.shapes[0]
-        out = []
-        for tol in (rtol, atol):
-            v = per_element(tol, shape) if is_vector(tol) else None
-            out.append(v if v is not None else torch.full((layout.total,), float(torch.as_tensor(tol).reshape(-1)[0]),
-                                                           dtype=torch.float64, device=device))
-        return out[0], out[1]
+        return tuple(torch.broadcast_to(torch.as_tensor(tol, dtype=dtype, device=device), shape).reshape(-1).contiguous()
+                     if form(tol) else scalar(tol) for tol in (rtol, atol))
     # tuple state: a sequence with one entry per component is the ordinary case (scalars: handled per segment by the
     # kernels); only vector ENTRIES need the per-element form
     def entries(tol):
+        if isinstance(tol, torch.Tensor) and tol.dim() == 1 and len(tol) == layout.n_seg:
+            return list(tol)
         if isinstance(tol, (list, tuple)) and len(tol) == layout.n_seg:
             return list(tol)
         return None
     er, ea = entries(rtol), entries(atol)
     has_vec = any(e is not None and any(isinstance(v, torch.Tensor) and v.numel() > 1 for v in e) for e in (er, ea))
-    if not has_vec:
+    if not (has_vec or (tuple_entries_too and (er is not None or ea is not None))):
         return None
-    flat = []
+    out = []
     for tol, ent, pad in ((rtol, er, 0.0), (atol, ea, 1.0)):
-        v = torch.full((layout.total,), pad, dtype=torch.float64, device=device)
-        for i, (off, n) in enumerate(zip(layout.offsets, layout.numels)):
-            e = ent[i] if ent is not None else tol
-            # `torch.as_tensor(tol_).expand(shape.numel())` (misc.py:115-123): a 0-dim / [1] / [n] entry; anything else —
-            # e.g. an entry shaped like its component — raises there, and therefore here
-            v[off:off + n] = torch.as_tensor(e, device=device).to(torch.float64).expand(n)
-        flat.append(v)
-    return flat[0], flat[1]
+        if ent is None:
+            out.append(scalar(tol))
+            continue
+        # `torch.as_tensor(tol_).expand(shape.numel())` (misc.py:115-123): a 0-dim / [1] / [n] entry — a Python float is
+        # an fp32 number at that point (the default dtype) —; anything else, e.g. an entry shaped like its component,
+        # raises there, and therefore here; the pieces are concatenated (promoted) and cast to W
+        pieces = [torch.as_tensor(e, device=device).expand(n) for e, n in zip(ent, layout.numels)]
+        common = functools.reduce(torch.promote_types, [p_.dtype for p_ in pieces])
+        v = torch.full((layout.total,), pad, dtype=dtype, device=device)
+        for p_, off, n in zip(pieces, layout.offsets, layout.numels):
+            v[off:off + n] = p_.to(common).to(dtype)
+        out.append(v)
+    return tuple(out)
 
 
 def empty_solution(ci: "CheckedInputs", like: torch.Tensor):

@@ -169,7 +169,8 @@ class _InitialStepShadow:
         self.segs = [(off, n, rt, at) for off, n, rt, at in lay.segments(*s._seg_tol) if n > 0]
         self.y0, self.f0 = y0, f0
         if s._vec_tol is not None:      # per-element tolerances
-            self.scale = [s._vec_tol[1][off:off + n] + y0[off:off + n].abs() * s._vec_tol[0][off:off + n]
+            part = lambda v, off, n: v if v.dim() == 0 else v[off:off + n]
+            self.scale = [part(s._vec_tol[1], off, n) + y0[off:off + n].abs() * part(s._vec_tol[0], off, n)
                           for off, n, _, _ in self.segs]
         else:
             self.scale = [at + y0[off:off + n].abs() * rt for off, n, rt, at in self.segs]
@@ -262,7 +263,10 @@ class RKAdaptiveStepsizeODESolver:
         # misc.py:80-82): the kernels take one (rtol, atol) per segment, so they are asked for the RAW error and initial-
         # step quantities (tolerances 0 and 1) and the per-element scaling and the norm run as torch ops in fp64, which is
         # also the reference's precision for this case.  Routed like a user norm: host-driven steps, no captured graphs.
-        self._vec_tol = vector_tolerances(rtol, atol, self.layout, y0.device)
+        self.kernels = _native.get_kernels(y0.device, y0.dtype)
+        self._vec_tol = vector_tolerances(rtol, atol, self.layout, y0.device, self.dtype,
+                                          tuple_entries_too=getattr(self.kernels, "literal_norms", False)
+                                          and dist_sync is None)
         if self._vec_tol is not None:
             rtol, atol = 0.0, 1.0
             if isinstance(self.norm, BuiltinNorm):
@@ -279,7 +283,6 @@ class RKAdaptiveStepsizeODESolver:
         self.step_t = None if step_t is None else torch.as_tensor(step_t, dtype=self.dtype).reshape(-1).tolist()
         self.jump_t = None if jump_t is None else torch.as_tensor(jump_t, dtype=self.dtype).reshape(-1).tolist()
 
-        self.kernels = _native.get_kernels(y0.device, y0.dtype)
         self.ops = Ops(self.kernels, self.np_dtype)      # elementwise kernels, differentiable when grad is needed
         self.plan = self.kernels.make_plan(self.layout.segments(rtol, atol), self.layout.total,
                                            self.layout.chunk, y0.device)
@@ -290,6 +293,7 @@ class RKAdaptiveStepsizeODESolver:
             raise NotImplementedError("lock-step sharded solves need a builtin norm (a user norm callable reduces "
                                       "only this rank's rows)")
         self._anchor = None        # t[0] (solver time) when `t` requires grad: every step time moves with it
+        self._t_grad = False       # `t` requires grad (output times carry their own gradient)
         tab = self.tableau
         self._beta = tab.beta_rows()
         self._c_err = SparseRow.from_dense(tab.c_error)
@@ -433,7 +437,7 @@ class RKAdaptiveStepsizeODESolver:
             # backprop through the solver: rows are autograd nodes, assembled by a differentiable stack
             rows = [self.y0]
             for i in range(1, len(t_host)):
-                rows.append(self._advance(t_host[i], None, t[i] if self._anchor is not None else None))
+                rows.append(self._advance(t_host[i], None, t[i] if self._t_grad else None))
             return torch.stack(rows, dim=0)
         solution = torch.empty(len(t_host), self.layout.total, dtype=self.y0.dtype, device=self.y0.device)
         solution[0].copy_(self.y0)
@@ -457,7 +461,10 @@ class RKAdaptiveStepsizeODESolver:
         return solution
 
     def _set_time_anchor(self, t: torch.Tensor) -> None:
-        self._anchor = t[0] if (torch.is_grad_enabled() and t.requires_grad) else None
+        self._t_grad = torch.is_grad_enabled() and t.requires_grad
+        # (the anchor can be lost on the way — a step ending on a `step_t` / `jump_t` point starts the next one at a
+        # constant —, the output times keep their own gradient: `_t_grad`)
+        self._anchor = t[0] if self._t_grad else None
         self.func.set_time_anchor(self._anchor)
 
     def _differentiable(self) -> bool:
@@ -563,9 +570,9 @@ class RKAdaptiveStepsizeODESolver:
     def _select_initial_step(self, t0: float, y0: torch.Tensor, f0: torch.Tensor) -> float:
         """Hairer II.4 starting step (misc.py:36-77), scalars in the state precision T."""
         T = self.np_dtype
-        # per-element tolerances are fp64 tensors: the heuristic's norms and everything formed from them promote to fp64
+        # per-element tolerances are W tensors: the heuristic's norms and everything formed from them promote to W
         # (misc.py:50-77 on tensors), only the constant 1e-6 floors stay in the state's type
-        S = np.float64 if self._vec_tol is not None else T
+        S = self._W if self._vec_tol is not None and not is_low(self._W) else T
         kern, plan = self.kernels, self.plan
         order = self.order - 1   # the reference passes `self.order - 1` (rk_common.py:217)
         # Values come from the kernels on detached data; when the solve is differentiated, the SAME formulas are
@@ -585,7 +592,7 @@ class RKAdaptiveStepsizeODESolver:
             q0, q1 = torch.empty_like(y0), torch.empty_like(y0)
             kern.init_scaled(plan, 0, y0, f0, y0, q0, q1)
             if self._vec_tol is not None:
-                vec_scale = self._vec_tol[1] + y0.abs() * self._vec_tol[0]      # misc.py:50, per element, fp64
+                vec_scale = self._vec_tol[1] + y0.abs() * self._vec_tol[0]      # misc.py:50, promoted as there
                 q0, q1 = q0 / vec_scale, q1 / vec_scale
             with torch.no_grad():
                 d0, d1 = S(_norm_value(self.norm(q0))), S(_norm_value(self.norm(q1)))
@@ -726,9 +733,11 @@ class RKAdaptiveStepsizeODESolver:
             if rec.anchor is not None:
                 num = num - (rec.anchor - rec.anchor.detach())
             x_shadow = num / width
-        elif rec.anchor is not None:
-            # x = (t - t0_step) / (t1_step - t0_step): the step boundaries move with the anchor, the width is a constant
-            x_shadow = ((t_shadow if t_shadow is not None else 0.0) - rec.anchor) / (rec.t1 - rec.t0)
+        elif rec.anchor is not None or t_shadow is not None:
+            # x = (t - t0_step) / (t1_step - t0_step): the step boundaries move with the anchor (if any), the width is a
+            # constant
+            x_shadow = ((t_shadow if t_shadow is not None else 0.0) - (rec.anchor if rec.anchor is not None else 0.0)) \
+                / (rec.t1 - rec.t0)
         mid = self._c_mid
         return self.ops.dense_eval(rec.y0, rec.y1, rec.k, mid.idx, mid.coef, rec.dt_signed, x,
                                    dt_shadow=rec.dt_shadow, x_shadow=x_shadow, out=out)
@@ -769,8 +778,17 @@ class RKAdaptiveStepsizeODESolver:
         ops = self.ops
         row0 = self._beta[0]
         plain = not (torch.is_grad_enabled() and (y0.requires_grad or f0.requires_grad or self._anchor is not None))
-        # graph of this trial's step size: only the first, heuristic one has any (the controller is under no_grad)
-        dsh, self._dt_shadow = (None if plain or on_step_t or on_jump_t else self._dt_shadow), None
+        # graph of this trial's step size: the first, heuristic one has one (the controller is under no_grad) — and a
+        # step cut short at a `step_t` / `jump_t` point: dt = t_point - t0 (rk_common.py:296-309) moves AGAINST whatever t0
+        # moves with (the first step size, t[0] when `t` requires grad), and t1 = t_point with nothing any more
+        clipped = on_step_t or on_jump_t
+        if plain:
+            dsh = None
+        elif clipped:
+            dsh = None if self._anchor is None else -self._anchor
+        else:
+            dsh = self._dt_shadow
+        self._dt_shadow = None
         dsh_signed = None if dsh is None else dsh * func.sign
         lookahead = (self._lookahead and plain and func.callback_step is _null
                      and func.callback_accept_step is _null and func.callback_reject_step is _null)
@@ -919,8 +937,9 @@ class RKAdaptiveStepsizeODESolver:
             rec.dt_shadow, rec.anchor = dsh_signed, self._anchor
             self._dense = rec
             if dsh is not None:
-                # every later time of the solve is t0 + dt0 + constants: it moves with the first step size
-                self._anchor = dsh if self._anchor is None else self._anchor + dsh
+                # every later time of the solve is t0 + dt0 + constants: it moves with the first step size — until a
+                # step ends on a prescribed point, a constant
+                self._anchor = None if clipped else (dsh if self._anchor is None else self._anchor + dsh)
                 func.set_time_anchor(self._anchor)
             if on_step_t and self.next_step_index != len(self._step_t) - 1:
                 self.next_step_index += 1
@@ -952,7 +971,7 @@ class RKAdaptiveStepsizeODESolver:
         return (func.callback_step is _null and func.callback_accept_step is _null
                 and func.callback_reject_step is _null
                 and not (torch.is_grad_enabled() and (self.y1.requires_grad or self.f1.requires_grad
-                                                      or self._anchor is not None)))
+                                                      or self._anchor is not None or self._t_grad)))
 
     def _graph_trial_step(self) -> None:
         """One trial step as ONE hipGraph replay (`options={'hip_graph': True}`; small states, where a step costs
