@@ -502,7 +502,9 @@ def gen_backprop():
              ("dopri5_step_t_mid", "dopri5", [0.0, 0.4, 1.0], dict(step_t=[0.55]), False),
              ("bosh3_jump_t_mid", "bosh3", [0.0, 0.4, 1.0], dict(jump_t=[0.55]), False),
              ("tsit5_tuple_step_jump", "tsit5", [0.0, 0.4, 1.0], dict(step_t=[0.2, 0.8], jump_t=[0.5]), True),
-             ("dopri5_rev_step_t", "dopri5", [1.0, 0.3, 0.0], dict(step_t=[0.6]), False)]
+             ("dopri5_rev_step_t", "dopri5", [1.0, 0.3, 0.0], dict(step_t=[0.6]), False),
+             # the heuristic first step clamped to min_step: `dt.clamp(...)` is a constant there (rk_common.py:271)
+             ("bosh3_min_step", "bosh3", [0.0, 0.4, 1.0], dict(min_step=0.5), False)]
     for tag, method, tt, opts, tup in cases:
         tol = dict(rtol=1e-4, atol=1e-6) if method in ("fehlberg2", "adaptive_heun") else {}
         out = run(method, tt, opts, tup, **tol)

@@ -31,7 +31,8 @@ CASES = [("dopri5", "dopri5", None, False, 1e-8), ("dopri8", "dopri8", None, Fal
          ("dopri5_step_t_mid", "dopri5", dict(step_t=[0.55]), False, 1e-9),
          ("bosh3_jump_t_mid", "bosh3", dict(jump_t=[0.55]), False, 1e-9),
          ("tsit5_tuple_step_jump", "tsit5", dict(step_t=[0.2, 0.8], jump_t=[0.5]), True, 1e-9),
-         ("dopri5_rev_step_t", "dopri5", dict(step_t=[0.6]), False, 1e-9)]
+         ("dopri5_rev_step_t", "dopri5", dict(step_t=[0.6]), False, 1e-9),
+         ("bosh3_min_step", "bosh3", dict(min_step=0.5), False, 1e-9)]      # heuristic first step clamped: a constant
 
 
 def _problem(z, dev):

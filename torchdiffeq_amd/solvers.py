@@ -748,6 +748,8 @@ class RKAdaptiveStepsizeODESolver:
         y0, f0, t0, dt = self.y1, self.f1, self.t1, self.dt
         if not math.isfinite(dt):
             dt = self.min_step
+        if self._dt_shadow is not None and not self.min_step <= dt <= self.max_step:
+            self._dt_shadow = None          # `dt.clamp(min_step, max_step)` (rk_common.py:271): a constant outside the range
         dt = _clamp(dt, self.min_step, self.max_step)
         if func.callback_step is not _null:
             func.callback_step(self._time_tensor(t0), y0, self._time_tensor(dt))
