@@ -735,6 +735,8 @@ elif mode == "hostexact":
             elif r < 0.4: opts['safety'] = 0.8
             elif r < 0.5 and not rev: opts['step_t'] = torch.tensor([float(t.min()) + 0.013])
             elif r < 0.6 and not rev: opts['jump_t'] = torch.tensor([float(t.min()) + 0.021])
+            elif r < 0.66 and not rev: opts['step_t'] = torch.tensor([float(t.min()) + 0.4 * float(t.max() - t.min())])
+            elif r < 0.72 and not low: opts['min_step'] = 0.3
             if rng.random() < 0.25: opts['dtype'] = rng.choice([torch.float32, torch.float64])
         else:
             if rng.random() < 0.5: opts['step_size'] = 0.0625
