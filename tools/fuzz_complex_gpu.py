@@ -24,6 +24,7 @@ rng = random.Random(seed)
 warnings.simplefilter("ignore")
 DEV = os.environ.get("FUZZ_DEV", "cuda")
 REAL = os.environ.get("FUZZ_REAL", "0") == "1"
+BACKPROP = os.environ.get("FUZZ_BACKPROP", "0") == "1"      # half of the non-adjoint cases differentiate through the solver
 NL = (lambda y: 0.1 * torch.tanh(y) * y.abs()) if REAL else (lambda y: 0.1j * y * y.abs())
 host = _fallback.KernelOrderHostKernels()
 orig_get = _native.get_kernels
@@ -72,6 +73,7 @@ for case in range(n_cases):
             opts["perturb"] = True
     rtol, atol = (1e-5, 1e-7) if cdt == torch.complex64 else (1e-8, 1e-10)
     lookahead = rng.random() < 0.7
+    backprop = BACKPROP and not adjoint and rng.random() < 0.5
     if os.environ.get("FUZZ_ONLY_CASE") and case != int(os.environ["FUZZ_ONLY_CASE"]):
         continue                      # (replay of one case: the random stream above is consumed identically)
     res = []
@@ -79,16 +81,24 @@ for case in range(n_cases):
         _native.get_kernels = orig_get if which == "hip" else (lambda device, dtype=None: host)
         os.environ["TDEQ_LOOKAHEAD"] = "1" if (lookahead or which == "host") else "0"
         nfe = [0]
-        wp = w.clone().requires_grad_(adjoint)
+        wp = w.clone().requires_grad_(adjoint or backprop)
 
         def f(tt, y):
             nfe[0] += 1
             if is_tuple:
                 return (-y[0] * wp * (1 + 0.2 * tt) + NL(y[0]), -0.4 * y[1] * (1 + y[0].abs().mean().to(y[1].dtype)))
             return -y * wp * (1 + 0.2 * tt) + NL(y)
-        x = y0.clone().requires_grad_(adjoint)
+        x = y0.clone().requires_grad_(adjoint or backprop)
         try:
-            if adjoint:
+            if backprop:
+                # backprop THROUGH the solver (autodiff._LinearOp nodes over the kernels), output times in the graph too
+                tg = t.clone().requires_grad_(True)
+                out = tda.odeint(f, (x, yb) if is_tuple else x, tg, method=method, rtol=rtol, atol=atol,
+                                 options={k: v for k, v in opts.items() if k != "hip_graph"})
+                y = out[0] if is_tuple else out
+                (y[-1].abs().pow(2).sum() + y[len(t) // 2].abs().sum()).backward()
+                res.append(("ok", [y.detach(), x.grad, wp.grad, tg.grad], nfe[0]))
+            elif adjoint:
                 o = {k: v for k, v in opts.items() if k != "hip_graph"}
                 out = tda.odeint_adjoint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=o,
                                          adjoint_params=(wp,))
@@ -103,7 +113,7 @@ for case in range(n_cases):
             res.append(("err", type(e).__name__ + ": " + str(e)[:90], 0))
     _native.get_kernels = orig_get
     a, b = res
-    desc = (case, method, str(cdt)[6:], shape, is_tuple, adjoint, rev, lookahead, {k: (v if not torch.is_tensor(v) else "t") for k, v in opts.items()})
+    desc = (case, method, str(cdt)[6:], shape, is_tuple, 'backprop' if backprop else adjoint, rev, lookahead, {k: (v if not torch.is_tensor(v) else "t") for k, v in opts.items()})
     if a[0] != b[0]:
         bad += 1
         print("STATUS", desc, a[1] if a[0] == "err" else "ok", "|", b[1] if b[0] == "err" else "ok")
@@ -116,7 +126,11 @@ for case in range(n_cases):
         print("NFE", desc, a[2], b[2])
         continue
     exact = method in FIXED and method != "implicit_adams"
-    tol = (1e-9 if adjoint else 1e-12) if rdt == torch.float64 else (2e-4 if adjoint else 3e-5)
+    tol = (1e-9 if (adjoint or backprop) else 1e-12) if rdt == torch.float64 else (2e-4 if (adjoint or backprop) else 3e-5)
+    if method == "dopri8":
+        tol = max(tol, 1e-6)    # a noise-dominated 9-term error estimate turns ONE ulp of a norm sum into 1e-3 of a step
+                                # size (the complex norm kernel adds re^2 + im^2 in double, the torch twin
+                                # squares a rounded modulus) — equal evaluation counts are still required above
     for i, (p, q) in enumerate(zip(a[1], b[1])):
         fin_p, fin_q = torch.isfinite(torch.view_as_real(p) if p.is_complex() else p), \
             torch.isfinite(torch.view_as_real(q) if q.is_complex() else q)
@@ -127,7 +141,7 @@ for case in range(n_cases):
                 break
             p, q = torch.where(torch.isfinite(p.abs()), p, 0), torch.where(torch.isfinite(q.abs()), q, 0)   # both blew up alike
         d = float((p - q).abs().max() / (q.abs().max() + 1e-30))
-        if (exact and not adjoint and d != 0.0) or not d <= tol:
+        if (exact and not adjoint and not backprop and d != 0.0) or not d <= tol:
             bad += 1
             print("VALUE", desc, i, d)
             break
