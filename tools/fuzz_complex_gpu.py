@@ -99,12 +99,24 @@ for case in range(n_cases):
                 (y[-1].abs().pow(2).sum() + y[len(t) // 2].abs().sum()).backward()
                 res.append(("ok", [y.detach(), x.grad, wp.grad, tg.grad], nfe[0]))
             elif adjoint:
-                o = {k: v for k, v in opts.items() if k != "hip_graph"}
-                out = tda.odeint_adjoint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=o,
-                                         adjoint_params=(wp,))
+                # with `hip_graph`: func as an nn.Module, so that the BACKWARD solve is captured as well (forward and
+                # augmented trial steps replayed; the torch twin runs both eagerly)
+                class Field(torch.nn.Module):
+                    def __init__(self):
+                        super().__init__()
+                        self.w = torch.nn.Parameter(w.clone())
+
+                    def forward(self, tt, y):
+                        if is_tuple:
+                            return (-y[0] * self.w * (1 + 0.2 * tt) + NL(y[0]),
+                                    -0.4 * y[1] * (1 + y[0].abs().mean().to(y[1].dtype)))
+                        return -y * self.w * (1 + 0.2 * tt) + NL(y)
+                field = Field()
+                o = dict(opts) if which == "hip" else {k: v for k, v in opts.items() if k != "hip_graph"}
+                out = tda.odeint_adjoint(field, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=o)
                 y = out[0] if is_tuple else out
                 y[-1].abs().pow(2).sum().backward()
-                res.append(("ok", [y.detach(), x.grad, wp.grad], nfe[0]))
+                res.append(("ok", [y.detach(), x.grad, field.w.grad], nfe[0]))
             else:
                 with torch.no_grad():
                     out = tda.odeint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=dict(opts))
