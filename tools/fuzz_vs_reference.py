@@ -742,6 +742,7 @@ elif mode == "hostexact":
             if rng.random() < 0.5: opts['step_size'] = 0.0625
             if rng.random() < 0.3: opts['interp'] = 'cubic'
             if rng.random() < 0.3: opts['perturb'] = True
+        t_grad = rng.random() < 0.5
         res = []
         for L in (ref, tda):
             nfe = [0]
@@ -751,17 +752,18 @@ elif mode == "hostexact":
                 if is_tuple: return (-y[0] * w * (1 + 0.2 * tt) + 0.1 * torch.sin(y[0]), -0.4 * y[1] * (1 + y[0].abs().mean().to(y[1].dtype)))
                 return -y * w * (1 + 0.2 * tt) + 0.1 * torch.sin(y)
             x = y0.clone().requires_grad_(grad is not None)
+            tt = t.clone().requires_grad_(True) if (grad and t_grad) else t       # the output times in the graph as well
             try:
                 if grad == 'adjoint':
-                    out = L.odeint_adjoint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=dict(opts), adjoint_params=(w,))
+                    out = L.odeint_adjoint(f, (x, yb) if is_tuple else x, tt, method=method, rtol=rtol, atol=atol, options=dict(opts), adjoint_params=(w,))
                 elif grad == 'backprop':
-                    out = L.odeint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=dict(opts))
+                    out = L.odeint(f, (x, yb) if is_tuple else x, tt, method=method, rtol=rtol, atol=atol, options=dict(opts))
                 else:
                     with torch.no_grad(): out = L.odeint(f, (x, yb) if is_tuple else x, t, method=method, rtol=rtol, atol=atol, options=dict(opts))
                 o = out[0] if is_tuple else out
                 vals = [o.detach()] + ([out[1].detach()] if is_tuple else [])
                 if grad:
-                    o[-1].pow(2).sum().backward(); vals += [x.grad, w.grad]
+                    (o[-1].pow(2).sum() + o[len(t) // 2].sum()).backward(); vals += [x.grad, w.grad] + ([tt.grad] if t_grad else [])
                 res.append(('ok', vals, nfe[0]))
             except Exception as e:
                 res.append(('err', type(e).__name__ + ': ' + str(e)[:60], 0))
@@ -772,7 +774,7 @@ elif mode == "hostexact":
         cmp = a[1] if grad != 'backprop' else a[1][:n_fwd]      # values to rounding, a different accumulation order of the cotangents
         exact = all(torch.equal(torch.view_as_real(p) if p.is_complex() else p, torch.view_as_real(q) if q.is_complex() else q) for p, q in zip(cmp, b[1]))
         if exact and grad == 'backprop':
-            exact = all(float((p - q).abs().max()) <= (1e-5 if rdt == torch.float32 else 1e-12) * float(p.abs().max() + 1e-30) for p, q in zip(a[1][n_fwd:], b[1][n_fwd:]))
+            exact = all(float((p - q).abs().max()) <= (1e-4 if rdt == torch.float32 else 1e-12) * float(p.abs().max() + 1e-30) for p, q in zip(a[1][n_fwd:], b[1][n_fwd:]))       # (fp32: the time gradient is a cancelling dot product over the state)
         if a[2] != b[2] or not exact:
             bad += 1; print('BITS', desc, a[2], b[2], [float((p - q).abs().max() / (p.abs().max() + 1e-30)) for p, q in zip(a[1], b[1])])
     print('done', n, 'bad', bad)
