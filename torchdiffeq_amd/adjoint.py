@@ -330,8 +330,13 @@ class OdeintAdjointMethod(torch.autograd.Function):
                 if t_requires_grad:
                     # effect of moving the measurement time t_i (adjoint.py:125-131)
                     func_eval = fwd.eval(t_host[i], y[i])
-                    dLd_cur_t = sum((fv.reshape(-1) * gv.reshape(-1)).sum() for fv, gv in
-                                    zip(fwd_layout.unpack(func_eval), fwd_layout.unpack(grad_y[i])))
+                    # ONE dot product over the state as the reference sees it — a tuple state is a single flat vector
+                    # there (adjoint.py:200-201) —: the same ATen reduction, hence the same last bit
+                    fe, gy = fwd_layout.unpack(func_eval), fwd_layout.unpack(grad_y[i])
+                    if len(fe) == 1:
+                        dLd_cur_t = fe[0].reshape(-1).dot(gy[0].reshape(-1))
+                    else:
+                        dLd_cur_t = torch.cat([v.reshape(-1) for v in fe]).dot(torch.cat([v.reshape(-1) for v in gy]))
                     if fwd.sign != 1.0:
                         dLd_cur_t = dLd_cur_t * fwd.sign
                     if sync is not None:
