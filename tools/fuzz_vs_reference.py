@@ -743,6 +743,14 @@ elif mode == "hostexact":
             if rng.random() < 0.3: opts['interp'] = 'cubic'
             if rng.random() < 0.3: opts['perturb'] = True
         t_grad = rng.random() < 0.5
+        adj_kw = {}
+        if grad == 'adjoint':
+            r = rng.random()
+            if r < 0.2: adj_kw['adjoint_options'] = dict(norm='seminorm')
+            elif r < 0.35: adj_kw.update(adjoint_rtol=rtol * 10, adjoint_atol=atol * 10)
+            elif r < 0.5 and method in ADAPT: adj_kw.update(adjoint_method=rng.choice(['bosh3', 'dopri5', 'rk4']), adjoint_options=dict())
+            elif r < 0.6 and is_tuple: adj_kw.update(adjoint_rtol=(rtol, rtol * 3, rtol, rtol * 10), adjoint_atol=atol)
+            if adj_kw.get('adjoint_method') == 'rk4': adj_kw['adjoint_options'] = dict(step_size=0.05)
         res = []
         for L in (ref, tda):
             nfe = [0]
@@ -755,7 +763,7 @@ elif mode == "hostexact":
             tt = t.clone().requires_grad_(True) if (grad and t_grad) else t       # the output times in the graph as well
             try:
                 if grad == 'adjoint':
-                    out = L.odeint_adjoint(f, (x, yb) if is_tuple else x, tt, method=method, rtol=rtol, atol=atol, options=dict(opts), adjoint_params=(w,))
+                    out = L.odeint_adjoint(f, (x, yb) if is_tuple else x, tt, method=method, rtol=rtol, atol=atol, options=dict(opts), adjoint_params=(w,), **adj_kw)
                 elif grad == 'backprop':
                     out = L.odeint(f, (x, yb) if is_tuple else x, tt, method=method, rtol=rtol, atol=atol, options=dict(opts))
                 else:
@@ -767,7 +775,7 @@ elif mode == "hostexact":
                 res.append(('ok', vals, nfe[0]))
             except Exception as e:
                 res.append(('err', type(e).__name__ + ': ' + str(e)[:60], 0))
-        a, b = res; desc = (case, method, str(dtype)[6:], shape, is_tuple, rev, grad, {k: (str(v)[6:] if k == 'dtype' else ('t' if torch.is_tensor(v) else v)) for k, v in opts.items()})
+        a, b = res; desc = (case, method, str(dtype)[6:], shape, is_tuple, rev, grad, sorted(adj_kw), {k: (str(v)[6:] if k == 'dtype' else ('t' if torch.is_tensor(v) else v)) for k, v in opts.items()})
         if a[0] != b[0] or (a[0] == 'err' and a[1] != b[1]): bad += 1; print('STATUS', desc, a[1] if a[0] == 'err' else 'ok', '|', b[1] if b[0] == 'err' else 'ok'); continue
         if a[0] == 'err': continue
         n_fwd = 2 if is_tuple else 1            # backprop gradients come from a hand-written backward (autodiff._LinearOp): same
