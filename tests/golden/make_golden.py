@@ -1235,10 +1235,66 @@ def gen_brow():
     save("brow.npz", **arrays)
 
 
+def gen_r4b():
+    """Found by the program-level differential runs of round 4b (tools/fuzz_programs_vs_reference.py,
+    tools/fuzz_api_programs_vs_reference.py): 16-bit states under EVERY explicit fixed-grid method, also on a 16-bit time
+    grid (solvers.py:108-126 with t.dtype bf16 / fp16; rk_common.py:110-157 — Python weights are second operands);
+    callbacks see a tensor state in its own shape (misc.py:313-333 wraps only tuple states); cubic interpolation
+    evaluates func at the step end once per output time (solvers.py:119-122)."""
+    arrays = {}
+    A2 = torch.tensor([[-0.1, 2.0, 0.3], [-2.0, -0.1, 0.0], [0.2, 0.1, -0.5]])
+    y0 = torch.tensor([[2.0, 0.0, 0.3], [1.0, 1.0, -1.0]])
+    arrays["low_A"], arrays["low_y0"] = A2, y0
+    for lname, ldtype in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        for tname, tdtype in (("t32", torch.float32), ("tlow", ldtype)):
+            for method in ("euler", "midpoint", "heun2", "heun3", "rk4"):
+                for oname, opts in (("plain", {}), ("cubic", dict(step_size=0.13, interp="cubic")),
+                                    ("perturb", dict(perturb=True))):
+                    for dname, tv in (("fwd", [0.0, 0.3, 0.55, 1.0]), ("rev", [1.0, 0.55, 0.3, 0.0])):
+                        t = torch.tensor(tv).to(tdtype)
+                        Al = A2.to(ldtype)
+                        y, nfe, _ = solve(lambda t_, y_: y_ @ Al.T - y_ * 0.5 * torch.cos(t_).to(y_.dtype),
+                                          y0.to(ldtype), t, method=method, options=dict(opts))
+                        assert y.dtype == ldtype
+                        key = f"lowgrid_{lname}_{tname}_{method}_{oname}_{dname}"
+                        arrays[key + "_y"], arrays[key + "_nfe"] = y.float(), nfe
+
+    # callback arguments: a [2, 3] tensor state, both directions
+    for method, opts in (("dopri5", {}), ("rk4", dict(step_size=0.25))):
+        for dname, tv in (("fwd", [0.0, 0.5, 1.0]), ("rev", [1.0, 0.5, 0.0])):
+            seen = []
+
+            class CbField(torch.nn.Module):
+                def forward(self, t, y):
+                    return y @ A2.T * torch.cos(t)
+
+                def callback_step(self, t0, y_, dt):
+                    seen.append(("step", tuple(y_.shape), float(t0), float(dt), float(y_.sum())))
+
+                def callback_accept_step(self, t0, y_, dt):
+                    seen.append(("accept", tuple(y_.shape), float(t0), float(dt), float(y_.sum())))
+            torchdiffeq.odeint(CbField(), y0, torch.tensor(tv), method=method, rtol=1e-4, atol=1e-6, options=dict(opts))
+            key = f"cb_{method}_{dname}"
+            arrays[key + "_kind"] = np.array([s[0] for s in seen])
+            arrays[key + "_shape"] = np.array([s[1] for s in seen])
+            arrays[key + "_vals"] = np.array([s[2:] for s in seen])
+
+    # evaluation times of a cubic-interpolated fixed-grid solve with several output times per step
+    calls = []
+
+    def counted(t_, y_):
+        calls.append(float(t_))
+        return -y_ * (1.0 + t_)
+    y = torchdiffeq.odeint(counted, y0, torch.tensor([0.0, 0.1, 0.2, 0.25, 0.7, 1.0]), method="heun2",
+                           options=dict(step_size=0.5, interp="cubic"))
+    arrays["cubic_calls"], arrays["cubic_y"] = np.array(calls), y
+    save("r4b.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
                      ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
-                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin), ("dropin", gen_dropin), ("brow", gen_brow)]:
+                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin), ("dropin", gen_dropin), ("brow", gen_brow), ("r4b", gen_r4b)]:
         if not only or name in only:
             fn()

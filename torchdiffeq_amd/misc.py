@@ -504,13 +504,8 @@ def combine_event_functions(event_fn, t0, y0):
     """event_handling.py:23-35: make every component of a multivariate event function initially positive
     and combine them with a min, so one sign change of the combined scalar marks the first event."""
     with torch.no_grad():
-        initial_signs = torch.sign(event_fn(t0, y0))
-
-    def combined_event_fn(t, y):
-        c = event_fn(t, y)
-        return torch.min(c * initial_signs)
-
-    return combined_event_fn
+        orientation = event_fn(t0, y0).sign()
+    return lambda t, y: torch.min(event_fn(t, y) * orientation)
 
 
 def find_event(interp_fn, sign0, t0, t1, event_fn, tol: float, time_tensor, scalar=np.float64):
@@ -653,6 +648,10 @@ def check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS) ->
         if is_tuple:
             def callback(t0, y0, dt, _callback=callback, _lay=layout):
                 return _callback(t0, _lay.unpack(y0), dt)
+        elif len(shapes[0]) != 1:
+            # a tensor state reaches the user's callback in ITS shape (the reference never flattens it)
+            def callback(t0, y0, dt, _callback=callback, _shape=shapes[0]):
+                return _callback(t0, y0.view(_shape), dt)
         if t_is_reversed:
             def callback(t0, y0, dt, _callback=callback):
                 return _callback(-t0, y0, dt)

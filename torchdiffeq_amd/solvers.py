@@ -1081,6 +1081,17 @@ class AdaptiveHeunSolver(RKAdaptiveStepsizeODESolver):
 # ---------------------------------------------------------------------------------------------------
 # Fixed grid
 # ---------------------------------------------------------------------------------------------------
+def _host_times(times: torch.Tensor):
+    """A time tensor as host scalars that round like its 0-dim elements (`_scalars`): a numpy array for fp32 / fp64
+    (its scalar type does IEEE arithmetic in the type itself), a list of `BFloat16Scalar` / `Float16Scalar` for the
+    16-bit types numpy cannot hold or would not round like ATen.  Returns (sequence, scalar type)."""
+    low = scalar_type(times.dtype) if times.dtype in (torch.bfloat16, torch.float16) else None
+    if low is None:
+        host = times.detach().cpu().numpy()
+        return host, host.dtype.type
+    return [low(v) for v in times.detach().float().cpu().tolist()], low
+
+
 def _uniform_grid(t: torch.Tensor, step_size) -> torch.Tensor:
     """Points t[0] + i·step_size covering [t[0], t[-1]], the last one moved onto t[-1] exactly.  Formed with tensor
     arithmetic in t.dtype on t.device — the point count ceil(span / step_size + 1) and every grid value must round as
@@ -1156,6 +1167,8 @@ class FixedGridODESolver(object):
         """`dt * c` as the reference forms it: a 0-dim tensor dt times a Python float is rounded in the
         grid dtype with c rounded first; a Python-float dt (event mode, solvers.py:134) multiplies in double
         and is rounded when it meets the time tensor."""
+        if is_low(type(dt)):
+            return dt * c                   # a 16-bit 0-dim tensor times a Python number: the number at fp32, one rounding
         if isinstance(dt, float):
             return scalar(dt * c)
         return scalar(dt * scalar(c))
@@ -1184,9 +1197,8 @@ class FixedGridODESolver(object):
                               "heun2, heun3, rk4), the output times as the grid, linear interpolation, no callback, no "
                               "autograd graph and a ROCm device; running the eager path".format(self.__class__.__name__))
         # host copies, in the grid's own dtype (dt = t1 - t0 is formed in t.dtype: solvers.py:112)
-        grid = time_grid.detach().cpu().numpy()
-        tt = t.detach().cpu().numpy()
-        scalar = grid.dtype.type
+        grid, scalar = _host_times(time_grid)
+        tt, _ = _host_times(t)
         linear = self.interp == "linear"
         grad_mode = torch.is_grad_enabled()
         time_grad = grad_mode and (time_grid.requires_grad or t.requires_grad)
@@ -1200,7 +1212,8 @@ class FixedGridODESolver(object):
         for n, (t0, t1) in enumerate(zip(grid[:-1], grid[1:])):
             dt = scalar(t1 - t0)
             if has_cb:
-                func.callback_step(torch.tensor(t0, device=self.device), y0, torch.tensor(dt, device=self.device))
+                func.callback_step(torch.tensor(t0, dtype=time_grid.dtype, device=self.device), y0,
+                                   torch.tensor(dt, dtype=time_grid.dtype, device=self.device))
             sh = _StepShadow(time_grid[n], time_grid[n + 1], sign) if time_grad else _NO_SHADOW
             # Without a graph, y1 goes straight into the output row when the grid point is an output time.
             differentiable = grad_mode and (time_grad or y0.requires_grad)
@@ -1213,7 +1226,6 @@ class FixedGridODESolver(object):
             y1, f0 = self._step(t0, dt, t1, y0, y1_out, sh)
             differentiable = differentiable or (grad_mode and y1.requires_grad)
 
-            f1 = None
             while j < len(tt) and t1 >= tt[j]:
                 tj_shadow = t[j] if time_grad else None
                 if linear:
@@ -1226,8 +1238,9 @@ class FixedGridODESolver(object):
                         rows[j] = ops.lerp(y0, y1, float(slope), sh.fraction(tj_shadow),
                                            out=None if differentiable or solution is None else solution[j])
                 else:
-                    if f1 is None:
-                        f1 = func.eval(t1, y1, shadow=sh.time(1.0))    # solvers.py:121, once per interval hit
+                    # solvers.py:121: evaluated anew for EVERY output time inside the step — a counting or stateful
+                    # func sees the reference's calls, and each output row hangs on its own graph node
+                    f1 = func.eval(t1, y1, shadow=sh.time(1.0))
                     rows[j] = self._cubic_hermite_interp(scalar, t0, y0, f0, t1, y1, f1, tt[j], sh, tj_shadow,
                                                          out=None if differentiable or solution is None
                                                          else solution[j])
@@ -1379,10 +1392,8 @@ class FixedGridODESolver(object):
             return _StepShadow(start + (float(ta) - t_first), start + (float(tb) - t_first), func.sign)
 
         sign0 = float(torch.sign(event_fn(time_tensor(t0), y0)).detach())
-        max_itrs = 20000
-        itr = 0
-        while True:
-            itr += 1
+        step_budget = 20000
+        for _ in range(step_budget):
             t1 = scalar(t0 + scalar(dt))
             sh = shadow(t0, t1)
             y1, f0 = self._step(t0, dt, t1, y0, None, sh)
@@ -1402,13 +1413,9 @@ class FixedGridODESolver(object):
                         return self._cubic_hermite_interp(scalar, t0, y0, f0, t1, y1, f1, t, sh, None)
                 event_time, y1 = find_event(interp_fn, sign0, t0, t1, event_fn, float(self.atol), time_tensor,
                                             scalar=scalar)
-                break
-            else:
-                t0, y0 = t1, y1
-            if itr >= max_itrs:
-                raise RuntimeError(f"Reached maximum number of iterations {max_itrs}.")
-        solution = torch.stack([self.y0, y1], dim=0)
-        return time_tensor(event_time), solution
+                return time_tensor(event_time), torch.stack([self.y0, y1], dim=0)
+            t0, y0 = t1, y1
+        raise RuntimeError(f"Reached maximum number of iterations {step_budget}.")
 
     def _cubic_hermite_interp(self, scalar, t0, y0, f0, t1, y1, f1, t, sh, t_shadow, out=None) -> torch.Tensor:
         """solvers.py:166-173; the basis values are scalars of t.dtype formed on the host."""
