@@ -1288,6 +1288,23 @@ def gen_r4b():
     y = torchdiffeq.odeint(counted, y0, torch.tensor([0.0, 0.1, 0.2, 0.25, 0.7, 1.0]), method="heun2",
                            options=dict(step_size=0.5, interp="cubic"))
     arrays["cubic_calls"], arrays["cubic_y"] = np.array(calls), y
+
+    # the adjoint norms take their time component as `t.abs()` (adjoint.py:250, 273), NOT as an rms: a time VJP whose
+    # scaled value is 1e29 squares to inf in fp32, and an inf norm would make the backward solve's first step 0
+    class Steep(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor([0.5, -0.25]))
+
+        def forward(self, t, y):
+            return -y + self.w * torch.sin(t * 1e20) * 1e3
+    for nname, norm in (("mixed", None), ("semi", "seminorm")):
+        f = Steep()
+        x = torch.tensor([[1.0, 2.0]], requires_grad=True)
+        y = torchdiffeq.odeint_adjoint(f, x, torch.tensor([0.0, 1e-18]), method="dopri5", rtol=1e-3, atol=1e-6,
+                                       adjoint_options=dict(norm=norm) if norm else None)
+        y[-1].sum().backward()
+        arrays[f"steep_{nname}_y"], arrays[f"steep_{nname}_gy"], arrays[f"steep_{nname}_gw"] = y.detach(), x.grad, f.w.grad
     save("r4b.npz", **arrays)
 
 

@@ -97,3 +97,26 @@ def test_cubic_interpolation_calls_are_the_reference_sequence(on):
                    options=dict(step_size=0.5, interp="cubic"))
     assert calls == Z["cubic_calls"].tolist()
     np.testing.assert_allclose(y.cpu().numpy(), Z["cubic_y"], rtol=0 if on == "cpu" else 1e-6, atol=0 if on == "cpu" else 1e-7)
+
+
+@pytest.mark.parametrize("nname,norm", [("mixed", None), ("semi", "seminorm")])
+def test_adjoint_norm_takes_the_time_component_as_abs_not_as_rms(on, nname, norm):
+    """adjoint.py:250, 273: `max(t.abs(), state_norm(y), ...)`.  The scaled time VJP of this field is ~1e29: its square
+    is inf in fp32, an rms of the one-element component would make the norm inf and the backward solve's initial step
+    0 ("underflow in dt 0.0") where the reference integrates — which the host path did until round 4b."""
+    class Steep(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor([0.5, -0.25], device=on))
+
+        def forward(self, t, y):
+            return -y + self.w * torch.sin(t * 1e20) * 1e3
+    f = Steep()
+    x = torch.tensor([[1.0, 2.0]], device=on, requires_grad=True)
+    y = tda.odeint_adjoint(f, x, torch.tensor([0.0, 1e-18], device=on), method="dopri5", rtol=1e-3, atol=1e-6,
+                           adjoint_options=dict(norm=norm) if norm else None)
+    y[-1].sum().backward()
+    tol = dict(rtol=0, atol=0) if on == "cpu" else dict(rtol=1e-5, atol=1e-30)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), Z[f"steep_{nname}_y"], **tol)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), Z[f"steep_{nname}_gy"], **tol)
+    np.testing.assert_allclose(f.w.grad.cpu().numpy(), Z[f"steep_{nname}_gw"], **tol)

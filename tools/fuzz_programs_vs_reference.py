@@ -171,7 +171,8 @@ def make_case(rng):
                 grad_t=rng.random() < 0.3, lr=rng.choice([0.05, 0.3]),
                 # (backprop gradients agree to rounding only, so a second iteration would compare different programs)
                 iters=rng.choice([1, 2, 3]) if api == "adjoint" else 1,
-                event=rng.random() < 0.2 and kind is not CNFField)
+                # (the event solve comes after the SGD update: only where the update itself is bit-identical)
+                event=rng.random() < 0.3 and kind is not CNFField and api == "adjoint")
 
 
 def run(lib, case):
@@ -225,10 +226,11 @@ def run(lib, case):
     return log
 
 
-def same(a, b, exact=True):
+def same(a, b, exact=True, state_dtype=None):
     if torch.is_tensor(a) and torch.is_tensor(b) and not exact and a.shape == b.shape and a.dtype == b.dtype:
         # backprop through plain odeint: the package's hand-written backward sums cotangents in its own order
-        tol = 1e-12 if a.dtype == torch.float64 else 1e-3
+        # (a time gradient is formed from the STATE's arithmetic even when t itself is fp64)
+        tol = 1e-11 if (state_dtype or a.dtype) == torch.float64 else 1e-3
         scale = float(a.double().abs().max()) + 1e-300
         return bool(((a.double() - b.double()).abs().nan_to_num() <= tol * scale).all())
     if torch.is_tensor(a) and torch.is_tensor(b):
@@ -250,7 +252,7 @@ def main():
             msgs.append(f"log length {len(la)} vs {len(lb)}: {la[-1]} | {lb[-1]}")
         for (na, va), (nb, vb) in zip(la, lb):
             exact = case["api"] == "adjoint" or na in ("sol", "loss", "nfe")
-            if na != nb or not same(va, vb, exact):
+            if na != nb or not same(va, vb, exact, case["w"].dtype):
                 if torch.is_tensor(va) and torch.is_tensor(vb) and va.shape == vb.shape:
                     d = float((va.double() - vb.double()).abs().max() / (va.double().abs().max() + 1e-300))
                     msgs.append(f"{na}: rel {d:.2e} dtype {va.dtype}/{vb.dtype}")

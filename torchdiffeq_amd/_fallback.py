@@ -24,6 +24,7 @@ re-associate a row).  T = the REAL dtype of the state (`y0.abs().dtype`), also f
 """
 from __future__ import annotations
 
+import math
 import warnings
 from typing import List, Optional, Sequence, Tuple
 
@@ -73,6 +74,10 @@ class HostPlan:
         # type (what the solver drivers use on this path — `literal_norms`)
         self.rms0 = [0.0] * self.n_seg
         self.rms1 = [0.0] * self.n_seg
+        # |x| of a one-element segment, not squared: the adjoint norms take their time component as `t.abs()`
+        # (adjoint.py:250, 273) — the rms of one element is the same number unless its square leaves the type's range
+        self.abs0 = [math.nan] * self.n_seg
+        self.abs1 = [math.nan] * self.n_seg
 
 
 def _nonfinite(*xs: torch.Tensor) -> float:
@@ -191,6 +196,7 @@ class HostKernels:
             tol = torch.fmax(y0[sl].abs(), y1[sl].abs()) * float(T(rtol)) + float(T(atol))
             r = e[sl] / tol
             plan.rms0[s] = rms = self._rms(r)
+            plan.abs0[s] = float(r.abs()) if n == 1 else math.nan
             plan.sums0[s] = self._sumsq(r) if not self.literal_norms else rms * rms * n     # (interface; unused on this path)
             plan.bad[s] = _nonfinite(y0[sl], y1[sl])
             if scaled_out is not None:
@@ -227,9 +233,11 @@ class HostKernels:
         for s, sl, q0, q1 in self._init_quotients(plan, mode, a, b, yscale):
             n = q0.numel()
             plan.rms0[s] = rms = self._rms(q0)
+            plan.abs0[s] = float(q0.abs()) if n == 1 else math.nan
             plan.sums0[s] = self._sumsq(q0) if not self.literal_norms else rms * rms * n
             if q1 is not None:
                 plan.rms1[s] = rms = self._rms(q1)
+                plan.abs1[s] = float(q1.abs()) if n == 1 else math.nan
                 plan.sums1[s] = self._sumsq(q1) if not self.literal_norms else rms * rms * n
             plan.bad[s] = _nonfinite(yscale[sl])
 

@@ -474,6 +474,8 @@ class AdjointBuiltinNorm(BuiltinNorm):
     (norm_tests.py:97-111) — it takes the reference's `(t, y, adj_y, *θ-adjoints)` and applies the mixed norm to the
     components of a tuple forward state, as the reference's `state_norm(y)` does."""
 
+    leading_scalar = True        # the first component is the time VJP, taken as `t.abs()` (adjoint.py:250, 273)
+
     def __init__(self, fwd_layout: Optional[StateLayout], n_params: int, seminorm: bool):
         super().__init__(n_skip_tail=n_params if seminorm else 0, name="adjoint-seminorm" if seminorm else "adjoint-mixed")
         self.fwd_layout = fwd_layout

@@ -402,7 +402,10 @@ class RKAdaptiveStepsizeODESolver:
             n -= self.norm.n_skip_tail
         literal = None
         if self._sync is None and getattr(self.kernels, "literal_norms", False):
-            literal = self.plan.rms1 if which else self.plan.rms0
+            literal = list(self.plan.rms1 if which else self.plan.rms0)
+            if getattr(self.norm, "leading_scalar", False) and numels[0] == 1:
+                # adjoint.py:250, 273: `max(t.abs(), ...)` — the time component is not squared
+                literal[0] = (self.plan.abs1 if which else self.plan.abs0)[0]
         val = 0.0
         for s in range(n):
             if numels[s] == 0:
