@@ -287,7 +287,52 @@ def dense_case(rng):
     return f"dense {str(dtype)[6:]} {kw}", program
 
 
-FAMILIES = [callbacks_case, event_grad_case, explicit_params_case, ragged_tuple_case, odd_dtype_case, dense_case]
+def stochastic_case(rng):
+    """A field that draws from torch's global RNG at every evaluation: the results agree bit for bit only if both
+    libraries evaluate func the same number of times in the same order — forward, initial-step heuristic, rejected
+    steps, interpolation, and every evaluation of the backward solve."""
+    g = gen(rng)
+    dtype = rng.choice([torch.float32, torch.float64])
+    method = rng.choice(ADAPTIVE + FIXED)
+    dim = rng.choice([1, 3])
+    y0 = torch.randn(2, dim, generator=g, dtype=torch.float64).to(dtype)
+    W = (torch.randn(dim, dim, generator=g) * 0.5).to(dtype)
+    t = times(rng, g, rng.choice([2, 4]), dtype)
+    kw = dict(rtol=rng.choice([1e-2, 1e-3]), atol=rng.choice([1e-3, 1e-4]))
+    if method in FIXED:
+        kw["options"] = dict(step_size=rng.choice([0.1, 0.26]), interp=rng.choice(["linear", "cubic"]))
+    api = rng.choice(["odeint", "odeint_adjoint"])
+    noise = rng.choice([1e-3, 1e-2])
+    seed_ = rng.randrange(10 ** 6)
+    tup = rng.random() < 0.3
+
+    def program(lib):
+        torch.manual_seed(seed_)
+        w_ = W.clone().requires_grad_(True)
+        calls = [0]
+
+        def f(t_, y_):
+            calls[0] += 1
+            if tup:
+                a, b = y_
+                return torch.tanh(a @ w_) + noise * torch.randn_like(a), -b + noise * torch.randn_like(b)
+            return torch.tanh(y_ @ w_) + noise * torch.randn_like(y_)
+        y = y0.clone().requires_grad_(True)
+        state = (y, torch.ones(3, dtype=dtype)) if tup else y
+        extra = dict(adjoint_params=(w_,)) if api == "odeint_adjoint" else {}
+        with torch.no_grad() if api == "odeint" else torch.enable_grad():
+            sol = getattr(lib, api)(f, state, t, method=method, **kw, **extra)
+        main = sol[0] if tup else sol
+        out = [("sol", main.detach().clone()), ("calls_fwd", calls[0])]
+        if api == "odeint_adjoint":
+            main[-1].sum().backward()
+            out += [("gW", w_.grad), ("gy", y.grad), ("calls", calls[0])]
+        out.append(("rng_after", torch.rand(1)))
+        return out
+    return f"stochastic {api} {method} {str(dtype)[6:]} tuple={tup} {kw}", program
+
+
+FAMILIES = [stochastic_case, callbacks_case, event_grad_case, explicit_params_case, ragged_tuple_case, odd_dtype_case, dense_case]
 
 
 def same(a, b, exact=True):
