@@ -14,11 +14,24 @@ import warnings
 import torch
 from torch import nn
 
-sys.path.insert(0, "/root/repo/tools")
-sys.path.insert(0, "/root/repo")
-sys.path.insert(0, "/root/reference")
-import torchdiffeq as ref  # noqa: E402
+import os  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torchdiffeq_amd as tda  # noqa: E402
+
+# TDEQ_FUZZ_DEVICE=cuda (GPU box, no reference there): the package's CPU host path (= the reference's arithmetic, which
+# the default mode of this tool establishes) against the HIP kernels on the device, to tolerance.
+DEVICE = os.environ.get("TDEQ_FUZZ_DEVICE")
+if DEVICE:
+    ref = tda
+else:
+    sys.path.insert(0, "/root/reference")
+    import torchdiffeq as ref  # noqa: E402
+TARGET = "cpu"      # where a program puts its tensors (switched by the device mode)
+
+
+def D(x):
+    return x.to(TARGET)
 
 torch.set_num_threads(1)
 warnings.simplefilter("ignore")
@@ -94,7 +107,7 @@ def callbacks_case(rng):
     tup = rng.random() < 0.3
 
     def program(lib):
-        f = copy.deepcopy(field)
+        f = copy.deepcopy(field).to(TARGET)
         f.log = []
         for n in names:
             setattr(f, n, f._make(n))
@@ -105,10 +118,10 @@ def callbacks_case(rng):
             wrap.forward = ff
             for n in names:
                 setattr(wrap, n, getattr(f, n))
-            state = (y0.clone().requires_grad_(True), torch.ones(2, dtype=dtype))
-            sol = getattr(lib, api)(wrap, state, t, method=method, **kw)[0]
+            state = (D(y0).clone().requires_grad_(True), torch.ones(2, dtype=dtype, device=TARGET))
+            sol = getattr(lib, api)(wrap, state, D(t), method=method, **kw)[0]
         else:
-            sol = getattr(lib, api)(f, y0.clone().requires_grad_(True), t, method=method, **kw)
+            sol = getattr(lib, api)(f, D(y0).clone().requires_grad_(True), D(t), method=method, **kw)
         out = [("sol", sol.detach().clone())]
         if api == "odeint_adjoint":
             sol[-1].sum().backward()
@@ -146,10 +159,10 @@ def event_grad_case(rng):
             return torch.stack([s[1], (-self.g - self.k * s[1:2]).squeeze(0)])
 
     def program(lib):
-        f = Ball()
-        p0 = pos0.clone().requires_grad_(True)
-        v0 = vel0.clone().requires_grad_(True)
-        t0 = torch.tensor(0.0, dtype=dtype, requires_grad=grad_t0)
+        f = Ball().to(TARGET)
+        p0 = D(pos0).clone().requires_grad_(True)
+        v0 = D(vel0).clone().requires_grad_(True)
+        t0 = torch.tensor(0.0, dtype=dtype, device=TARGET, requires_grad=grad_t0)
         state = (p0, v0) if tupled else torch.cat([p0, v0])
         ev = (lambda t, s: s[0]) if tupled else (lambda t, s: s[0:1])
         et, es = lib.odeint_event(f, state, t0, event_fn=ev, method=method, options=opts or None,
@@ -183,16 +196,16 @@ def explicit_params_case(rng):
     norm = rng.choice([None, "seminorm"])
 
     def program(lib):
-        w_ = W.clone().requires_grad_(True)
-        b_ = b.clone().requires_grad_(which != "frozen")
-        u_ = unused.clone().requires_grad_(True)
+        w_ = D(W).clone().requires_grad_(True)
+        b_ = D(b).clone().requires_grad_(which != "frozen")
+        u_ = D(unused).clone().requires_grad_(True)
         params = {"both": (w_, b_), "W": (w_,), "none": (), "with_unused": (w_, u_, b_), "frozen": (w_, b_)}[which]
         f = lambda t_, y_: torch.sin(y_ @ w_.t() + b_) * torch.exp(-t_)  # noqa: E731
         k = dict(kw)
         if norm:
             k["adjoint_options"] = dict(norm=norm)
-        y = y0.clone().requires_grad_(True)
-        sol = lib.odeint_adjoint(f, y, t, method=method, adjoint_params=params, **k)
+        y = D(y0).clone().requires_grad_(True)
+        sol = lib.odeint_adjoint(f, y, D(t), method=method, adjoint_params=params, **k)
         (sol ** 2).sum().backward()
         return [("sol", sol.detach().clone()), ("gW", w_.grad), ("gb", b_.grad), ("gu", u_.grad), ("gy", y.grad)]
     return f"explicit_params {which} {method} {str(dtype)[6:]} norm={norm} {kw}", program
@@ -225,9 +238,9 @@ def ragged_tuple_case(rng):
             return torch.tanh(a @ self.m) + c, -b * self.s + a.sum() * 0.05, torch.cos(t) * self.s - c
 
     def program(lib):
-        f = F()
-        st = tuple(x.clone().requires_grad_(True) for x in (a0, b0, c0))
-        sol = getattr(lib, api)(f, st, t, method=method, **kw)
+        f = F().to(TARGET)
+        st = tuple(D(x).clone().requires_grad_(True) for x in (a0, b0, c0))
+        sol = getattr(lib, api)(f, st, D(t), method=method, **kw)
         loss = sum((s[-1] ** 2).sum() for s in sol)
         loss.backward()
         out = [(f"sol{i}", s.detach().clone()) for i, s in enumerate(sol)]
@@ -254,11 +267,11 @@ def odd_dtype_case(rng):
     api = rng.choice(["odeint", "odeint_adjoint"]) if dtype.is_complex else "odeint"
 
     def program(lib):
-        a_ = A.clone().requires_grad_(True)
+        a_ = D(A).clone().requires_grad_(True)
         f = lambda t_, y_: y_ @ a_ - y_ * 0.5  # noqa: E731
-        y = y0.clone().requires_grad_(True)
+        y = D(y0).clone().requires_grad_(True)
         extra = dict(adjoint_params=(a_,)) if api == "odeint_adjoint" else {}
-        sol = getattr(lib, api)(f, y, t, method=method, **kw, **extra)
+        sol = getattr(lib, api)(f, y, D(t), method=method, **kw, **extra)
         out = [("sol", sol.detach().clone())]
         if api == "odeint_adjoint":
             sol[-1].abs().sum().backward()
@@ -278,11 +291,12 @@ def dense_case(rng):
     qs = [float(t0) + (float(t1) - float(t0)) * rng.random() for _ in range(4)]
 
     def program(lib):
-        f = lambda t_, y_: torch.sin(A @ y_) - 0.1 * y_ * t_  # noqa: E731
-        sol, fn = lib.odeint_dense(f, y0, t0, t1, **kw)
-        out = [("sol", sol.detach().clone())]
+        A_ = D(A)
+        f = lambda t_, y_: torch.sin(A_ @ y_) - 0.1 * y_ * t_  # noqa: E731
+        fn = lib.odeint_dense(f, D(y0), D(t0), D(t1), **kw)
+        out = []
         for q in qs:
-            out.append((f"q{q:.3f}", fn(torch.tensor(q, dtype=dtype)).detach().clone()))
+            out.append((f"q{q:.3f}", fn(torch.tensor(q, dtype=dtype, device=TARGET)).detach().clone()))
         return out
     return f"dense {str(dtype)[6:]} {kw}", program
 
@@ -357,7 +371,81 @@ def attempt(lib, program):
         return [("raised", f"{type(e).__name__}: {str(e)[:200]}")]
 
 
+def rel_diff(a, b):
+    """Largest relative difference between two logged values (tensors / tuples / numbers), None if incomparable."""
+    if isinstance(a, tuple) and isinstance(b, tuple):
+        if len(a) != len(b):
+            return None
+        ds = [rel_diff(x, y) for x, y in zip(a, b)]
+        return None if any(d is None for d in ds) else max(ds, default=0.0)
+    if torch.is_tensor(a) and torch.is_tensor(b):
+        b = b.cpu()
+        if a.shape != b.shape or a.dtype != b.dtype:
+            return None
+        work = torch.complex128 if a.is_complex() else torch.float64
+        return float((a.to(work) - b.to(work)).abs().max() / (a.to(work).abs().max() + 1e-30)) if a.numel() else 0.0
+    if a is None and b is None:
+        return 0.0
+    if isinstance(a, (int, float)) and isinstance(b, (int, float)):
+        return 0.0 if a == b else float("inf")
+    return 0.0 if a == b else None
+
+
+def main_device():
+    """Host path (CPU) vs HIP kernels (TDEQ_FUZZ_DEVICE) on the same programs, to tolerance.  The stochastic family
+    (device RNG differs) and bf16 states (host path by design) are left out."""
+    global TARGET
+    from torchdiffeq_amd import _fallback
+    bad = ran = counts = 0
+    worst = {}
+    for case_no in range(n_cases):
+        made = rng.choice(FAMILIES)(rng)
+        desc, program = made[0], made[1]
+        if desc.startswith("stochastic") or "bfloat16" in desc or (only is not None and case_no != only):
+            continue
+        wide = "float64" in desc or "complex128" in desc
+        TARGET = "cpu"
+        la = attempt(tda, program)
+        TARGET = DEVICE
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", _fallback.HostPathWarning)       # the device run must be on the kernels
+            _fallback._warned = False
+            lb = attempt(tda, program)
+        TARGET = "cpu"
+        ran += 1
+        msgs = []
+        if len(la) != len(lb):
+            counts += 1                     # another number of steps / evaluations: fp32 noise; an fp64 case is reported
+            if wide:
+                msgs.append(f"log length {len(la)} vs {len(lb)}: {str(la[-1])[:120]} | {str(lb[-1])[:120]}")
+        else:
+            for (na, va), (nb, vb) in zip(la, lb):
+                d = rel_diff(va, vb) if na == nb else None
+                kind = ("grad" if na.startswith("g") else "log" if na.startswith("log") else "sol") + ("64" if wide else "32")
+                if d is None:
+                    msgs.append(f"{na}/{nb}: {str(va)[:100]} | {str(vb)[:100]}")
+                    continue
+                if d == float("inf") and not wide:
+                    counts += 1
+                    continue
+                worst[kind] = max(worst.get(kind, 0.0), d)
+                limit = {"sol64": 1e-6, "grad64": 1e-5, "log64": 1e-6, "sol32": 2e-3, "grad32": 5e-2, "log32": 0.3}[kind]
+                if not d <= limit:
+                    msgs.append(f"{na}: rel {d:.2e} (limit {limit:.0e})")
+        if msgs:
+            bad += 1
+            print(f"case {case_no}: {desc}")
+            for m in msgs[:5]:
+                print("    ", m)
+        if (case_no + 1) % 25 == 0:
+            print(f"... {case_no + 1} cases, {bad} beyond tolerance", flush=True)
+    print(f"seed {seed}: {ran} programs host path vs {DEVICE}, {bad} beyond tolerance, {counts} fp32 cases with another step / "
+          f"evaluation count, worst relative differences {({k: float(f'{v:.2e}') for k, v in sorted(worst.items())})}")
+
+
 def main():
+    if DEVICE:
+        return main_device()
     bad = 0
     for case_no in range(n_cases):
         made = rng.choice(FAMILIES)(rng)

@@ -17,10 +17,20 @@ import warnings
 import torch
 from torch import nn
 
-sys.path.insert(0, "/root/repo")
-sys.path.insert(0, "/root/reference")
-import torchdiffeq as ref  # noqa: E402
+import os  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torchdiffeq_amd as tda  # noqa: E402
+
+# TDEQ_FUZZ_DEVICE=cuda (GPU box, no reference there): the same programs, the package's CPU host path — which IS the
+# reference's arithmetic bit for bit (the default mode of this tool establishes that) — against the HIP kernels on the
+# device.  Compared to tolerance: the kernels sum tableau rows left to right and the device's GEMM / tanh round differently.
+DEVICE = os.environ.get("TDEQ_FUZZ_DEVICE")
+if DEVICE:
+    ref = tda
+else:
+    sys.path.insert(0, "/root/reference")
+    import torchdiffeq as ref  # noqa: E402
 
 torch.set_num_threads(1)
 warnings.simplefilter("ignore")
@@ -175,6 +185,18 @@ def make_case(rng):
                 event=rng.random() < 0.3 and kind is not CNFField and api == "adjoint")
 
 
+def to_device(case, device):
+    moved = dict(case)
+    moved["field"] = copy.deepcopy(case["field"]).to(device)
+    moved["y0"] = tuple(c.to(device) for c in case["y0"]) if isinstance(case["y0"], tuple) else case["y0"].to(device)
+    moved["t"], moved["w"] = case["t"].to(device), case["w"].to(device)
+    kw = dict(case["kw"])
+    if "options" in kw:
+        kw["options"] = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in kw["options"].items()}
+    moved["kw"] = kw
+    return moved
+
+
 def run(lib, case):
     field = copy.deepcopy(case["field"])
     field.nfe = 0
@@ -241,6 +263,8 @@ def same(a, b, exact=True, state_dtype=None):
 
 
 def main():
+    if DEVICE:
+        return main_device()
     bad = 0
     for case_no in range(n_cases):
         case = make_case(rng)
@@ -268,6 +292,60 @@ def main():
         if (case_no + 1) % 25 == 0:
             print(f"... {case_no + 1} cases, {bad} with differences", flush=True)
     print(f"seed {seed}: {n_cases} programs, {bad} with differences")
+
+
+def main_device():
+    """Host path (CPU) vs HIP kernels (TDEQ_FUZZ_DEVICE), one iteration per program, to tolerance."""
+    from torchdiffeq_amd import _fallback
+    worst, nfe_diff, bad, ran = {}, 0, 0, 0
+    for case_no in range(n_cases):
+        case = make_case(rng)
+        case["iters"] = 1
+        if only is not None and case_no != only:
+            continue
+        f64 = case["w"].dtype == torch.float64
+        la = run(tda, case)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", _fallback.HostPathWarning)       # the device run must be on the kernels
+            _fallback._warned = False
+            lb = run(tda, to_device(case, DEVICE))
+        ran += 1
+        msgs = []
+        if len(la) != len(lb):
+            msgs.append(f"log length {len(la)} vs {len(lb)}: {str(la[-1])[:150]} | {str(lb[-1])[:150]}")
+        for (na, va), (nb, vb) in zip(la, lb):
+            if na == "nfe":
+                nfe_diff += va != vb
+                if f64 and va != vb:
+                    msgs.append(f"nfe {va} vs {vb}")
+                continue
+            if na == "raised" or nb == "raised":
+                if va != vb:
+                    msgs.append(f"{na}/{nb}: {str(va)[:120]} | {str(vb)[:120]}")
+                continue
+            if va is None or vb is None:
+                if (va is None) != (vb is None):
+                    msgs.append(f"{na}: None on one side")
+                continue
+            vb = vb.cpu()
+            d = float((va.double() - vb.double()).abs().max() / (va.double().abs().max() + 1e-30))
+            kind = ("sol" if na in ("sol", "loss", "event_t", "event_y") else "gt" if na == "gt" else "grad") + \
+                ("64" if f64 else "32")
+            worst[kind] = max(worst.get(kind, 0.0), d)
+            limit = {"sol64": 1e-6, "grad64": 1e-5, "gt64": 1e-5, "sol32": 2e-3, "grad32": 5e-2, "gt32": 1.0}[kind]
+            if not d <= limit:
+                msgs.append(f"{na}: rel {d:.2e} (limit {limit:.0e})")
+        if msgs:
+            bad += 1
+            print(f"case {case_no}: {case['kind'].__name__} {case['api']} {case['method']} "
+                  f"{str(case['t'].dtype)[6:]}/{str(case['w'].dtype)[6:]} kw={case['kw']} grad_t={case['grad_t']} "
+                  f"event={case['event']}")
+            for m in msgs[:6]:
+                print("    ", m)
+        if (case_no + 1) % 25 == 0:
+            print(f"... {case_no + 1} cases, {bad} beyond tolerance", flush=True)
+    print(f"seed {seed}: {ran} programs host path vs {DEVICE}, {bad} beyond tolerance, {nfe_diff} with another "
+          f"evaluation count (fp32 noise), worst relative differences {({k: float(f'{v:.2e}') for k, v in sorted(worst.items())})}")
 
 
 if __name__ == "__main__":
