@@ -1305,6 +1305,53 @@ def gen_r4b():
                                        adjoint_options=dict(norm=norm) if norm else None)
         y[-1].sum().backward()
         arrays[f"steep_{nname}_y"], arrays[f"steep_{nname}_gy"], arrays[f"steep_{nname}_gw"] = y.detach(), x.grad, f.w.grad
+
+    # grid_constructor(func, y0, t): y0 in the state's own form — a tensor state in its shape, a tuple state (and the
+    # adjoint's augmented one) as the UNPADDED concatenation — and func usable on it (solvers.py:103)
+    for sname in ("tensor2d", "tuple"):
+        seen = []
+        w = torch.tensor([0.5, -0.3, 0.8], requires_grad=True)
+
+        def grid(func, y, tt):
+            d = func(tt[0], y)
+            seen.append((tuple(y.shape), tuple(d.shape), float(d.abs().max())))
+            return torch.linspace(float(tt[0]), float(tt[-1]), 2 + int(float(d.abs().max()) * 3)).to(tt)
+        if sname == "tensor2d":
+            f = lambda t_, y_: -y_ * w * (1 + t_) + torch.sin(y_)       # noqa: E731
+            state = torch.tensor([[1.0, 2.0, 3.0], [0.5, 0.1, -1.0]], requires_grad=True)
+        else:
+            f = lambda t_, y_: (-y_[0] * w * (1 + t_), torch.sin(y_[1]) - y_[0].sum())     # noqa: E731
+            state = (torch.tensor([[1.0, 2.0, 3.0]], requires_grad=True), torch.tensor([0.5, 0.1]))
+        sol = torchdiffeq.odeint_adjoint(f, state, torch.tensor([0.0, 0.4, 1.0]), method="rk4",
+                                         options=dict(grid_constructor=grid), adjoint_params=(w,))
+        (sol[0] if sname == "tuple" else sol)[-1].sum().backward()
+        arrays[f"grid_{sname}_yshapes"] = np.array([s[0][0] if len(s[0]) == 1 else -1 for s in seen])
+        arrays[f"grid_{sname}_dmax"] = np.array([s[2] for s in seen])
+        arrays[f"grid_{sname}_gw"] = w.grad
+        arrays[f"grid_{sname}_y"] = (sol[0] if sname == "tuple" else sol).detach()
+
+    # complex128 through odeint_adjoint: the backward solve's error ratio is formed on the concatenated augmented state
+    # (|z| and z / real round position-dependently in ATen's vectorised loops) — a case where per-segment evaluation
+    # gave another last bit in step 77 of the backward solve
+    # (the values of the fuzz case that showed it: tools/fuzz_api_programs_vs_reference.py, seed 32, case 5)
+    yc = torch.view_as_complex(torch.tensor(
+        [0.9763743281364441, 0.4763857126235962, 0.3485761880874634, 1.0541315078735352, -0.37900879979133606,
+         0.24454638361930847, 0.20677243173122406, 0.1580955982208252, 0.5700197219848633, 0.023011041805148125,
+         0.09842822700738907, -1.2679963111877441], dtype=torch.float64).reshape(2, 3, 2))
+    Ac = torch.view_as_complex(torch.tensor(
+        [-1.0376341342926025, -0.14303676784038544, -0.03842546045780182, -0.5508574843406677, 0.22360268235206604,
+         -0.5132613182067871, -0.1185542568564415, -0.09384410828351974, -0.07820449024438858, -0.5325219035148621,
+         -0.5970337986946106, 0.1508079320192337, 0.046314921230077744, 0.8552271127700806, 0.10754086822271347,
+         0.02906198613345623, -0.2525499761104584, 0.6338606476783752], dtype=torch.float64).reshape(3, 3, 2))
+    arrays["cplx_y0"], arrays["cplx_A"] = torch.view_as_real(yc), torch.view_as_real(Ac)
+    for method in ("bosh3", "dopri5"):
+        a_ = Ac.clone().requires_grad_(True)
+        x = yc.clone().requires_grad_(True)
+        y = torchdiffeq.odeint_adjoint(lambda t_, y_: y_ @ a_ - y_ * 0.5, x, torch.linspace(0.0, 1.0, 4, dtype=torch.float64),
+                                       method=method, adjoint_params=(a_,))
+        y[-1].abs().sum().backward()
+        arrays[f"cplx_{method}_y"] = torch.view_as_real(y.detach())
+        arrays[f"cplx_{method}_gA"], arrays[f"cplx_{method}_gy"] = torch.view_as_real(a_.grad), torch.view_as_real(x.grad)
     save("r4b.npz", **arrays)
 
 

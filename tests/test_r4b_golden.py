@@ -122,3 +122,51 @@ def test_adjoint_norm_takes_the_time_component_as_abs_not_as_rms(on, nname, norm
     # (dL/dw = 1e-18-sized integral of an oscillating integrand, far below atol: its digits follow the step sequence,
     #  which on the device differs by the usual fp32 noise — what matters there is that the backward solve RUNS)
     np.testing.assert_allclose(f.w.grad.cpu().numpy(), Z[f"steep_{nname}_gw"], **(tol if on == "cpu" else dict(rtol=0.5)))
+
+
+@pytest.mark.parametrize("sname", ["tensor2d", "tuple"])
+def test_grid_constructor_gets_func_and_state_in_the_references_form(on, sname):
+    """solvers.py:103 `self.grid_constructor(self.func, self.y0, t)`: y0 is a tensor state in ITS shape, a tuple state —
+    also the adjoint's augmented state of the backward solve — as the unpadded concatenation of its components (never
+    the package's chunk-padded flat buffer), and `func(t, y0)` works on it.  This grid is refined by the field's size."""
+    seen = []
+    w = torch.tensor([0.5, -0.3, 0.8], device=on, requires_grad=True)
+
+    def grid(func, y, tt):
+        d = func(tt[0], y)
+        seen.append((tuple(y.shape), tuple(d.shape), float(d.abs().max())))
+        return torch.linspace(float(tt[0]), float(tt[-1]), 2 + int(float(d.abs().max()) * 3), device=on).to(tt)
+    if sname == "tensor2d":
+        f = lambda t_, y_: -y_ * w * (1 + t_) + torch.sin(y_)       # noqa: E731
+        state = torch.tensor([[1.0, 2.0, 3.0], [0.5, 0.1, -1.0]], device=on, requires_grad=True)
+    else:
+        f = lambda t_, y_: (-y_[0] * w * (1 + t_), torch.sin(y_[1]) - y_[0].sum())     # noqa: E731
+        state = (torch.tensor([[1.0, 2.0, 3.0]], device=on, requires_grad=True), torch.tensor([0.5, 0.1], device=on))
+    sol = tda.odeint_adjoint(f, state, torch.tensor([0.0, 0.4, 1.0], device=on), method="rk4",
+                             options=dict(grid_constructor=grid), adjoint_params=(w,))
+    (sol[0] if sname == "tuple" else sol)[-1].sum().backward()
+    assert all(s[0] == s[1] for s in seen)
+    assert [s[0][0] if len(s[0]) == 1 else -1 for s in seen] == Z[f"grid_{sname}_yshapes"].tolist()
+    tol = dict(rtol=0, atol=0) if on == "cpu" else dict(rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([s[2] for s in seen], Z[f"grid_{sname}_dmax"], **tol)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), Z[f"grid_{sname}_gw"], **tol)
+    np.testing.assert_allclose((sol[0] if sname == "tuple" else sol).detach().cpu().numpy(), Z[f"grid_{sname}_y"], **tol)
+
+
+@pytest.mark.parametrize("method", ["bosh3", "dopri5"])
+def test_complex_adjoint_is_the_reference_bit_for_bit_on_the_host_path(method):
+    """|z| and z / real are not single IEEE operations: ATen's vectorised loop and its scalar tail round them differently,
+    and which one an element gets depends on its position in the tensor.  The reference forms the error ratio of the
+    backward solve on the concatenated augmented state (rk_common.py:22-27), so must the host path (`_fallback._joint`)."""
+    y0 = torch.view_as_complex(torch.tensor(Z["cplx_y0"]))
+    A = torch.view_as_complex(torch.tensor(Z["cplx_A"]))
+    a_ = A.clone().requires_grad_(True)
+    x = y0.clone().requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", tda.HostPathWarning)
+        y = tda.odeint_adjoint(lambda t_, y_: y_ @ a_ - y_ * 0.5, x, torch.linspace(0.0, 1.0, 4, dtype=torch.float64),
+                               method=method, adjoint_params=(a_,))
+    y[-1].abs().sum().backward()
+    assert torch.equal(torch.view_as_real(y.detach()), torch.tensor(Z[f"cplx_{method}_y"]))
+    assert torch.equal(torch.view_as_real(a_.grad), torch.tensor(Z[f"cplx_{method}_gA"]))
+    assert torch.equal(torch.view_as_real(x.grad), torch.tensor(Z[f"cplx_{method}_gy"]))

@@ -346,7 +346,165 @@ def stochastic_case(rng):
     return f"stochastic {api} {method} {str(dtype)[6:]} tuple={tup} {kw}", program
 
 
-FAMILIES = [stochastic_case, callbacks_case, event_grad_case, explicit_params_case, ragged_tuple_case, odd_dtype_case, dense_case]
+def options_case(rng):
+    """The adaptive solvers' option pool, several at once (rk_common.py:160-214, 266-361): step-size clamps and factors,
+    an evaluation budget that may run out, a user norm, step_t / jump_t (also together, also outside the interval, also
+    with decreasing time), through odeint or odeint_adjoint."""
+    g = gen(rng)
+    dtype = rng.choice([torch.float32, torch.float64])
+    method = rng.choice(ADAPTIVE)
+    dim = rng.choice([2, 3])
+    y0 = torch.randn(2, dim, generator=g, dtype=torch.float64).to(dtype)
+    W = (torch.randn(dim, dim, generator=g) * 0.8).to(dtype)
+    t = times(rng, g, rng.choice([2, 3, 5]), dtype)
+    lo, hi = float(t.min()), float(t.max())
+    kw = tol(rng)
+    opts = {}
+    if rng.random() < 0.3:
+        opts["min_step"] = rng.choice([1e-4, 1e-2, 0.2])
+    if rng.random() < 0.3:
+        opts["max_step"] = rng.choice([0.01, 0.05, 0.3])
+    if rng.random() < 0.3:
+        opts["ifactor"] = rng.choice([2.0, 5.0])
+    if rng.random() < 0.3:
+        opts["dfactor"] = rng.choice([0.1, 0.5])
+    if rng.random() < 0.3:
+        opts["safety"] = rng.choice([0.7, 0.95])
+    if rng.random() < 0.2:
+        opts["max_num_steps"] = rng.choice([3, 10, 40])
+    if rng.random() < 0.25:
+        opts["first_step"] = rng.choice([1e-3, 0.05, 5.0])
+    if rng.random() < 0.25:
+        opts["norm"] = rng.choice(["linf", "l1"])
+    pts = lambda k: torch.tensor(sorted(lo - 0.1 + (hi - lo + 0.2) * rng.random() for _ in range(k)), dtype=dtype)  # noqa: E731
+    if rng.random() < 0.35:
+        opts["step_t"] = pts(rng.choice([1, 3]))
+    if rng.random() < 0.35:
+        opts["jump_t"] = pts(rng.choice([1, 2]))
+    if rng.random() < 0.1:
+        opts["dtype"] = rng.choice([torch.float32, torch.float64])
+    api = rng.choice(["odeint", "odeint_adjoint"])
+    adj_inherits = rng.random() < 0.5
+
+    def program(lib):
+        w_ = D(W).clone().requires_grad_(True)
+        calls = []
+
+        def f(t_, y_):
+            calls.append(float(t_))
+            # (discontinuous in t at the jump points, as jump_t is meant for)
+            kick = sum((t_ > float(j)).to(y_.dtype) for j in opts.get("jump_t", []))
+            return torch.tanh(y_ @ w_) * (1.0 + 0.5 * kick) - 0.2 * y_
+        o = {k: (D(v) if torch.is_tensor(v) else v) for k, v in opts.items()}
+        if "norm" in o:
+            o["norm"] = {"linf": lambda x: x.abs().max(), "l1": lambda x: x.abs().mean()}[o["norm"]]
+        y = D(y0).clone().requires_grad_(True)
+        extra = {}
+        if api == "odeint_adjoint":
+            extra["adjoint_params"] = (w_,)
+            if not adj_inherits:
+                extra["adjoint_options"] = {k: v for k, v in o.items() if k in ("max_num_steps", "safety")}
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            sol = getattr(lib, api)(f, y, D(t), method=method, options=o, **kw, **extra)
+        out = [("sol", sol.detach().clone()), ("calls_fwd", len(calls)),
+               ("warnings", sorted(str(w.message)[:60] for w in caught
+                                   # (not the libraries' own: the package's host-path notice, and a PyTorch notice the reference's
+                                   #  `float(tensor)` conversions trigger under autograd)
+                                   if "host path" not in str(w.message) and "Converting a tensor" not in str(w.message)))]
+        if api == "odeint_adjoint":
+            sol[-1].sum().backward()
+            out += [("gW", w_.grad), ("gy", y.grad), ("calls", len(calls))]
+        out.append(("times", torch.tensor(calls, dtype=torch.float64)))
+        return out
+    shown = {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in opts.items()}
+    return f"options {api} {method} {str(dtype)[6:]} rev={bool(t[0] > t[-1])} {shown} {kw} inherit={adj_inherits}", program
+
+
+def direct_event_case(rng):
+    """`odeint(..., event_fn=...)` called directly (odeint.py:87-101): len(t) must be 2, the result is (event_t, solution);
+    a vector-valued event function (combined by `min` of the sign-normalised components); grids for the fixed-grid
+    methods from a user `grid_constructor`."""
+    g = gen(rng)
+    dtype = rng.choice([torch.float32, torch.float64])
+    method = rng.choice(ADAPTIVE + FIXED)
+    y0 = torch.tensor([rng.choice([1.0, 2.0]), rng.choice([0.0, 0.5])], dtype=dtype)
+    rev = rng.random() < 0.3
+    npts = rng.choice([2, 2, 3])
+    t = torch.tensor([0.0, 10.0, 20.0][:npts], dtype=dtype)
+    if rev:
+        t = -t
+    thr = rng.choice([0.2, 0.5])
+    vector_event = rng.random() < 0.5
+    opts = {}
+    if method in FIXED:
+        opts["step_size"] = rng.choice([0.05, 0.02])
+        if rng.random() < 0.4:
+            opts["interp"] = "cubic"
+    kw = tol(rng)
+    api = rng.choice(["odeint", "odeint_adjoint"])
+
+    def program(lib):
+        k_ = torch.tensor(1.3, dtype=dtype, device=TARGET, requires_grad=True)
+
+        def f(t_, y_):
+            return torch.stack([y_[1], -k_ * y_[0] - 0.1 * y_[1]])
+        if vector_event:
+            ev = lambda t_, y_: torch.stack([y_[0] - thr, y_[0] + 5.0])  # noqa: E731
+        else:
+            ev = lambda t_, y_: y_[0] - thr  # noqa: E731
+        extra = dict(adjoint_params=(k_,)) if api == "odeint_adjoint" else {}
+        y = D(y0).clone().requires_grad_(True)
+        res = getattr(lib, api)(f, y, D(t), event_fn=ev, method=method, options=dict(opts) or None, **kw, **extra)
+        et, sol = res
+        out = [("event_t", et.detach().clone()), ("sol", sol.detach().clone())]
+        if api == "odeint_adjoint":
+            (et + sol[-1].sum()).backward()
+            out += [("gk", k_.grad), ("gy", y.grad)]
+        return out
+    return f"direct_event {api} {method} {str(dtype)[6:]} rev={rev} npts={npts} vector={vector_event} {opts} {kw}", program
+
+
+def grid_constructor_case(rng):
+    g = gen(rng)
+    dtype = rng.choice([torch.float32, torch.float64])
+    method = rng.choice(FIXED)
+    y0 = torch.randn(3, generator=g, dtype=torch.float64).to(dtype)
+    t = times(rng, g, rng.choice([2, 4]), dtype)
+    extra_pts = rng.choice([1, 4])
+    interp = rng.choice(["linear", "cubic"])
+    api = rng.choice(["odeint", "odeint_adjoint"])
+    bad_grid = rng.random() < 0.15
+
+    def program(lib):
+        w_ = torch.tensor([0.5, -0.3, 0.8], dtype=dtype, device=TARGET, requires_grad=True)
+        seen = []
+
+        def grid(func, y, tt):
+            d = func(tt[0], y)               # a grid constructor may look at the field: func and y0 in the reference's form
+            seen.append((tuple(y.shape), tt.detach().clone(), d.detach().clone()))
+            inner = [tt[:-1] + (tt[1:] - tt[:-1]) * (i + 1) / (extra_pts + 1) for i in range(extra_pts)]
+            full = torch.sort(torch.cat([tt] + inner), descending=bool(tt[0] > tt[-1])).values
+            return full[1:] if bad_grid else full
+        f = lambda t_, y_: -y_ * w_ * (1 + t_) + torch.sin(y_)  # noqa: E731
+        y = D(y0).clone().requires_grad_(True)
+        extra = dict(adjoint_params=(w_,)) if api == "odeint_adjoint" else {}
+        sol = getattr(lib, api)(f, y, D(t), method=method, options=dict(grid_constructor=grid, interp=interp), **extra)
+        out = [("sol", sol.detach().clone())]
+        if api == "odeint_adjoint":
+            sol[-1].sum().backward()
+            out += [("gw", w_.grad), ("gy", y.grad)]
+        out.append(("grid_calls", len(seen)))
+        out += [(f"grid{i}", s) for i, s in enumerate(seen)]
+        return out
+    return f"grid_constructor {api} {method} {str(dtype)[6:]} extra={extra_pts} {interp} bad={bad_grid}", program
+
+
+FAMILIES = [options_case, direct_event_case, grid_constructor_case, stochastic_case, callbacks_case, event_grad_case, explicit_params_case, ragged_tuple_case, odd_dtype_case, dense_case]
+
+
+if os.environ.get("TDEQ_FUZZ_FAMILY"):         # e.g. TDEQ_FUZZ_FAMILY=odd_dtype,ragged_tuple
+    FAMILIES = [f for f in FAMILIES if f.__name__[:-5] in os.environ["TDEQ_FUZZ_FAMILY"].split(",")]
 
 
 def same(a, b, exact=True):

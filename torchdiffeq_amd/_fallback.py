@@ -78,6 +78,15 @@ class HostPlan:
         # (adjoint.py:250, 273) — the rms of one element is the same number unless its square leaves the type's range
         self.abs0 = [math.nan] * self.n_seg
         self.abs1 = [math.nan] * self.n_seg
+        self.uniform_tol = len({(s[2], s[3]) for s in self.segs}) <= 1
+        self._join = None
+
+    def join_index(self, device) -> torch.Tensor:
+        """Element indices of the segments, back to back — the reference's UNPADDED flat state (misc.py:206-209)."""
+        if self._join is None or self._join.device != device:
+            self._join = torch.cat([torch.arange(off, off + n, device=device) for off, n, _, _ in self.segs]) \
+                if self.segs else torch.zeros(0, dtype=torch.long, device=device)
+        return self._join
 
 
 def _nonfinite(*xs: torch.Tensor) -> float:
@@ -189,12 +198,31 @@ class HostKernels:
                 out.copy_(s)
 
     # -- norms -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _joint(plan: HostPlan, like: torch.Tensor) -> bool:
+        """Complex states of several segments: |z| and z / real are not single IEEE operations, and ATen's vectorised
+        loop and its scalar tail round them differently in the last bit (~1 element in 1e3) — which of the two an
+        element gets depends on its POSITION in the tensor the operation runs on.  The reference runs them on the
+        unpadded concatenation of all components (rk_common.py:22-27, misc.py:50-66), so the quotients are formed on
+        that same tensor here and sliced afterwards (real types: every operation is exactly rounded, position-free)."""
+        return like.is_complex() and plan.n_seg > 1 and plan.uniform_tol
+
     def _error_sums(self, plan: HostPlan, e, y0, y1, scaled_out) -> None:
         T = self._T(y0)
+        joint = None
+        if self._joint(plan, y0):
+            idx = plan.join_index(y0.device)
+            _, _, rtol, atol = plan.segs[0]
+            joint = e[idx] / (torch.fmax(y0[idx].abs(), y1[idx].abs()) * float(T(rtol)) + float(T(atol)))
+            lo = 0
         for s, (off, n, rtol, atol) in enumerate(plan.segs):
             sl = slice(off, off + n)
-            tol = torch.fmax(y0[sl].abs(), y1[sl].abs()) * float(T(rtol)) + float(T(atol))
-            r = e[sl] / tol
+            if joint is not None:
+                r = joint[lo:lo + n]
+                lo += n
+            else:
+                tol = torch.fmax(y0[sl].abs(), y1[sl].abs()) * float(T(rtol)) + float(T(atol))
+                r = e[sl] / tol
             plan.rms0[s] = rms = self._rms(r)
             plan.abs0[s] = float(r.abs()) if n == 1 else math.nan
             plan.sums0[s] = self._sumsq(r) if not self.literal_norms else rms * rms * n     # (interface; unused on this path)
@@ -221,6 +249,17 @@ class HostKernels:
 
     def _init_quotients(self, plan, mode, a, b, yscale):
         T = self._T(yscale)
+        if self._joint(plan, yscale):           # see _joint: the reference's tensor, sliced afterwards
+            idx = plan.join_index(yscale.device)
+            _, _, rtol, atol = plan.segs[0]
+            scale = yscale[idx].abs() * operand(T, rtol) + float(T(atol))
+            q0 = (a[idx] / scale) if mode == 0 else ((a[idx] - b[idx]) / scale)
+            q1 = (b[idx] / scale) if mode == 0 else None
+            lo = 0
+            for s, (off, n, _, _) in enumerate(plan.segs):
+                yield s, slice(off, off + n), q0[lo:lo + n], None if q1 is None else q1[lo:lo + n]
+                lo += n
+            return
         for s, (off, n, rtol, atol) in enumerate(plan.segs):
             sl = slice(off, off + n)
             scale = yscale[sl].abs() * operand(T, rtol) + float(T(atol))       # misc.py:50: |y0| * rtol, then atol + ...

@@ -1152,10 +1152,31 @@ class FixedGridODESolver(object):
         """The integration grid for output times `t` (solvers.py:70-96): the user's `grid_constructor(func, y0, t)`,
         else the uniform `step_size` grid, else `t` itself (the same tensor object: that is what graph mode tests)."""
         if self._user_grid is not None:
-            return self._user_grid(self.func, self.y0, t)
+            return self._user_grid(*self._reference_view(), t)
         if self.step_size is None:
             return t
         return _uniform_grid(t, self.step_size)
+
+    def _reference_view(self):
+        """(func, y0) as the reference hands them to a user's `grid_constructor(func, y0, t)` (solvers.py:103): a tensor
+        state in ITS shape, a tuple state — also the adjoint's augmented one — as the plain concatenation of its
+        components (misc.py:206-209), not this package's chunk-padded flat buffer; `func(t, y)` maps such a state to its
+        derivative in the same form (t in solver time, like every call of the reference's wrapped func)."""
+        lay, func = self.layout, self.func
+        if not lay.is_tuple:
+            shape = lay.shapes[0]
+            return (lambda t, y, **kw: func(t, y.reshape(-1), **kw).view(shape)), self.y0.view(shape)
+
+        def joined(flat):
+            return torch.cat([c.reshape(-1) for c in lay.unpack(flat)]) if lay.n_seg else flat
+
+        def on_joined(t, y, **kw):
+            parts, off = [], 0
+            for n, shape in zip(lay.numels, lay.shapes):
+                parts.append(y[off:off + n].view(shape))
+                off += n
+            return joined(func(t, lay.pack(parts, dtype=self.dtype), **kw))
+        return on_joined, joined(self.y0)
 
     # -- one step ------------------------------------------------------------------------------------
     def _step(self, t0, dt, t1, y0: torch.Tensor, y1_out: Optional[torch.Tensor], sh: "_StepShadow"):
