@@ -549,6 +549,24 @@ def rel_diff(a, b):
     return 0.0 if a == b else None
 
 
+class kernel_backend:
+    """TDEQ_FUZZ_DEVICE=oracle (build container, no GPU): the second run keeps its tensors on the CPU but takes the HIP
+    path's host logic — padded segment layout, segmented norms, fused packing, carried partial sums — over the C oracle's
+    kernels (bit-identical to the HIP kernels, tests/test_kernels_gpu.py), exactly what the `dev="cpu"` tests do."""
+
+    def __enter__(self):
+        if DEVICE == "oracle":
+            from torchdiffeq_amd import _native
+            from oracle.kernels import OracleKernels
+            self.prev, ok = _native.get_kernels, OracleKernels()
+            _native.get_kernels = lambda d, dtype=None: ok
+
+    def __exit__(self, *exc):
+        if DEVICE == "oracle":
+            from torchdiffeq_amd import _native
+            _native.get_kernels = self.prev
+
+
 def main_device():
     """Host path (CPU) vs HIP kernels (TDEQ_FUZZ_DEVICE) on the same programs, to tolerance.  The stochastic family
     (device RNG differs) and bf16 states (host path by design) are left out."""
@@ -561,11 +579,13 @@ def main_device():
         desc, program = made[0], made[1]
         if desc.startswith("stochastic") or "bfloat16" in desc or (only is not None and case_no != only):
             continue
+        if DEVICE == "oracle" and "complex" in desc:
+            continue            # (the oracle object is the real kernels' twin; complex states have their own, oracle/complex_norms.py)
         wide = "float64" in desc or "complex128" in desc
         TARGET = "cpu"
         la = attempt(tda, program)
-        TARGET = DEVICE
-        with warnings.catch_warnings():
+        TARGET = "cpu" if DEVICE == "oracle" else DEVICE
+        with warnings.catch_warnings(), kernel_backend():
             warnings.simplefilter("error", _fallback.HostPathWarning)       # the device run must be on the kernels
             _fallback._warned = False
             lb = attempt(tda, program)

@@ -177,6 +177,15 @@ def make_case(rng):
     else:
         y0 = z0
     w = torch.randn(npts, batch, dim, generator=g, dtype=torch.float64).to(dtype)
+    r = rng.random()
+    if r < 0.12:
+        w[1:] = 0               # the loss sees the initial row only: every backward interval starts from a zero adjoint
+    elif r < 0.24:
+        w[-1] = 0               # ... the last output not at all (zero cotangent at the start of the backward solve)
+    elif r < 0.36:
+        w[:-1] = 0              # ... only the last
+    elif r < 0.45:
+        w[rng.randrange(npts)] = 0
     return dict(field=field, api=api, method=method, t=t, kw=kw, y0=y0, w=w, kind=kind,
                 grad_t=rng.random() < 0.3, lr=rng.choice([0.05, 0.3]),
                 # (backprop gradients agree to rounding only, so a second iteration would compare different programs)
@@ -294,6 +303,23 @@ def main():
     print(f"seed {seed}: {n_cases} programs, {bad} with differences")
 
 
+class kernel_backend:
+    """TDEQ_FUZZ_DEVICE=oracle (build container, no GPU): the second run keeps its tensors on the CPU but takes the HIP
+    path's host logic over the C oracle's kernels (bit-identical to the HIP kernels), as the `dev="cpu"` tests do."""
+
+    def __enter__(self):
+        if DEVICE == "oracle":
+            from torchdiffeq_amd import _native
+            from oracle.kernels import OracleKernels
+            self.prev, ok = _native.get_kernels, OracleKernels()
+            _native.get_kernels = lambda d, dtype=None: ok
+
+    def __exit__(self, *exc):
+        if DEVICE == "oracle":
+            from torchdiffeq_amd import _native
+            _native.get_kernels = self.prev
+
+
 def main_device():
     """Host path (CPU) vs HIP kernels (TDEQ_FUZZ_DEVICE), one iteration per program, to tolerance."""
     from torchdiffeq_amd import _fallback
@@ -305,10 +331,10 @@ def main_device():
             continue
         f64 = case["w"].dtype == torch.float64
         la = run(tda, case)
-        with warnings.catch_warnings():
+        with warnings.catch_warnings(), kernel_backend():
             warnings.simplefilter("error", _fallback.HostPathWarning)       # the device run must be on the kernels
             _fallback._warned = False
-            lb = run(tda, to_device(case, DEVICE))
+            lb = run(tda, to_device(case, "cpu" if DEVICE == "oracle" else DEVICE))
         ran += 1
         msgs = []
         if len(la) != len(lb):
