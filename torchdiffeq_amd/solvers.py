@@ -927,11 +927,8 @@ class RKAdaptiveStepsizeODESolver:
         if err_partial is not None and lookahead:
             accept_step = accept_dev      # the device's decision is the one its look-ahead stage was built on
         else:
-            accept_step = error_ratio <= 1
-            if dt > self.max_step:
-                accept_step = False
-            if dt <= self.min_step:
-                accept_step = True
+            # rk_common.py:324-332: a step at the floor is always taken, one above the ceiling never, else the error decides
+            accept_step = bool(dt <= self.min_step or (error_ratio <= 1 and not dt > self.max_step))
 
         # ---- update state (rk_common.py:335-361) ----
         if accept_step:
