@@ -1352,6 +1352,13 @@ def gen_r4b():
         y[-1].abs().sum().backward()
         arrays[f"cplx_{method}_y"] = torch.view_as_real(y.detach())
         arrays[f"cplx_{method}_gA"], arrays[f"cplx_{method}_gy"] = torch.view_as_real(a_.grad), torch.view_as_real(x.grad)
+
+    # non-finite stages under heun3: the reference multiplies EVERY stage by its weight, also the tableau's zeros
+    # (fixed_grid.py:38-44: `k1 * 0.0 + k2 * (2/3)`), so an inf stage turns the rows into NaN, not inf
+    yb = torchdiffeq.odeint(lambda t_, y_: torch.where(t_ > 0.4, torch.full_like(y_, float("inf")), -y_),
+                            torch.tensor([1.0, 2.0, 0.5], dtype=torch.float64), torch.tensor([0.0, 1.0, 3.0], dtype=torch.float64),
+                            method="heun3", options=dict(step_size=0.25))
+    arrays["heun3_inf_field_y"] = yb
     save("r4b.npz", **arrays)
 
 

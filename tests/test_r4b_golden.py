@@ -170,3 +170,17 @@ def test_complex_adjoint_is_the_reference_bit_for_bit_on_the_host_path(method):
     assert torch.equal(torch.view_as_real(y.detach()), torch.tensor(Z[f"cplx_{method}_y"]))
     assert torch.equal(torch.view_as_real(a_.grad), torch.tensor(Z[f"cplx_{method}_gA"]))
     assert torch.equal(torch.view_as_real(x.grad), torch.tensor(Z[f"cplx_{method}_gy"]))
+
+
+def test_heun3_with_a_non_finite_stage_gives_the_references_rows_on_the_host_path():
+    """fixed_grid.py:38-44 multiplies every stage by its tableau weight, the zeros too: `k1 * 0.0` is NaN for an inf k1.
+    The host path evaluates that literal expression (the HIP kernels do not read zero-weight terms: inf stays inf there,
+    DESIGN.md §8)."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", tda.HostPathWarning)
+        y = tda.odeint(lambda t_, y_: torch.where(t_ > 0.4, torch.full_like(y_, float("inf")), -y_),
+                       torch.tensor([1.0, 2.0, 0.5], dtype=torch.float64), torch.tensor([0.0, 1.0, 3.0], dtype=torch.float64),
+                       method="heun3", options=dict(step_size=0.25))
+    ref = torch.tensor(Z["heun3_inf_field_y"])
+    assert torch.equal(y.isnan(), ref.isnan()) and torch.equal(y.nan_to_num(), ref.nan_to_num())
+    assert bool(ref[-1].isnan().all())

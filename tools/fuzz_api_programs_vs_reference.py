@@ -500,7 +500,62 @@ def grid_constructor_case(rng):
     return f"grid_constructor {api} {method} {str(dtype)[6:]} extra={extra_pts} {interp} bad={bad_grid}", program
 
 
-FAMILIES = [options_case, direct_event_case, grid_constructor_case, stochastic_case, callbacks_case, event_grad_case, explicit_params_case, ragged_tuple_case, odd_dtype_case, dense_case]
+def blowup_case(rng):
+    """Fields that leave the finite range: y' = y^2 (finite-time blow-up), a NaN switched on after some time, an inf
+    derivative — what is raised (class and text, rk_common.py:286-290 `non-finite values in state`, `underflow in dt`,
+    `max_num_steps exceeded`), after how many evaluations, and what a fixed-grid method returns (inf / nan rows)."""
+    g = gen(rng)
+    dtype = rng.choice([torch.float32, torch.float64])
+    method = rng.choice(ADAPTIVE + FIXED)
+    kind = rng.choice(["square", "nan_after", "inf_field", "huge"])
+    y0 = (torch.rand(3, generator=g, dtype=torch.float64) + 0.5).to(dtype)
+    t = torch.tensor([0.0, 1.0, 3.0], dtype=dtype)
+    if rng.random() < 0.3:
+        t = -t
+    kw = tol(rng)
+    opts = {}
+    if method in FIXED:
+        opts["step_size"] = rng.choice([0.05, 0.25])
+    elif rng.random() < 0.4:
+        opts["max_num_steps"] = rng.choice([20, 200])
+    tup = rng.random() < 0.3
+    api = rng.choice(["odeint", "odeint", "odeint_adjoint"])
+
+    def program(lib):
+        calls = [0]
+        w_ = torch.tensor(1.0, dtype=dtype, device=TARGET, requires_grad=True)
+        sgn = -1.0 if float(t[-1]) < 0 else 1.0
+
+        def core(t_, y_):
+            calls[0] += 1
+            if kind == "square":
+                return sgn * y_ * y_ * w_
+            if kind == "nan_after":
+                return torch.where(sgn * t_ > 0.7, torch.full_like(y_, float("nan")), -y_ * w_)
+            if kind == "inf_field":
+                return torch.where(sgn * t_ > 0.4, torch.full_like(y_, float("inf")), -y_ * w_)
+            return sgn * y_ * 1e30 * w_
+        f = (lambda t_, y_: (core(t_, y_[0]), -y_[1])) if tup else core
+        y = D(y0).clone().requires_grad_(api == "odeint_adjoint")
+        state = (y, torch.ones(2, dtype=dtype, device=TARGET)) if tup else y
+        extra = dict(adjoint_params=(w_,)) if api == "odeint_adjoint" else {}
+        out = []
+        try:
+            with torch.no_grad() if api == "odeint" else torch.enable_grad():
+                sol = getattr(lib, api)(f, state, D(t), method=method, options=dict(opts) or None, **kw, **extra)
+            main = sol[0] if tup else sol
+            out.append(("sol", main.detach().clone()))
+            if api == "odeint_adjoint":
+                main[-1].sum().backward()
+                out += [("gw", w_.grad), ("gy", y.grad)]
+        except Exception as e:  # noqa: BLE001
+            out.append(("raised", f"{type(e).__name__}: {str(e)[:70]}"))
+        out.append(("calls", calls[0]))
+        return out
+    return f"blowup {kind} {api} {method} {str(dtype)[6:]} tuple={tup} rev={float(t[-1]) < 0} {opts} {kw}", program
+
+
+FAMILIES = [blowup_case, options_case, direct_event_case, grid_constructor_case, stochastic_case, callbacks_case, event_grad_case, explicit_params_case, ragged_tuple_case, odd_dtype_case, dense_case]
 
 
 if os.environ.get("TDEQ_FUZZ_FAMILY"):         # e.g. TDEQ_FUZZ_FAMILY=odd_dtype,ragged_tuple

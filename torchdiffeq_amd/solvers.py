@@ -1619,9 +1619,15 @@ class Heun3(FixedGridODESolver):
         k1 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
         ya = ops.fixed_stage(1, y0, [k1], [third], dts, sh.dt_signed())
         k2 = func.eval(scalar(t0 + self._tmul(scalar, dt, third)), ya, shadow=sh.time(third))
-        yb = ops.fixed_stage(0, y0, [k2], [two_thirds], dts, sh.dt_signed())   # k1's weight is a structural zero
+        # The tableau's structural zeros (k1 in the third stage, k2 in the result): the kernels do not read a term whose
+        # weight is zero; the torch-op host path evaluates the reference's literal `k1 * 0.0 + k2 * (2/3)`
+        # (fixed_grid.py:38-44) — the same number for finite stages, and NaN instead of inf once a stage is non-finite
+        literal = getattr(self.kernels, "literal_row_sums", False)
+        yb = ops.fixed_stage(0, y0, *(([k1, k2], [0.0, two_thirds]) if literal else ([k2], [two_thirds])),
+                             dts, sh.dt_signed())
         k3 = func.eval(scalar(t0 + self._tmul(scalar, dt, two_thirds)), yb, shadow=sh.time(two_thirds))
-        y1 = ops.fixed_stage(0, y0, [k1, k3], [1 / 4, 3 / 4], dts, sh.dt_signed(), out=y1_out)   # k2: structural zero
+        y1 = ops.fixed_stage(0, y0, *(([k1, k2, k3], [1 / 4, 0.0, 3 / 4]) if literal else ([k1, k3], [1 / 4, 3 / 4])),
+                             dts, sh.dt_signed(), out=y1_out)
         return y1, k1
 
     _graph_times = ((0.0, 2), (1 / 3, 0), (2 / 3, 0))                    # t0 (NEXT), t0 + dt/3, t0 + 2dt/3
