@@ -17,6 +17,10 @@
  * imported reference itself (tests/golden/make_golden.py -> tests/golden/ npz files).
  *
  * Signatures mirror include/tdeq_hip.h (minus the stream) so the same test harness drives both.
+ *
+ * OpenMP: every loop is `parallel for ... if(large)` — the threads only start from 16384 elements (9 chunks).  The
+ * parity tests' states are a handful of elements; forking 8+ spin-waiting threads for them made a 10 s test take
+ * minutes whenever anything else ran on the machine.  Results do not depend on the thread count either way.
  */
 #include <math.h>
 #include <stddef.h>
@@ -45,7 +49,7 @@ int oracle_abi_version(void) { return 1; }
         T c[ORACLE_MAX_TERMS];                                                                        \
         const T dtT = (T)dt;                                                                          \
         for (int j = 0; j < nt; ++j) c[j] = (T)coef[j] * dtT;                                         \
-        _Pragma("omp parallel for schedule(static)")                                                  \
+        _Pragma("omp parallel for schedule(static) if(n > 16384)")                                    \
         for (int64_t i = 0; i < n; ++i) {                                                             \
             T acc = k[0][i] * c[0];                                                                   \
             for (int j = 1; j < nt; ++j) acc = acc + k[j][i] * c[j];                                  \
@@ -83,7 +87,7 @@ int oracle_stage_combine(void* out, const void* y0, const void* const* k, const 
             const int64_t c0 = segs[s].chunk_start;                                                   \
             const int64_t c1 = (s + 1 < n_seg) ? segs[s + 1].chunk_start : n_chunks;                  \
             const T rtol = (T)segs[s].rtol, atol = (T)segs[s].atol;                                   \
-            _Pragma("omp parallel for schedule(static)")                                              \
+            _Pragma("omp parallel for schedule(static) if(c1 - c0 > 8)")                              \
             for (int64_t b = c0; b < c1; ++b) {                                                       \
                 int64_t valid = segs[s].numel - (b - c0) * chunk;                                     \
                 if (valid > chunk) valid = chunk;                                                     \
@@ -205,7 +209,7 @@ int oracle_init_norms(int mode, const void* a, const void* b, const void* yscale
         const T dt = (T)dt_, x = (T)x_;                                                               \
         for (int j = 0; j < nt; ++j) c[j] = (T)coef[j] * dt;                                          \
         const T two_dt = (T)2 * dt;                                                                   \
-        _Pragma("omp parallel for schedule(static)")                                                  \
+        _Pragma("omp parallel for schedule(static) if(n > 16384)")                                    \
         for (int64_t i = 0; i < n; ++i) {                                                             \
             T acc = k[0][i] * c[0];                                                                   \
             for (int j = 1; j < nt; ++j) acc = acc + k[j][i] * c[j];                                  \
@@ -270,7 +274,7 @@ int oracle_interp_fit(void* coeffs, const void* y0, const void* y1, const void* 
     static void NAME(int stage, T* out, const T* y0, const T* k1, const T* k2, const T* k3,           \
                      const T* k4, double dt_, int64_t n) {                                            \
         const T dt = (T)dt_, third = (T)(1.0 / 3.0);                                                  \
-        _Pragma("omp parallel for schedule(static)")                                                  \
+        _Pragma("omp parallel for schedule(static) if(n > 16384)")                                    \
         for (int64_t i = 0; i < n; ++i) {                                                             \
             if (stage == 1) out[i] = y0[i] + (dt * k1[i]) * third;                                    \
             else if (stage == 2) out[i] = y0[i] + dt * (k2[i] - k1[i] * third);                       \
@@ -320,7 +324,7 @@ int oracle_lerp(void* out, const void* y0, const void* y1, double slope, int64_t
         T wT[8];                                                                                      \
         const T dtT = (T)dt;                                                                          \
         for (int j = 0; j < nt; ++j) wT[j] = (T)w[j];                                                 \
-        _Pragma("omp parallel for schedule(static)")                                                  \
+        _Pragma("omp parallel for schedule(static) if(n > 16384)")                                    \
         for (int64_t i = 0; i < n; ++i) {                                                             \
             if (mode == 1) { out[i] = y0[i] + (k[0][i] * dtT) * wT[0]; continue; }                    \
             T acc = k[0][i] * wT[0];                                                                  \
@@ -358,7 +362,7 @@ int oracle_weighted_sum(void* out, const void* const* x, const double* w, int n_
         for (int j = 0; j < nt; ++j) {                                                                \
             const T wj = (T)w[j];                                                                     \
             T* o = outs[j];                                                                           \
-            _Pragma("omp parallel for schedule(static)")                                              \
+            _Pragma("omp parallel for schedule(static) if(n > 16384)")                                \
             for (int64_t i = 0; i < n; ++i) o[i] = g[i] * wj;                                         \
         }                                                                                             \
     }
@@ -410,7 +414,7 @@ int oracle_multi_dot(const void* g, const void* const* x, int n_x, int64_t n, do
         T c[ORACLE_MAX_TERMS], e[ORACLE_MAX_TERMS];                                                   \
         const T dtT = (T)dt;                                                                          \
         for (int j = 0; j < nt; ++j) { c[j] = (T)coef[j] * dtT; e[j] = (T)ecoef[j] * dtT; }           \
-        _Pragma("omp parallel for schedule(static)")                                                  \
+        _Pragma("omp parallel for schedule(static) if(n > 16384)")                                    \
         for (int64_t i = 0; i < n; ++i) {                                                             \
             T acc = k[0][i] * c[0];                                                                   \
             T err = k[0][i] * e[0];                                                                   \
@@ -456,7 +460,7 @@ typedef struct oracle_multi_out {
         const T dtT = (T)dt;                                                                          \
         for (int o = 0; o < n_out; ++o)                                                               \
             for (int j = 0; j < nt; ++j) c[o][j] = (T)outs[o].coef[j] * dtT;                          \
-        _Pragma("omp parallel for schedule(static)")                                                  \
+        _Pragma("omp parallel for schedule(static) if(n > 16384)")                                    \
         for (int64_t i = 0; i < n; ++i) {                                                             \
             for (int o = 0; o < n_out; ++o) {                                                         \
                 int started = (o == 0 && acc_in != NULL);                                             \
@@ -500,7 +504,7 @@ int oracle_stage_combine_multi(const oracle_multi_out* outs, int n_out, const vo
             const int64_t c0 = segs[s].chunk_start;                                                   \
             const int64_t c1 = (s + 1 < n_seg) ? segs[s + 1].chunk_start : n_chunks;                  \
             const T rtol = (T)segs[s].rtol, atol = (T)segs[s].atol;                                   \
-            _Pragma("omp parallel for schedule(static)")                                              \
+            _Pragma("omp parallel for schedule(static) if(c1 - c0 > 8)")                              \
             for (int64_t b = c0; b < c1; ++b) {                                                       \
                 int64_t valid = segs[s].numel - (b - c0) * chunk;                                     \
                 if (valid > chunk) valid = chunk;                                                     \
@@ -735,7 +739,7 @@ int oracle_init_scaled(int mode, const void* a, const void* b, const void* yscal
         T b[ORACLE_MAX_TERMS], m[ORACLE_MAX_TERMS];                                                   \
         for (int j = 0; j < nt; ++j) { b[j] = (T)cb[j]; m[j] = cm ? (T)cm[j] : (T)0; }                \
         const T dtT = (T)dt;                                                                          \
-        _Pragma("omp parallel for schedule(static)")                                                  \
+        _Pragma("omp parallel for schedule(static) if(n > 16384)")                                    \
         for (int64_t i = 0; i < n; ++i) {                                                             \
             T dy = b[0] * f[0][i];                                                                    \
             for (int j = 1; j < nt; ++j) dy = dy + b[j] * f[j][i];                                    \
@@ -779,7 +783,7 @@ int oracle_adams_predict(void* y_out, void* dy_out, void* delta_out, const void*
                      int64_t n_chunks, int64_t n, double* out_count, double* out_bad) {               \
         const T cT = (T)c;                                                                            \
         if (compute) {                                                                                \
-            _Pragma("omp parallel for schedule(static)")                                              \
+            _Pragma("omp parallel for schedule(static) if(n > 16384)")                                \
             for (int64_t i = 0; i < n; ++i) {                                                         \
                 const T d = cT * f[i] + delta[i];                                                     \
                 dy_out[i] = d;                                                                        \
@@ -790,7 +794,7 @@ int oracle_adams_predict(void* y_out, void* dy_out, void* delta_out, const void*
             const int64_t base = segs[s].chunk_start * chunk;                                         \
             const T rtol = (T)segs[s].rtol, atol = (T)segs[s].atol;                                   \
             double cnt = 0.0, bad = 0.0;                                                              \
-            _Pragma("omp parallel for schedule(static) reduction(+:cnt,bad)")                         \
+            _Pragma("omp parallel for schedule(static) if(segs[s].numel > 16384) reduction(+:cnt,bad)")  \
             for (int64_t t = 0; t < segs[s].numel; ++t) {                                             \
                 const T d0 = dy_old[base + t], d1 = dy_out[base + t];                                 \
                 const T e = ABS(d0 - d1);                                                             \
