@@ -1362,10 +1362,38 @@ def gen_r4b():
     save("r4b.npz", **arrays)
 
 
+def gen_programs():
+    """40 training-loop programs of tools/fuzz_programs_vs_reference.py (seed 7) run by the REFERENCE: every logged value
+    — solution, loss, each parameter gradient, dL/dy0, dL/dt, the evaluation count after every SGD iteration, event time
+    and state — as tests/golden/programs.npz; tests/test_programs_golden.py replays the same programs on the package."""
+    sys.path.insert(0, os.path.join(HERE, "..", "..", "tools"))
+    argv, sys.argv = sys.argv, ["fuzz_programs_vs_reference.py", "7", "40"]
+    try:
+        import fuzz_programs_vs_reference as fz
+    finally:
+        sys.argv = argv
+    assert fz.ref is torchdiffeq
+    arrays = {}
+    for case_no in range(40):
+        case = fz.make_case(fz.rng)
+        log = fz.run(torchdiffeq, case)
+        arrays[f"p{case_no}_n"] = np.array(len(log))
+        arrays[f"p{case_no}_desc"] = np.array(f"{case['kind'].__name__} {case['api']} {case['method']} {case['kw']}")
+        for i, (name, value) in enumerate(log):
+            arrays[f"p{case_no}_{i}_name"] = np.array(name)
+            if value is None:
+                arrays[f"p{case_no}_{i}_none"] = np.array(1)
+            elif torch.is_tensor(value):
+                arrays[f"p{case_no}_{i}_val"] = value
+            else:
+                arrays[f"p{case_no}_{i}_val"] = np.array(value)
+    save("programs.npz", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
                      ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
-                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin), ("dropin", gen_dropin), ("brow", gen_brow), ("r4b", gen_r4b)]:
+                     ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin), ("dropin", gen_dropin), ("brow", gen_brow), ("r4b", gen_r4b), ("programs", gen_programs)]:
         if not only or name in only:
             fn()
