@@ -516,8 +516,8 @@ def blowup_case(rng):
     opts = {}
     if method in FIXED:
         opts["step_size"] = rng.choice([0.05, 0.25])
-    elif rng.random() < 0.4:
-        opts["max_num_steps"] = rng.choice([20, 200])
+    elif rng.random() < 0.4 or kind == "huge":
+        opts["max_num_steps"] = rng.choice([20, 200])       # ("huge" without a budget walks 1e-30-sized steps for minutes)
     tup = rng.random() < 0.3
     api = rng.choice(["odeint", "odeint", "odeint_adjoint"])
 
