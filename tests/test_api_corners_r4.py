@@ -125,3 +125,4 @@ def test_cubic_interpolation_evaluates_the_step_end_once_per_output_time(on):
     # two steps x two stage evaluations, + f1 for the 3 output times in (0, 0.5] and the 2 in (0.5, 1]
     assert len(calls) == 2 * 2 + 3 + 2
     assert calls == [0.0, 0.5, 0.5, 0.5, 0.5, 0.5, 1.0, 1.0, 1.0]
+

@@ -367,3 +367,19 @@ def test_step_controller_on_device_sums_equals_fused_controller(hip_kernels, dty
     assert np.array_equal(np.array(words[3 * n:3 * n + 4]), np.array(ref_words[3 * n:3 * n + 4]), equal_nan=True)
     assert plan_b.ctrl_dev.cpu().tolist() == ref_dev
     assert torch.equal(tn_a, tn_b)
+
+
+@pytest.mark.parametrize("lookahead", [True, False])
+def test_max_num_steps_is_exceeded_after_the_references_number_of_evaluations(cpu_backend, monkeypatch, lookahead):
+    """rk_common.py:243-249: the budget is checked at the head of every trial step.  The look-ahead must not have
+    evaluated func for a trial step the budget no longer allows: the reference raises after 2 + 20 x 6 = 122 evaluations
+    (found by tools/fuzz_api_programs_vs_reference.py, blow-up family under TDEQ_FUZZ_DEVICE=oracle: 123 before r04b).
+    Host logic over the oracle — the same `_step_until` / `_adaptive_step` the HIP path runs."""
+    monkeypatch.setenv("TDEQ_LOOKAHEAD", "1" if lookahead else "0")
+    f = _Counting(lambda t, y: y * y)
+    with pytest.raises(AssertionError, match=r"max_num_steps exceeded \(20>=20\)"):
+        with torch.no_grad():
+            tda.odeint(f, torch.tensor([1.0, 0.7, 1.3], dtype=torch.float64), torch.tensor([0.0, 1.0, 3.0], dtype=torch.float64),
+                       method="dopri5", rtol=1e-3, atol=1e-9, options=dict(max_num_steps=20))
+    assert f.nfe == 122
+

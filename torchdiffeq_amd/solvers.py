@@ -384,6 +384,7 @@ class RKAdaptiveStepsizeODESolver:
         self._max_rows = _native.TDEQ_MAX_DENSE_OUTPUTS if os.environ.get("TDEQ_DENSE_MULTI", "1") != "0" else 1
         self._t_end = -math.inf     # last output time of the running `integrate` (look-ahead only before it)
         self._pre = None            # (stage input, stage times, k_1) of the trial step enqueued ahead
+        self._last_trial = False    # set by _step_until: the max_num_steps budget of this output interval ends with this trial
 
     @classmethod
     def valid_callbacks(cls):
@@ -648,6 +649,9 @@ class RKAdaptiveStepsizeODESolver:
         while next_t > self.t1:
             assert n_steps < self.max_num_steps, \
                 "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
+            # (the last trial this budget allows enqueues no look-ahead evaluation: if it does not reach next_t, the
+            #  assertion above comes next, after the reference's number of evaluations)
+            self._last_trial = n_steps + 1 >= self.max_num_steps
             self._trial_step()
             n_steps += 1
 
@@ -903,7 +907,7 @@ class RKAdaptiveStepsizeODESolver:
                                         err_rem[1], dt_signed)
                 self._sync.reduce_device(self._plan_dev.out, self.plan.n_seg)
                 kern.step_controller(self.plan, self._plan_dev, self._plan_glob, ctrl, tnext, y0.dtype)
-            if t1 < self._t_end and not self._hold_pre:
+            if t1 < self._t_end and not self._hold_pre and not self._last_trial:
                 # accepted or rejected, another trial step follows: enqueue its first stage and func evaluation now
                 yi_n = torch.empty_like(y0)
                 kern.stage_combine_sel(yi_n, y1, f1, y0, f0, row0.coef[0], self.plan)
