@@ -384,7 +384,7 @@ class RKAdaptiveStepsizeODESolver:
         self._max_rows = _native.TDEQ_MAX_DENSE_OUTPUTS if os.environ.get("TDEQ_DENSE_MULTI", "1") != "0" else 1
         self._t_end = -math.inf     # last output time of the running `integrate` (look-ahead only before it)
         self._pre = None            # (stage input, stage times, k_1) of the trial step enqueued ahead
-        self._last_trial = False    # set by _step_until: the max_num_steps budget of this output interval ends with this trial
+        self._last_trial = False    # (_step_until) this trial step is the last one the max_num_steps budget allows
 
     @classmethod
     def valid_callbacks(cls):
