@@ -49,11 +49,15 @@ def test_program_matches_the_reference_run(i):
     case = _case(i)
     assert f"{case['kind'].__name__} {case['api']} {case['method']} {case['kw']}" == str(Z[f"p{i}_desc"]), \
         "the generator no longer produces the program the fixture was made from"
-    torch.set_num_threads(1)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        import torchdiffeq_amd as tda
-        log = fz.run(tda, case)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)        # as the fixture was made (the states are tiny: ATen would not split them anyway)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            import torchdiffeq_amd as tda
+            log = fz.run(tda, case)
+    finally:
+        torch.set_num_threads(threads)
     assert len(log) == int(Z[f"p{i}_n"]), (log[-1], str(Z[f"p{i}_desc"]))
     exact_grads = case["api"] == "adjoint"
     for j, (name, value) in enumerate(log):

@@ -33,8 +33,6 @@ TARGET = "cpu"      # where a program puts its tensors (switched by the device m
 def D(x):
     return x.to(TARGET)
 
-torch.set_num_threads(1)
-warnings.simplefilter("ignore")
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
@@ -677,6 +675,8 @@ def main_device():
 
 
 def main():
+    torch.set_num_threads(1)               # (process-wide settings only when run as a tool: tests import this module)
+    warnings.simplefilter("ignore")
     if DEVICE:
         return main_device()
     bad = 0

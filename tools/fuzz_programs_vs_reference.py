@@ -32,8 +32,6 @@ else:
     sys.path.insert(0, "/root/reference")
     import torchdiffeq as ref  # noqa: E402
 
-torch.set_num_threads(1)
-warnings.simplefilter("ignore")
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
@@ -272,6 +270,8 @@ def same(a, b, exact=True, state_dtype=None):
 
 
 def main():
+    torch.set_num_threads(1)               # (process-wide settings only when run as a tool: tests import this module)
+    warnings.simplefilter("ignore")
     if DEVICE:
         return main_device()
     bad = 0

@@ -209,11 +209,15 @@ class HostKernels:
 
     def _error_sums(self, plan: HostPlan, e, y0, y1, scaled_out) -> None:
         T = self._T(y0)
+        # misc.py:81 `torch.max(y0.abs(), y1.abs())` propagates a NaN of the trial state into the tolerance and the ratio
+        # (the step is then rejected with a NaN step size); the kernels' fmax ignores it and leaves the verdict to their
+        # non-finite census — same exception, but not the same number of trial steps before it
+        larger = torch.maximum if self.literal_norms else torch.fmax
         joint = None
         if self._joint(plan, y0):
             idx = plan.join_index(y0.device)
             _, _, rtol, atol = plan.segs[0]
-            joint = e[idx] / (torch.fmax(y0[idx].abs(), y1[idx].abs()) * float(T(rtol)) + float(T(atol)))
+            joint = e[idx] / (larger(y0[idx].abs(), y1[idx].abs()) * float(T(rtol)) + float(T(atol)))
             lo = 0
         for s, (off, n, rtol, atol) in enumerate(plan.segs):
             sl = slice(off, off + n)
@@ -221,7 +225,7 @@ class HostKernels:
                 r = joint[lo:lo + n]
                 lo += n
             else:
-                tol = torch.fmax(y0[sl].abs(), y1[sl].abs()) * float(T(rtol)) + float(T(atol))
+                tol = larger(y0[sl].abs(), y1[sl].abs()) * float(T(rtol)) + float(T(atol))
                 r = e[sl] / tol
             plan.rms0[s] = rms = self._rms(r)
             plan.abs0[s] = float(r.abs()) if n == 1 else math.nan
