@@ -780,11 +780,14 @@ elif mode == "hostexact":
         if a[0] == 'err': continue
         n_fwd = 2 if is_tuple else 1            # backprop gradients come from a hand-written backward (autodiff._LinearOp): same
         cmp = a[1] if grad != 'backprop' else a[1][:n_fwd]      # values to rounding, a different accumulation order of the cotangents
-        exact = all(torch.equal(torch.view_as_real(p) if p.is_complex() else p, torch.view_as_real(q) if q.is_complex() else q) for p, q in zip(cmp, b[1]))
+        real = lambda x: torch.view_as_real(x) if x.is_complex() else x
+        same_bits = lambda p, q: torch.equal(real(p).isnan(), real(q).isnan()) and torch.equal(real(p).nan_to_num(), real(q).nan_to_num())   # (a NaN both sides have at the same place is the same result)
+        exact = all(same_bits(p, q) for p, q in zip(cmp, b[1]))
         if exact and grad == 'backprop':
             exact = all(float((p - q).abs().max()) <= ((2e-3 if (t_grad and j == len(a[1]) - n_fwd - 1) else 1e-4) if rdt == torch.float32 else 1e-12) * float(p.abs().max() + 1e-30) for j, (p, q) in enumerate(zip(a[1][n_fwd:], b[1][n_fwd:])))       # (fp32: the time gradient is a cancelling dot product over the state — both libraries are ~1e-4 from the fp64 value)
         if a[2] != b[2] or not exact:
             bad += 1; print('BITS', desc, a[2], b[2], [float((p - q).abs().max() / (p.abs().max() + 1e-30)) for p, q in zip(a[1], b[1])])
+            if os.environ.get('FUZZ_DUMP'): torch.save((a[1], b[1]), os.environ['FUZZ_DUMP'])      # the two result lists of the last mismatch
     print('done', n, 'bad', bad)
 else:
     raise SystemExit("mode must be fixed | adaptive | adjoint | backprop | event | complex | tableau | eventgrad | callbacks | hessian | vectol | brow | hostexact")
