@@ -1359,6 +1359,24 @@ def gen_r4b():
                             torch.tensor([1.0, 2.0, 0.5], dtype=torch.float64), torch.tensor([0.0, 1.0, 3.0], dtype=torch.float64),
                             method="heun3", options=dict(step_size=0.25))
     arrays["heun3_inf_field_y"] = yb
+
+    # ... and in an adaptive method's error row: near the blow-up of y' = y^2 one dopri8 stage is inf while its weight in
+    # c_error is 0 -> `inf * 0 = NaN` error estimate -> NaN step size; the solve ends in `underflow in dt 0.0` after 470
+    # evaluations (a row sum over the non-zero stages only stays finite and needs 1133)
+    calls = []
+
+    def square(t_, y_):
+        calls.append(1)
+        return y_[0] * y_[0], -y_[1]
+    state = (torch.tensor([1.1101932525634766, 1.453037977218628, 1.1249815225601196]), torch.ones(2))
+    try:
+        with torch.no_grad():
+            torchdiffeq.odeint(square, state, torch.tensor([0.0, 1.0, 3.0]), method="dopri8", rtol=1e-3, atol=1e-6,
+                               options=dict(max_num_steps=200))
+        msg = ""
+    except AssertionError as exc:
+        msg = str(exc)
+    arrays["blowup_dopri8_calls"], arrays["blowup_dopri8_message"] = np.array(len(calls)), np.array(msg)
     save("r4b.npz", **arrays)
 
 

@@ -184,3 +184,23 @@ def test_heun3_with_a_non_finite_stage_gives_the_references_rows_on_the_host_pat
     ref = torch.tensor(Z["heun3_inf_field_y"])
     assert torch.equal(y.isnan(), ref.isnan()) and torch.equal(y.nan_to_num(), ref.nan_to_num())
     assert bool(ref[-1].isnan().all())
+
+
+def test_dopri8_blow_up_ends_after_the_references_number_of_evaluations_on_the_host_path():
+    """rk_common.py:79-89 multiplies every stage by its weight: near the blow-up of y' = y^2 a dopri8 stage is inf while its
+    weight in the error row is 0, `inf * 0 = NaN`, the step size becomes NaN and the solve ends in `underflow in dt 0.0`
+    after 470 evaluations.  The host path's rows keep their zero weights (`tableaus.SparseRow.literal`); summed over the
+    non-zero stages only the estimate stayed finite and the same assertion came after 1133 (the kernels' behaviour,
+    DESIGN.md §8)."""
+    calls = []
+
+    def square(t_, y_):
+        calls.append(1)
+        return y_[0] * y_[0], -y_[1]
+    state = (torch.tensor([1.1101932525634766, 1.453037977218628, 1.1249815225601196]), torch.ones(2))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", tda.HostPathWarning)
+        with pytest.raises(AssertionError) as info, torch.no_grad():
+            tda.odeint(square, state, torch.tensor([0.0, 1.0, 3.0]), method="dopri8", rtol=1e-3, atol=1e-6,
+                       options=dict(max_num_steps=200))
+    assert str(info.value) == str(Z["blowup_dopri8_message"]) and len(calls) == int(Z["blowup_dopri8_calls"])

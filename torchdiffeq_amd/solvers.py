@@ -295,10 +295,11 @@ class RKAdaptiveStepsizeODESolver:
         self._anchor = None        # t[0] (solver time) when `t` requires grad: every step time moves with it
         self._t_grad = False       # `t` requires grad (output times carry their own gradient)
         tab = self.tableau
-        self._beta = tab.beta_rows()
-        self._c_err = SparseRow.from_dense(tab.c_error)
-        self._c_mid = SparseRow.from_dense(tab.c_mid)
-        self._c_sol = SparseRow.from_dense(tab.c_sol)
+        # rows without their zero weights for the kernels; the torch-op host path multiplies every slot like the reference
+        literal_rows = bool(getattr(self.kernels, "literal_row_sums", False))
+        row = SparseRow.literal if literal_rows else SparseRow.from_dense
+        self._beta = tab.beta_rows(literal_rows)
+        self._c_err, self._c_mid, self._c_sol = row(tab.c_error), row(tab.c_mid), row(tab.c_sol)
         # stage abscissae rounded to the state dtype, as the reference's tableau cast (rk_common.py:201)
         self._alpha = [self.np_dtype(a) for a in tab.alpha]
         self._alpha_is_one = [a == 1.0 for a in tab.alpha]

@@ -55,6 +55,13 @@ class SparseRow:
     def from_dense(values: Sequence[float]) -> "SparseRow":
         return _sparse_row(tuple(float(v) for v in values))
 
+    @staticmethod
+    def literal(values: Sequence[float]) -> "SparseRow":
+        """EVERY slot of the dense row, the zero weights too — the row as the reference multiplies it
+        (`k * (beta_i * dt)`, rk_common.py:79-89: `inf * 0` is NaN).  For the torch-op host path, which evaluates the
+        reference's expressions literally; the kernels never read a zero-weight stage."""
+        return _literal_row(tuple(float(v) for v in values))
+
 
 @functools.lru_cache(maxsize=None)
 def _sparse_row(values: Tuple[float, ...]) -> SparseRow:
@@ -68,6 +75,12 @@ def _sparse_row(values: Tuple[float, ...]) -> SparseRow:
         nz = [(0, 0.0)]
     idx = tuple(i for i, _ in nz)
     return SparseRow(idx, RowCoefs((v for _, v in nz), idx, len(values)))
+
+
+@functools.lru_cache(maxsize=None)
+def _literal_row(values: Tuple[float, ...]) -> SparseRow:
+    idx = tuple(range(len(values)))
+    return SparseRow(idx, RowCoefs(values, idx, len(values)))
 
 
 @dataclasses.dataclass(frozen=True)
@@ -89,8 +102,8 @@ class Tableau:
         """True when the last stage input already equals y1 (rk_common.py:83: no extra combine)."""
         return self.c_sol[-1] == 0.0 and tuple(self.c_sol[:-1]) == tuple(self.beta[-1])
 
-    def beta_rows(self) -> List[SparseRow]:
-        return [SparseRow.from_dense(r) for r in self.beta]
+    def beta_rows(self, literal: bool = False) -> List[SparseRow]:
+        return [(SparseRow.literal if literal else SparseRow.from_dense)(r) for r in self.beta]
 
     def dense(self):
         """Dense fp64 numpy views (alpha, beta rows, c_sol, c_error, c_mid) for tests."""
