@@ -1377,6 +1377,25 @@ def gen_r4b():
     except AssertionError as exc:
         msg = str(exc)
     arrays["blowup_dopri8_calls"], arrays["blowup_dopri8_message"] = np.array(len(calls)), np.array(msg)
+
+    # event solve on a trajectory that turns NaN (a diverged training run): the bisection takes the NaN sign for a sign
+    # change and still returns a finite time, the state NaN; gradients NaN
+    class NanField(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor(1.0))
+
+        def forward(self, t_, y_):
+            return torch.where(t_ > 0.55, torch.full_like(y_, float("nan")), -y_ * self.w)
+    for iface in ("odeint", "odeint_adjoint"):
+        f = NanField()
+        x = torch.tensor([1.0, 2.0], requires_grad=True)
+        et, ys = torchdiffeq.odeint_event(f, x, torch.tensor(0.0), event_fn=lambda t_, y_: y_[0] - 0.1, method="rk4",
+                                          options=dict(step_size=0.1), odeint_interface=getattr(torchdiffeq, iface),
+                                          atol=1e-6, rtol=1e-4)   # (at atol 1e-9 the fp32 bisection ends ON the grid point: finite)
+        (et + 0).backward()
+        arrays[f"nan_event_{iface}_t"], arrays[f"nan_event_{iface}_y"] = et.detach(), ys.detach()
+        arrays[f"nan_event_{iface}_gw"], arrays[f"nan_event_{iface}_gy"] = f.w.grad, x.grad
     save("r4b.npz", **arrays)
 
 

@@ -204,3 +204,27 @@ def test_dopri8_blow_up_ends_after_the_references_number_of_evaluations_on_the_h
             tda.odeint(square, state, torch.tensor([0.0, 1.0, 3.0]), method="dopri8", rtol=1e-3, atol=1e-6,
                        options=dict(max_num_steps=200))
     assert str(info.value) == str(Z["blowup_dopri8_message"]) and len(calls) == int(Z["blowup_dopri8_calls"])
+
+
+@pytest.mark.parametrize("iface", ["odeint", "odeint_adjoint"])
+def test_event_solve_on_a_trajectory_that_turns_nan_returns_the_references_time(on, iface):
+    """odeint.py:160-231 / event_handling.py:5-20: a NaN sign "differs" from every sign, so the bisection still returns
+    a finite event time for a trajectory that left the finite range (a diverged training run), the state NaN, every
+    gradient NaN.  The first-order correction `odeint_event` attaches here must not turn that time into NaN."""
+    class NanField(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor(1.0, device=on))
+
+        def forward(self, t_, y_):
+            return torch.where(t_ > 0.55, torch.full_like(y_, float("nan")), -y_ * self.w)
+    f = NanField()
+    x = torch.tensor([1.0, 2.0], device=on, requires_grad=True)
+    et, ys = tda.odeint_event(f, x, torch.tensor(0.0, device=on), event_fn=lambda t_, y_: y_[0] - 0.1, method="rk4",
+                              options=dict(step_size=0.1), odeint_interface=getattr(tda, iface), atol=1e-6, rtol=1e-4)
+    (et + 0).backward()
+    assert bool(torch.isfinite(et.detach()))
+    assert float(et.detach()) == pytest.approx(float(Z[f"nan_event_{iface}_t"]), rel=0 if on == "cpu" else 1e-6)
+    assert np.array_equal(ys.detach().cpu().numpy(), Z[f"nan_event_{iface}_y"], equal_nan=True)
+    assert bool(f.w.grad.isnan()) and bool(np.isnan(Z[f"nan_event_{iface}_gw"]))
+    assert bool(x.grad.isnan().all()) and bool(np.isnan(Z[f"nan_event_{iface}_gy"]).all())

@@ -181,6 +181,21 @@ def odeint_dense(func, y0, t0, t1, *, rtol=1e-7, atol=1e-9, method=None, options
     return dense_output_fn
 
 
+class _NonFiniteAnchor(torch.autograd.Function):
+    """A real 0-dim zero that depends on a NON-FINITE event state: what `odeint_event` adds to the event time of a
+    trajectory that left the finite range, so that the time stays in the autograd graph; every gradient through it is
+    NaN, which is what differentiating through that state gives in the reference (odeint.py:195-231)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        ctx.like = y
+        return torch.zeros((), dtype=y.real.dtype if y.is_complex() else y.dtype, device=y.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.full_like(ctx.like, float("nan"))
+
+
 def odeint_event(func, y0, t0, *, event_fn, reverse_time=False, odeint_interface=odeint, **kwargs):
     """Solve from `t0` until `event_fn(t, y)` crosses zero; returns `(event_t, solution)` whose gradients see the
     event time as a function of the trajectory (same contract as odeint.py:160-231: parameters of the event
@@ -214,6 +229,12 @@ def odeint_event(func, y0, t0, *, event_fn, reverse_time=False, odeint_interface
 
     # first-order data at the event: f(t*, y*), dc/dt, dc/dy (all constants of the correction below)
     y_const = y_event.detach()
+    if not bool(torch.isfinite(y_const).all()):
+        # a trajectory that has left the finite range (a diverged training run): the reference still hands back the
+        # time its bisection ended at (a NaN sign "differs" from every sign) and the non-finite state; a first-order
+        # correction through NaNs would only turn the time into NaN as well.  The added zero keeps event_t in the graph
+        # (gradients through it are NaN, as the reference's).
+        return event_t + _NonFiniteAnchor.apply(y_event).to(event_t.dtype), solution
     with torch.no_grad(), device_guard(y_const.device):
         nfe_before = flat_func.nfe
         f_event = flat_func(ts_value, y_const)
