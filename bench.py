@@ -1189,6 +1189,141 @@ def run_adjoint(args, rank, world, device):
 # ---------------------------------------------------------------------------------------------------
 # launch
 # ---------------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------------
+# the contract line (what the driver parses) and the extras file (everything else)
+# ---------------------------------------------------------------------------------------------------
+CONTRACT_MAX_BYTES = 4096
+
+
+def _num(x, digits=6):
+    """Scalars only: floats rounded to `digits` significant figures, everything that is not a number -> None."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, int):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if x == x and abs(x) != float("inf") else None
+    return None
+
+
+def _short(s, limit=96):
+    return s if s is None or len(s) <= limit else s[:limit - 1] + "~"
+
+
+def contract_line(out, extras_path=None):
+    """The ONE line the driver parses: scalars and short tokens only — no prose, no per-kernel tables, no per-rank
+    arrays (min / max over ranks as scalars).  Everything else `out` holds goes to the extras file.  Same shape at
+    every N and for both workloads; tests/test_bench_line.py pins len(line) < CONTRACT_MAX_BYTES."""
+    cfg = out.get("config") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["metric"] = _short(line["metric"], 120)
+    line["value"], line["ms_per_step"] = _num(line["value"], 7), _num(line["ms_per_step"], 7)
+    line["config"] = {k: (_short(v, 160) if isinstance(v, str) else v) for k, v in cfg.items()
+                      if isinstance(v, (str, int, float, bool)) or v is None}
+    blocks = (out.get("blocks") or {}).get("ms_per_step") or {}
+    if blocks:
+        line["block_ms_per_step"] = {k: _num(blocks.get(k)) for k in ("min", "median", "max")}
+    per_rank = (out.get("blocks") or {}).get("per_rank_ms_per_step")
+    if per_rank:
+        line["rank_ms_per_step"] = {"min": _num(min(per_rank)), "max": _num(max(per_rank))}
+    rf = out.get("roofline")
+    if isinstance(rf, dict):
+        cold = rf.get("cold") if isinstance(rf.get("cold"), dict) else {}
+        line["roofline"] = {
+            "bound": rf.get("bound"), "kernel": _short(rf.get("kernel"), 72), "achieved": _num(rf.get("achieved")),
+            "peak": rf.get("peak"), "unit": rf.get("unit"),
+            # frac = IN SITU: algorithmic bytes / this kernel's average launch duration inside the timed region (the
+            # figure the committed rocprofv3 --stats summary must agree with; the launch's inputs were just written by
+            # func, so the 256 MiB Infinity Cache serves part of the reads).  frac_hbm_cold = the same kernel on
+            # rotating buffer sets several times that cache: every byte from DRAM.
+            "frac": _num(rf.get("frac")), "frac_is": "in_situ", "frac_in_situ": _num(rf.get("frac")),
+            "frac_hbm_cold": _num(rf.get("frac_hbm_cold", cold.get("frac"))),
+            "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"),
+            "avg_launch_ms": _num(rf.get("avg_launch_ms")), "avg_launch_ms_cold": _num(cold.get("avg_launch_ms")),
+            "launches_timed": rf.get("launches_timed"),
+            # FETCH_SIZE + WRITE_SIZE per launch with the guide's gfx950 corrections: requests on the L2's fabric side,
+            # Infinity-Cache hits included (MI355X_MICROARCH.md, HBM section) - an upper bound on DRAM bytes
+            "traffic": _num(rf.get("traffic"), 9), "traffic_counts": "l2_fabric_bytes",
+            "l2_fabric_bytes": _num(rf.get("traffic"), 9),
+            "traffic_source": _short(os.path.basename((rf.get("traffic_source") or "").split(" ")[0]) or None, 48)}
+    so = out.get("solver_only")
+    if isinstance(so, dict) and "error" not in so:
+        line["solver_only"] = {k: _num(so.get(k)) for k in ("stages_per_s", "us_per_step", "GBps_moved",
+                                                            "frac_of_hbm_peak_moved") if k in so}
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                "kind": cb.get("kind"), "sample": _short(cb.get("sample"), 120),
+                                "reference_8core_value": _num((cb.get("reference_8core") or {}).get("value"))}
+        tc = cb.get("reference_op_sequence_on_torch_cpu")
+        if isinstance(tc, dict) and "value" in tc:
+            line["cpu_baseline"]["torch_cpu_value"], line["cpu_baseline"]["torch_cpu_cores"] = \
+                _num(tc["value"]), tc.get("cores")
+    for k in ("rel_err_vs_reference", "rel_err", "nfe", "reference_nfe", "rccl_ranks", "backend",
+              "ms_per_pass", "nfe_fwd", "nfe_bwd", "extras_timed_out", "extras_hung_in"):
+        if k in out:
+            v = out[k]
+            line[k] = _num(v) if isinstance(v, float) else (_short(v, 64) if isinstance(v, str) else v)
+    adj = out.get("adjoint") if isinstance(out.get("adjoint"), dict) else {}
+    for k in ("ms_per_pass", "nfe_fwd", "nfe_bwd", "fwd_ms", "bwd_ms", "rk_stages_per_pass"):
+        if k in adj and isinstance(adj[k], (int, float)):
+            line[k] = _num(adj[k])
+    if "bwd_ms_incl_allreduce" in adj:
+        line["bwd_ms"] = _num(adj["bwd_ms_incl_allreduce"])
+    # N > 1 linear line: the other regimes the same ranks ran, one scalar pair each (tables in the extras file)
+    for regime in ("weak", "strong", "lockstep"):
+        r = out.get(regime)
+        if isinstance(r, dict) and "value" in r:
+            line[regime] = {"value": _num(r.get("value"), 7), "ms_per_step": _num(r.get("ms_per_step"), 7)}
+    for mode in ("strong", "weak", "strong_hip_graph_auto"):
+        r = adj.get(mode)
+        if isinstance(r, dict) and "ms_per_pass" in r:
+            line.setdefault("adjoint", {})[mode] = {
+                "ms_per_pass": _num(r["ms_per_pass"]), "rk_stages_per_s": _num(r.get("rk_stages_per_s")),
+                "nfe_fwd": r.get("nfe_fwd"), "nfe_bwd": r.get("nfe_bwd"),
+                "allreduce_calls": (r.get("allreduce") or {}).get("calls"),
+                "allreduce_ms": _num((r.get("allreduce") or {}).get("ms"))}
+    ar = out.get("allreduce") or adj.get("allreduce")
+    if isinstance(ar, dict):
+        line["allreduce"] = {k: _num(ar.get(k)) for k in ("calls", "bytes", "ms") if k in ar}
+    if out.get("note"):
+        line["note"] = _short(out["note"], 120)
+    line["extras_file"] = extras_path
+    text = json.dumps(line)
+    if len(text) >= CONTRACT_MAX_BYTES:      # cannot happen with the fields above; never emit an unparseable line
+        for k in ("solver_only", "block_ms_per_step", "rank_ms_per_step", "note", "allreduce", "adjoint", "lockstep"):
+            line.pop(k, None)
+        text = json.dumps(line)
+    assert len(text) < CONTRACT_MAX_BYTES, len(text)
+    return text
+
+
+def write_extras(out):
+    """Everything measured (per-kernel breakdowns, the other configs, per-rank tables, definitions in prose) as one
+    JSON file: gpurun_out/bench_extras_n{N}.json (TDEQ_BENCH_EXTRAS_DIR overrides the directory).  Returns the path
+    relative to the repo root, or None when nothing could be written."""
+    d = os.environ.get("TDEQ_BENCH_EXTRAS_DIR") or os.path.join(ROOT, "gpurun_out")
+    name = f"bench_extras_n{out.get('n_gpus', 1)}" + \
+        ("_adjoint" if str(out.get("metric", "")).startswith("odeint_adjoint") else "") + ".json"
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, name)
+        with open(path, "w") as fh:
+            json.dump(out, fh, indent=1, default=repr)
+        return os.path.relpath(path, ROOT)
+    except Exception:
+        return None
+
+
+def emit(out):
+    """Extras to their file (and a digest to stderr); the contract line LAST on stdout, alone."""
+    path = write_extras(out)
+    sys.stderr.write(f"bench.py: extras -> {path}\n")
+    sys.stderr.flush()
+    print(contract_line(out, path), flush=True)
+
+
 class _Watchdog:
     """Fires once after `seconds`: rank 0 prints the JSON line built so far, marked `extras_timed_out` and naming the
     extra measurement that was running (`extras_hung_in`), then the process exits WITHOUT waiting for anything
@@ -1210,7 +1345,7 @@ class _Watchdog:
                 line["extras_hung_in"] = progress.get("current")
                 line["extras_done"] = list(progress.get("done", ()))
                 line["extras_timeout_s"] = seconds
-                print(json.dumps(line, default=repr), flush=True)
+                emit(line)
             except Exception:
                 pass
         os._exit(0)
@@ -1469,7 +1604,7 @@ def main():
     if rank == 0:
         if os.environ.get("TDEQ_BENCH_NOTE"):
             out["note"] = os.environ["TDEQ_BENCH_NOTE"]
-        print(json.dumps(out), flush=True)
+        emit(out)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

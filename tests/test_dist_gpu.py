@@ -19,46 +19,65 @@ def test_rccl_world1_allreduce_tail_and_lockstep():
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_bench_self_launches_two_ranks_gloo():
+def _run_bench(argv, env, tmp_path, timeout):
+    """bench.py as a subprocess: (return code, the contract line = the ONLY stdout line starting with '{', the extras
+    file's content or None, raw stdout/stderr tails)."""
+    import json
+    env = dict(env, TDEQ_BENCH_EXTRAS_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py")] + argv, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    extras = None
+    for f in os.listdir(tmp_path):
+        if f.startswith("bench_extras_n") and f.endswith(".json"):
+            extras = json.load(open(os.path.join(tmp_path, f)))
+    return r, lines, extras
+
+
+def test_bench_self_launches_two_ranks_gloo(tmp_path):
     """`python bench.py --gpus 2` as a plain command (no torchrun wrapper): it re-launches itself as 2 ranks; with
-    fewer GPUs than ranks the ranks share the device over gloo and the line says so.  One JSON line with n_gpus 2,
-    the strong-scaling object and the adjoint object with its all-reduce."""
+    fewer GPUs than ranks the ranks share the device over gloo and the line says so.  ONE stdout JSON line < 4 KB
+    (the contract: scalars only) with n_gpus 2 and one scalar pair per regime; the per-rank breakdowns, the adjoint
+    objects with their all-reduce and the census are in the extras file the line names."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     if torch.cuda.device_count() < 2:
         env["TDEQ_DIST_BACKEND"] = "gloo"
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "10",
-                        "--warmup", "3"], env=env, capture_output=True, text=True, timeout=900)
+    r, lines, out = _run_bench(["--gpus", "2", "--steps", "10", "--warmup", "3"], env, tmp_path, 900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
-    # r04: N > 1 defaults to STRONG scaling — BASELINE.json's metric is quoted at batch 65536 in total — and the line
-    # carries the per-rank kernel-floor breakdown that answers "launch gaps or kernel floor?"
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
-    assert out["config"]["global_batch"] == 65536 and out["config"]["rows_per_gpu"] == 32768
-    assert out["strong"]["value"] > 0 and out["weak"]["value"] > 0 and out["lockstep"]["value"] > 0
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])
+    line = json.loads(lines[0])
+    two_gpus = torch.cuda.device_count() >= 2
+    # the contract line: N > 1 defaults to STRONG scaling (BASELINE.json's metric is quoted at batch 65536 in total)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["steps"] == 10
+    assert line["config"]["global_batch"] == 65536 and line["config"]["rows_per_gpu"] == 32768
+    assert line["strong"]["value"] > 0 and line["weak"]["value"] > 0 and line["lockstep"]["value"] > 0
+    assert line["backend"] == ("nccl" if two_gpus else "gloo") and line["rccl_ranks"] == (2 if two_gpus else None)
+    assert line["rank_ms_per_step"]["min"] <= line["rank_ms_per_step"]["max"]
+    for mode in ("strong", "weak"):
+        assert line["adjoint"][mode]["allreduce_calls"] == 1 and line["adjoint"][mode]["ms_per_pass"] > 0
+    assert not any(isinstance(v, list) for v in line.values())          # no per-rank arrays in the contract line
+    assert line["extras_file"].endswith("bench_extras_n2.json") and out is not None
+    # the extras file: everything else
+    assert out["value"] == pytest.approx(line["value"], rel=1e-5)
     assert out["weak"]["config"]["global_batch"] == 2 * 65536
     bd = out["breakdown"]
-    assert [r["rank"] for r in bd["per_rank"]] == [0, 1] and bd["floor_ms"] > 0
-    for r in bd["per_rank"]:
-        assert r["solver_dispatches_per_call"] >= 7 and r["func_dispatches_per_call"] >= 6
-        assert r["solver_kernel_us"] > 0 and r["func_kernel_us"] > 0
-    assert abs(bd["floor_ms"] - (max(r["floor_us"] for r in bd["per_rank"]) * 1e-3)) < 1e-9
+    assert [r_["rank"] for r_ in bd["per_rank"]] == [0, 1] and bd["floor_ms"] > 0
+    for r_ in bd["per_rank"]:
+        assert r_["solver_dispatches_per_call"] >= 7 and r_["func_dispatches_per_call"] >= 6
+        assert r_["solver_kernel_us"] > 0 and r_["func_kernel_us"] > 0
+    assert abs(bd["floor_ms"] - (max(r_["floor_us"] for r_ in bd["per_rank"]) * 1e-3)) < 1e-9
     assert out["adjoint"]["strong"]["breakdown"]["floor_ms"] > 0
     for mode in ("strong", "weak"):
         ar = out["adjoint"][mode]["allreduce"]
         assert ar["calls"] == 1 and ar["bytes"] >= 4 * 98880 and ar["ms"] > 0
-    # what the collective backend connected, in the line itself (r03)
-    two_gpus = torch.cuda.device_count() >= 2
-    assert out["backend"] == ("nccl" if two_gpus else "gloo")
-    assert out["rccl_ranks"] == (2 if two_gpus else None) and out["comm"]["comm_ranks"] == 2
-    assert [d["rank"] for d in out["comm"]["devices"]] == [0, 1]
+    assert out["comm"]["comm_ranks"] == 2 and [d["rank"] for d in out["comm"]["devices"]] == [0, 1]
     assert "extras_timed_out" not in out and set(out["extras_s"]) >= {"weak", "lockstep", "adjoint"}
 
 
-def test_bench_census_through_rccl_at_world_size_one():
+def test_bench_census_through_rccl_at_world_size_one(tmp_path):
     """bench.py's communicator census — the all-reduce of ones ON THE DEVICE and the gather of the ranks' GPU identities
     that every N > 1 run performs before timing anything — executed through RCCL itself: TDEQ_DIST_FORCE_INIT=1 creates
     the nccl process group (bound to the rank's GPU, as dist.init_from_env does for N ranks) at world size 1."""
@@ -66,11 +85,12 @@ def test_bench_census_through_rccl_at_world_size_one():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TDEQ_DIST_FORCE_INIT="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
                MASTER_ADDR="127.0.0.1", MASTER_PORT="29723")
     env.pop("TDEQ_DIST_BACKEND", None)
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "1", "--steps", "5",
-                        "--warmup", "2", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
-                       timeout=600)
+    r, lines, out = _run_bench(["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-extras", "--no-cpu-baseline"], env,
+                               tmp_path, 600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    line = json.loads(lines[-1])
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    assert line["backend"] == "nccl" and line["rccl_ranks"] == 1 and line["value"] > 0
     assert out["backend"] == "nccl" and out["rccl_ranks"] == 1 and out["comm"]["comm_ranks"] == 1
     dev = out["comm"]["devices"][0]
     assert dev["rank"] == 0 and dev["device_index"] == 0 and dev["device_name"]

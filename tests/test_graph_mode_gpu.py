@@ -272,6 +272,37 @@ def test_uncapturable_func_falls_back_to_eager():
     assert float((y0 * 2).sum()) == 12.0
 
 
+def test_auto_mode_remembers_a_func_that_cannot_be_captured():
+    """hip_graph='auto' on a func with a host read inside (advisor r04): the first solve that tries the capture records
+    the func as refused — ONE warning worded for auto, look-ahead back on for the rest of that solve — and later solves
+    of the same func object do not try again (no capture attempt, no warning), all with the eager result."""
+    from torchdiffeq_amd.solvers import _GraphStep
+    tda.clear_graph_cache()
+
+    class F(torch.nn.Module):
+        def forward(self, t, y):
+            scale = float(t)              # device -> host read: illegal while a stream is capturing
+            return -y * (1.0 + 0.1 * scale)
+
+    f = F()
+    y0 = torch.tensor([[1.0, 2.0, 3.0]], dtype=torch.float64, device="cuda")
+    t = torch.tensor([0.0, 1.0, 2.0], dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        ref = tda.odeint(f, y0, t, method="dopri5", rtol=1e-7, atol=1e-9)
+        msgs = []
+        for rep in range(4):             # 1st: eager ("later"), 2nd: capture attempt fails -> refused, 3rd/4th: never
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                y = tda.odeint(f, y0, t, method="dopri5", rtol=1e-7, atol=1e-9, options=dict(hip_graph="auto"))
+            assert torch.equal(y, ref), rep
+            msgs.append([str(w.message) for w in rec if "hip_graph" in str(w.message)])
+    flat = [m for ms in msgs for m in ms]
+    assert len(flat) == 1 and "hip_graph='auto'" in flat[0] and "capturing it failed" in flat[0], msgs
+    assert f in _GraphStep._refused and not _GraphStep._cache.get(f)
+    assert msgs[2] == [] and msgs[3] == []
+    tda.clear_graph_cache()
+
+
 def test_graph_is_reused_across_solves_of_the_same_func():
     """Second and later solves with the same func object and state layout replay the graph captured by the first
     (no capture, no eager warm-up step) with the new initial state — and see in-place parameter updates."""

@@ -409,6 +409,16 @@ class _GraphStep:
             warnings.warn("hip_graph='auto': {} is not captured into a hipGraph — {}; its solves run on the eager "
                           "path (pass hip_graph=True to capture it regardless)".format(type(base).__name__, reason))
 
+    def evict(self, s) -> None:
+        """Drop this captured step from the per-func cache (its capture failed: nothing to replay)."""
+        try:
+            per_func = self._cache.get(s.func.base_func)
+            if per_func is not None:
+                for k in [k for k, g in per_func.items() if g is self]:
+                    del per_func[k]
+        except TypeError:
+            pass
+
     @staticmethod
     def _key(s):
         c = s._ctrl

@@ -664,10 +664,20 @@ class RKAdaptiveStepsizeODESolver:
                 self._graph_trial_step()
             except _CaptureFailed as exc:
                 # a failed capture executes nothing: the static buffers still hold the current state, continue
-                # with the eager path from it
-                warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({}); continuing with "
-                              "the eager path".format(exc))
+                # with the eager path from it.  The half-built captured step never goes back to the per-func cache:
+                # "auto" remembers the func as unfit (one warning per func object, no retry on the next solve of a
+                # training loop); hip_graph=True drops the entry so that the next solve starts a fresh capture.
+                g, self._g = self._g, None
+                if self._graph_auto and g is not None:
+                    g.refuse(self, "capturing it failed ({}): a host synchronisation, .item() or data-dependent "
+                                   "Python branch inside func".format(exc))
+                else:
+                    if g is not None:
+                        g.evict(self)
+                    warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({}); continuing with "
+                                  "the eager path".format(exc))
                 self.hip_graph = False
+                self._hold_pre = False
                 self._adaptive_step()
         else:
             self._adaptive_step()
