@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 17
+#define TDEQ_ABI_VERSION 18
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 /* interleaved (re, im) complex states — accepted by the NORM entry points only (tdeq_error_norm, tdeq_error_norm_partial[_ctrl],
@@ -47,6 +47,19 @@ extern "C" {
  * TDEQ_F32 / TDEQ_F64).  |z| = hypot(re, im), z / real = z * (1 / real): torchdiffeq/_impl/misc.py:80-82 as ATen rounds it. */
 #define TDEQ_C64 2
 #define TDEQ_C128 3
+/* bfloat16 / float16 states (r05).  The reference integrates them in their own precision (misc.py:185-187,
+ * rk_common.py:61-65): every ATen op computes in float32 and rounds its result to the storage type, a `torch.sum` over a
+ * tableau row accumulates the rounded products in float32 and rounds once.  Accepted by the entry points of the
+ * host-driven step — tdeq_stage_combine, tdeq_stage_combine_fill, tdeq_stage_combine_err, tdeq_error_norm,
+ * tdeq_init_norms, tdeq_init_scaled, tdeq_dense_eval, tdeq_dense_eval_multi, tdeq_interp_fit, tdeq_rk4_38_stage,
+ * tdeq_lerp, tdeq_fixed_stage, tdeq_weighted_sum — with exactly that rounding (tdeq_kernels_lp.hpp); every other
+ * entry point returns TDEQ_EINVAL for them.  Scalars: `dt`, tableau weights, `slope`, tolerances are rounded to the
+ * storage type where the reference holds them as 0-dim tensors of the state's type or as FIRST operands, and taken at
+ * float32 where ATen takes a Python number as SECOND operand of `*` (rk4's 1/3, `* dt`; tdeq_init_norms' rtol).
+ * The norm entry points report per segment the sum of fl(|q|^2) — for a segment of ONE element |q| itself (the adjoint's
+ * norms take their time component as `t.abs()`, adjoint.py:250, and the caller squares it with the same rounding). */
+#define TDEQ_BF16 4
+#define TDEQ_F16 5
 #define TDEQ_MAX_TERMS 14      /* dopri8: 13 stages + FSAL slot (dopri8.py:5-70) */
 #define TDEQ_MAX_SUM_TERMS 8    /* tdeq_weighted_sum */
 #define TDEQ_MAX_DENSE_OUTPUTS 16 /* tdeq_dense_eval_multi */
@@ -144,6 +157,20 @@ int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void
                     size_t workspace_bytes, int dtype, void* stream);
 
 /*
+ * tdeq_error_norm for PER-ELEMENT tolerances: `rtol` / `atol` tensors that broadcast against the state (misc.py:80-82 —
+ * the reference needs no code for it) or tuple tolerances with vector entries (flat vectors, misc.py:115-123).  A
+ * dimensioned tolerance is a device vector of fp64 (the time dtype of rk_common.py:186-187) over the flat, padded state;
+ * the other one may be 0-dim (`*_vec` NULL, value in `*_scalar`); at least one must be dimensioned.  Promotion as ATen
+ * does it: rtol[i] * max(|y0|,|y1|) in fp64 when rtol is dimensioned, in T (rtol cast to T) when it is 0-dim; the sum
+ * with atol, err / tol and the sum of squares in fp64.  The segment table's rtol / atol are ignored.
+ */
+int tdeq_error_norm_vec(const void* y0, const void* y1, const void* const* k, const double* coef, int n_terms, double dt,
+                        const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
+                        const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
+                        double* out_sumsq, double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
+                        void* stream);
+
+/*
  * Fused pair for the END of a trial step (same results as tdeq_stage_combine + tdeq_error_norm, fewer bytes):
  *   tdeq_stage_combine_err   the step's last combine (last stage row, or the c_sol combine of a non-FSAL pair)
  *                            also stores  err_out = (e_0 k_0 + e_1 k_1) + ...,  e_j = fl_T(fl_T(err_coef_j)*fl_T(dt)),
@@ -185,6 +212,9 @@ int tdeq_error_norm_partial(const void* err_partial, const void* y0, const void*
  * `acc_in` may be NULL.  Outputs may alias nothing that is read.
  */
 #define TDEQ_MAX_MULTI_OUT 4
+/* streaming launches whose streams add up to more than this many MiB use non-temporal loads and stores (tdeq_abi.hip
+ * stream_policy; TDEQ_NT_THRESHOLD_MB overrides, TDEQ_COMBINE_POLICY=0..3 forces one policy) */
+#define TDEQ_NT_THRESHOLD_DEFAULT_MB 512
 typedef struct tdeq_multi_out {
     void* out;                      /* T[n]                                                                   */
     double coef[TDEQ_MAX_TERMS];    /* fp64 tableau weights of this output's row over the n_terms streams       */

@@ -80,6 +80,9 @@ def test_gpu_state_without_the_library_is_rejected_loudly(monkeypatch, tmp_path)
     monkeypatch.setattr(_native, "_LIB_PATH", str(tmp_path / "no_such_lib.so"))
     with pytest.raises(_native.NativeLibraryError):
         _native.get_kernels(torch.device("cuda", 0), torch.float32)
+    monkeypatch.setattr(_native, "_LOW_HIP_KERNELS", None)
+    with pytest.raises(_native.NativeLibraryError):           # r05: reduced-precision states too (csrc/tdeq_kernels_lp.hpp)
+        _native.get_kernels(torch.device("cuda", 0), torch.bfloat16)
     with pytest.warns(_fallback.HostPathWarning) if not _fallback._warned else contextlib.nullcontext():
         assert _native.get_kernels(torch.device("cpu"), torch.float32).name == "host"
 

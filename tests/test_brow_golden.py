@@ -194,9 +194,13 @@ def test_low_precision_state_warns_and_selects_the_low_backend(monkeypatch):
     with pytest.warns(_fallback.HostPathWarning, match="bfloat16"):
         k = _native.get_kernels(torch.device("cpu"), torch.bfloat16)
     assert isinstance(k, _fallback.LowPrecisionHostKernels)
+    # r05: on a ROCm device the same interface is served by the HIP kernels of csrc/tdeq_kernels_lp.hpp — no warning, and the
+    # library is required (the class derives from the torch-op one only for the operations the kernels do not cover)
+    from torchdiffeq_amd import _lowp
     with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        assert isinstance(_native.get_kernels(torch.device("cuda:0"), torch.float16), _fallback.LowPrecisionHostKernels)
+        warnings.simplefilter("error", _fallback.HostPathWarning)
+        k16 = _native.get_kernels(torch.device("cuda:0"), torch.float16)
+    assert isinstance(k16, _lowp.LowPrecisionHipKernels) and k16.name == "hip-low" and not k16.device_controller
     with pytest.raises(TypeError, match="float8|supports"):
         tda.odeint(lambda t, y: -y, torch.ones(2).to(torch.float8_e4m3fn), torch.tensor([0.0, 1.0]))
 

@@ -1,0 +1,85 @@
+"""Per-element tolerances on the fused norm kernel (r05, tdeq_error_norm_vec): `rtol` / `atol` tensors that broadcast
+against the state (torchdiffeq/_impl/misc.py:80-82: plain broadcasting in the reference) go into the error-norm launch
+as two more fp64 streams instead of a materialised raw error + ~10 ATen passes in fp64."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+pytestmark = pytest.mark.gpu
+
+import torchdiffeq_amd as tda  # noqa: E402
+from torchdiffeq_amd import _native  # noqa: E402
+
+COEFS = (0.0371, -0.211, 0.5, 1.25, -0.0625, 0.33, 0.9)
+
+
+@pytest.mark.parametrize("form", ["both", "rtol_only", "atol_only"])
+@pytest.mark.parametrize("n", [1, 1031, 5000])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_kernel_equals_the_references_broadcast_expression(dtype, n, form):
+    """misc.py:81-82 evaluated literally by ATen on the same device — type promotion included (a dimensioned fp64
+    tolerance promotes, a 0-dim one does not) — against the kernel's fp64 sum of squares."""
+    g = torch.Generator().manual_seed(n)
+    r = lambda: torch.randn(n, generator=g, dtype=torch.float64).to(dtype).cuda()
+    y0, y1, ks = r(), r(), [r() for _ in range(6)]
+    rtol_v = (torch.rand(n, generator=g, dtype=torch.float64) * 1e-3 + 1e-6).cuda()
+    atol_v = (torch.rand(n, generator=g, dtype=torch.float64) * 1e-5 + 1e-8).cuda()
+    rtol = rtol_v if form != "atol_only" else torch.tensor(3e-4, dtype=torch.float64, device="cuda")
+    atol = atol_v if form != "rtol_only" else torch.tensor(2e-6, dtype=torch.float64, device="cuda")
+    kern = _native.get_kernels(torch.device("cuda:0"), dtype)
+    plan = kern.make_plan([(0, n, 0.0, 1.0)], n, 1024, torch.device("cuda:0"))
+    dt = 0.0371
+    kern.error_norm_vec(plan, y0, y1, ks, COEFS[:6], dt, rtol if rtol.dim() else float(rtol), atol if atol.dim() else float(atol))
+    sumsq, _, bad = kern.read_norms(plan)
+    # the reference's expression; the error row in the kernels' order (left to right, every product and sum rounded in T)
+    dtT = torch.tensor(dt, dtype=torch.float64).to(dtype)
+    err = None
+    for k_, c in zip(ks, COEFS):
+        p = k_ * (torch.tensor(c, dtype=torch.float64).to(dtype) * dtT).cuda()
+        err = p if err is None else err + p
+    tol = atol + rtol * torch.max(y0.abs(), y1.abs())
+    q = err / tol
+    assert q.dtype == torch.float64
+    assert sumsq[0] == pytest.approx(float(q.abs().pow(2).sum()), rel=1e-12) and bad == [0.0]
+
+
+def test_solve_with_vector_tolerances_takes_the_fused_kernel(monkeypatch):
+    """A no-grad dopri5 solve with a per-element rtol: every trial step's error ratio comes from tdeq_error_norm_vec (the
+    raw-error route `error_scaled` is never taken), and the steps are those of the torch-op evaluation of the same
+    formula (TDEQ-internal switch off) — equal evaluation counts, solutions equal to fp64 rounding."""
+    from torchdiffeq_amd import solvers
+    g = torch.Generator().manual_seed(0)
+    A = (torch.randn(12, 12, generator=g, dtype=torch.float64) / 4 - 0.2 * torch.eye(12, dtype=torch.float64)).cuda()
+    y0 = torch.randn(300, 12, generator=g, dtype=torch.float64).cuda()
+    t = torch.tensor([0.0, 0.7, 2.0], dtype=torch.float64, device="cuda")
+    rtol = torch.logspace(-8, -4, 12, dtype=torch.float64, device="cuda").expand(300, 12)
+    kern = _native.get_kernels(torch.device("cuda:0"), torch.float64)
+    calls = {"vec": 0, "scaled": 0}
+    real_vec, real_scaled = kern.error_norm_vec, kern.error_scaled
+    monkeypatch.setattr(kern, "error_norm_vec", lambda *a, **k: (calls.__setitem__("vec", calls["vec"] + 1), real_vec(*a, **k))[1])
+    monkeypatch.setattr(kern, "error_scaled", lambda *a, **k: (calls.__setitem__("scaled", calls["scaled"] + 1), real_scaled(*a, **k))[1])
+    nfe = [0]
+
+    def f(t_, y_):
+        nfe[0] += 1
+        return y_ @ A.T * torch.cos(t_)
+    with torch.no_grad():
+        y = tda.odeint(f, y0, t, rtol=rtol, atol=1e-9, method="dopri5")
+    n_fused, nfe[0] = nfe[0], 0
+    assert calls["vec"] == (n_fused - 2) // 6 and calls["scaled"] == 0
+    # the same solve with the fused kernel switched off: the r04 route (raw error + torch ops in fp64)
+    orig_init = solvers.RKAdaptiveStepsizeODESolver.__init__
+
+    def init_without(self, *a, **k):
+        orig_init(self, *a, **k)
+        self._vec_fused = None
+    monkeypatch.setattr(solvers.RKAdaptiveStepsizeODESolver, "__init__", init_without)
+    with torch.no_grad():
+        y_ref = tda.odeint(f, y0, t, rtol=rtol, atol=1e-9, method="dopri5")
+    assert calls["scaled"] > 0 and nfe[0] == n_fused
+    assert float((y - y_ref).abs().max()) < 1e-12

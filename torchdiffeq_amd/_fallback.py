@@ -229,7 +229,7 @@ class HostKernels:
                 r = e[sl] / tol
             plan.rms0[s] = rms = self._rms(r)
             plan.abs0[s] = float(r.abs()) if n == 1 else math.nan
-            plan.sums0[s] = self._sumsq(r) if not self.literal_norms else rms * rms * n     # (interface; unused on this path)
+            plan.sums0[s] = self._sumsq(r)      # the fp64 sum itself: lock-step sharding (dist_sync) all-reduces it
             plan.bad[s] = _nonfinite(y0[sl], y1[sl])
             if scaled_out is not None:
                 scaled_out[sl] = r
@@ -277,11 +277,11 @@ class HostKernels:
             n = q0.numel()
             plan.rms0[s] = rms = self._rms(q0)
             plan.abs0[s] = float(q0.abs()) if n == 1 else math.nan
-            plan.sums0[s] = self._sumsq(q0) if not self.literal_norms else rms * rms * n
+            plan.sums0[s] = self._sumsq(q0)
             if q1 is not None:
                 plan.rms1[s] = rms = self._rms(q1)
                 plan.abs1[s] = float(q1.abs()) if n == 1 else math.nan
-                plan.sums1[s] = self._sumsq(q1) if not self.literal_norms else rms * rms * n
+                plan.sums1[s] = self._sumsq(q1)
             plan.bad[s] = _nonfinite(yscale[sl])
 
     def init_scaled(self, plan, mode: int, a, b, yscale, out0, out1=None) -> None:

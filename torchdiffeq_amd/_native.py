@@ -18,9 +18,10 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 17
+TDEQ_ABI_VERSION = 18
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_C64, TDEQ_C128 = 2, 3        # interleaved complex: the norm entry points only (include/tdeq_hip.h)
+TDEQ_BF16, TDEQ_F16 = 4, 5        # reduced-precision states: the entry points of the host-driven step (LowPrecisionHipKernels)
 TDEQ_MAX_TERMS = 14
 TDEQ_INLINE_SEGMENTS = 16
 TDEQ_CHUNK_QUANTUM = 1024
@@ -74,6 +75,11 @@ ABI_SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_error_norm_vec": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
+                                           ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p,
+                                           ctypes.c_double, ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int,
+                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_stage_combine_err": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
                                               _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_double,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
@@ -211,6 +217,10 @@ def dtype_code(dtype: torch.dtype) -> int:
         return TDEQ_C64
     if dtype == torch.complex128:
         return TDEQ_C128
+    if dtype == torch.bfloat16:
+        return TDEQ_BF16
+    if dtype == torch.float16:
+        return TDEQ_F16
     raise TypeError(f"torchdiffeq_amd supports float32 / float64 (and complex64 / complex128) states, got {dtype}")
 
 
@@ -379,6 +389,19 @@ class HipKernels:
                                         plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
                                         plan.workspace.data_ptr(), plan.workspace_bytes,
                                         dtype_code(y0.dtype), self._stream()), "tdeq_error_norm")
+
+    def error_norm_vec(self, plan: NormPlan, y0, y1, ks, coefs, dt: float, rtol, atol) -> None:
+        """`error_norm` with per-element tolerances (tdeq_error_norm_vec): `rtol` / `atol` = an fp64 device vector over the
+        flat padded state, or a host float for a 0-dim tolerance (at least one vector)."""
+        ptrs, cf, n = self._terms(ks, coefs)
+        dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
+        rv, rs = (rtol.data_ptr(), 0.0) if isinstance(rtol, torch.Tensor) else (None, float(rtol))
+        av, as_ = (atol.data_ptr(), 0.0) if isinstance(atol, torch.Tensor) else (None, float(atol))
+        self._arm(plan, 1)
+        _check(self.lib.tdeq_error_norm_vec(y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, rv, rs, av, as_, plan.segs, dev,
+                                            plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
+                                            plan.workspace.data_ptr(), plan.workspace_bytes, dtype_code(y0.dtype),
+                                            self._stream()), "tdeq_error_norm_vec")
 
     def stage_combine_err(self, out, err_out, y0, ks, coefs, err_coefs, dt: float) -> None:
         """Last combine of a step + partial embedded error over the same stages (tdeq_stage_combine_err)."""
@@ -823,6 +846,7 @@ def on_state_device(method):
 _KERNELS: Optional[HipKernels] = None
 _HOST_KERNELS = None
 _LOW_KERNELS = None
+_LOW_HIP_KERNELS = None
 _COMPLEX_KERNELS = None
 
 
@@ -833,16 +857,24 @@ def get_kernels(device: torch.device, dtype: Optional[torch.dtype] = None):
     libtdeq_hip.so raises `NativeLibraryError` here (no silent substitute on the GPU); complex states through
     `ComplexHipKernels` (real kernels on the (re, im) view + the complex norm kernels).  A state that the kernels do
     not take — not on a ROCm device (BASELINE.json configs[0] is a CPU case; the reference runs wherever its tensors
-    live, odeint.py:49-108) or below fp32 (misc.py:185-187) — -> `_fallback.HostKernels` / `LowPrecisionHostKernels`,
-    the same interface in torch ops, with one `HostPathWarning` per process."""
-    global _KERNELS, _HOST_KERNELS, _LOW_KERNELS, _COMPLEX_KERNELS
+    live, odeint.py:49-108) — -> `_fallback.HostKernels` / `LowPrecisionHostKernels`, the same interface in torch ops,
+    with one `HostPathWarning` per process.  bf16 / fp16 states on a ROCm device -> `_lowp.LowPrecisionHipKernels`."""
+    global _KERNELS, _HOST_KERNELS, _LOW_KERNELS, _LOW_HIP_KERNELS, _COMPLEX_KERNELS
     device = torch.device(device)
     is_complex = dtype is not None and dtype.is_complex
     if dtype in (torch.bfloat16, torch.float16):
-        # states below fp32: integrated in their own precision like the reference's (misc.py:185-187), with ATen's
-        # reduced-precision rounding — torch ops by nature, on whatever device the state lives
+        # states below fp32: integrated in their own precision like the reference's (misc.py:185-187), every operation
+        # rounded to the storage type as ATen rounds it — on a ROCm device by the HIP kernels of csrc/tdeq_kernels_lp.hpp
+        # (`_lowp.LowPrecisionHipKernels`: a missing library raises here, as for fp32), elsewhere by torch ops
+        if device.type == "cuda":
+            if _LOW_HIP_KERNELS is None:
+                if _KERNELS is None:
+                    _KERNELS = HipKernels(load_library())
+                from . import _lowp
+                _LOW_HIP_KERNELS = _lowp.LowPrecisionHipKernels(_KERNELS)
+            return _LOW_HIP_KERNELS
         from . import _fallback
-        _fallback.warn_once(f"the state is {dtype}")
+        _fallback.warn_once(f"the state is {dtype} on '{device}'")
         if _LOW_KERNELS is None:
             _LOW_KERNELS = _fallback.LowPrecisionHostKernels()
         return _LOW_KERNELS

@@ -54,6 +54,30 @@ def _auto_backward_due(base_func, total: int) -> bool:
     return True
 
 
+class _AliasParams(torch.overrides.TorchFunctionMode):
+    """While func is evaluated for a CAPTURED backward step: every torch call that receives one of the adjoint parameters
+    gets a fresh leaf ALIAS of it instead (same storage, no history) — wherever func found the parameter: a closure cell, a
+    global, a list, an attribute of some object.  The VJPs are then taken wrt the aliases, so the parameters' own
+    AccumulateGrad nodes (created on the user's stream, kept alive by the outer graph) stay out of the capture; see
+    _AugmentedDynamics.__init__.  For an nn.Module that owns its parameters `torch.func.functional_call` does the same
+    by attribute substitution; this mode is the route for any other callable with explicit `adjoint_params`
+    (torchdiffeq/_impl/adjoint.py:161-164 accepts those)."""
+
+    def __init__(self, originals, aliases):
+        super().__init__()
+        self._alias = {id(o): a for o, a in zip(originals, aliases)}
+
+    def _sub(self, x):
+        if isinstance(x, torch.Tensor):
+            return self._alias.get(id(x), x)
+        if type(x) in (list, tuple):
+            return type(x)(self._sub(v) for v in x)
+        return x
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        return func(*[self._sub(a) for a in args], **{k: self._sub(v) for k, v in (kwargs or {}).items()})
+
+
 class _AugmentedDynamics(OdeFunc):
     """d/ds [vjp_t, y, adj_y, adj_θ] = [-(∂f/∂t)·a, f, -(∂f/∂y)ᵀa, -(∂f/∂θ)ᵀa]   (adjoint.py:72-105).
 
@@ -74,8 +98,11 @@ class _AugmentedDynamics(OdeFunc):
         # by the very graph whose backward is running; autograd would synchronise the capturing stream with the
         # default stream and the capture dies (measured: a segfault inside hipGraph capture).  Captured evaluations
         # therefore run func through `torch.func.functional_call` on fresh leaf ALIASES of the parameters (same
-        # storage: in-place optimizer updates are seen by every replay).  Possible when func is an nn.Module and every
-        # adjoint parameter is one of its parameters.
+        # storage: in-place optimizer updates are seen by every replay) when func is an nn.Module and every adjoint
+        # parameter is one of its parameters; any other callable (a closure over tensors with explicit `adjoint_params`,
+        # adjoint.py:161-164) is evaluated under `_AliasParams`, which hands the same aliases to every torch call that
+        # would have received a parameter (r05).  Either way `proxy_is_faithful` compares the aliased VJPs with the direct
+        # ones once before anything is captured.
         self.proxy_names = None
         self.use_proxy = False
         base = fwd.base_func
@@ -105,9 +132,13 @@ class _AugmentedDynamics(OdeFunc):
             t_ = (t_user * sign_f if sign_f != 1.0 else t_user).detach().requires_grad_(True)
             y_in = tuple(v.detach().requires_grad_(True) for v in y_views)
             y_arg = y_in if fwd.layout.is_tuple else y_in[0]
-            if use_proxy:
+            if use_proxy and self.proxy_names is not None:
                 leaves = tuple(p.detach().requires_grad_(True) for p in self.params)
                 f = torch.func.functional_call(fwd.base_func, dict(zip(self.proxy_names, leaves)), (t_, y_arg))
+            elif use_proxy:
+                leaves = tuple(p.detach().requires_grad_(True) for p in self.params)
+                with _AliasParams(self.params, leaves):
+                    f = fwd.base_func(t_, y_arg)
             else:
                 leaves = self.params
                 f = fwd.base_func(t_, y_arg)
@@ -282,12 +313,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
             from .solvers import _graph_request
             wanted, auto = _graph_request(options.get("hip_graph"))
             auto_second_sight = False
-            if wanted and aug_func.proxy_names is None:
-                if not auto and "hip_graph" in ctx.adjoint_options:
-                    warnings.warn("hip_graph: the adjoint's backward solve can only be captured when func is an "
-                                  "nn.Module and every adjoint parameter is one of its parameters; running it eagerly")
-                options["hip_graph"] = False
-            elif wanted and auto and not _auto_backward_due(fwd.base_func, aug_layout.total):
+            if wanted and auto and not _auto_backward_due(fwd.base_func, aug_layout.total):
                 # "auto": nothing would be captured in this backward solve (state too large, func refused, or first sight
                 # of func — first solves are eager) — so func is not evaluated for the proxy check either
                 options["hip_graph"] = False
@@ -301,9 +327,10 @@ class OdeintAdjointMethod(torch.autograd.Function):
                     aug_func.use_proxy = True
                     auto_second_sight = auto    # (the first backward solve of func ran with the option off)
                 else:
-                    warnings.warn("hip_graph: func reaches some of its parameters other than by attribute lookup on the "
-                                  "module (torch.func.functional_call cannot re-route them), so the backward solve "
-                                  "cannot be captured with correct parameter gradients; running it eagerly")
+                    warnings.warn("hip_graph: func reaches some of its adjoint parameters in a way that cannot be re-routed to "
+                                  "leaf aliases (a module parameter used other than by attribute lookup, a pre-computed "
+                                  "view of a parameter held by a closure), so the backward solve cannot be captured with "
+                                  "correct parameter gradients; running it eagerly")
                     options["hip_graph"] = False
             if sync is not None:
                 # lock-step backward solve: [vjp_t | θ-adjoints] replicated (all-reduced per evaluation), y / adj_y

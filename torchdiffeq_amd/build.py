@@ -11,7 +11,8 @@ import sys
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SOURCES = [os.path.join(_PKG, "csrc", "tdeq_abi.hip")]
-HEADERS = [os.path.join(_PKG, "csrc", "tdeq_kernels.hpp"), os.path.join(_PKG, "csrc", "tdeq_kernels_complex.hpp"),
+HEADERS = [os.path.join(_PKG, "csrc", h) for h in ("tdeq_kernels.hpp", "tdeq_kernels_complex.hpp", "tdeq_kernels_lp.hpp",
+                                                   "tdeq_abi_lp.hpp")] + [
            os.path.join(_ROOT, "include", "tdeq_hip.h")]
 OUTPUT = os.path.join(_PKG, "libtdeq_hip.so")
 

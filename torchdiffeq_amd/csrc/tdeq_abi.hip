@@ -7,6 +7,7 @@
 
 #include "tdeq_kernels.hpp"
 #include "tdeq_kernels_complex.hpp"
+#include "tdeq_kernels_lp.hpp"
 
 namespace {
 using namespace tdeq;
@@ -32,15 +33,29 @@ inline int check_launch() {
     return (int)e;
 }
 
-// Cache policy of the stage_combine streams (bit 0: non-temporal loads, bit 1: non-temporal store).
-// Read once from TDEQ_COMBINE_POLICY for tuning runs; the default is the measured best.
-inline int combine_policy() {
-    static const int policy = [] {
+// Cache policy of a streaming launch (bit 0: non-temporal loads, bit 1: non-temporal stores), chosen from the bytes
+// its streams touch.  Measured on the MI355X (tools/stream_count.hip, profiles/r05_stream_count.json): with every byte
+// coming from DRAM, 5 read + 2 write streams run at 5.4 TB/s with the default policy and at 6.0 TB/s with both hints
+// (10 R + 4 W fp64: 5.6 -> 5.9-6.3) — the hints keep single-use lines from churning through L2 / the Infinity Cache.
+// A launch whose streams fit the 256 MiB Infinity Cache is better off WITHOUT them (its inputs were just written by
+// func and are still resident; its outputs are read by func next).  TDEQ_COMBINE_POLICY = 0..3 forces one policy for
+// every launch (tuning runs); TDEQ_NT_THRESHOLD_MB moves the switch point.
+constexpr int64_t kNtDefaultThreshold = (int64_t)TDEQ_NT_THRESHOLD_DEFAULT_MB << 20;
+constexpr int kNtPolicy = 3;
+
+inline int stream_policy(int64_t stream_bytes) {
+    static const int forced = [] {
         const char* e = getenv("TDEQ_COMBINE_POLICY");
-        const int v = e ? atoi(e) : 0;
-        return (v >= 0 && v <= 3) ? v : 0;
+        if (!e || !*e || *e == 'a') return -1;      // unset / "auto"
+        const int v = atoi(e);
+        return (v >= 0 && v <= 3) ? v : -1;
     }();
-    return policy;
+    if (forced >= 0) return forced;
+    static const int64_t threshold = [] {
+        const char* e = getenv("TDEQ_NT_THRESHOLD_MB");
+        return (e && *e) ? ((int64_t)atoll(e) << 20) : kNtDefaultThreshold;
+    }();
+    return stream_bytes > threshold ? kNtPolicy : 0;
 }
 
 // ---- stage_combine --------------------------------------------------------------------------------
@@ -66,7 +81,7 @@ int launch_combine(void* out, const void* y0, const void* const* k, const double
         hipExtLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 0>), dim3(g), dim3(kBlock), 0, s, ev_start, ev_stop, 0, a);
     } else if (vec) {
         const unsigned g = stream_grid(n / L, kBlock * U);
-        switch (combine_policy()) {   // tuning knob, see combine_policy()
+        switch (stream_policy((int64_t)(NT + 2) * n * (int64_t)sizeof(T))) {   // see stream_policy()
             case 1: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 1>), dim3(g), dim3(kBlock), 0, s, a); break;
             case 2: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 2>), dim3(g), dim3(kBlock), 0, s, a); break;
             case 3: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 3>), dim3(g), dim3(kBlock), 0, s, a); break;
@@ -120,8 +135,17 @@ int launch_combine_err(void* out, void* err_out, const void* y0, const void* con
     }
     a.c.n = n;
     constexpr int L = VecOf<T>::L;
-    if (vec) hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    if (vec) {
+        const dim3 g(stream_grid(n / L, kBlock)), b(kBlock);
+        switch (stream_policy((int64_t)(NT + 3) * n * (int64_t)sizeof(T))) {
+            case 1: hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 1>), g, b, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 2>), g, b, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 3>), g, b, 0, s, a); break;
+            default: hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 0>), g, b, 0, s, a);
+        }
+    } else {
+        hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    }
     return check_launch();
 }
 
@@ -177,11 +201,23 @@ int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, 
     a.n_out = n_out;
     a.n = n;
     constexpr int L = VecOf<T>::L;
-    if (vec && ev_start && ev_stop)      // measurement hook (tdeq_stage_combine_multi_timed)
-        hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s,
-                              ev_start, ev_stop, 0, a);
-    else if (vec) hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    if (vec) {
+        const dim3 g(stream_grid(n / L, kBlock)), b(kBlock);
+        const bool timed = ev_start && ev_stop;      // measurement hook (tdeq_stage_combine_multi_timed)
+        const int64_t streams = NT + 1 + (acc_in ? 1 : 0) + n_out;
+#define TDEQ_MULTI(P)                                                                                                   \
+    if (timed) hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, P>), g, b, 0, s, ev_start, ev_stop, 0, a); \
+    else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, P>), g, b, 0, s, a);
+        switch (stream_policy(streams * n * (int64_t)sizeof(T))) {
+            case 1: TDEQ_MULTI(1) break;
+            case 2: TDEQ_MULTI(2) break;
+            case 3: TDEQ_MULTI(3) break;
+            default: TDEQ_MULTI(0)
+        }
+#undef TDEQ_MULTI
+    } else {
+        hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    }
     return check_launch();
 }
 
@@ -264,6 +300,44 @@ int launch_error(void* scaled, const void* y0, const void* y1, const void* const
     return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
 }
 
+template <typename T, int NT>
+int launch_error_vec(const void* y0, const void* y1, const void* const* k, const double* coef, double dt,
+                     const double* rtol_v, double rtol_s, const double* atol_v, double atol_s, const SegTable& st,
+                     double* out_sumsq, double* out_bad, double* ws, hipStream_t s) {
+    ErrVecArgs<T, NT> a;
+    a.y0 = static_cast<const T*>(y0);
+    a.y1 = static_cast<const T*>(y1);
+    const T dtT = (T)dt;
+    for (int j = 0; j < NT; ++j) {
+        a.k[j] = static_cast<const T*>(k[j]);
+        a.c[j] = (T)coef[j] * dtT;
+    }
+    a.rtol_v = rtol_v;
+    a.atol_v = atol_v;
+    a.rtol_s = rtol_s;
+    a.atol_s = atol_s;
+    a.st = st;
+    a.part_sumsq = ws;
+    a.part_bad = ws + 2 * st.n_chunks;
+    hipLaunchKernelGGL((error_norm_vec_kernel<T, NT>), dim3((unsigned)st.n_chunks), dim3(kBlock), 0, s, a);
+    const int e = check_launch();
+    if (e) return e;
+    return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
+}
+
+template <typename T>
+int dispatch_error_vec(const void* y0, const void* y1, const void* const* k, const double* coef, int nt, double dt,
+                       const double* rtol_v, double rtol_s, const double* atol_v, double atol_s, const SegTable& st,
+                       double* out_sumsq, double* out_bad, double* ws, hipStream_t s) {
+    switch (nt) {
+#define TDEQ_CASE(N) case N: return launch_error_vec<T, N>(y0, y1, k, coef, dt, rtol_v, rtol_s, atol_v, atol_s, st, out_sumsq, out_bad, ws, s);
+        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+        TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
+#undef TDEQ_CASE
+    }
+    return TDEQ_EINVAL;
+}
+
 template <typename T>
 int dispatch_error(void* scaled, const void* y0, const void* y1, const void* const* k, const double* coef,
                    int nt, double dt, const SegTable& st, double* out_sumsq, double* out_bad, double* ws,
@@ -340,7 +414,9 @@ int launch_error_partial(const void* partial, const void* y0, const void* y1, co
     a.part_sumsq = ws;
     a.part_bad = ws + 2 * st.n_chunks;
     const dim3 g((unsigned)st.n_chunks), b(kBlock);
-    if (vec) hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true>), g, b, 0, s, a);
+    if (vec && (stream_policy((int64_t)(NT + 3) * st.n_chunks * st.chunk * (int64_t)sizeof(T)) & 1))
+        hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 1>), g, b, 0, s, a);
+    else if (vec) hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 0>), g, b, 0, s, a);
     else hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, false>), g, b, 0, s, a);
     const int e = check_launch();
     if (e) return e;
@@ -454,8 +530,18 @@ int launch_combine_sel(void* out, const void* y_acc, const void* f_acc, const vo
     a.n = n;
     constexpr int L = VecOf<T>::L;
     const bool vec = aligned16(out) && aligned16(y_acc) && aligned16(f_acc) && aligned16(y_rej) && aligned16(f_rej);
-    if (vec) hipLaunchKernelGGL((stage_combine_sel_kernel<T, true>), dim3(stream_grid(n / L, kBlock)), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((stage_combine_sel_kernel<T, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    if (vec) {
+        const dim3 g(stream_grid(n / L, kBlock)), b(kBlock);
+        // (reads 2 of the 4 inputs; the k tensors of the step just finished are the cache's other tenants)
+        switch (stream_policy((int64_t)3 * n * (int64_t)sizeof(T))) {
+            case 1: hipLaunchKernelGGL((stage_combine_sel_kernel<T, true, 1>), g, b, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((stage_combine_sel_kernel<T, true, 2>), g, b, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((stage_combine_sel_kernel<T, true, 3>), g, b, 0, s, a); break;
+            default: hipLaunchKernelGGL((stage_combine_sel_kernel<T, true, 0>), g, b, 0, s, a);
+        }
+    } else {
+        hipLaunchKernelGGL((stage_combine_sel_kernel<T, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    }
     return check_launch();
 }
 
@@ -928,6 +1014,10 @@ int launch_adams_correct(void* y_out, void* dy_out, const void* f, const void* d
 }
 
 inline bool bad_dtype(int dtype) { return dtype != TDEQ_F32 && dtype != TDEQ_F64; }
+// bfloat16 / float16 states: the entry points of the host-driven step (tdeq_kernels_lp.hpp; include/tdeq_hip.h lists them)
+inline bool lp_dtype(int dtype) { return dtype == TDEQ_BF16 || dtype == TDEQ_F16; }
+
+#include "tdeq_abi_lp.hpp"
 // the norm entry points also take interleaved complex states (TDEQ_C64 / TDEQ_C128: tdeq_kernels_complex.hpp)
 inline bool bad_norm_dtype(int dtype) { return bad_dtype(dtype) && dtype != TDEQ_C64 && dtype != TDEQ_C128; }
 
@@ -944,11 +1034,13 @@ size_t tdeq_workspace_bytes(int64_t n_chunks) {
 
 int tdeq_stage_combine(void* out, const void* y0, const void* const* k, const double* coef, int n_terms,
                        double dt, int64_t n, int dtype, void* stream) {
-    if (!out || !y0 || !k || !coef || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !y0 || !k || !coef || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_dispatch_combine<lp::BF16, 1>(out, nullptr, y0, k, coef, nullptr, n_terms, dt, n, nullptr, nullptr, 0, s);
+    if (dtype == TDEQ_F16) return lp_dispatch_combine<lp::F16, 1>(out, nullptr, y0, k, coef, nullptr, n_terms, dt, n, nullptr, nullptr, 0, s);
     return dtype == TDEQ_F32 ? dispatch_combine<float>(out, y0, k, coef, n_terms, dt, n, s)
                              : dispatch_combine<double>(out, y0, k, coef, n_terms, dt, n, s);
 }
@@ -967,10 +1059,12 @@ int tdeq_stage_combine_timed(void* out, const void* y0, const void* const* k, co
 int tdeq_stage_combine_fill(void* out, const void* y0, const void* const* k, const double* coef, int n_terms,
                             double dt, int64_t n, int dtype, void* fill_dst, const double* fill_vals, int n_fill,
                             void* stream) {
-    if (!out || !y0 || !k || !coef || n < 1 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !y0 || !k || !coef || n < 1 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > 2 || !k[0] || (n_terms == 2 && !k[1])) return TDEQ_EINVAL;
     if (!fill_dst || !fill_vals || n_fill < 1 || n_fill > 16) return TDEQ_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_dispatch_combine<lp::BF16, 1>(out, nullptr, y0, k, coef, nullptr, n_terms, dt, n, fill_dst, fill_vals, n_fill, s);
+    if (dtype == TDEQ_F16) return lp_dispatch_combine<lp::F16, 1>(out, nullptr, y0, k, coef, nullptr, n_terms, dt, n, fill_dst, fill_vals, n_fill, s);
     if (dtype == TDEQ_F32)
         return n_terms == 1 ? launch_combine_fill<float, 1>(out, y0, k, coef, dt, n, fill_dst, fill_vals, n_fill, s)
                             : launch_combine_fill<float, 2>(out, y0, k, coef, dt, n, fill_dst, fill_vals, n_fill, s);
@@ -983,7 +1077,7 @@ int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void
                     const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
                     double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
                     void* stream) {
-    if (!y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || bad_norm_dtype(dtype))
+    if (!y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || (bad_norm_dtype(dtype) && !lp_dtype(dtype)))
         return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
@@ -993,6 +1087,11 @@ int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void
     if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
+    // bf16 / fp16: out_sumsq[s] = sum of fl(|r|^2) — |r| itself for a one-element segment (tdeq_kernels_lp.hpp norm_term)
+    if (dtype == TDEQ_BF16)
+        return lp_dispatch_error<lp::BF16>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
+    if (dtype == TDEQ_F16)
+        return lp_dispatch_error<lp::F16>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
     if (dtype == TDEQ_C64)
         return dispatch_cplx_error<float>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
     if (dtype == TDEQ_C128)
@@ -1002,13 +1101,38 @@ int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void
                : dispatch_error<double>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
 }
 
+int tdeq_error_norm_vec(const void* y0, const void* y1, const void* const* k, const double* coef, int n_terms, double dt,
+                        const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
+                        const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
+                        double* out_sumsq, double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
+                        void* stream) {
+    if (!y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!rtol_vec && !atol_vec) return TDEQ_EINVAL;      // two 0-dim tolerances: tdeq_error_norm (a different promotion)
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    SegTable st;
+    const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
+    if (e) return e;
+    if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    return dtype == TDEQ_F32
+               ? dispatch_error_vec<float>(y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
+                                           out_sumsq, out_nonfinite, ws, s)
+               : dispatch_error_vec<double>(y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
+                                            out_sumsq, out_nonfinite, ws, s);
+}
+
 int tdeq_stage_combine_err(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
                            const double* err_coef, int n_terms, double dt, int64_t n, int dtype, void* stream) {
-    if (!out || !err_out || !y0 || !k || !coef || !err_coef || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !err_out || !y0 || !k || !coef || !err_coef || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // (bf16 / fp16: err_out is the row sum over THESE stages rounded once — a caller that continues it rounds twice)
+    if (dtype == TDEQ_BF16) return lp_dispatch_combine<lp::BF16, 2>(out, err_out, y0, k, coef, err_coef, n_terms, dt, n, nullptr, nullptr, 0, s);
+    if (dtype == TDEQ_F16) return lp_dispatch_combine<lp::F16, 2>(out, err_out, y0, k, coef, err_coef, n_terms, dt, n, nullptr, nullptr, 0, s);
     return dtype == TDEQ_F32 ? dispatch_combine_err<float>(out, err_out, y0, k, coef, err_coef, n_terms, dt, n, s)
                              : dispatch_combine_err<double>(out, err_out, y0, k, coef, err_coef, n_terms, dt, n, s);
 }
@@ -1169,7 +1293,7 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, 
                     double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
                     void* stream) {
     if ((mode != 0 && mode != 1) || !a || !b || !yscale || !out_sumsq || !out_nonfinite || !workspace ||
-        bad_norm_dtype(dtype))
+        (bad_norm_dtype(dtype) && !lp_dtype(dtype)))
         return TDEQ_EINVAL;
     SegTable st;
     const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
@@ -1177,6 +1301,8 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, 
     if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
+    if (dtype == TDEQ_BF16) return lp_launch_init<lp::BF16>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, nullptr, nullptr, s);
+    if (dtype == TDEQ_F16) return lp_launch_init<lp::F16>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, nullptr, nullptr, s);
     if (dtype == TDEQ_C64) return launch_cplx_init<float>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, nullptr, nullptr, s);
     if (dtype == TDEQ_C128) return launch_cplx_init<double>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, nullptr, nullptr, s);
     return dtype == TDEQ_F32 ? launch_init<float>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, s)
@@ -1186,12 +1312,15 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, 
 int tdeq_init_scaled(int mode, const void* a, const void* b, const void* yscale, const tdeq_segment* segs,
                      const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, void* out0, void* out1,
                      int dtype, void* stream) {
-    if ((mode != 0 && mode != 1) || !a || !b || !yscale || !out0 || (mode == 0 && !out1) || bad_norm_dtype(dtype))
+    if ((mode != 0 && mode != 1) || !a || !b || !yscale || !out0 || (mode == 0 && !out1) ||
+        (bad_norm_dtype(dtype) && !lp_dtype(dtype)))
         return TDEQ_EINVAL;
     SegTable st;
     const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
     if (e) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_launch_init<lp::BF16>(mode, a, b, yscale, st, nullptr, nullptr, nullptr, out0, out1, s);
+    if (dtype == TDEQ_F16) return lp_launch_init<lp::F16>(mode, a, b, yscale, st, nullptr, nullptr, nullptr, out0, out1, s);
     if (dtype == TDEQ_C64) return launch_cplx_init<float>(mode, a, b, yscale, st, nullptr, nullptr, nullptr, out0, out1, s);
     if (dtype == TDEQ_C128) return launch_cplx_init<double>(mode, a, b, yscale, st, nullptr, nullptr, nullptr, out0, out1, s);
     const dim3 g((unsigned)st.n_chunks), blk(kBlock);
@@ -1214,11 +1343,13 @@ int tdeq_init_scaled(int mode, const void* a, const void* b, const void* yscale,
 int tdeq_dense_eval(void* out, const void* y0, const void* y1, const void* f0, const void* f1,
                     const void* const* k, const double* coef, int n_terms, double dt, double x, int64_t n,
                     int dtype, void* stream) {
-    if (!out || !y0 || !y1 || !f0 || !f1 || !k || !coef || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !y0 || !y1 || !f0 || !f1 || !k || !coef || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_dense_eval<lp::BF16>(out, n, y0, y1, f0, f1, k, coef, n_terms, dt, &x, 1, n, s);
+    if (dtype == TDEQ_F16) return lp_dense_eval<lp::F16>(out, n, y0, y1, f0, f1, k, coef, n_terms, dt, &x, 1, n, s);
     return dtype == TDEQ_F32
                ? dispatch_dense<float, false>(out, y0, y1, f0, f1, k, coef, n_terms, dt, x, n, s)
                : dispatch_dense<double, false>(out, y0, y1, f0, f1, k, coef, n_terms, dt, x, n, s);
@@ -1227,12 +1358,14 @@ int tdeq_dense_eval(void* out, const void* y0, const void* y1, const void* f0, c
 int tdeq_dense_eval_multi(void* out, int64_t out_stride, const void* y0, const void* y1, const void* f0,
                           const void* f1, const void* const* k, const double* coef, int n_terms, double dt,
                           const double* x, int n_x, int64_t n, int dtype, void* stream) {
-    if (!out || !y0 || !y1 || !f0 || !f1 || !k || !coef || !x || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !y0 || !y1 || !f0 || !f1 || !k || !coef || !x || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS || n_x < 1 || n_x > TDEQ_MAX_DENSE_OUTPUTS) return TDEQ_EINVAL;
     if (n_x > 1 && out_stride < n) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_dense_eval<lp::BF16>(out, out_stride, y0, y1, f0, f1, k, coef, n_terms, dt, x, n_x, n, s);
+    if (dtype == TDEQ_F16) return lp_dense_eval<lp::F16>(out, out_stride, y0, y1, f0, f1, k, coef, n_terms, dt, x, n_x, n, s);
     return dtype == TDEQ_F32
                ? dispatch_dense_multi<float>(out, out_stride, y0, y1, f0, f1, k, coef, n_terms, dt, x, n_x, n, s)
                : dispatch_dense_multi<double>(out, out_stride, y0, y1, f0, f1, k, coef, n_terms, dt, x, n_x, n, s);
@@ -1241,11 +1374,13 @@ int tdeq_dense_eval_multi(void* out, int64_t out_stride, const void* y0, const v
 int tdeq_interp_fit(void* coeffs, const void* y0, const void* y1, const void* f0, const void* f1,
                     const void* const* k, const double* coef, int n_terms, double dt, int64_t n, int dtype,
                     void* stream) {
-    if (!coeffs || !y0 || !y1 || !f0 || !f1 || !k || !coef || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!coeffs || !y0 || !y1 || !f0 || !f1 || !k || !coef || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_dispatch_fit<lp::BF16>(coeffs, y0, y1, f0, f1, k, coef, n_terms, dt, n, s);
+    if (dtype == TDEQ_F16) return lp_dispatch_fit<lp::F16>(coeffs, y0, y1, f0, f1, k, coef, n_terms, dt, n, s);
     return dtype == TDEQ_F32
                ? dispatch_dense<float, true>(coeffs, y0, y1, f0, f1, k, coef, n_terms, dt, 0.0, n, s)
                : dispatch_dense<double, true>(coeffs, y0, y1, f0, f1, k, coef, n_terms, dt, 0.0, n, s);
@@ -1253,9 +1388,11 @@ int tdeq_interp_fit(void* coeffs, const void* y0, const void* y1, const void* f0
 
 int tdeq_rk4_38_stage(int stage, void* out, const void* y0, const void* k1, const void* k2, const void* k3,
                       const void* k4, double dt, int64_t n, int dtype, void* stream) {
-    if (!out || !y0 || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !y0 || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n == 0) return (stage >= 1 && stage <= 4) ? 0 : TDEQ_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_dispatch_rk4<lp::BF16>(stage, out, y0, k1, k2, k3, k4, dt, n, s);
+    if (dtype == TDEQ_F16) return lp_dispatch_rk4<lp::F16>(stage, out, y0, k1, k2, k3, k4, dt, n, s);
     return dtype == TDEQ_F32 ? dispatch_rk4<float>(stage, out, y0, k1, k2, k3, k4, dt, n, s)
                              : dispatch_rk4<double>(stage, out, y0, k1, k2, k3, k4, dt, n, s);
 }
@@ -1322,20 +1459,24 @@ int tdeq_grid_commit(void* solution, int64_t row_stride, void* y_cur, const void
 }
 
 int tdeq_lerp(void* out, const void* y0, const void* y1, double slope, int64_t n, int dtype, void* stream) {
-    if (!out || !y0 || !y1 || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !y0 || !y1 || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_launch_lerp<lp::BF16>(out, y0, y1, slope, n, s);
+    if (dtype == TDEQ_F16) return lp_launch_lerp<lp::F16>(out, y0, y1, slope, n, s);
     return dtype == TDEQ_F32 ? launch_lerp<float>(out, y0, y1, slope, n, s)
                              : launch_lerp<double>(out, y0, y1, slope, n, s);
 }
 
 int tdeq_fixed_stage(int mode, void* out, const void* y0, const void* const* k, const double* w, int n_terms,
                      double dt, int64_t n, int dtype, void* stream) {
-    if (!out || !y0 || !k || !w || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !y0 || !k || !w || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if ((mode != 0 && mode != 1) || n_terms < 1 || n_terms > 4 || (mode == 1 && n_terms != 1)) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_dispatch_fixed<lp::BF16>(mode, out, y0, k, w, n_terms, dt, n, s);
+    if (dtype == TDEQ_F16) return lp_dispatch_fixed<lp::F16>(mode, out, y0, k, w, n_terms, dt, n, s);
     if (dtype == TDEQ_F32)
         return mode == 0 ? dispatch_fixed<float, 0>(out, y0, k, w, n_terms, dt, n, s)
                          : dispatch_fixed<float, 1>(out, y0, k, w, n_terms, dt, n, s);
@@ -1359,11 +1500,13 @@ int tdeq_fixed_stage_dev(int mode, void* out, const void* y0, const void* const*
 
 int tdeq_weighted_sum(void* out, const void* const* x, const double* w, int n_terms, int64_t n, int dtype,
                       void* stream) {
-    if (!out || !x || !w || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !x || !w || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_SUM_TERMS) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!x[j]) return TDEQ_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_dispatch_weighted<lp::BF16>(out, x, w, n_terms, n, s);
+    if (dtype == TDEQ_F16) return lp_dispatch_weighted<lp::F16>(out, x, w, n_terms, n, s);
     return dtype == TDEQ_F32 ? dispatch_fixed<float, 2>(out, nullptr, x, w, n_terms, 0.0, n, s)
                              : dispatch_fixed<double, 2>(out, nullptr, x, w, n_terms, 0.0, n, s);
 }

@@ -121,7 +121,7 @@ struct CombineErrArgs {
     T e[NT];
 };
 
-template <typename T, int NT, bool VEC>
+template <typename T, int NT, bool VEC, int POLICY = 0>
 __global__ __launch_bounds__(kBlock) void stage_combine_err_kernel(const CombineErrArgs<T, NT> a) {
     using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
     constexpr int L = VEC ? VecOf<T>::L : 1;
@@ -133,12 +133,12 @@ __global__ __launch_bounds__(kBlock) void stage_combine_err_kernel(const Combine
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
         E kk[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.c.k[j])[i];
-        out[i] = combine_one<T, NT, E>(a.c, y0[i], kk);
+        for (int j = 0; j < NT; ++j) kk[j] = ld_stream<POLICY>(reinterpret_cast<const E*>(a.c.k[j]) + i);
+        st_stream<POLICY>(out + i, combine_one<T, NT, E>(a.c, ld_stream<POLICY>(y0 + i), kk));
         E err = kk[0] * a.e[0];
 #pragma unroll
         for (int j = 1; j < NT; ++j) err = err + kk[j] * a.e[j];
-        eo[i] = err;
+        st_stream<POLICY>(eo + i, err);
     }
     if (VEC) {   // scalar tail (n % L elements)
         const int64_t t = ne * L + threadIdx.x;
@@ -219,15 +219,15 @@ struct MultiArgs {
     const double* dt_dev;             // non-null (hipGraph mode): c[][] holds fl_T(coef) and is multiplied by T(dt_dev[1]) here
 };
 
-template <typename T, int NT, typename E>
+template <typename T, int NT, typename E, int POLICY = 0>
 __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int64_t i) {
     const E* __restrict__ y0 = reinterpret_cast<const E*>(a.y0);
     E kk[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.k[j])[i];
-    const E y = y0[i];
+    for (int j = 0; j < NT; ++j) kk[j] = ld_stream<POLICY>(reinterpret_cast<const E*>(a.k[j]) + i);
+    const E y = ld_stream<POLICY>(y0 + i);
     E acc0 = y;                       // placeholder when there is no acc_in (never read then)
-    if (a.acc_in) acc0 = reinterpret_cast<const E*>(a.acc_in)[i];
+    if (a.acc_in) acc0 = ld_stream<POLICY>(reinterpret_cast<const E*>(a.acc_in) + i);
 #pragma unroll
     for (int o = 0; o < kMaxMultiOut; ++o) {
         if (o < a.n_out) {
@@ -243,19 +243,21 @@ __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int
                     started = true;
                 }
             }
-            reinterpret_cast<E*>(a.out[o])[i] = ((a.add_y0 >> o) & 1u) ? y + s : s;
+            st_stream<POLICY>(reinterpret_cast<E*>(a.out[o]) + i, ((a.add_y0 >> o) & 1u) ? y + s : s);
         }
     }
 }
 
-template <typename T, int NT, bool VEC>
+// POLICY (VEC only): cache policy of the streams, see ld_stream / st_stream — chosen per launch by the host side
+// (tdeq_abi.hip stream_policy(): non-temporal for launches whose streams exceed the 256 MiB Infinity Cache).
+template <typename T, int NT, bool VEC, int POLICY = 0>
 __global__ __launch_bounds__(kBlock) void stage_combine_multi_kernel(const MultiArgs<T, NT> a) {
     using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
     constexpr int L = VEC ? VecOf<T>::L : 1;
     const int64_t ne = a.n / L;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const T dtT = a.dt_dev ? (T)a.dt_dev[1] : (T)1;          // ctrl_dev[1] = sign * T(dt) of the device-resident controller
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) multi_elem<T, NT, E>(a, dtT, i);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) multi_elem<T, NT, E, POLICY>(a, dtT, i);
     if (VEC) {   // scalar tail (n % L elements)
         const int64_t t = ne * L + threadIdx.x;
         if (blockIdx.x == 0 && t < a.n) multi_elem<T, NT, T>(a, dtT, t);
@@ -417,6 +419,60 @@ __global__ __launch_bounds__(kBlock) void error_norm_kernel(const ErrArgs<T, NT>
     }
 }
 
+// Per-element tolerances (misc.py:80-82 with `rtol` / `atol` TENSORS that broadcast against the state — plain
+// broadcasting in the reference; tuple tolerances with vector entries become such flat vectors, misc.py:115-123).  The
+// tolerances are tensors of the time dtype W = fp64 (rk_common.py:186-187), so type promotion decides each operation:
+//   rtol dimensioned:  rtol[i] * max(|y0|,|y1|)  is an fp64 product;   rtol 0-dim:  the product stays in T (rtol cast to T)
+//   the sum with atol (dimensioned or 0-dim fp64 next to an fp64 tensor), the quotient err / tol and the norm are fp64
+//   whenever either tolerance is dimensioned — which is the only case this kernel is launched for.
+// Two extra fp64 streams at most; the raw error is never materialised (r04: error_scaled + ~10 ATen passes in fp64).
+template <typename T, int NT>
+struct ErrVecArgs {
+    const T* y0;
+    const T* y1;
+    const T* k[NT];
+    T c[NT];
+    const double* rtol_v;   // per element of the flat (padded) state, or null: rtol_s
+    const double* atol_v;
+    double rtol_s, atol_s;
+    SegTable st;
+    double* part_sumsq;
+    double* part_bad;
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(kBlock) void error_norm_vec_kernel(const ErrVecArgs<T, NT> a) {
+    __shared__ double red[2 * (kBlock / kWave)];
+    const int64_t b = blockIdx.x;
+    const tdeq_segment seg = find_segment(a.st, b);
+    const int64_t base = b * a.st.chunk;
+    int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+    valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
+    const T rtolT = (T)a.rtol_s;
+    double acc[2] = {0.0, 0.0};
+    // consecutive lanes read consecutive elements: 4- / 8-byte state loads and 8-byte tolerance loads, all coalesced;
+    // two elements per lane and iteration keep 2 (NT + 4) loads in flight
+#pragma unroll 2
+    for (int64_t t = threadIdx.x; t < valid; t += kBlock) {
+        const int64_t i = base + t;
+        T e = a.k[0][i] * a.c[0];
+#pragma unroll
+        for (int j = 1; j < NT; ++j) e = e + a.k[j][i] * a.c[j];
+        const T y0 = a.y0[i], y1 = a.y1[i];
+        const T m = smax(sabs(y0), sabs(y1));
+        const double prod = a.rtol_v ? a.rtol_v[i] * (double)m : (double)(rtolT * m);
+        const double tol = (a.atol_v ? a.atol_v[i] : a.atol_s) + prod;
+        const double r = (double)e / tol;
+        acc[0] += r * r;
+        acc[1] += (__builtin_isfinite(y0) && __builtin_isfinite(y1)) ? 0.0 : 1.0;
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        a.part_sumsq[b] = acc[0];
+        a.part_bad[b] = acc[1];
+    }
+}
+
 // Error norm continuing a partial error sum produced by stage_combine_err_kernel:
 //   err = (partial + c_0 k_0) + ... over the NT >= 0 remaining stages; everything else as error_norm_kernel.
 template <typename T, int NT>
@@ -440,7 +496,7 @@ __device__ __forceinline__ void tol_accumulate(T e, T y0, T y1, T rtol, T atol, 
     bad += (__builtin_isfinite(y0) && __builtin_isfinite(y1)) ? 0.0 : 1.0;
 }
 
-template <typename T, int NT, bool VEC>
+template <typename T, int NT, bool VEC, int POLICY = 0>
 __global__ __launch_bounds__(kBlock) void error_norm_partial_kernel(const ErrPartialArgs<T, NT> a) {
     using V = typename VecOf<T>::type;
     constexpr int L = VecOf<T>::L;
@@ -466,10 +522,10 @@ __global__ __launch_bounds__(kBlock) void error_norm_partial_kernel(const ErrPar
         const V* pe = reinterpret_cast<const V*>(a.partial + base);
 #pragma unroll 2
         for (int64_t i = threadIdx.x; i < nv; i += kBlock) {
-            V e = pe[i];
+            V e = ld_stream<POLICY>(pe + i);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) e = e + reinterpret_cast<const V*>(a.k[j] + base)[i] * cc[j];
-            const V v0 = y0[i], v1 = y1[i];
+            for (int j = 0; j < NT; ++j) e = e + ld_stream<POLICY>(reinterpret_cast<const V*>(a.k[j] + base) + i) * cc[j];
+            const V v0 = ld_stream<POLICY>(y0 + i), v1 = ld_stream<POLICY>(y1 + i);
 #pragma unroll
             for (int q = 0; q < L; ++q) tol_accumulate<T>(e[q], v0[q], v1[q], rtol, atol, acc[0], acc[1]);
         }
@@ -1002,7 +1058,7 @@ struct SelArgs {
     int64_t n;
 };
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, int POLICY = 0>
 __global__ __launch_bounds__(kBlock) void stage_combine_sel_kernel(const SelArgs<T> a) {
     using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
     constexpr int L = VEC ? VecOf<T>::L : 1;
@@ -1015,7 +1071,8 @@ __global__ __launch_bounds__(kBlock) void stage_combine_sel_kernel(const SelArgs
     const E* __restrict__ y = reinterpret_cast<const E*>(ys);
     const E* __restrict__ f = reinterpret_cast<const E*>(fs);
     E* __restrict__ out = reinterpret_cast<E*>(a.out);
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) out[i] = y[i] + f[i] * c;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
+        st_stream<POLICY>(out + i, ld_stream<POLICY>(y + i) + ld_stream<POLICY>(f + i) * c);
     if (VEC) {
         const int64_t t = ne * L + threadIdx.x;
         if (blockIdx.x == 0 && t < a.n) a.out[t] = ys[t] + fs[t] * c;

@@ -267,9 +267,17 @@ class RKAdaptiveStepsizeODESolver:
         self._vec_tol = vector_tolerances(rtol, atol, self.layout, y0.device, self.dtype,
                                           tuple_entries_too=getattr(self.kernels, "literal_norms", False)
                                           and dist_sync is None)
+        self._vec_fused = None
         if self._vec_tol is not None:
             rtol, atol = 0.0, 1.0
             if isinstance(self.norm, BuiltinNorm):
+                # r05: the per-step error norm stays ONE fused launch (tdeq_error_norm_vec: the tolerance vectors are two more
+                # fp64 streams of the same kernel) for real fp32 / fp64 states with fp64 tolerances; the once-per-solve
+                # initial-step norms and everything else keep the callable below
+                if hasattr(self.kernels, "error_norm_vec") and self._wide and dist_sync is None \
+                        and y0.dtype in (torch.float32, torch.float64):
+                    self._vec_fused = tuple(v.contiguous() if v.dim() else float(v) for v in self._vec_tol) \
+                        + (self.norm.n_skip_tail,)
                 self.norm = component_norm(self.layout, self.norm.n_skip_tail)
         self._seg_tol = (rtol, atol)
         w = self._w
@@ -311,8 +319,10 @@ class RKAdaptiveStepsizeODESolver:
         self._fuse = None
         # (not on the torch-op host path, which hands every row to ATen's `torch.sum` whole — `literal_row_sums`,
         # _fallback.py: splitting a row re-associates it, and for bf16 / fp16 states would round it twice)
+        # (nor for reduced-precision states on the HIP kernels — `split_row_sums` False: a row is rounded ONCE)
         if self._c_err.idx[:n_lead] == last.idx and len(self._c_err.idx) - n_lead <= 2 \
-                and not getattr(self.kernels, "literal_row_sums", False):
+                and not getattr(self.kernels, "literal_row_sums", False) \
+                and getattr(self.kernels, "split_row_sums", True):
             self._fuse = (self._c_err.coef[:n_lead], self._c_err.idx[n_lead:], self._c_err.coef[n_lead:])
         # Carried partial sums (tableaus.carry_plan / tdeq_stage_combine_multi): fewer bytes per step for the same bits.
         # TDEQ_CARRY: unset / "auto" = the tableaus where it is a measured gain (CARRY_DEFAULT_ON); "1" = every
@@ -1046,6 +1056,18 @@ class RKAdaptiveStepsizeODESolver:
         err/tol (padding zero-filled) and the user's own function reduces it."""
         err = self._c_err
         y0, y1 = y0.detach(), y1.detach()
+        if self._vec_fused is not None:
+            # per-element tolerances under the built-in norm: err / tol and the per-segment sums in one launch, in the
+            # reference's promoted precision (fp64); max over the components of sqrt(mean) as misc.py:22-33
+            rtol_v, atol_v, n_skip = self._vec_fused
+            self.kernels.error_norm_vec(self.plan, y0, y1, [k[j].detach() for j in err.idx], err.coef, dt_signed,
+                                        rtol_v, atol_v)
+            sumsq, _, bad = self.kernels.read_norms(self.plan)
+            ratio = 0.0
+            for s_, n_ in list(zip(sumsq, self._numels))[:len(self._numels) - n_skip]:
+                if n_:
+                    ratio = _nan_max(ratio, math.sqrt(s_ / n_))
+            return ratio, any(b != 0 for b in bad)
         scaled = torch.empty_like(y0)
         self.kernels.error_scaled(self.plan, scaled, y0, y1, [k[j].detach() for j in err.idx], err.coef, dt_signed)
         _, _, bad = self.kernels.read_norms(self.plan)
