@@ -52,8 +52,10 @@ extern "C" {
  * tableau row accumulates the rounded products in float32 and rounds once.  Accepted by the entry points of the
  * host-driven step — tdeq_stage_combine, tdeq_stage_combine_fill, tdeq_stage_combine_err, tdeq_error_norm,
  * tdeq_init_norms, tdeq_init_scaled, tdeq_dense_eval, tdeq_dense_eval_multi, tdeq_interp_fit, tdeq_rk4_38_stage,
- * tdeq_lerp, tdeq_fixed_stage, tdeq_weighted_sum — with exactly that rounding (tdeq_kernels_lp.hpp); every other
- * entry point returns TDEQ_EINVAL for them.  Scalars: `dt`, tableau weights, `slope`, tolerances are rounded to the
+ * tdeq_lerp, tdeq_fixed_stage, tdeq_weighted_sum — with exactly that rounding (tdeq_kernels_lp.hpp), and by the
+ * look-ahead pair tdeq_error_norm_partial_ctrl (err_partial MUST be NULL: the whole error row in `k` / `coef`, 1..14
+ * terms — a row is rounded once, there is no partial sum to continue; the controller forms the ratio, the next step and
+ * its stage times in the state's type) + tdeq_stage_combine_sel; every other entry point returns TDEQ_EINVAL for them.  Scalars: `dt`, tableau weights, `slope`, tolerances are rounded to the
  * storage type where the reference holds them as 0-dim tensors of the state's type or as FIRST operands, and taken at
  * float32 where ATen takes a Python number as SECOND operand of `*` (rk4's 1/3, `* dt`; tdeq_init_norms' rtol).
  * The norm entry points report per segment the sum of fl(|q|^2) — for a segment of ONE element |q| itself (the adjoint's

@@ -183,12 +183,16 @@ def test_dense_output_and_fixed_grid_stages_bit_exact(low, n):
     same(out, olp.weighted_sum(ks[:3], (0.7, -1.3, 2.0)))
 
 
-def test_entry_points_outside_the_host_driven_step_refuse_reduced_precision():
+def test_entry_points_outside_the_step_refuse_reduced_precision():
+    """hipGraph-mode and backward-helper entry points have no 16-bit kernels: TDEQ_EINVAL, not a misread buffer."""
+    import ctypes
     lib = _native.load_library()
     y = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
-    rc = lib.tdeq_stage_combine_sel(y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), 0.1,
-                                    y.data_ptr(), 64, _native.TDEQ_BF16, None)
-    assert rc == -1
+    ptrs = (ctypes.c_void_p * 1)(y.data_ptr())
+    w = (ctypes.c_double * 1)(0.5)
+    assert lib.tdeq_scale_many(ptrs, y.data_ptr(), w, 1, 64, _native.TDEQ_BF16, None) == -1
+    assert lib.tdeq_stage_combine_dev(y.data_ptr(), None, y.data_ptr(), ptrs, w, None, 1, y.data_ptr(), 64,
+                                      _native.TDEQ_F16, None) == -1
 
 
 @pytest.mark.parametrize("method,kw", [("dopri5", dict(rtol=1e-2, atol=1e-3)), ("dopri8", dict(rtol=1e-2, atol=1e-3)),
@@ -223,3 +227,44 @@ def test_solves_run_on_the_hip_kernels_and_follow_the_torch_op_path(method, kw):
     assert n_hip == nfe[0], (n_hip, nfe[0])
     err = float((y.float() - y_host.float()).abs().max() / y_host.float().abs().max())
     assert err < 0.02, err
+
+
+@pytest.mark.parametrize("method", ["dopri5", "dopri8", "bosh3", "tsit5"])
+def test_device_controller_and_look_ahead_take_the_host_loops_steps(monkeypatch, method):
+    """The norm launch's finalize step runs the step controller on the device IN THE STATE'S TYPE (ratio = ATen's
+    sqrt(mean) sequence in bf16, next step size, the next trial step's stage times with bf16 arithmetic and nextafter)
+    and the next first stage is enqueued ahead (tdeq_stage_combine_sel).  Same solve with TDEQ_LOOKAHEAD=0 — every
+    decision taken by the host loop from the read-back sums: identical evaluation counts and bit-identical solutions,
+    forwards and in decreasing time, including rejected steps."""
+    from torchdiffeq_amd import solvers
+    g = torch.Generator().manual_seed(1)
+    A = (torch.randn(16, 16, generator=g) / 2 - 0.2 * torch.eye(16)).to(torch.bfloat16).cuda()
+    y0 = (3 * torch.randn(512, 16, generator=g)).to(torch.bfloat16).cuda()
+    nfe = [0]
+
+    def f(t_, y_):
+        nfe[0] += 1
+        return (y_ @ A.T) * (2 + 2 * torch.sin(3 * t_))
+    seen = {}
+    for t in (torch.linspace(0.0, 3.0, 7, device="cuda"), torch.linspace(2.0, -1.0, 4, device="cuda")):
+        out = {}
+        for la in ("1", "0"):
+            monkeypatch.setenv("TDEQ_LOOKAHEAD", la)
+            nfe[0] = 0
+            made = []
+            orig = solvers.RKAdaptiveStepsizeODESolver.__init__
+
+            def spy(self, *a, **k):
+                orig(self, *a, **k)
+                made.append(self)
+            monkeypatch.setattr(solvers.RKAdaptiveStepsizeODESolver, "__init__", spy)
+            with torch.no_grad():
+                y = tda.odeint(f, y0, t, method=method, rtol=3e-2, atol=1e-3, options=dict(first_step=2.0))
+            monkeypatch.setattr(solvers.RKAdaptiveStepsizeODESolver, "__init__", orig)
+            s = made[-1]
+            assert s.kernels.name == "hip-low" and bool(s._lookahead) == (la == "1")
+            out[la] = (y, nfe[0], s.n_accepted, s.n_rejected)
+        assert out["1"][1:] == out["0"][1:], (out["1"][1:], out["0"][1:])
+        assert torch.equal(out["1"][0].view(torch.int16), out["0"][0].view(torch.int16))
+        seen[float(t[-1])] = out["1"][1:]
+    assert any(v[2] > 0 for v in seen.values())      # the large first step is rejected: that path is compared too

@@ -12,8 +12,10 @@ methods' predictor / corrector, segment packing, the backward-pass helpers `scal
 from the torch-op class — same numbers, more launches.
 
 Selection: `_native.get_kernels` for a bf16 / fp16 state on a `cuda` device; a missing libtdeq_hip.so raises there.
-Steps are host-driven (no device controller / look-ahead / captured graphs: those fuse the error row across launches,
-which would round a reduced-precision row sum twice).
+The loop is the fp32 one: the norm launch's finalize step also runs the step controller on the device in the state's type
+and the next trial step's first stage + func evaluation are enqueued before the decision is read back (look-ahead).  What
+reduced precision does not get: the fused error split and carried partial sums (a row would be rounded twice) and
+captured graphs.
 """
 from __future__ import annotations
 
@@ -40,7 +42,8 @@ class LowPlan(HostPlan):
 @_no_grad_methods
 class LowPrecisionHipKernels(LowPrecisionHostKernels):
     name = "hip-low"
-    device_controller = False
+    device_controller = True     # tdeq_error_norm_partial_ctrl on the WHOLE error row + tdeq_stage_combine_sel (look-ahead)
+    whole_row_controller = True  # ... i.e. without the fused error split the fp32 / fp64 controller launch continues
     literal_row_sums = False     # the kernels skip structural zeros of a row, like the fp32 / fp64 ones
     split_row_sums = False       # ... but a row is never split over two launches (it is rounded ONCE): no fused error split
     literal_norms = True         # plan.rms0 / rms1 / abs0 hold the norm values in the state's type (read_norms)
@@ -80,6 +83,27 @@ class LowPrecisionHipKernels(LowPrecisionHostKernels):
                                        p.out_ptr, p.bad_ptr, p.workspace.data_ptr(), p.workspace_bytes,
                                        dtype_code(y0.dtype), hip._stream()), "tdeq_error_norm")
         plan.pending = ("err", y0.dtype)
+
+    def error_norm_ctrl(self, plan: LowPlan, y0, y1, ks, coefs, dt: float, ctrl, next_times) -> None:
+        """`error_norm` whose finalize step also runs the step controller on the device (tdeq_error_norm_partial_ctrl
+        with err_partial = NULL: the whole error row in one launch): accept flag, next step size and the next trial
+        step's stage times, all in the state's type — read with `read_ctrl`."""
+        hip, p = self._hip, plan.hip
+        ptrs, cf, n = hip._terms(ks, coefs)
+        hip._arm(p, 1, ctrl=True)
+        from ._native import _check, dtype_code
+        _check(hip.lib.tdeq_error_norm_partial_ctrl(
+            None, y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, p.segs,
+            p.segs_dev.data_ptr() if p.segs_dev is not None else None, p.n_seg, p.chunk, p.n_chunks, p.out_ptr, p.bad_ptr,
+            ctypes.byref(ctrl), p.ctrl_ptr, p.ctrl_dev.data_ptr(), next_times.data_ptr(), 0, p.workspace.data_ptr(),
+            p.workspace_bytes, dtype_code(y0.dtype), hip._stream()), "tdeq_error_norm_partial_ctrl")
+        plan.pending = None
+
+    def read_ctrl(self, plan: LowPlan):
+        return self._hip.read_ctrl(plan.hip)
+
+    def stage_combine_sel(self, out, y_acc, f_acc, y_rej, f_rej, coef: float, plan: LowPlan) -> None:
+        self._hip.stage_combine_sel(out, y_acc, f_acc, y_rej, f_rej, coef, plan.hip)
 
     def error_norm_partial(self, plan, err_partial, y0, y1, ks, coefs, dt: float) -> None:
         raise NotImplementedError("a continued error sum is rounded twice: not for reduced-precision states")

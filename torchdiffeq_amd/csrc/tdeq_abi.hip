@@ -360,14 +360,15 @@ struct CtrlBundle {
     int state_in_dev;     // hipGraph mode: (t0, dt) of the trial step and the kernels' dt live in ctrl_dev
 };
 
+// tkind: the state's real type — 0 fp64, 1 fp32 (callers pass `sizeof(T) == 4`), 2 bfloat16, 3 float16
 int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, double* out_bad, const CtrlBundle& cb,
-                         bool is_f32, hipStream_t s) {
+                         int tkind, hipStream_t s) {
     CtrlArgs a;
     a.part_sumsq = ws;
     a.part_bad = ws + 2 * st.n_chunks;
     a.st = st;
     a.c = *cb.ctrl;
-    a.is_f32 = is_f32 ? 1 : 0;
+    a.is_f32 = tkind;
     a.out_sumsq = out_sumsq;
     a.out_bad = out_bad;
     a.out_ctrl = cb.out_ctrl;
@@ -1202,6 +1203,26 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
                                  double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev,
                                  void* next_times, int state_in_dev, void* workspace, size_t workspace_bytes,
                                  int dtype, void* stream) {
+    if (lp_dtype(dtype)) {
+        // bf16 / fp16: the WHOLE error row in one launch (a row is rounded once: no partial sum to continue — err_partial
+        // must be NULL), then finalize + controller in the state's type; not in hipGraph mode
+        if (err_partial || !y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || state_in_dev)
+            return TDEQ_EINVAL;
+        if (!ctrl || !out_ctrl || !ctrl_dev || !next_times || n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+        for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+        if (ctrl->n_times < 1 || ctrl->n_times > TDEQ_MAX_STAGE_TIMES || ctrl->n_norm_seg < 0 || ctrl->n_norm_seg > n_seg)
+            return TDEQ_EINVAL;
+        SegTable st;
+        const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
+        if (e) return e;
+        if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        double* ws = static_cast<double*>(workspace);
+        const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times, 0};
+        return dtype == TDEQ_BF16
+                   ? lp_dispatch_error<lp::BF16>(nullptr, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s, &cb)
+                   : lp_dispatch_error<lp::F16>(nullptr, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s, &cb);
+    }
     if (!err_partial || !y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_norm_dtype(dtype))
         return TDEQ_EINVAL;
     if (!ctrl || !out_ctrl || !ctrl_dev || !next_times) return TDEQ_EINVAL;
@@ -1281,9 +1302,11 @@ int tdeq_step_commit(void* y_prev, void* f_prev, void* y_cur, void* f_cur, const
 
 int tdeq_stage_combine_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej,
                            double coef, const double* ctrl_dev, int64_t n, int dtype, void* stream) {
-    if (!out || !y_acc || !f_acc || !y_rej || !f_rej || !ctrl_dev || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !y_acc || !f_acc || !y_rej || !f_rej || !ctrl_dev || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16) return lp_launch_sel<lp::BF16>(out, y_acc, f_acc, y_rej, f_rej, coef, ctrl_dev, n, s);
+    if (dtype == TDEQ_F16) return lp_launch_sel<lp::F16>(out, y_acc, f_acc, y_rej, f_rej, coef, ctrl_dev, n, s);
     return dtype == TDEQ_F32 ? launch_combine_sel<float>(out, y_acc, f_acc, y_rej, f_rej, coef, ctrl_dev, n, s)
                              : launch_combine_sel<double>(out, y_acc, f_acc, y_rej, f_rej, coef, ctrl_dev, n, s);
 }

@@ -80,7 +80,8 @@ int lp_dispatch_combine(void* out, void* err_out, const void* y0, const void* co
 // ---- error norm: the sum of fl_S(|r|^2) per segment (|r| itself for a one-element segment) + the non-finite census ----
 template <typename S, int NT>
 int lp_launch_error(void* scaled, const void* y0, const void* y1, const void* const* k, const double* coef, double dt,
-                    const SegTable& st, double* out_sumsq, double* out_bad, double* ws, hipStream_t s) {
+                    const SegTable& st, double* out_sumsq, double* out_bad, double* ws, hipStream_t s,
+                    const CtrlBundle* cb = nullptr) {
     lp::ErrArgs<NT> a;
     a.scaled = static_cast<uint16_t*>(scaled);
     a.y0 = static_cast<const uint16_t*>(y0);
@@ -105,14 +106,17 @@ int lp_launch_error(void* scaled, const void* y0, const void* y1, const void* co
     }
     const int e = check_launch();
     if (e) return e;
+    // with a controller bundle: finalize + the step controller in the state's type (tkind 2 / 3), as for fp32 / fp64
+    if (cb) return launch_finalize_ctrl(st, ws, out_sumsq, out_bad, *cb, S::code == TDEQ_BF16 ? 2 : 3, s);
     return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
 }
 
 template <typename S>
 int lp_dispatch_error(void* scaled, const void* y0, const void* y1, const void* const* k, const double* coef, int nt,
-                      double dt, const SegTable& st, double* out_sumsq, double* out_bad, double* ws, hipStream_t s) {
+                      double dt, const SegTable& st, double* out_sumsq, double* out_bad, double* ws, hipStream_t s,
+                      const CtrlBundle* cb = nullptr) {
     switch (nt) {
-#define TDEQ_CASE(N) case N: return lp_launch_error<S, N>(scaled, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, s);
+#define TDEQ_CASE(N) case N: return lp_launch_error<S, N>(scaled, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, s, cb);
         TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
         TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
 #undef TDEQ_CASE
@@ -332,4 +336,23 @@ int lp_dispatch_weighted(void* out, const void* const* x, const double* w, int n
 #undef TDEQ_CASE
     }
     return TDEQ_EINVAL;
+}
+
+// ---- look-ahead first stage ----
+template <typename S>
+int lp_launch_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej, double coef,
+                  const double* ctrl_dev, int64_t n, hipStream_t s) {
+    lp::SelArgs a;
+    a.out = static_cast<uint16_t*>(out);
+    a.y_acc = static_cast<const uint16_t*>(y_acc);
+    a.f_acc = static_cast<const uint16_t*>(f_acc);
+    a.y_rej = static_cast<const uint16_t*>(y_rej);
+    a.f_rej = static_cast<const uint16_t*>(f_rej);
+    a.coef = rs<S>(coef);
+    a.ctrl_dev = ctrl_dev;
+    a.n = n;
+    const bool vec = aligned16(out) && aligned16(y_acc) && aligned16(f_acc) && aligned16(y_rej) && aligned16(f_rej);
+    if (vec) hipLaunchKernelGGL((lp::sel_kernel<S, true>), dim3(stream_grid(n / lp::kVec, kBlock)), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((lp::sel_kernel<S, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
+    return check_launch();
 }

@@ -696,7 +696,7 @@ struct CtrlArgs {
     const double* part_bad;
     SegTable st;              // n_seg <= TDEQ_INLINE_SEGMENTS
     tdeq_step_ctrl c;
-    int is_f32;
+    int is_f32;               // kind of T: 0 = fp64, 1 = fp32, 2 = bfloat16, 3 = float16 (ctl_seg_norm / ctl_round_T)
     double* out_sumsq;        // [n_seg]   device or pinned host
     double* out_bad;          // [n_seg]
     double* out_ctrl;         // [4] = {accept, dt_next, ratio, t0_next}
@@ -734,6 +734,69 @@ __device__ __forceinline__ double ctl_prev(double x) {
     if (x == 0.0) return -__longlong_as_double(1LL);
     const long long b = __double_as_longlong(x);
     return __longlong_as_double(x > 0.0 ? b - 1 : b + 1);
+}
+
+// ---- reduced-precision states (tkind 2 = bfloat16, 3 = float16; tdeq_kernels_lp.hpp holds the state-sized kernels) ----
+// A value rounded to the storage type, kept in a float: what a 0-dim tensor of that type holds.
+__device__ __forceinline__ float ctl_rnd16(float x, int tkind) {
+    if (tkind == 2) {
+        const uint32_t u = __float_as_uint(x);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return x;
+        return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+    }
+    return (float)(_Float16)x;
+}
+__device__ __forceinline__ uint16_t ctl_bits16(float x, int tkind) {     // x already rounded
+    if (tkind == 2) return (uint16_t)(__float_as_uint(x) >> 16);
+    const _Float16 h = (_Float16)x;
+    uint16_t b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+}
+__device__ __forceinline__ float ctl_from_bits16(uint16_t b, int tkind) {
+    if (tkind == 2) return __uint_as_float((uint32_t)b << 16);
+    _Float16 h;
+    __builtin_memcpy(&h, &b, 2);
+    return (float)h;
+}
+// nextafter(x, x - 1) in the storage type (misc.py:174-197, Perturb.PREV; `_scalars._LowScalar.nextafter` on the host)
+__device__ __forceinline__ float ctl_prev16(float x, int tkind) {
+    const float y = ctl_rnd16(x - 1.0f, tkind);
+    if (x != x) return x;
+    if (x == y) return y;
+    if (x == 0.0f) return ctl_from_bits16(0x8001u, tkind);
+    const uint16_t b = ctl_bits16(x, tkind);
+    return ctl_from_bits16(x > 0.0f ? (uint16_t)(b - 1u) : (uint16_t)(b + 1u), tkind);
+}
+// sqrt(mean(|x|^2)) of one segment from its fp64 sum (misc.py:22-23).  fp32 / fp64: sqrt(sum / n) in fp64 (the caller
+// rounds the max to T).  Reduced precision: ATen's own sequence — float32 sum / n rounded to the type, sqrt rounded — on
+// the sum of ROUNDED squares the 16-bit norm kernels report; a one-element segment reports |x| itself and is squared here
+// (tdeq_kernels_lp.hpp norm_term; `_lowp.LowPrecisionHipKernels.read_norms` is the host twin).
+__device__ __forceinline__ double ctl_seg_norm(double sum, int64_t numel, int tkind) {
+    if (tkind < 2) return __builtin_sqrt(sum / (double)numel);
+    float total = (float)sum;
+    if (numel == 1) {
+        const float a = ctl_rnd16(total, tkind);
+        total = ctl_rnd16(a * a, tkind);
+    }
+    const float mean = ctl_rnd16(total / (float)numel, tkind);
+    return (double)ctl_rnd16(__builtin_sqrtf(mean), tkind);
+}
+// T(x) of a host double for the three kinds of T the controller writes back
+__device__ __forceinline__ double ctl_round_T(double x, int tkind) {
+    if (tkind == 0) return x;
+    if (tkind == 1) return (double)(float)x;
+    return (double)ctl_rnd16((float)x, tkind);
+}
+// stage time i in reduced precision: every operation of `t0 + alpha_i * dt` rounded to the type (rk_common.py:72-78 on
+// 0-dim tensors of the state's type), alpha_i already rounded by the host
+__device__ __forceinline__ uint16_t ctl_stage_time16(const tdeq_step_ctrl& c, double t0n, double dtn, int i, int tkind) {
+    const float t0T = ctl_rnd16((float)t0n, tkind), dtT = ctl_rnd16((float)dtn, tkind);
+    const float t1T = ctl_rnd16((float)(t0n + dtn), tkind);
+    float tt;
+    if ((c.alpha_is_one >> i) & 1u) tt = ctl_prev16(t1T, tkind);
+    else tt = ctl_rnd16(t0T + ctl_rnd16((float)c.alpha[i] * dtT, tkind), tkind);
+    return ctl_bits16((float)c.time_sign * tt, tkind);
 }
 
 // Stage time i of the next trial step (rk_common.py:72-78), one lane per stage.
@@ -777,7 +840,7 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         for (int s = threadIdx.x; s < a.c.n_norm_seg && s < n_seg; s += kBlock) {
             const int64_t numel = get_segment(a.st, s).numel;
             if (numel == 0) continue;
-            const double v = __builtin_sqrt(sums[s] / (double)numel);
+            const double v = ctl_seg_norm(sums[s], numel, a.is_f32);
             if (v != v) part[1] = 1.0;
             else part[0] = v > part[0] ? v : part[0];
         }
@@ -855,9 +918,9 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         for (int s = 0; s < c.n_norm_seg && s < n_seg && !a.presummed; ++s) {
             const int64_t numel = a.st.inl[s].numel;
             if (numel == 0) continue;
-            val = ctl_nan_max(val, __builtin_sqrt(seg_val[0][s] / (double)numel));
+            val = ctl_nan_max(val, ctl_seg_norm(seg_val[0][s], numel, a.is_f32));
         }
-        const double ratio = a.is_f32 ? (double)(float)val : val;
+        const double ratio = a.is_f32 == 1 ? (double)(float)val : val;      // (16-bit kinds: rounded per segment already)
         // accept / reject (rk_common.py:324-330)
         bool accept = ratio <= 1.0;
         if (step_dt > c.max_step) accept = false;
@@ -879,7 +942,7 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         dtn = ctl_clamp(dtn, c.min_step, c.max_step);
         // device-side consumers first (the look-ahead stage is next in the stream), then the host's words
         a.ctrl_dev[0] = accept ? 1.0 : 0.0;
-        a.ctrl_dev[1] = (a.is_f32 ? (double)(float)dtn : dtn) * c.time_sign;
+        a.ctrl_dev[1] = ctl_round_T(dtn, a.is_f32) * c.time_sign;
         a.ctrl_dev[2] = t0n;
         a.ctrl_dev[3] = dtn;
         next_step[0] = t0n;
@@ -892,7 +955,8 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
     __syncthreads();
     const int i = threadIdx.x;
     if (i < c.n_times) {
-        if (a.is_f32) static_cast<float*>(a.next_times)[i] = ctl_stage_time<float>(c, next_step[0], next_step[1], i);
+        if (a.is_f32 >= 2) static_cast<uint16_t*>(a.next_times)[i] = ctl_stage_time16(c, next_step[0], next_step[1], i, a.is_f32);
+        else if (a.is_f32) static_cast<float*>(a.next_times)[i] = ctl_stage_time<float>(c, next_step[0], next_step[1], i);
         else static_cast<double*>(a.next_times)[i] = ctl_stage_time<double>(c, next_step[0], next_step[1], i);
     }
     if (i < n_seg && !a.presummed) {

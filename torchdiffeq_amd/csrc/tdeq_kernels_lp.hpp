@@ -310,6 +310,42 @@ struct LerpF {
     }
 };
 
+// Look-ahead first stage of the NEXT trial step (stage_combine_sel_kernel's 16-bit twin): the device controller's words
+// {accept, sign * fl_S(dt')} select the pair the step starts from and give its size;  out = y + fl(f * fl(coef * dt')).
+struct SelArgs {
+    uint16_t* out;
+    const uint16_t* y_acc;
+    const uint16_t* f_acc;
+    const uint16_t* y_rej;
+    const uint16_t* f_rej;
+    float coef;              // fl_S(coef)
+    const double* ctrl_dev;
+    int64_t n;
+};
+
+template <typename S, bool VEC>
+__global__ __launch_bounds__(kBlock) void sel_kernel(const SelArgs a) {
+    constexpr int L = VEC ? kVec : 1;
+    const bool accept = a.ctrl_dev[0] != 0.0;
+    const float c = S::rnd(a.coef * (float)a.ctrl_dev[1]);
+    const uint16_t* ys = accept ? a.y_acc : a.y_rej;
+    const uint16_t* fs = accept ? a.f_acc : a.f_rej;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
+        float y[L], f[L], r[L];
+        load_elems<S, L>(ys, i, y);
+        load_elems<S, L>(fs, i, f);
+#pragma unroll
+        for (int q = 0; q < L; ++q) r[q] = S::rnd(y[q] + S::rnd(f[q] * c));
+        store_elems<S, L>(a.out, i, r);
+    }
+    if (VEC) {
+        const int64_t t = ne * L + threadIdx.x;
+        if (blockIdx.x == 0 && t < a.n) a.out[t] = (uint16_t)S::st(S::rnd(S::ld(ys[t]) + S::rnd(S::ld(fs[t]) * c)));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Norm passes: one workgroup per chunk -> fp64 partials per chunk (same workspace layout and finalize launch as the
 // fp32 / fp64 kernels: tdeq_kernels.hpp norm_finalize_kernel).

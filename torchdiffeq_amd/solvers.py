@@ -343,8 +343,13 @@ class RKAdaptiveStepsizeODESolver:
         # are all-reduced between the norm's finalize and the controller kernel without leaving the GPU)
         sync_dev = self._sync is not None and self._sync.on_device and y0.device.type == "cuda" \
             and hasattr(self.kernels, "step_controller")
+        # (reduced-precision states on the HIP kernels — `whole_row_controller`: the controller launch takes the WHOLE error
+        #  row instead of continuing a fused partial sum; builtin norms without the adjoint's |t| component, stage times in
+        #  the state's type)
+        self._whole_row_ctrl = bool(getattr(self.kernels, "whole_row_controller", False)) and self._fuse is None \
+            and not getattr(self.norm, "leading_scalar", False) and func.time_dtype == y0.dtype and dist_sync is None
         device_ctrl = (getattr(self.kernels, "device_controller", True)
-                       and self._fuse is not None and isinstance(self.norm, BuiltinNorm)
+                       and (self._fuse is not None or self._whole_row_ctrl) and isinstance(self.norm, BuiltinNorm)
                        and len(self._beta) <= _native.TDEQ_MAX_STAGE_TIMES and n_norm_seg >= 0
                        and self.step_t is None and self.jump_t is None and (self._sync is None or sync_dev)
                        and self._wide)          # the device controller computes in fp64: W = fp64 only
@@ -914,11 +919,14 @@ class RKAdaptiveStepsizeODESolver:
 
         # ---- error ratio (misc.py:80-82) ----
         err = self._c_err
-        if err_partial is not None and lookahead:
+        use_ctrl = lookahead and (err_partial is not None or (self._whole_row_ctrl and builtin_norm))
+        if use_ctrl:
             ctrl = self._ctrl
             ctrl.t0, ctrl.dt = t0, dt
             tnext = torch.empty(ctrl.n_times, dtype=func.time_dtype, device=y0.device)
-            if self._sync is None:
+            if err_partial is None:
+                kern.error_norm_ctrl(self.plan, y0, y1, [k[j] for j in err.idx], err.coef, dt_signed, ctrl, tnext)
+            elif self._sync is None:
                 kern.error_norm_partial_ctrl(self.plan, err_partial, y0, y1, [k[j] for j in err_rem[0]],
                                              err_rem[1], dt_signed, ctrl, tnext)
             else:
@@ -949,7 +957,7 @@ class RKAdaptiveStepsizeODESolver:
             y1_nonfinite = any(b != 0 for b in bad)
         else:
             error_ratio, y1_nonfinite = self._user_norm_ratio(y0, y1, k, dt_signed)
-        if err_partial is not None and lookahead:
+        if use_ctrl:
             accept_step = accept_dev      # the device's decision is the one its look-ahead stage was built on
         else:
             # rk_common.py:324-332: a step at the floor is always taken, one above the ceiling never, else the error decides
@@ -982,7 +990,7 @@ class RKAdaptiveStepsizeODESolver:
                 func.callback_reject_step(self._time_tensor(t0), y0, self._time_tensor(dt))
             self.t0 = t0   # (y, f, t1) unchanged: the step is retried from t0 with a smaller dt
             self.n_rejected += 1
-        if err_partial is not None and lookahead:
+        if use_ctrl:
             self.dt = dt_next_dev         # already clamped (tdeq_error_norm_partial_ctrl)
         else:
             if self._wide:
