@@ -341,7 +341,7 @@ def same_device_reference(field, y0, device):
             "note": "the HIP solve runs with callbacks here (host-driven loop), like its twin"}
 
 
-def make_stepper(field, y0, hip_graph=False, lookahead=None, dist_sync=None):
+def make_stepper(field, y0, hip_graph=False, lookahead=None, dist_sync=None, rtol=None, atol=None):
     """A Dopri5Solver in the middle of a long solve (no output time ahead — where the look-ahead first stage
     applies), ready for `_trial_step()` calls."""
     from torchdiffeq_amd.misc import OdeFunc, StateLayout, rms_norm
@@ -352,8 +352,8 @@ def make_stepper(field, y0, hip_graph=False, lookahead=None, dist_sync=None):
     if lookahead is not None:
         os.environ["TDEQ_LOOKAHEAD"] = "1" if lookahead else "0"
     try:
-        solver = Dopri5Solver(func=func, y0=y0.reshape(-1), rtol=RTOL, atol=ATOL, norm=rms_norm, hip_graph=hip_graph,
-                              dist_sync=dist_sync)
+        solver = Dopri5Solver(func=func, y0=y0.reshape(-1), rtol=RTOL if rtol is None else rtol,
+                              atol=ATOL if atol is None else atol, norm=rms_norm, hip_graph=hip_graph, dist_sync=dist_sync)
     finally:
         if lookahead is not None:
             if prev is None:
@@ -714,6 +714,9 @@ def run_linear(args, rank, world, device, parity=True):
     value = 6e3 / ms_per_step * (1 if strong else world)
 
     breakdown = None
+    if os.environ.get("TDEQ_BENCH_BREAKDOWN") and world == 1:
+        with torch.no_grad():
+            breakdown = kernel_breakdown(solver._trial_step, min(20, args.steps))
     if strong:
         # launch gaps or kernel floor?  (every rank profiles its own shard's steps; collective: all ranks call this)
         with torch.no_grad():
@@ -808,6 +811,152 @@ def run_linear(args, rank, world, device, parity=True):
         torch.cuda.synchronize()
         solver._g.release()
     return out, field, y0
+
+
+# ---------------------------------------------------------------------------------------------------
+# r05 regimes (N = 1, extras file): reduced-precision states, per-element tolerances, the func lever
+# ---------------------------------------------------------------------------------------------------
+def lowp_steps(dtype, backend, steps, warmup, device):
+    """dopri5 trial steps of the cfg2-shaped workload with a bf16 / fp16 STATE: `backend` "hip" = the kernels of
+    csrc/tdeq_kernels_lp.hpp (what a reduced-precision cuda state selects), "torch-op" = the package's torch-op host path
+    forced onto the same device (what r04 ran for such states)."""
+    from torchdiffeq_amd import _fallback, _native
+    A, y0 = make_problem(device)
+    # a pure rotation (the skew-symmetric part of cfg2's matrix): |y| stays put — with cfg2's -0.1 I the state decays below
+    # atol, a 16-bit error estimate becomes exactly 0 and `ratio == 0 -> dt * ifactor` (misc.py:88) runs dt to inf
+    A = (A + 0.1 * torch.eye(DIM, device=device)).to(dtype)
+    y0 = y0.to(dtype)
+    At = A.T.contiguous()
+    orig = _native.get_kernels
+    if backend == "torch-op":
+        low = _fallback.LowPrecisionHostKernels()
+        _native.get_kernels = lambda dev_, dt_=None: low if dt_ in (torch.bfloat16, torch.float16) else orig(dev_, dt_)
+    try:
+        blocks = []
+        with torch.no_grad():
+            for _ in range(3):          # a fresh solve per block (a 16-bit solve of this field lasts ~100 steps)
+                solver = make_stepper(lambda t, y: y @ At, y0, rtol=1e-2, atol=1e-3)
+                for _ in range(warmup):
+                    solver._trial_step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    solver._trial_step()
+                torch.cuda.synchronize()
+                blocks.append((time.perf_counter() - t0) / steps)
+            breakdown = None
+            if backend == "hip":
+                b = kernel_breakdown(solver._trial_step, 10)
+                breakdown = {k: b[k] for k in ("solver_kernel_us", "func_kernel_us", "floor_us", "dispatches_per_call",
+                                               "top_kernels")}
+    finally:
+        _native.get_kernels = orig
+    ms = 1e3 * statistics.median(blocks)
+    return {"backend": solver.kernels.name, "lookahead": bool(solver._lookahead), "ms_per_step": ms,
+            "rk_stages_per_s": 6e3 / ms, "accepted": solver.n_accepted, "rejected": solver.n_rejected,
+            "steps_timed": steps, "breakdown": breakdown}
+
+
+def lowp_combine_rate(dtype, device, nt=5, n=BATCH * DIM, sets=8, launches=48):
+    """The 16-bit stage combine (nt stages + y0 read, y_i written: 7 streams of 16.8 MB) on rotating buffer sets (cold)
+    and on one set (warm)."""
+    from torchdiffeq_amd import _native
+    k = _native.get_kernels(device, dtype)
+    bufs = [(torch.randn(n, device=device).to(dtype), [torch.randn(n, device=device).to(dtype) for _ in range(nt)],
+             torch.empty(n, dtype=dtype, device=device)) for _ in range(sets)]
+    coefs = (0.1, -0.2, 0.3, 0.25, -0.15, 0.05, 0.4)[:nt]
+    for y0, ks, out in bufs:
+        k.stage_combine(out, y0, ks, coefs, 0.1)
+    torch.cuda.synchronize()
+
+    def timed(rotate):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(launches):
+            y0, ks, out = bufs[i % sets if rotate else 0]
+            k.stage_combine(out, y0, ks, coefs, 0.1)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / launches
+    nbytes = (nt + 2) * n * 2
+    out = {"kernel": f"lp::map_kernel<{'BF16' if dtype == torch.bfloat16 else 'F16'}, {nt + 1}, 1, true, CombineF>",
+           "algorithmic_bytes_per_launch": nbytes}
+    for label, rotate in (("cold", True), ("warm", False)):
+        ms = statistics.median(timed(rotate) for _ in range(5))
+        out[label] = {"avg_launch_ms": ms, "GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBPS,
+                      "buffer_sets": sets if rotate else 1}
+    return out
+
+
+def low_precision_regime(device):
+    res = {"workload": "dopri5 trial steps, dy/dt = A y (rotation), 65536 x 128, rtol 1e-2 atol 1e-3, state in bf16 / fp16"}
+    for name, dtype in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        entry = {"stage_combine": lowp_combine_rate(dtype, device)}
+        try:
+            hip = lowp_steps(dtype, "hip", 40, 5, device)
+            ref = lowp_steps(dtype, "torch-op", 10, 2, device)
+            entry.update({"hip_kernels": hip, "torch_op_host_path": ref, "speedup": ref["ms_per_step"] / hip["ms_per_step"]})
+        except AssertionError as exc:
+            # float16: the initial-step heuristic underflows the type's range in the reference as well ("underflow in dt
+            # 0.0", tests/test_brow_golden.py) — adaptive solves of fp16 states do not start; fixed grids do
+            entry["adaptive_steps"] = {"error": str(exc)}
+        res[name] = entry
+    return res
+
+
+def vector_tolerance_regime(field, y0, device, steps=60, warmup=10):
+    """cfg2 trial steps with a PER-ELEMENT rtol (an fp64 vector over the state, misc.py:80-82): the fused launch
+    (tdeq_error_norm_vec: the tolerance vector is one more 8-byte stream of the norm kernel) vs the r04 route (raw error
+    materialised + the scaling and the norm as fp64 torch ops) vs the scalar-tolerance step next to them."""
+    rtol_vec = torch.full(y0.shape, RTOL, dtype=torch.float64, device=device)
+    out = {}
+    for label, kw, fused in (("scalar_tolerances", {}, None), ("vector_rtol_fused", dict(rtol=rtol_vec), True),
+                             ("vector_rtol_torch_ops", dict(rtol=rtol_vec), False)):
+        solver = make_stepper(field, y0, **kw)
+        if fused is False:
+            solver._vec_fused = None
+        with torch.no_grad():
+            for _ in range(warmup):
+                solver._trial_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                solver._trial_step()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+        out[label] = {"ms_per_step": ms, "lookahead": bool(solver._lookahead), "fused_norm": solver._vec_fused is not None}
+    out["extra_ms_fused"] = out["vector_rtol_fused"]["ms_per_step"] - out["scalar_tolerances"]["ms_per_step"]
+    out["extra_ms_torch_ops"] = out["vector_rtol_torch_ops"]["ms_per_step"] - out["scalar_tolerances"]["ms_per_step"]
+    out["note"] = "per-element tolerances run host-driven steps (no look-ahead); the scalar line is the default path"
+    return out
+
+
+def tunableop_lever(args):
+    """The headline workload once more in a child process with PyTorch's TunableOp switched on (the user-side lever on
+    `func`: its six y @ A.T GEMMs are 45 % of the step and run at a third of the HBM rate under hipBLASLt's default
+    heuristic).  Reported NEXT to the headline, never instead of it: the contract value stays the default-heuristic one."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1", PYTORCH_TUNABLEOP_VERBOSE="0",
+                   PYTORCH_TUNABLEOP_FILENAME=os.path.join(tmp, "tunableop_results.csv"), TDEQ_BENCH_EXTRAS_DIR=tmp,
+                   TDEQ_BENCH_BREAKDOWN="1")
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps),
+                                "--warmup", str(max(args.warmup, 10)), "--no-extras", "--no-cpu-baseline"], env=env,
+                               capture_output=True, text=True, timeout=float(os.environ.get("TDEQ_TUNABLEOP_TIMEOUT", "150")))
+        except subprocess.TimeoutExpired:
+            return {"error": "tuning did not finish within the time bound"}
+        took = time.perf_counter() - t0
+        try:
+            child = json.load(open(os.path.join(tmp, "bench_extras_n1.json")))
+        except Exception:
+            return {"error": "child produced no result", "stderr_tail": r.stderr[-300:]}
+    bd = child.get("breakdown") or {}
+    return {"env": "PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1", "ms_per_step": child.get("ms_per_step"),
+            "value": child.get("value"), "func_kernel_us": bd.get("func_kernel_us"),
+            "solver_kernel_us": bd.get("solver_kernel_us"), "rel_err_vs_reference": child.get("rel_err_vs_reference"),
+            "nfe": child.get("nfe"), "child_wall_s": round(took, 1)}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1589,6 +1738,14 @@ def main():
                 return pred
             ex.run("adjoint_strong_scaling_prediction", adjoint_prediction)
             ex.run("configs", lambda: other_configs(device))
+            ex.run("low_precision", lambda: low_precision_regime(device))
+            ex.run("vector_tolerances", lambda: vector_tolerance_regime(field, y0, device))
+
+            def default_breakdown():
+                with torch.no_grad():
+                    b = kernel_breakdown(make_stepper(field, y0)._trial_step, 20)
+                return {k: b[k] for k in ("solver_kernel_us", "func_kernel_us", "floor_us", "dispatches_per_call")}
+            ex.run("breakdown_default_heuristic", default_breakdown)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             def eager():
                 with torch.no_grad():
@@ -1596,8 +1753,10 @@ def main():
             ex.run("reference_style_eager_gpu", eager)
             ex.run("same_device_reference", lambda: same_device_reference(field, y0, device))
             ex.run("adjoint_same_device_reference", lambda: adjoint_same_device_reference(device))
-            watchdog.cancel()           # the CPU leg is bounded by its own clock
+            watchdog.cancel()           # the CPU leg and the TunableOp child are bounded by their own clocks
             out["cpu_baseline"] = cpu_baseline()
+            if extras and os.environ.get("TDEQ_BENCH_TUNABLEOP", "1") != "0":
+                ex.run("func_lever_tunableop", lambda: tunableop_lever(args))
         watchdog.cancel()
         if rank == 0:
             out["extras_s"] = ex.seconds

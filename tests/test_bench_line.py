@@ -112,7 +112,8 @@ def test_error_line_is_small_and_parseable(capsys):
 def test_driver_command_prints_one_small_line(tmp_path):
     """`python bench.py --gpus 1 --steps 2 --warmup 1` (the driver's command shape): exactly one stdout line that is
     JSON, it is the LAST line, < 4 KB, with `roofline` and `cpu_baseline`; the extras file exists and holds the rest."""
-    env = dict(os.environ, TDEQ_BENCH_EXTRAS_DIR=str(tmp_path))
+    # (the TunableOp child of the extras is a second bench process of ~1 min: not in the test suite)
+    env = dict(os.environ, TDEQ_BENCH_EXTRAS_DIR=str(tmp_path), TDEQ_BENCH_TUNABLEOP="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -131,4 +132,6 @@ def test_driver_command_prints_one_small_line(tmp_path):
     assert line["nfe"] == line["reference_nfe"] == 68 and line["rel_err_vs_reference"] < 1e-5
     _scalars_only(line)
     extras = json.load(open(os.path.join(tmp_path, "bench_extras_n1.json")))
-    assert {"configs", "shard_regime", "adjoint_full", "solver_only", "extras_s"} <= set(extras)
+    assert {"configs", "shard_regime", "adjoint_full", "solver_only", "extras_s", "low_precision", "vector_tolerances"} <= set(extras)
+    assert extras["low_precision"]["bf16"]["hip_kernels"]["backend"] == "hip-low"
+    assert extras["vector_tolerances"]["vector_rtol_fused"]["fused_norm"] is True

@@ -19,7 +19,7 @@ for rows in (65536, 32768, 16384, 8192):
     field = lambda t, y: y @ At
     for name, kw in (("lookahead", dict(lookahead=True)), ("hip_graph", dict(hip_graph=True))):
         from torchdiffeq_amd import solvers
-        solvers._GRAPH_MODE_MAX_ELEMENTS = 1 << 24          # let the captured path run at every size for this comparison
+        solvers.adaptive._GRAPH_MODE_MAX_ELEMENTS = solvers.fixed._GRAPH_MODE_MAX_ELEMENTS = 1 << 24          # let the captured path run at every size for this comparison
         solver = bench.make_stepper(field, y0, **kw)
         st = bench.block_stats(bench.time_steps(solver, 100, 30, 1, dev, n_blocks=3), 100)
         solver = bench.make_stepper(field, y0, **kw)

@@ -1,112 +1,19 @@
 #!/usr/bin/env python
-"""bf16 / fp16 states (r05): one dopri5 trial step of the 65536 x 128 linear workload (BASELINE.json configs[1] at
-reduced precision) on the HIP kernels of csrc/tdeq_kernels_lp.hpp vs the package's torch-op host path
-(`_fallback.LowPrecisionHostKernels`, what r04 ran for such states) on the same MI355X, and the HBM rate of the 16-bit
-stage combine (7 streams of 16.8 MB: rows of 5 stages).
+"""bf16 / fp16 states (r05): bench.py's `low_precision` extras object on its own —
 
     python tools/lowp_bench.py > gpurun_out/r05_lowp_bench.json
-"""
+
+dopri5 trial steps of the 65536 x 128 workload with a reduced-precision STATE on the HIP kernels of
+csrc/tdeq_kernels_lp.hpp vs the package's torch-op host path (what r04 ran for such states) on the same MI355X, and the HBM
+rate of the 16-bit stage combine."""
 import json
 import os
-import statistics
 import sys
-import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from torchdiffeq_amd import _fallback, _native  # noqa: E402
-
-
-def steps_per_second(dtype, backend, steps, warmup):
-    dev = torch.device("cuda", 0)
-    A, y0 = bench.make_problem(dev)
-    # a pure rotation (the skew-symmetric part of cfg2's matrix): |y| stays put, so hundreds of consecutive trial steps can
-    # be timed — with cfg2's -0.1 I the state decays below atol, a 16-bit error estimate becomes exactly 0 and the
-    # controller's `ratio == 0 -> dt * ifactor` branch (misc.py:88) runs the step size to inf (in the reference too)
-    A = (A + 0.1 * torch.eye(bench.DIM, device=dev)).to(dtype)
-    y0 = y0.to(dtype)
-    At = A.T.contiguous()
-    orig = _native.get_kernels
-    if backend == "torch-op":
-        low = _fallback.LowPrecisionHostKernels()
-        _native.get_kernels = lambda device, dt=None: low if dt in (torch.bfloat16, torch.float16) else orig(device, dt)
-    try:
-        bench.RTOL, bench.ATOL = 1e-2, 1e-3          # what a 16-bit state can resolve (1e-7 underflows dt, as in the reference)
-        blocks = []
-        with torch.no_grad():
-            for _ in range(3):          # a fresh solve per block: both backends take the same <= 60 steps of it
-                solver = bench.make_stepper(lambda t, y: y @ At, y0)
-                name = solver.kernels.name
-                for _ in range(warmup):
-                    solver._trial_step()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    solver._trial_step()
-                torch.cuda.synchronize()
-                blocks.append((time.perf_counter() - t0) / steps)
-    finally:
-        _native.get_kernels = orig
-    ms = 1e3 * statistics.median(blocks)
-    breakdown = None
-    if backend == "hip":
-        with torch.no_grad():
-            b = bench.kernel_breakdown(solver._trial_step, 10, is_solver=lambda n: "tdeq::" in n)
-        breakdown = {k: b[k] for k in ("solver_kernel_us", "func_kernel_us", "floor_us", "dispatches_per_call", "top_kernels")}
-    return {"backend": name, "breakdown": breakdown, "ms_per_step": ms, "rk_stages_per_s": 6e3 / ms, "accepted": solver.n_accepted,
-            "rejected": solver.n_rejected, "steps_timed": steps}
-
-
-def combine_rate(dtype, nt=5, n=bench.BATCH * bench.DIM, sets=8, launches=48):
-    dev = torch.device("cuda", 0)
-    k = _native.get_kernels(dev, dtype)
-    bufs = []
-    for _ in range(sets):
-        bufs.append((torch.randn(n, device=dev).to(dtype), [torch.randn(n, device=dev).to(dtype) for _ in range(nt)],
-                     torch.empty(n, dtype=dtype, device=dev)))
-    coefs = (0.1, -0.2, 0.3, 0.25, -0.15, 0.05, 0.4)[:nt]
-    for y0, ks, out in bufs:
-        k.stage_combine(out, y0, ks, coefs, 0.1)
-    torch.cuda.synchronize()
-
-    def timed(rotate):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(launches):
-            y0, ks, out = bufs[i % sets if rotate else 0]
-            k.stage_combine(out, y0, ks, coefs, 0.1)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / launches
-    nbytes = (nt + 2) * n * 2
-    out = {"kernel": f"lp::map_kernel<{'BF16' if dtype == torch.bfloat16 else 'F16'}, {nt + 1}, 1, true, CombineF> "
-                     f"({nt} stages + y0 read, y_i written)", "algorithmic_bytes_per_launch": nbytes}
-    for label, rotate in (("cold", True), ("warm", False)):
-        ms = statistics.median(timed(rotate) for _ in range(5))
-        out[label] = {"avg_launch_ms": ms, "GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / 8000.0,
-                      "buffer_sets": sets if rotate else 1}
-    return out
-
-
-def main():
-    res = {"workload": "dopri5 trial steps, dy/dt = A y, 65536 x 128, rtol 1e-2 atol 1e-3 (the tolerances only shape the "
-                       "accept / reject sequence; the work per trial step is fixed)", "dtypes": {}}
-    for name, dtype in (("bf16", torch.bfloat16), ("f16", torch.float16)):
-        entry = {"stage_combine": combine_rate(dtype)}
-        try:
-            hip = steps_per_second(dtype, "hip", 40, 5)
-            ref = steps_per_second(dtype, "torch-op", 10, 2)
-            entry.update({"hip_kernels": hip, "torch_op_host_path": ref, "speedup": ref["ms_per_step"] / hip["ms_per_step"]})
-        except AssertionError as exc:
-            # float16: the initial-step heuristic's 1e-6 floor underflows the type's range in the reference as well
-            # ("underflow in dt 0.0", tests/test_brow_golden.py) — adaptive solves of fp16 states do not start
-            entry["adaptive_steps"] = {"error": str(exc)}
-        res["dtypes"][name] = entry
-    print(json.dumps(res, indent=1))
-
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(bench.low_precision_regime(torch.device("cuda", 0)), indent=1))

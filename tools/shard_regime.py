@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from torchdiffeq_amd import solvers  # noqa: E402
 
-solvers._GRAPH_MODE_MAX_ELEMENTS = 1 << 24      # measure the captured step beyond its shipped size limit too
+solvers.adaptive._GRAPH_MODE_MAX_ELEMENTS = solvers.fixed._GRAPH_MODE_MAX_ELEMENTS = 1 << 24      # measure the captured step beyond its shipped size limit too
 
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)

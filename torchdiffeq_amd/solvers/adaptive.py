@@ -1,111 +1,33 @@
-"""Host drivers of the explicit Runge–Kutta solvers (dopri5, dopri8, rk4) over the HIP kernels.
-
-The accept/reject loop stays on the host (one per process / shard): per trial step it issues S
-`stage_combine` launches interleaved with the user's `func`, one fused `error_norm` launch, reads back
-n_seg doubles, and runs the step controller in Python doubles — instead of the reference's ≈220 eager
-ops and ≈19 device->host syncs per trial step.  Control flow and numerics follow
-
-  RKAdaptiveStepsizeODESolver   torchdiffeq/_impl/rk_common.py:161-369
-  _runge_kutta_step             rk_common.py:43-90
-  _select_initial_step / _compute_error_ratio / _optimal_step_size   misc.py:36-95
-  _interp_fit / _interp_evaluate  interp.py:1-48 (fused, evaluated lazily: only for requested outputs)
-  FixedGridODESolver / RK4      solvers.py:52-181, fixed_grid.py:24-29, rk_common.py:110-118
-  AdamsBashforth(Moulton)       fixed_adams.py:164-228
-
-with time-like scalars (t0, t1, dt, rtol, ...) as host doubles instead of 0-dim device tensors.
-"""
+"""Adaptive embedded Runge–Kutta pairs driven from the host: the trial-step loop, the device-resident controller with its
+look-ahead first stage, captured trial steps (torchdiffeq/_impl/rk_common.py:161-369, misc.py:36-95, interp.py:1-48)."""
 from __future__ import annotations
 
-import bisect
-import collections
-import math
-import os
-import warnings
-from typing import List, Optional, Sequence
+import bisect  # noqa: F401
+import collections  # noqa: F401
+import math  # noqa: F401
+import os  # noqa: F401
+import warnings  # noqa: F401
+from typing import List, Optional, Sequence  # noqa: F401
 
-import numpy as np
+import numpy as np  # noqa: F401
 import torch
 
-from . import _native
+from .. import _native
 # captured trial steps, their cache and the "auto" policy live in _graph.py; the size limits and step thresholds are READ
 # here (tools patch `solvers._GRAPH_MODE_MAX_ELEMENTS` to measure beyond the shipped limit)
-from ._graph import (_AUTO_CAPTURE_AFTER_STEPS, _AUTO_MIN_GRID_STEPS, _GRAPH_AUTO_MAX_ELEMENTS,  # noqa: F401
+from .._graph import (_AUTO_CAPTURE_AFTER_STEPS, _AUTO_MIN_GRID_STEPS, _GRAPH_AUTO_MAX_ELEMENTS,  # noqa: F401
                      _GRAPH_MODE_MAX_ELEMENTS, _CaptureFailed, _DtCell, _GraphStep, _capture, _graph_request,
                      _held_tensor_ptrs, _reusable_across_solves, _scalar_state, _side_effect_fingerprint, _side_stream,
                      clear_graph_cache)
-from ._scalars import is_low, power, rdiv, scalar_type
-from .autodiff import Ops, stitch
-from .misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, component_norm, find_event, handle_unused_kwargs, rms_norm,
+from .._scalars import is_low, power, rdiv, scalar_type  # noqa: F401
+from ..autodiff import Ops, stitch  # noqa: F401
+from ..misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, component_norm, find_event, handle_unused_kwargs, rms_norm,  # noqa: F401
                    vector_tolerances)
-from .misc import _null_callback as _null
-from .tableaus import (ADAPTIVE_HEUN, ADAPTIVE_TABLEAUS, BOSH3, CARRY_DEFAULT_ON, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau,
+from ..misc import _null_callback as _null
+from ..tableaus import (ADAPTIVE_HEUN, ADAPTIVE_TABLEAUS, BOSH3, CARRY_DEFAULT_ON, DOPRI5, DOPRI8, FEHLBERG2, TSIT5, SparseRow, Tableau,  # noqa: F401
                        adams_coefficients, carry_plan)
-
-
-def _nan_max(a: float, b: float) -> float:
-    """torch.max semantics: NaN propagates."""
-    if math.isnan(a) or math.isnan(b):
-        return math.nan
-    return max(a, b)
-
-
-def _nan_min(a: float, b: float) -> float:
-    if math.isnan(a) or math.isnan(b):
-        return math.nan
-    return min(a, b)
-
-
-def _clamp(x: float, lo: float, hi: float) -> float:
-    """torch.clamp semantics for host doubles (NaN stays NaN)."""
-    if math.isnan(x):
-        return x
-    return min(max(x, lo), hi)
-
-
-def _norm_value(x) -> float:
-    """|value| of what a user's `norm` callable returned.  More than one element is the reference's error: its next
-    statement compares the result (`d0 < 1e-5`, `error_ratio <= 1`: misc.py:60, rk_common.py:303)."""
-    if isinstance(x, torch.Tensor) and x.numel() != 1:
-        raise RuntimeError("Boolean value of Tensor with more than one value is ambiguous (the `norm` callable must "
-                           "return a scalar)")
-    return abs(float(x))
-
-
-def _as_float(x) -> float:
-    if isinstance(x, torch.Tensor):
-        return float(x.item())
-    return float(x)
-
-
-def optimal_step_size(last_step: float, error_ratio: float, safety: float, ifactor: float,
-                      dfactor: float, order: int) -> float:
-    """Next step size — the reference's I-controller (misc.py:85-95) in host doubles."""
-    if error_ratio == 0:
-        return last_step * ifactor
-    if error_ratio < 1:
-        dfactor = 1.0
-    exponent = 1.0 / order
-    try:
-        scaled = safety / error_ratio ** exponent
-    except (OverflowError, ZeroDivisionError):
-        scaled = math.inf
-    factor = _nan_min(ifactor, _nan_max(scaled, dfactor))
-    return last_step * factor
-
-
-@np.errstate(all="ignore")     # host scalars follow IEEE silently, as 0-dim tensors do
-def optimal_step_size_in(W, last_step, error_ratio, safety, ifactor, dfactor, order) -> float:
-    """The same controller with every operation rounded in the host scalar type W (misc.py:85-95 on 0-dim tensors of
-    the solver option `dtype`, rk_common.py:176-194) — for W other than fp64."""
-    with np.errstate(all="ignore"):
-        last_step, ratio = W(last_step), W(error_ratio)
-        if ratio == 0:
-            return float(last_step * W(ifactor))
-        floor = W(1.0) if ratio < 1 else W(dfactor)
-        exponent = W(1.0) / W(order)                  # torch.tensor(order, dtype).reciprocal()
-        scaled = W(safety) / ratio ** exponent
-        factor = _nan_min(W(ifactor), _nan_max(scaled, floor))
-        return float(last_step * factor)
+from ._common import _nan_max, _nan_min, _clamp, _norm_value, _as_float, optimal_step_size, optimal_step_size_in, _StepShadow, _NoShadow, _NO_SHADOW  # noqa: F401
+from .events import AdaptiveEvents
 
 
 class _LockStep:
@@ -221,7 +143,7 @@ class _DenseRecord:
         self.anchor = None        # time anchor (graph of the step's start time) when the step was taken
 
 
-class RKAdaptiveStepsizeODESolver:
+class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
     """Adaptive embedded RK pair driven from the host; subclasses set `order` and `tableau`."""
     order: int
     tableau: Tableau
@@ -522,39 +444,6 @@ class RKAdaptiveStepsizeODESolver:
         coeffs = torch.stack(planes) if planes else torch.empty(0, 5, self.layout.total, dtype=self.y0.dtype,
                                                                  device=self.y0.device)
         return times, coeffs
-
-    @_native.on_state_device
-    def integrate_until_event(self, t0: torch.Tensor, event_fn):
-        """(event_t, solution[2, total]): step until `event_fn(t, y)` changes sign, then bisect on the last
-        step's dense output (solvers.py:44-49, rk_common.py:252-264, event_handling.py:5-20)."""
-        self._set_time_anchor(t0.reshape(-1))
-        self._before_integrate([float(t0.detach().to(self.dtype))])
-        event_time, y1 = self._advance_until_event(event_fn)
-        solution = torch.stack([self.y0, y1], dim=0)
-        return self._time_tensor(float(event_time)), solution
-
-    def _advance_until_event(self, event_fn):
-        ev = lambda: event_fn(self._time_tensor(self.t1), self.y1)
-        if ev() == 0:
-            return self.t1, self.y1
-        n_steps = 0
-        sign0 = float(torch.sign(ev()).detach())
-        while sign0 == float(torch.sign(ev()).detach()):
-            assert n_steps < self.max_num_steps, \
-                "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
-            self._adaptive_step()
-            n_steps += 1
-
-        def interp_fn(t):
-            return self._interp_evaluate(float(t))
-
-        atol = self.atol
-        if isinstance(atol, torch.Tensor):
-            atol = atol.min().item()
-        elif not isinstance(atol, (int, float)):
-            atol = min(float(a) for a in atol)
-        return find_event(interp_fn, sign0, self.t0, self.t1, event_fn, self._w(float(atol)), self._time_tensor,
-                          scalar=self._W)
 
     def _before_integrate(self, t_host: List[float]) -> None:
         t0 = t_host[0]
@@ -1126,777 +1015,3 @@ class AdaptiveHeunSolver(RKAdaptiveStepsizeODESolver):
 # ---------------------------------------------------------------------------------------------------
 # Fixed grid
 # ---------------------------------------------------------------------------------------------------
-def _host_times(times: torch.Tensor):
-    """A time tensor as host scalars that round like its 0-dim elements (`_scalars`): a numpy array for fp32 / fp64
-    (its scalar type does IEEE arithmetic in the type itself), a list of `BFloat16Scalar` / `Float16Scalar` for the
-    16-bit types numpy cannot hold or would not round like ATen.  Returns (sequence, scalar type)."""
-    low = scalar_type(times.dtype) if times.dtype in (torch.bfloat16, torch.float16) else None
-    if low is None:
-        host = times.detach().cpu().numpy()
-        return host, host.dtype.type
-    return [low(v) for v in times.detach().float().cpu().tolist()], low
-
-
-def _uniform_grid(t: torch.Tensor, step_size) -> torch.Tensor:
-    """Points t[0] + i·step_size covering [t[0], t[-1]], the last one moved onto t[-1] exactly.  Formed with tensor
-    arithmetic in t.dtype on t.device — the point count ceil(span / step_size + 1) and every grid value must round as
-    the reference's do (solvers.py:86-96; on a ROCm device a tensor divided by a host scalar is a multiplication by
-    its reciprocal, which host arithmetic would not reproduce), and the grid keeps the autograd graph of `t`."""
-    first, last = t[0], t[-1]
-    count = float(torch.ceil((last - first) / step_size + 1).detach())
-    if not math.isfinite(count):
-        torch.arange(0, count)          # step_size 0 / nan: torch's own RuntimeError ("unsupported range: 0 -> inf")
-    count = int(count)
-    grid = torch.arange(count, dtype=t.dtype, device=t.device) * step_size + first
-    grid[-1] = last
-    return grid
-
-
-class FixedGridODESolver(object):
-    """Fixed-grid explicit RK driver (solvers.py:52-181): grid from `t`, `step_size` or `grid_constructor`;
-    outputs by linear (default) or cubic Hermite interpolation between grid points.  Time-like scalars
-    keep `t.dtype` (no fp64 promotion in the fixed-grid path).  Subclasses implement `_step`."""
-    order: int
-    flat_state_native = True
-
-    def __init__(self, func: OdeFunc, y0: torch.Tensor, step_size=None, grid_constructor=None,
-                 interp="linear", perturb=False, hip_graph=None, **unused_kwargs):
-        self.atol = unused_kwargs.pop("atol")
-        # `hip_graph=True` (an extension, not a reference option): replay one captured hipGraph per grid interval
-        # instead of launching a step's kernels one by one — see RK4._integrate_graph.  "auto": where it applies
-        # (rk4, small states), without the warning otherwise.
-        self.hip_graph, self._graph_auto = _graph_request(hip_graph)
-        self._graph_explicit = hip_graph is not None
-        unused_kwargs.pop("rtol", None)
-        unused_kwargs.pop("norm", None)
-        unused_kwargs.pop("dist_sync", None)          # fixed grids are in lock step by construction
-        unused_kwargs.pop("dist_replicated", None)
-        handle_unused_kwargs(self, unused_kwargs)
-        del unused_kwargs
-        if not isinstance(func, OdeFunc):
-            raise TypeError("solver classes of torchdiffeq_amd take the wrapped func built by check_inputs")
-        if step_size is not None and grid_constructor is not None:
-            raise ValueError("step_size and grid_constructor are mutually exclusive arguments.")
-        self.func, self.y0, self.layout = func, y0, func.layout
-        self.dtype, self.device = y0.dtype, y0.device
-        self.kernels = _native.get_kernels(y0.device, y0.dtype)
-        self.ops = Ops(self.kernels, func.np_dtype)
-        self.interp, self.perturb = interp, perturb
-        # where the grid comes from: a user callable, a uniform spacing, or — neither given — the output times
-        self.step_size = step_size
-        self._user_grid = grid_constructor
-
-    @classmethod
-    def valid_callbacks(cls):
-        return {"callback_step"}
-
-    def _time_grid(self, t: torch.Tensor) -> torch.Tensor:
-        """The integration grid for output times `t` (solvers.py:70-96): the user's `grid_constructor(func, y0, t)`,
-        else the uniform `step_size` grid, else `t` itself (the same tensor object: that is what graph mode tests)."""
-        if self._user_grid is not None:
-            return self._user_grid(*self._reference_view(), t)
-        if self.step_size is None:
-            return t
-        return _uniform_grid(t, self.step_size)
-
-    def _reference_view(self):
-        """(func, y0) as the reference hands them to a user's `grid_constructor(func, y0, t)` (solvers.py:103): a tensor
-        state in ITS shape, a tuple state — also the adjoint's augmented one — as the plain concatenation of its
-        components (misc.py:206-209), not this package's chunk-padded flat buffer; `func(t, y)` maps such a state to its
-        derivative in the same form (t in solver time, like every call of the reference's wrapped func)."""
-        lay, func = self.layout, self.func
-        if not lay.is_tuple:
-            shape = lay.shapes[0]
-            return (lambda t, y, **kw: func(t, y.reshape(-1), **kw).view(shape)), self.y0.view(shape)
-
-        def joined(flat):
-            return torch.cat([c.reshape(-1) for c in lay.unpack(flat)]) if lay.n_seg else flat
-
-        def on_joined(t, y, **kw):
-            parts, off = [], 0
-            for n, shape in zip(lay.numels, lay.shapes):
-                parts.append(y[off:off + n].view(shape))
-                off += n
-            return joined(func(t, lay.pack(parts, dtype=self.dtype), **kw))
-        return on_joined, joined(self.y0)
-
-    # -- one step ------------------------------------------------------------------------------------
-    def _step(self, t0, dt, t1, y0: torch.Tensor, y1_out: Optional[torch.Tensor], sh: "_StepShadow"):
-        """Return (y(t1), f0 = func(t0, y0)); y(t1) is written into `y1_out` when given (no-grad callers).
-        t0 and t1 are numpy scalars of the grid's dtype; `dt` is one too in `integrate`, and the Python float
-        `step_size` in `integrate_until_event`.  `sh` carries the autograd shadows of t0 / dt when the grid
-        requires grad."""
-        raise NotImplementedError
-
-    @staticmethod
-    def _tmul(scalar, dt, c: float):
-        """`dt * c` as the reference forms it: a 0-dim tensor dt times a Python float is rounded in the
-        grid dtype with c rounded first; a Python-float dt (event mode, solvers.py:134) multiplies in double
-        and is rounded when it meets the time tensor."""
-        if is_low(type(dt)):
-            return dt * c                   # a 16-bit 0-dim tensor times a Python number: the number at fp32, one rounding
-        if isinstance(dt, float):
-            return scalar(dt * c)
-        return scalar(dt * scalar(c))
-
-    def _first_perturb(self) -> Perturb:
-        return Perturb.NEXT if self.perturb else Perturb.NONE
-
-    def _last_perturb(self) -> Perturb:
-        return Perturb.PREV if self.perturb else Perturb.NONE
-
-    # -- integrate -----------------------------------------------------------------------------------
-    @_native.on_state_device
-    def integrate(self, t: torch.Tensor) -> torch.Tensor:
-        func, ops = self.func, self.ops
-        time_grid = self._time_grid(t)
-        assert time_grid[0] == t[0] and time_grid[-1] == t[-1]
-        if self.interp not in ("linear", "cubic"):
-            raise ValueError(f"Unknown interpolation method {self.interp}")
-        if self.hip_graph:
-            if self._graph_capable(t, time_grid) and not (self._graph_auto and
-                                                          self.layout.total > _GRAPH_AUTO_MAX_ELEMENTS):
-                return self._integrate_graph(t)
-            if not self._graph_auto and self._graph_explicit:
-                # (asked for by option; a process-wide TDEQ_HIP_GRAPH=1 default applies where it can and stays silent)
-                warnings.warn("{}: hip_graph=True needs an explicit Runge-Kutta fixed-grid method (euler, midpoint, "
-                              "heun2, heun3, rk4), the output times as the grid, linear interpolation, no callback, no "
-                              "autograd graph and a ROCm device; running the eager path".format(self.__class__.__name__))
-        # host copies, in the grid's own dtype (dt = t1 - t0 is formed in t.dtype: solvers.py:112)
-        grid, scalar = _host_times(time_grid)
-        tt, _ = _host_times(t)
-        linear = self.interp == "linear"
-        grad_mode = torch.is_grad_enabled()
-        time_grad = grad_mode and (time_grid.requires_grad or t.requires_grad)
-        sign = func.sign
-
-        rows: List[Optional[torch.Tensor]] = [self.y0] + [None] * (len(tt) - 1)
-        solution = None
-        has_cb = func.callback_step is not _null
-        j = 1
-        y0 = self.y0
-        for n, (t0, t1) in enumerate(zip(grid[:-1], grid[1:])):
-            dt = scalar(t1 - t0)
-            if has_cb:
-                func.callback_step(torch.tensor(t0, dtype=time_grid.dtype, device=self.device), y0,
-                                   torch.tensor(dt, dtype=time_grid.dtype, device=self.device))
-            sh = _StepShadow(time_grid[n], time_grid[n + 1], sign) if time_grad else _NO_SHADOW
-            # Without a graph, y1 goes straight into the output row when the grid point is an output time.
-            differentiable = grad_mode and (time_grad or y0.requires_grad)
-            y1_out = None
-            if not differentiable:
-                if solution is None:
-                    solution = torch.empty(len(tt), self.layout.total, dtype=self.dtype, device=self.device)
-                if linear and j < len(tt) and t1 == tt[j]:
-                    y1_out = solution[j]
-            y1, f0 = self._step(t0, dt, t1, y0, y1_out, sh)
-            differentiable = differentiable or (grad_mode and y1.requires_grad)
-
-            while j < len(tt) and t1 >= tt[j]:
-                tj_shadow = t[j] if time_grad else None
-                if linear:
-                    if tt[j] == t1:
-                        rows[j] = y1
-                    elif tt[j] == t0:
-                        rows[j] = y0
-                    else:
-                        slope = scalar(scalar(tt[j] - t0) / scalar(t1 - t0))
-                        rows[j] = ops.lerp(y0, y1, float(slope), sh.fraction(tj_shadow),
-                                           out=None if differentiable or solution is None else solution[j])
-                else:
-                    # solvers.py:121: evaluated anew for EVERY output time inside the step — a counting or stateful
-                    # func sees the reference's calls, and each output row hangs on its own graph node
-                    f1 = func.eval(t1, y1, shadow=sh.time(1.0))
-                    rows[j] = self._cubic_hermite_interp(scalar, t0, y0, f0, t1, y1, f1, tt[j], sh, tj_shadow,
-                                                         out=None if differentiable or solution is None
-                                                         else solution[j])
-                j += 1
-            y0 = y1
-        if any(r.requires_grad for r in rows) and grad_mode:
-            return torch.stack(rows, dim=0)
-        if solution is None:
-            solution = torch.empty(len(tt), self.layout.total, dtype=self.dtype, device=self.device)
-        for i, r in enumerate(rows):
-            if r.data_ptr() != solution[i].data_ptr():
-                solution[i].copy_(r)
-        return solution
-
-    # -- hipGraph mode ----------------------------------------------------------------------------------------
-    _graph_times = None          # per method: ((fraction of dt, mode bits), ...) of its stage times — see _integrate_graph
-
-    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
-        """The method's step on device-resident step data: evaluations at the 0-dim tensors `ts`, stage kernels that
-        read the step size from `dt_dev` (`ctrl.ctrl_dev[1]`); returns y(t1)."""
-        raise NotImplementedError
-
-    def _graph_capable(self, t: torch.Tensor, time_grid: torch.Tensor) -> bool:
-        if not (self._graph_times is not None and time_grid is t and self.interp == "linear"
-                and self.func.callback_step is _null and self.device.type == "cuda"
-                and hasattr(self.kernels, "grid_advance_stages")):
-            return False
-        if not torch.is_grad_enabled():
-            return True
-        if t.requires_grad or self.y0.requires_grad:
-            return False
-        # grad mode with neither y0 nor t in the graph: func's own parameters may still be (plain `odeint` training).
-        # The replayed kernels write into raw buffers — a solution without an autograd graph — so such a solve has to
-        # take the eager path.  One probe evaluation tells (as RKAdaptiveStepsizeODESolver._graph_step_ok reads f1);
-        # it is not counted.
-        nfe = self.func.nfe
-        probe = self.func.eval(float(t[0].detach()), self.y0, self._first_perturb())
-        self.func.nfe = nfe
-        return not probe.requires_grad
-
-    def _integrate_graph(self, t: torch.Tensor) -> torch.Tensor:
-        """`integrate` for small states, where a step costs launch latency, not bandwidth: ONE hipGraph — the method's
-        evaluations of `func`, its stage kernels with the step size read from device memory, tdeq_grid_commit (y1 ->
-        output row and next state) and tdeq_grid_advance_stages (next step's dt and stage times, formed on the device
-        with the host's rounding sequence) — is captured once and replayed per grid interval.  Same kernels and
-        operation order as the eager path, so the solution is bit-identical.  euler, midpoint, heun2, heun3, rk4 (r03:
-        the method is data — `_graph_times` — plus its `_graph_step`).  `func` must be capturable (static shapes, no
-        host synchronisation, no Python side effects it relies on: it runs only for the first step and once more
-        during capture)."""
-        func, kern = self.func, self.kernels
-        n_t = len(t)
-        solution = torch.empty(n_t, self.layout.total, dtype=self.dtype, device=self.device)
-        solution[0].copy_(self.y0)
-        if n_t == 1:
-            return solution
-        grid = t.detach().contiguous()
-        y_cur = self.y0.clone()
-        counter = torch.full((), -1, dtype=torch.int64, device=self.device)
-        fracs, modes = [f for f, _ in self._graph_times], [m for _, m in self._graph_times]
-        n_eval = len(fracs)
-        times = torch.empty(n_eval, dtype=func.time_dtype, device=self.device)
-        # {unused, sign * dt}: the layout tdeq_stage_combine_dev reads its step size from (a norm plan's ctrl_dev)
-        ctrl = _DtCell(torch.zeros(2, dtype=torch.float64, device=self.device))
-        dt_dev = ctrl.ctrl_dev[1:]
-        kern.grid_advance_stages(grid, counter, self.perturb, func.sign, fracs, modes, times, dt_dev)      # step 0
-        ts = times.unbind(0)
-
-        def step():
-            y1 = self._graph_step(ts, y_cur, dt_dev, ctrl)
-            kern.grid_commit(solution, y_cur, y1, counter)
-            kern.grid_advance_stages(grid, counter, self.perturb, func.sign, fracs, modes, times, dt_dev)
-
-        # the first step runs eagerly on a side stream (library / allocator warm-up before capture) ...
-        current = torch.cuda.current_stream(self.device)
-        side = _side_stream(self.device)
-        side.wait_stream(current)
-        auto = self._graph_auto
-        before = _side_effect_fingerprint(func.base_func, self.device) if auto else None
-        with torch.cuda.stream(side):
-            step()
-        current.wait_stream(side)
-        if auto and n_t > 2:
-            # "auto": replay only what is safe and worth it — a func whose evaluation visibly changed its own state (a
-            # counter, a cache, random numbers) is not captured; nor is a grid too short to pay for the capture
-            base = func.base_func
-            reason = None
-            try:
-                reason = _GraphStep._refused.get(base)
-            except TypeError:
-                pass
-            if reason is None and _side_effect_fingerprint(base, self.device) != before:
-                reason = ("evaluating it changed its own attributes, buffers or the device's random-number state (an "
-                          "evaluation counter, a cache, dropout ...), which a replay would not repeat")
-                try:
-                    _GraphStep._refused[base] = reason
-                except TypeError:
-                    pass
-                warnings.warn("hip_graph='auto': {} is not captured into a hipGraph — {}; its solves run on the eager "
-                              "path (pass hip_graph=True to capture it regardless)".format(type(base).__name__, reason))
-            if reason is not None or n_t - 2 < _AUTO_MIN_GRID_STEPS:
-                for _ in range(n_t - 2):
-                    step()
-                return solution
-        if n_t > 2:
-            # ... the others are replays of one captured step
-            graph = torch.cuda.CUDAGraph()
-            nfe_before = func.nfe
-            try:
-                with _capture(graph):
-                    step()
-            except Exception as exc:      # func is not capturable: nothing has run, the same body works eagerly
-                func.nfe = nfe_before
-                warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({!r}); continuing with "
-                              "the eager path".format(exc))
-                for _ in range(n_t - 2):
-                    step()
-                return solution
-            func.nfe = nfe_before
-            for _ in range(n_t - 2):
-                graph.replay()
-            func.nfe += n_eval * (n_t - 2)
-            # the graph and its private memory pool go away with this frame: let the replays finish first
-            current.synchronize()
-        return solution
-
-    @_native.on_state_device
-    def integrate_until_event(self, t0: torch.Tensor, event_fn):
-        """Fixed steps of `step_size` until the event function changes sign, then bisection on the linear /
-        cubic interpolant of that step (solvers.py:129-164).  Times are kept in the state dtype (:132).
-        When the start time requires grad its gradient is carried by step shadows, as in `integrate`: the reference
-        forms `t1 = t0 + dt` and the interpolation fraction `(t - t0) / (t1 - t0)` on the tensor `t0` itself, so the
-        state at the (detached) event time depends on it — which is what `odeint_event` turns into d(event time)/d t0."""
-        assert self.step_size is not None, \
-            "Event handling for fixed step solvers currently requires `step_size` to be provided in options."
-        func, ops = self.func, self.ops
-        scalar = func.np_dtype
-        time_tensor = lambda v: torch.tensor(float(v), dtype=func.time_dtype, device=self.device)     # solvers.py:132
-        start = t0 if (torch.is_grad_enabled() and torch.is_tensor(t0) and t0.requires_grad) else None
-        t0 = scalar(float(t0.detach()))
-        t_first = float(t0)
-        y0 = self.y0
-        dt = float(self.step_size)
-        if self.interp not in ("linear", "cubic"):
-            raise ValueError(f"Unknown interpolation method {self.interp}")
-
-        def shadow(ta, tb):
-            if start is None:
-                return _NO_SHADOW
-            return _StepShadow(start + (float(ta) - t_first), start + (float(tb) - t_first), func.sign)
-
-        sign0 = float(torch.sign(event_fn(time_tensor(t0), y0)).detach())
-        step_budget = 20000
-        for _ in range(step_budget):
-            t1 = scalar(t0 + scalar(dt))
-            sh = shadow(t0, t1)
-            y1, f0 = self._step(t0, dt, t1, y0, None, sh)
-            sign1 = float(torch.sign(event_fn(time_tensor(t1), y1)).detach())
-            if sign0 != sign1:
-                if self.interp == "linear":
-                    def interp_fn(t, t0=t0, t1=t1, y0=y0, y1=y1, sh=sh):
-                        if t == t0:
-                            return y0
-                        if t == t1:
-                            return y1
-                        return ops.lerp(y0, y1, float(scalar(scalar(t - t0) / scalar(t1 - t0))), sh.fraction(None, t))
-                else:
-                    f1 = func.eval(t1, y1, shadow=sh.time(1.0))
-
-                    def interp_fn(t, t0=t0, t1=t1, y0=y0, y1=y1, f0=f0, f1=f1, sh=sh):
-                        return self._cubic_hermite_interp(scalar, t0, y0, f0, t1, y1, f1, t, sh, None)
-                event_time, y1 = find_event(interp_fn, sign0, t0, t1, event_fn, float(self.atol), time_tensor,
-                                            scalar=scalar)
-                return time_tensor(event_time), torch.stack([self.y0, y1], dim=0)
-            t0, y0 = t1, y1
-        raise RuntimeError(f"Reached maximum number of iterations {step_budget}.")
-
-    def _cubic_hermite_interp(self, scalar, t0, y0, f0, t1, y1, f1, t, sh, t_shadow, out=None) -> torch.Tensor:
-        """solvers.py:166-173; the basis values are scalars of t.dtype formed on the host."""
-        one, two, three = scalar(1), scalar(2), scalar(3)
-        h = scalar(scalar(t - t0) / scalar(t1 - t0))
-        omh = scalar(one - h)
-        h00 = scalar(scalar(scalar(one + scalar(two * h)) * omh) * omh)
-        h10 = scalar(scalar(h * omh) * omh)
-        hh = scalar(h * h)
-        h01 = scalar(hh * scalar(three - scalar(two * h)))
-        h11 = scalar(hh * scalar(h - one))
-        dt = scalar(t1 - t0)
-        sign = scalar(self.func.sign)       # f0 / f1 are raw func outputs: fold the time sign into their weights
-        ws = [float(h00), float(scalar(h10 * dt) * sign), float(h01), float(scalar(h11 * dt) * sign)]
-        scalars, w_fn = (), None
-        if sh is not _NO_SHADOW:
-            hf, dtf, sg = float(h), float(dt), float(sign)
-            d_h = [-6 * hf * (1 - hf), (1 - hf) * (1 - 3 * hf) * dtf * sg, 6 * hf * (1 - hf),
-                   (3 * hf * hf - 2 * hf) * dtf * sg]
-            d_dt = [0.0, float(h10) * sg, 0.0, float(h11) * sg]
-            scalars = [(sh.fraction(t_shadow, t), d_h), (sh.width(), d_dt)]
-            device = y0.device
-
-            def w_fn(live):
-                """The basis as torch expressions of (h, dt) — cubic in h, so second-order time gradients need its
-                curvature (values from the host scalars, gradients through the shadows)."""
-                h_s, dt_s = live
-                h_t = torch.full((), hf, dtype=torch.float64, device=device)
-                dt_t = torch.full((), dtf, dtype=torch.float64, device=device)
-                if h_s is not None:
-                    h_t = h_t + (h_s - h_s.detach()).double()
-                if dt_s is not None:
-                    dt_t = dt_t + (dt_s - dt_s.detach()).double()
-                omh_t = 1 - h_t
-                b00, b10 = (1 + 2 * h_t) * omh_t * omh_t, h_t * omh_t * omh_t
-                b01, b11 = h_t * h_t * (3 - 2 * h_t), h_t * h_t * (h_t - 1)
-                d00, d10 = -6 * h_t * omh_t, omh_t * (1 - 3 * h_t)
-                d01, d11 = 6 * h_t * omh_t, 3 * h_t * h_t - 2 * h_t
-                zero = torch.zeros((), dtype=torch.float64, device=device)
-                return ([b00, b10 * dt_t * sg, b01, b11 * dt_t * sg],
-                        [[d00, d10 * dt_t * sg, d01, d11 * dt_t * sg], [zero, b10 * sg, zero, b11 * sg]])
-        return self.ops.weighted_sum([y0, f0, y1, f1], ws, scalars, out=out, w_fn=w_fn)
-
-
-class _StepShadow:
-    """Autograd shadows of one fixed-grid step's time scalars (solver time): t0, t1 are entries of the
-    time grid tensor (whose graph leads back to `t`); host scalars give the values, these only the gradient."""
-    __slots__ = ("t0", "t1", "sign")
-
-    def __init__(self, t0, t1, sign):
-        self.t0, self.t1, self.sign = t0, t1, sign
-
-    def width(self):
-        """dt in solver time."""
-        return self.t1 - self.t0
-
-    def dt_signed(self):
-        """The scalar handed to the kernels as `dt` (time sign folded in)."""
-        return (self.t1 - self.t0) * self.sign
-
-    def time(self, c: float):
-        """User time of the stage at t0 + c dt."""
-        return (self.t0 + (self.t1 - self.t0) * c) * self.sign
-
-    def fraction(self, t_shadow, t_const=None):
-        """(t - t0) / (t1 - t0) for an output time t (`t_const`: the value of a time that is not in the graph — it
-        matters as soon as the step width itself carries a gradient)."""
-        if t_shadow is not None:
-            num = t_shadow - self.t0
-        else:
-            num = -self.t0 if t_const is None else float(t_const) - self.t0
-        return num / (self.t1 - self.t0)
-
-
-class _NoShadow:
-    def width(self):
-        return None
-
-    def dt_signed(self):
-        return None
-
-    def time(self, c):
-        return None
-
-    def fraction(self, t_shadow, t_const=None):
-        return None
-
-
-_NO_SHADOW = _NoShadow()
-
-
-class Euler(FixedGridODESolver):
-    """Forward Euler (fixed_grid.py:6-11): dy = dt * f0."""
-    order = 1
-
-    def _step(self, t0, dt, t1, y0, y1_out, sh):
-        func = self.func
-        f0 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
-        y1 = self.ops.combine(y0, [f0], [1.0], float(dt) * func.sign, sh.dt_signed(), out=y1_out)
-        return y1, f0
-
-    _graph_times = ((0.0, 2),)                                           # t0 (NEXT under `perturb`)
-
-    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
-        f0 = self.func.eval_at(ts[0], y_cur)
-        y1 = torch.empty_like(y_cur)
-        self.kernels.stage_combine_dev(y1, None, y_cur, [f0], (1.0,), None, ctrl)
-        return y1
-
-
-class Midpoint(FixedGridODESolver):
-    """Explicit midpoint (fixed_grid.py:14-21): y_mid = y0 + f0*(dt/2); dy = dt * f(t0 + dt/2, y_mid)."""
-    order = 2
-
-    def _step(self, t0, dt, t1, y0, y1_out, sh):
-        func, ops = self.func, self.ops
-        scalar = type(t0)
-        dts = float(dt) * func.sign
-        half_dt = self._tmul(scalar, dt, 0.5)
-        f0 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
-        if is_low(func.np_dtype) and not (torch.is_grad_enabled() and (y0.requires_grad or f0.requires_grad)):
-            # 16-bit states: `f0 * half_dt` takes the scalar at fp32 (ATen's second-operand rule), not rounded to the state
-            y_mid = torch.empty_like(y0)
-            self.kernels.scaled_add(y_mid, y0, f0, float(half_dt) * func.sign)
-        else:
-            y_mid = ops.combine(y0, [f0], [0.5], dts, sh.dt_signed())
-        k2 = func.eval(scalar(t0 + half_dt), y_mid, shadow=sh.time(0.5))
-        y1 = ops.combine(y0, [k2], [1.0], dts, sh.dt_signed(), out=y1_out)
-        return y1, f0
-
-    _graph_times = ((0.0, 2), (0.5, 0))                                  # t0 (NEXT), t0 + dt/2
-
-    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
-        func, kern = self.func, self.kernels
-        f0 = func.eval_at(ts[0], y_cur)
-        y_mid = torch.empty_like(y_cur)
-        kern.stage_combine_dev(y_mid, None, y_cur, [f0], (0.5,), None, ctrl)
-        k2 = func.eval_at(ts[1], y_mid)
-        y1 = torch.empty_like(y_cur)
-        kern.stage_combine_dev(y1, None, y_cur, [k2], (1.0,), None, ctrl)
-        return y1
-
-
-class Heun2(FixedGridODESolver):
-    """Heun's 2nd-order method through the reference's rk2 step (fixed_grid.py:49-60, rk_common.py:142-157)."""
-    order = 2
-
-    def _step(self, t0, dt, t1, y0, y1_out, sh):
-        func, ops = self.func, self.ops
-        scalar = type(t0)
-        dts = float(dt) * func.sign
-        k1 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
-        ya = ops.fixed_stage(1, y0, [k1], [1.0], dts, sh.dt_signed())
-        k2 = func.eval(scalar(t0 + self._tmul(scalar, dt, 1.0)), ya, self._last_perturb(), shadow=sh.time(1.0))
-        y1 = ops.fixed_stage(0, y0, [k1, k2], [0.5, 0.5], dts, sh.dt_signed(), out=y1_out)
-        return y1, k1
-
-    _graph_times = ((0.0, 2), (1.0, 4))                                  # t0 (NEXT), t0 + dt*1.0 (PREV) — not t1 itself
-
-    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
-        func, kern = self.func, self.kernels
-        k1 = func.eval_at(ts[0], y_cur)
-        ya = torch.empty_like(y_cur)
-        kern.fixed_stage_dev(1, ya, y_cur, [k1], (1.0,), dt_dev)
-        k2 = func.eval_at(ts[1], ya)
-        y1 = torch.empty_like(y_cur)
-        kern.fixed_stage_dev(0, y1, y_cur, [k1, k2], (0.5, 0.5), dt_dev)
-        return y1
-
-
-class Heun3(FixedGridODESolver):
-    """Heun's 3rd-order method through the reference's rk3 step (fixed_grid.py:32-46, rk_common.py:121-140)."""
-    order = 3
-
-    def _step(self, t0, dt, t1, y0, y1_out, sh):
-        func, ops = self.func, self.ops
-        scalar = type(t0)
-        dts = float(dt) * func.sign
-        third, two_thirds = 1 / 3, 2 / 3
-        k1 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
-        ya = ops.fixed_stage(1, y0, [k1], [third], dts, sh.dt_signed())
-        k2 = func.eval(scalar(t0 + self._tmul(scalar, dt, third)), ya, shadow=sh.time(third))
-        # The tableau's structural zeros (k1 in the third stage, k2 in the result): the kernels do not read a term whose
-        # weight is zero; the torch-op host path evaluates the reference's literal `k1 * 0.0 + k2 * (2/3)`
-        # (fixed_grid.py:38-44) — the same number for finite stages, and NaN instead of inf once a stage is non-finite
-        literal = getattr(self.kernels, "literal_row_sums", False)
-        yb = ops.fixed_stage(0, y0, *(([k1, k2], [0.0, two_thirds]) if literal else ([k2], [two_thirds])),
-                             dts, sh.dt_signed())
-        k3 = func.eval(scalar(t0 + self._tmul(scalar, dt, two_thirds)), yb, shadow=sh.time(two_thirds))
-        y1 = ops.fixed_stage(0, y0, *(([k1, k2, k3], [1 / 4, 0.0, 3 / 4]) if literal else ([k1, k3], [1 / 4, 3 / 4])),
-                             dts, sh.dt_signed(), out=y1_out)
-        return y1, k1
-
-    _graph_times = ((0.0, 2), (1 / 3, 0), (2 / 3, 0))                    # t0 (NEXT), t0 + dt/3, t0 + 2dt/3
-
-    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
-        func, kern = self.func, self.kernels
-        third, two_thirds = 1 / 3, 2 / 3
-        k1 = func.eval_at(ts[0], y_cur)
-        ya = torch.empty_like(y_cur)
-        kern.fixed_stage_dev(1, ya, y_cur, [k1], (third,), dt_dev)
-        k2 = func.eval_at(ts[1], ya)
-        yb = torch.empty_like(y_cur)
-        kern.fixed_stage_dev(0, yb, y_cur, [k2], (two_thirds,), dt_dev)
-        k3 = func.eval_at(ts[2], yb)
-        y1 = torch.empty_like(y_cur)
-        kern.fixed_stage_dev(0, y1, y_cur, [k1, k3], (1 / 4, 3 / 4), dt_dev)
-        return y1
-
-
-def _rk4_38_step(solver, t0, dt, t1, y0, k1, y1_out, sh):
-    """One 3/8-rule step (rk_common.py:110-118); `k1` = func(t0, y0) when the caller already has it (the Adams
-    methods' start-up steps, fixed_adams.py:200), else it is evaluated here.  Returns (y1, k1)."""
-    func, ops = solver.func, solver.ops
-    scalar = type(t0)
-    third, two_thirds = 1 / 3, 2 / 3
-    dts = float(dt) * func.sign
-    stages = [(scalar(t0 + solver._tmul(scalar, dt, third)), Perturb.NONE),
-              (scalar(t0 + solver._tmul(scalar, dt, two_thirds)), Perturb.NONE),
-              (t1, solver._last_perturb())]
-    shadows = [sh.time(third), sh.time(two_thirds), sh.time(1.0)]
-    if k1 is None:
-        stages.insert(0, (t0, solver._first_perturb()))
-        shadows.insert(0, sh.time(0.0))
-    ts = func.time_tensors(solver.kernels, stages, shadows=shadows)
-    dsh = sh.dt_signed()
-    if k1 is None:
-        k1 = func.eval_at(ts[0], y0)
-        ts = ts[1:]
-    ya = ops.rk4_stage(1, y0, k1, None, None, None, dts, dsh)
-    k2 = func.eval_at(ts[0], ya)
-    yb = ops.rk4_stage(2, y0, k1, k2, None, None, dts, dsh)
-    k3 = func.eval_at(ts[1], yb)
-    yc = ops.rk4_stage(3, y0, k1, k2, k3, None, dts, dsh)
-    k4 = func.eval_at(ts[2], yc)
-    y1 = ops.rk4_stage(4, y0, k1, k2, k3, k4, dts, dsh, out=y1_out)
-    return y1, k1
-
-
-class RK4(FixedGridODESolver):
-    """Fixed-grid 4th-order RK, 3/8 rule (fixed_grid.py:24-29 -> rk_common.py:110-118)."""
-    order = 4
-
-    def _step(self, t0, dt, t1, y0, y1_out, sh):
-        return _rk4_38_step(self, t0, dt, t1, y0, None, y1_out, sh)
-
-    # -- hipGraph mode (FixedGridODESolver._integrate_graph) ------------------------------------------------
-    _graph_times = ((0.0, 2), (1 / 3, 0), (2 / 3, 0), (0.0, 1 | 4))     # t0 (NEXT), t0 + dt/3, t0 + 2dt/3, t1 (PREV)
-
-    def _graph_step(self, ts, y_cur, dt_dev, ctrl):
-        func, kern = self.func, self.kernels
-        k1 = func.eval_at(ts[0], y_cur)
-        ya = torch.empty_like(y_cur)
-        kern.rk4_stage_dev(1, ya, y_cur, k1, None, None, None, dt_dev)
-        k2 = func.eval_at(ts[1], ya)
-        yb = torch.empty_like(y_cur)
-        kern.rk4_stage_dev(2, yb, y_cur, k1, k2, None, None, dt_dev)
-        k3 = func.eval_at(ts[2], yb)
-        yc = torch.empty_like(y_cur)
-        kern.rk4_stage_dev(3, yc, y_cur, k1, k2, k3, None, dt_dev)
-        k4 = func.eval_at(ts[3], yc)
-        y1 = torch.empty_like(y_cur)
-        kern.rk4_stage_dev(4, y1, y_cur, k1, k2, k3, k4, dt_dev)
-        return y1
-
-
-# ---------------------------------------------------------------------------------------------------
-# Adams–Bashforth(–Moulton) multistep methods on a fixed grid
-# ---------------------------------------------------------------------------------------------------
-_ADAMS_MIN_ORDER = 4
-_ADAMS_MAX_ORDER = 12
-_ADAMS_MAX_ITERS = 4
-
-
-class AdamsBashforthMoulton(FixedGridODESolver):
-    """`implicit_adams` / `fixed_adams` (fixed_adams.py:164-223): variable-order (up to `max_order`) Adams–Bashforth
-    predictor and, with `implicit=True`, an Adams–Moulton corrector solved by at most `max_iters` fixed-point
-    iterations; the first steps — until three past derivatives exist — are 3/8-rule RK4 steps.
-
-    The history `prev_f` is a deque of SEPARATE contiguous func outputs (newest first), read once per step by
-    tdeq_adams_predict (predictor sum, the corrector's constant part and y0 + dy in one pass: order+1 reads, 1 or 3
-    writes); each corrector iteration is ONE tdeq_adams_correct launch (new dy, next evaluation point and the
-    convergence census of `_has_converged`), with one polled read-back per iteration — the reference spends ~2·order
-    + 12 eager ops and a host sync there.  The method's quirks are kept: the corrected derivative never replaces
-    the predictor's in the history (`_update_history(t0, f)` finds `prev_t == t0`, :222), and a step whose iteration
-    did not converge warns and drops the OLDEST derivative (:219-221)."""
-    order = 4
-
-    def __init__(self, func, y0, rtol=1e-3, atol=1e-4, implicit=True, max_iters=_ADAMS_MAX_ITERS,
-                 max_order=_ADAMS_MAX_ORDER, dist_sync=None, **kwargs):
-        super().__init__(func, y0, rtol=rtol, atol=atol, **kwargs)
-        self.max_order = self._checked_max_order(max_order)
-        self.implicit, self.max_iters = implicit, max_iters
-        self.rtol, self.atol = rtol, atol           # the corrector's convergence test (`_converged`)
-        # past derivatives, newest first, and the time the newest one belongs to (`_update_history`)
-        self.prev_t, self.prev_f = None, collections.deque(maxlen=self.max_order - 1)
-        self._sync = _LockStep(dist_sync) if dist_sync is not None else None
-        self._plan = None
-        # A 0-dim fp32 state meets the reference's fp64 coefficient tensors as 0-dim x 0-dim, which PyTorch promotes
-        # to fp64 (a dimensioned fp32 tensor would stay fp32): products and sums of `_dot_product` run in fp64 and are
-        # rounded once by `.type_as(y0)` — see _step_zero_dim.
-        self._zero_dim_f32 = (not self.layout.is_tuple and tuple(self.layout.shapes[0]) == ()
-                              and y0.dtype in (torch.float32, torch.complex64))        # complex64 promotes to complex128 alike
-
-    @staticmethod
-    def _checked_max_order(max_order) -> int:
-        """The option's two documented reactions (fixed_adams.py:170-172): orders beyond the coefficient table are
-        refused, orders below the multistep minimum only ever take the RK4 start-up steps."""
-        assert max_order <= _ADAMS_MAX_ORDER, "max_order must be at most {}".format(_ADAMS_MAX_ORDER)
-        if max_order < _ADAMS_MIN_ORDER:
-            warnings.warn("max_order is below {}, so the solver reduces to `rk4`.".format(_ADAMS_MIN_ORDER))
-        return int(max_order)
-
-    def _step_zero_dim(self, t1, y0, f0, hist, order, dt64, sh):
-        """The step for a 0-dim fp32 state with the reference's type promotion (fixed_adams.py:205-216): the history
-        dot products and `dt * m0 * f` are formed in fp64 (0-dim fp64 coefficient x 0-dim fp32 derivative promotes) and
-        rounded to fp32 once.  Same kernels, on fp64 copies of the one-element tensors; through `ops`, so the step is
-        recorded for autograd when something requires grad (func's parameters, y0, t)."""
-        func, ops = self.func, self.ops
-        sign = func.sign
-        dsh = sh.dt_signed()
-        wrt_dt = lambda dw: [(dsh, list(dw))] if dsh is not None else []
-        bash, _ = adams_coefficients(order)
-        low, wide = y0.dtype, (torch.float64 if y0.dtype == torch.float32 else torch.complex128)
-        h64 = [h.to(wide) for h in hist]
-        dot64 = lambda coefs, sc=(): ops._long_sum(h64, list(coefs), list(sc)).to(low)     # left to right in fp64, one rounding
-        add = lambda a, b: ops.weighted_sum([a, b], [1.0, 1.0])
-
-        dy = dot64([dt64 * b * sign for b in bash], wrt_dt(bash))
-        y = add(y0, dy)
-        if not self.implicit:
-            return y, f0
-        _, moulton = adams_coefficients(order + 1)
-        delta = ops.weighted_sum([dot64(moulton[1:])], [dt64 * sign], wrt_dt([1.0]))
-        if self._plan is None:
-            self._plan = self.kernels.make_plan(self.layout.segments(self.rtol, self.atol), self.layout.total,
-                                                self.layout.chunk, self.device)
-        c = dt64 * moulton[0] * sign
-        last = self._last_perturb()
-        converged = False
-        for _ in range(self.max_iters):
-            f = func.eval(t1, y, last, shadow=sh.time(1.0))
-            dy_new = add(ops.weighted_sum([f.to(wide)], [c], wrt_dt([moulton[0]])).to(low), delta)
-            y = add(y0, dy_new)
-            self.kernels.adams_correct(self._plan, dy_new.detach(), dy.detach(), compute=False)
-            dy = dy_new
-            converged = self._converged()
-            if converged:
-                break
-        if not converged:
-            warnings.warn("Functional iteration did not converge. Solution may be incorrect.")
-            self.prev_f.pop()
-        return y, f0
-
-    def _update_history(self, t, f) -> None:
-        if self.prev_t is None or self.prev_t != t:
-            self.prev_f.appendleft(f)
-            self.prev_t = t
-
-    def _converged(self) -> bool:
-        """`_has_converged` (fixed_adams.py:189-192) from the census of the last tdeq_adams_correct launch."""
-        counts, _, _ = self.kernels.read_norms(self._plan)
-        if self._sync is not None:      # sharded batch in lock step: every rank iterates until all have converged
-            counts = self._sync._allreduce(list(counts), self.device)
-        return not any(c != 0.0 for c in counts)
-
-    def _step(self, t0, dt, t1, y0, y1_out, sh):
-        func, ops = self.func, self.ops
-        f0 = func.eval(t0, y0, self._first_perturb(), shadow=sh.time(0.0))
-        self._update_history(t0, f0)
-        order = min(len(self.prev_f), self.max_order - 1)
-        if order < _ADAMS_MIN_ORDER - 1:
-            y1, _ = _rk4_38_step(self, t0, dt, t1, y0, self.prev_f[0], y1_out, sh)
-            return y1, f0
-        sign = func.sign
-        dt64 = float(dt)
-        bash, _ = adams_coefficients(order)
-        hist = [self.prev_f[j] for j in range(order)]
-        if self._zero_dim_f32:
-            return self._step_zero_dim(t1, y0, f0, hist, order, dt64, sh)
-        cb = [dt64 * b * sign for b in bash]            # `dt * bashforth_coeffs` in fp64 (:205); the sign is exact
-        dsh = sh.dt_signed()
-        if not self.implicit:
-            y1, _, _ = ops.adams_predict(y0, hist, cb, None, 0.0, dsh, list(bash), out=y1_out)
-            return y1, f0
-        _, moulton = adams_coefficients(order + 1)
-        y, dy, delta = ops.adams_predict(y0, hist, cb, list(moulton[1:]), dt64 * sign, dsh, list(bash))
-        if self._plan is None:
-            self._plan = self.kernels.make_plan(self.layout.segments(self.rtol, self.atol), self.layout.total,
-                                                self.layout.chunk, self.device)
-        c = dt64 * moulton[0] * sign                      # `dt * moulton_coeffs[0]`: 0-dim fp32/fp64 x fp64 -> fp64 (:214)
-        last = self._last_perturb()
-        converged = False
-        for _ in range(self.max_iters):
-            f = func.eval(t1, y, last, shadow=sh.time(1.0))
-            y, dy = ops.adams_correct(self._plan, y0, f, delta, dy, c, dsh, moulton[0])
-            converged = self._converged()
-            if converged:
-                break
-        if not converged:
-            warnings.warn("Functional iteration did not converge. Solution may be incorrect.")
-            self.prev_f.pop()
-        self._update_history(t0, f)
-        return y, f0
-
-
-class AdamsBashforth(AdamsBashforthMoulton):
-    """`explicit_adams` (fixed_adams.py:226-228)."""
-
-    def __init__(self, func, y0, **kwargs):
-        super().__init__(func, y0, implicit=False, **kwargs)
-
-
-SOLVER_CLASSES = {"dopri8": Dopri8Solver, "dopri5": Dopri5Solver, "tsit5": Tsit5Solver, "bosh3": Bosh3Solver,
-                  "fehlberg2": Fehlberg2, "adaptive_heun": AdaptiveHeunSolver, "euler": Euler,
-                  "midpoint": Midpoint, "heun2": Heun2, "heun3": Heun3, "rk4": RK4,
-                  "explicit_adams": AdamsBashforth, "implicit_adams": AdamsBashforthMoulton,
-                  "fixed_adams": AdamsBashforthMoulton}
