@@ -37,7 +37,7 @@ def error_ratio_parts(err, y0, y1, rtol: float, atol: float) -> Tuple[torch.Tens
 
 def segment_sums(r: torch.Tensor, segs: Sequence[Tuple[int, int]]) -> List[float]:
     """sum |r|^2 per segment (element offset, numel) in fp64, |r|^2 = re^2 + im^2 formed in double (misc.py:22 squares the
-    rounded modulus and accumulates in T; the kernels' fp64 accumulation takes the components — DESIGN.md §8)."""
+    rounded modulus and accumulates in T; the kernels' fp64 accumulation takes the components — docs/LAB_NOTEBOOK.md §8)."""
     out = []
     for off, n in segs:
         v = torch.view_as_real(r[off:off + n]).double()

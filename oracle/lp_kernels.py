@@ -7,7 +7,7 @@ The reference integrates a reduced-precision state with ordinary ATen ops on ten
 scalar is cast to `y0.abs().dtype`: torchdiffeq/_impl/rk_common.py:61-65, misc.py:185-187), so the restatement IS the
 reference's own torch expressions, evaluated by ATen's CPU kernels on bf16 / fp16 tensors — each function cites the lines
 it repeats (paths relative to torchdiffeq/_impl/).  Two deliberate differences, the same the fp32 / fp64 oracle has
-(DESIGN.md §8): a tableau row is summed over its NON-ZERO weights, left to right (`_row_sum`: products rounded to the
+(docs/LAB_NOTEBOOK.md §8): a tableau row is summed over its NON-ZERO weights, left to right (`_row_sum`: products rounded to the
 state's type, accumulated in float32, rounded once — what `torch.sum(k * c, dim=-1)` does for a reduced-precision
 tensor, with the order fixed), and norms are reported as fp64 sums of the rounded squares.
 

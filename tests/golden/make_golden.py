@@ -1225,7 +1225,7 @@ def gen_brow():
                 finals[i, j] = float(last.reshape(-1)[-1])
             except RuntimeError:
                 table[i, j] = 0
-    # ---- known residue: a 0-dim fp32 state on an fp64 time grid under an adaptive method ----
+    # ---- known residue (docs/LAB_NOTEBOOK.md §8): a 0-dim fp32 state on an fp64 time grid under an adaptive method ----
     y = torchdiffeq.odeint(lambda t_, y_: -y_ * torch.cos(t_), torch.tensor(1.5), torch.linspace(0.0, 2.0, 5, dtype=torch.float64),
                            method="dopri5")
     arrays["zero_dim_f32_on_f64_grid_dopri5"] = y

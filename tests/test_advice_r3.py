@@ -12,7 +12,7 @@ import torchdiffeq_amd as tda
 @pytest.mark.parametrize("method", ["rk4", "euler", "midpoint", "heun3"])
 def test_fixed_grid_graph_mode_keeps_parameter_gradients(method):
     """Plain `odeint` training (grad mode on, only func's parameters require grad) under hip_graph=True: the replayed
-    kernels write raw buffers, so the solve has to take the eager path (one probe evaluation decides) and the gradients
+    kernels write raw buffers, so the solve has to take the eager path (decided from what func holds) and the gradients
     must equal the eager ones; under no_grad the same call is captured."""
     torch.manual_seed(0)
     lin = torch.nn.Linear(6, 6).cuda()
@@ -35,20 +35,38 @@ def test_fixed_grid_graph_mode_keeps_parameter_gradients(method):
     assert torch.equal(y_eager, y_graph)
 
 
-def test_fixed_grid_graph_capability_probe_is_not_counted(cpu_backend, monkeypatch):
-    """The probe evaluation of `_graph_capable` leaves `func.nfe` alone and only runs in grad mode."""
+def test_fixed_grid_graph_capability_is_decided_without_evaluating_func(cpu_backend, monkeypatch):
+    """Advisor r04: whether a grad-mode solve may replay captured steps is decided from what func HOLDS (module
+    parameters, closure cells, ...), not by a probe evaluation — func is not called (no RNG / counter side effects, no
+    extra evaluation), and a func whose parameter dependence is gated by time is still found out."""
     from torchdiffeq_amd import solvers
     from torchdiffeq_amd.misc import OdeFunc, StateLayout
     lin = torch.nn.Linear(3, 3).double()
+    frozen = torch.nn.Linear(3, 3).double().requires_grad_(False)
+    w = torch.ones(3, dtype=torch.float64, requires_grad=True)
     y0 = torch.ones(3, dtype=torch.float64)
     t = torch.linspace(0.0, 1.0, 4, dtype=torch.float64)
-    func = OdeFunc(lambda t_, y_: lin(y_), StateLayout([y0.shape], False), 1.0, y0.dtype, y0.device)
-    s = solvers.RK4(func=func, y0=y0, atol=1e-9, hip_graph=True)
-    monkeypatch.setattr(s, "device", torch.device("cuda"))               # the capability question only
-    monkeypatch.setattr(s.kernels, "grid_advance_stages", lambda *a, **k: None, raising=False)
-    assert s._graph_capable(t, t) is False and func.nfe == 0             # parameters require grad: eager
-    with torch.no_grad():
-        assert s._graph_capable(t, t) is True and func.nfe == 0
+    calls = [0]
+
+    def counted(f):
+        def g(t_, y_):
+            calls[0] += 1
+            return f(t_, y_)
+        return g
+    cases = [(counted(lambda t_, y_: lin(y_)), False),                                  # a module in a closure cell
+             (counted(lambda t_, y_: lin(y_) if float(t_) > 0.5 else -y_), False),      # gated by time: t[0] would not show it
+             (counted(lambda t_, y_: y_ * w), False),                                   # a leaf tensor in a closure cell
+             (counted(lambda t_, y_: frozen(y_)), True),                                # nothing requires grad: replay is fine
+             (counted(lambda t_, y_: -y_), True)]
+    for f, capable in cases:
+        func = OdeFunc(f, StateLayout([y0.shape], False), 1.0, y0.dtype, y0.device)
+        s = solvers.RK4(func=func, y0=y0, atol=1e-9, hip_graph=True)
+        monkeypatch.setattr(s, "device", torch.device("cuda"))               # the capability question only
+        monkeypatch.setattr(s.kernels, "grid_advance_stages", lambda *a, **k: None, raising=False)
+        assert s._graph_capable(t, t) is capable
+        with torch.no_grad():
+            assert s._graph_capable(t, t) is True
+    assert calls[0] == 0
 
 
 # -- 2. the "running the eager path" warning of fixed-grid solvers: only for an explicit option ---------------------------
@@ -100,7 +118,7 @@ def test_proxy_check_uses_solver_time_and_a_nonzero_cotangent(cpu_backend):
 # -- 4. the one known residue of the 0-dim promotion emulation, bounded ---------------------------------------------------
 def test_zero_dim_fp32_state_on_an_fp64_grid_residue_is_bounded(dev):
     """A 0-dim fp32 state on an fp64 time grid under dopri5 differs from the reference by ~1.3e-6 relative (the
-    reference's 0-dim x 0-dim promotions inside the adaptive step are not emulated — DESIGN.md §8).  Bounded here so
+    reference's 0-dim x 0-dim promotions inside the adaptive step are not emulated — docs/LAB_NOTEBOOK.md §8).  Bounded here so
     that a regression is visible; rk4 / Adams on the same inputs are bit-identical (tests/test_dropin_golden.py)."""
     from _cases import load, rel_err
     ref = load("brow.npz")["zero_dim_f32_on_f64_grid_dopri5"]

@@ -46,9 +46,9 @@ def test_dtype_option_step_sequence(dev, state, method, kw, opt, direction):
         assert all(float(np.float32(d)) == d for d in f.accept), "step sizes must be fp32 numbers under dtype=float32"
     # first step: the heuristic's scalar arithmetic, reproduced operation by operation (_scalars.py) — to the last bit on
     # the CPU's fp64 sums, an fp32 ulp otherwise; later steps follow the error ratio, whose fp32 sums cancel to ~1 %
-    # noise at this tolerance (summation order)
+    # noise at this tolerance (summation order, docs/LAB_NOTEBOOK.md §12)
     np.testing.assert_allclose(f.accept[0], ref_acc[0], rtol=3e-7 if state == "f32" else 1e-12)
-    # (dopri8: a 9-term cancelling error sum — DESIGN.md §12 — so its ratio carries the most noise)
+    # (dopri8: a 9-term cancelling error sum — docs/LAB_NOTEBOOK.md §12 — so its ratio carries the most noise)
     # on the GPU func itself (a hipBLASLt GEMM) rounds differently from the CPU reference's: more noise in fp32
     noise = {"f32": 2e-2 if dev == "cpu" else 0.15, "f64": 1e-7}[state] * (100 if method == "dopri8" else 1)
     np.testing.assert_allclose(f.accept, ref_acc, rtol=min(noise, 0.5))

@@ -233,7 +233,7 @@ def test_complex_solve_with_captured_steps_and_lookahead(tag):
     finally:
         os.environ.pop("TDEQ_LOOKAHEAD")
     assert nfe == nfe_host
-    # host-driven loop: the controller's `pow` is libm's instead of the device's (<= 2 ulp of fp64 in dt_next)
+    # host-driven loop: the controller's `pow` is libm's instead of the device's (<= 2 ulp of fp64 in dt_next, docs/LAB_NOTEBOOK.md §8)
     err = float((y_plain - y_host).abs().max() / y_host.abs().max())
     assert err < (1e-5 if tag == "c64" else 1e-12), err
     # captured steps use the same device controller as the look-ahead path: the same bits

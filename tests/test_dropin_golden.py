@@ -197,7 +197,7 @@ def test_flat_state_padding_is_zero_so_step_size_gradients_stay_finite(where, mo
 def test_empty_states(where, method):
     """Edge case: a state without elements.  Fixed-grid methods and empty COMPONENTS of a tuple behave as in the
     reference (shapes [len(t), 0, ...]); an entirely empty state under an adaptive method returns the empty solution
-    here, where the reference fails with 'underflow in dt 0.0' (its RMS norm of nothing is NaN) — DESIGN.md §8."""
+    here, where the reference fails with 'underflow in dt 0.0' (its RMS norm of nothing is NaN) — docs/LAB_NOTEBOOK.md §8."""
     t = torch.tensor([0.0, 0.5, 1.0])
     with torch.no_grad():
         y = tda.odeint(lambda t_, y_: -y_, torch.empty(0, 3), t, method=method)
@@ -348,7 +348,7 @@ def test_adjoint_callbacks_see_the_reference_tuple_for_a_tuple_state(where, meth
 @pytest.mark.parametrize("direction", ["fwd", "rev"])
 @pytest.mark.parametrize("method", ["euler", "midpoint", "heun3", "rk4", "explicit_adams", "implicit_adams"])
 def test_zero_dim_fp32_state_on_an_fp64_grid_with_perturb(where, method, direction):
-    """The last piece of the 0-dim promotion artefact: with `perturb` the reference perturbs the FIRST
+    """The last piece of the 0-dim promotion artefact (docs/LAB_NOTEBOOK.md §8): with `perturb` the reference perturbs the FIRST
     evaluation time in fp32 (the state is still fp32 there) and every later one in fp64.  Polynomial field (no libm), so
     the MI355X result equals the CPU reference bit for bit as well."""
     z = load("dropin.npz")

@@ -75,7 +75,7 @@ def test_cfg4_vs_reference(device):
     """cfg4: dopri8, 16384 x 512 fp64, rtol 1e-9 / atol 1e-11.  Reference: NFE 67 = 2 + 13*5, 5 accepted.
     dopri8's embedded error estimate is a 9-term cancelling sum; at the first (heuristic, tiny) step it is pure
     rounding noise — ATen's blocked summation order vs the kernels' left-to-right order give different noise, so
-    the second step size differs; from there the sequences re-converge.  Solution bound: a fraction of the solve's own
+    the second step size differs; from there the sequences re-converge (docs/LAB_NOTEBOOK.md §8).  Solution bound: a fraction of the solve's own
     distance from the closed form (both 4.0e-7)."""
     z, y_end, nfe, _ = _solve_linear("cfg4", 16384, 512, torch.float64, "dopri8", device, with_callbacks=False)
     err = fs.sample_rel_err(y_end[torch.from_numpy(z["rows"]).to(device)], z["y_end_rows"], z["y_end_absmax"])

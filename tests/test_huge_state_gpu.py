@@ -1,5 +1,5 @@
 """Maximum sizes: a flat state of MORE than 2^31 elements (fp32: 8.6 GB per state-sized tensor — 3 % of the MI355X's 288 GB;
-the layouts are sized for that HBM).  Element indices, the exact-cover grid and the chunk table must be
+the layouts are sized for that HBM, docs/LAB_NOTEBOOK.md §2).  Element indices, the exact-cover grid and the chunk table must be
 64-bit throughout: stage combine, fused error combine, the segmented error norm (2^20 + 3 chunks of partials) and a whole
 adaptive solve, checked at windows around 0, 2^31 and the end and against chunked torch reductions."""
 import math

@@ -6,7 +6,7 @@ through `odeint_adjoint` EVERY logged value — solutions, losses, all gradients
 event — must equal the reference's in every bit (each iteration starts from parameters updated with the previous
 iteration's gradients, so one differing bit anywhere shows up downstream); backprop through plain `odeint` gives the
 solution, loss and evaluation count bit for bit and the gradients to rounding (the package's hand-written backward adds the
-cotangents in its own order, DESIGN.md header (9))."""
+cotangents in its own order, CHANGELOG.md (9))."""
 import os
 import sys
 import warnings

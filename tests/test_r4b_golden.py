@@ -22,7 +22,7 @@ LOW = {"bf16": torch.bfloat16, "f16": torch.float16}
 @pytest.mark.parametrize("tname", ["t32", "tlow"])
 @pytest.mark.parametrize("lname", ["bf16", "f16"])
 def test_sixteen_bit_states_on_fixed_grids_are_the_reference_bit_for_bit(lname, tname, method, opts, direction):
-    """CPU host path (the 16-bit element types have no HIP kernels): every stored row equals the
+    """CPU host path (the 16-bit element types have no HIP kernels, docs/LAB_NOTEBOOK.md §10): every stored row equals the
     reference's in every bit, with the same number of evaluations.  heun3's `k * (1/3)` / `k * (2/3)` take the Python
     weight at fp32 (ATen's second-operand rule), which is what this pins; `tlow` = the time grid in the state's own
     16-bit type (dt, the stage times and the interpolation weights are then 16-bit 0-dim tensors in the reference)."""
@@ -81,7 +81,7 @@ def test_callbacks_see_a_tensor_state_in_its_own_shape(on, method, options, dire
         return          # (a noise-driven extra trial step on the device: the shapes above are what this test is about)
     assert [s[0] for s in seen] == list(Z[key + "_kind"])
     # values: exact on the CPU host path; on the MI355X the fp32 error ratio carries summation-order noise, which the
-    # controller turns into slightly different adaptive step sizes — the fixed grid stays at rounding
+    # controller turns into slightly different adaptive step sizes (docs/LAB_NOTEBOOK.md §12) — the fixed grid stays at rounding
     rtol = 1e-12 if on == "cpu" else (0.2 if method == "dopri5" else 2e-6)
     np.testing.assert_allclose(np.array([s[2:] for s in seen]), Z[key + "_vals"], rtol=rtol, atol=1e-6)
 
@@ -175,7 +175,7 @@ def test_complex_adjoint_is_the_reference_bit_for_bit_on_the_host_path(method):
 def test_heun3_with_a_non_finite_stage_gives_the_references_rows_on_the_host_path():
     """fixed_grid.py:38-44 multiplies every stage by its tableau weight, the zeros too: `k1 * 0.0` is NaN for an inf k1.
     The host path evaluates that literal expression (the HIP kernels do not read zero-weight terms: inf stays inf there,
-    DESIGN.md §8)."""
+    docs/LAB_NOTEBOOK.md §8)."""
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", tda.HostPathWarning)
         y = tda.odeint(lambda t_, y_: torch.where(t_ > 0.4, torch.full_like(y_, float("inf")), -y_),
@@ -191,7 +191,7 @@ def test_dopri8_blow_up_ends_after_the_references_number_of_evaluations_on_the_h
     weight in the error row is 0, `inf * 0 = NaN`, the step size becomes NaN and the solve ends in `underflow in dt 0.0`
     after 470 evaluations.  The host path's rows keep their zero weights (`tableaus.SparseRow.literal`); summed over the
     non-zero stages only the estimate stayed finite and the same assertion came after 1133 (the kernels' behaviour,
-    DESIGN.md §8)."""
+    docs/LAB_NOTEBOOK.md §8)."""
     calls = []
 
     def square(t_, y_):

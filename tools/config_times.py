@@ -88,7 +88,7 @@ res["cfg4_dopri8_linear_fp64"] = {"wall_s": w, "nfe": nfe, "stages_per_s": (nfe 
                                    "rel_err_vs_expm": float((y[-1] - exact).abs().max() / exact.abs().max())}
 
 # cfg3 — SURVEY.md §8(d) inputs exactly (tests/_fullsize.py; r01 drew y0 from another seed, hence its NFE 86 vs the
-# reference's 74 was not comparable — see DESIGN §6), full batch and the 1/8 shard of an 8-GPU strong-scaling run
+# reference's 74 was not comparable — see docs/LAB_NOTEBOOK.md §6), full batch and the 1/8 shard of an 8-GPU strong-scaling run
 import _fullsize as fs  # noqa: E402
 
 

@@ -141,7 +141,7 @@ for case in range(n_cases):
     tol = (1e-9 if (adjoint or backprop) else 1e-12) if rdt == torch.float64 else (2e-4 if (adjoint or backprop) else 3e-5)
     if method == "dopri8":
         tol = max(tol, 1e-6)    # a noise-dominated 9-term error estimate turns ONE ulp of a norm sum into 1e-3 of a step
-                                # size (the complex norm kernel adds re^2 + im^2 in double, the torch twin
+                                # size (docs/LAB_NOTEBOOK.md §8; the complex norm kernel adds re^2 + im^2 in double, the torch twin
                                 # squares a rounded modulus) — equal evaluation counts are still required above
     for i, (p, q) in enumerate(zip(a[1], b[1])):
         fin_p, fin_q = torch.isfinite(torch.view_as_real(p) if p.is_complex() else p), \

@@ -119,7 +119,7 @@ for case in range(n_cases):
                 ya, yb = y
                 # (a sum written out: `yb.sum()` adds in a different order on the two devices, and ONE ulp in f moves a
                 # step size by 1e-3 wherever an error estimate is rounding noise — dopri8 after a small first step,
-                # seed 777 case 86: err/tol 1.5e-8 — DESIGN §12)
+                # seed 777 case 86: err/tol 1.5e-8 — docs/LAB_NOTEBOOK.md §12)
                 coupling = ((yb[0] + yb[1]) + yb[2]) + yb[3]
                 return (ya * (tt * 0.5 - 1.0) * self.a - ya * ya * ya * 0.1 + coupling * 0.01, yb * (-0.5) * (1.0 + tt))
             return y * (tt * 0.5 - 1.0) * self.a - y * y * y * 0.1

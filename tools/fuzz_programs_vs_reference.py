@@ -210,7 +210,7 @@ def run(lib, case):
     y0 = case["y0"]
     istuple = isinstance(y0, tuple)
     # (a CNF-style field under odeint_adjoint with y0 in the graph: the reference hands func a no-grad VIEW of a
-    #  requires-grad tensor, and torch.autograd.grad wrt that view raises inside forward — a PyTorch quirk)
+    #  requires-grad tensor, and torch.autograd.grad wrt that view raises inside forward — a PyTorch quirk, docs/LAB_NOTEBOOK.md §8)
     y0_grad = not (istuple and case["api"] == "adjoint")
     leaves = [c.clone().requires_grad_(y0_grad) for c in (y0 if istuple else (y0,))]
     t = case["t"].clone().requires_grad_(case["grad_t"])

@@ -9,7 +9,7 @@ use) and compared: bit for bit for the explicit fixed-grid and Adams methods, to
 the implicit RK methods, 1e-9 for the adaptive methods, 1e-9 / 1e-6 for gradients.  Test infrastructure, like oracle/.
 Last runs (round 1): fixed 1050 cases, adaptive 400, adjoint 220, backprop 120, event 100 — no mismatch other than
 non-converged implicit solves (both libraries warn), rounding-level iteration-count flips, dopri8's noise-level first
-step and the 0-dim fp32 state on an fp64 grid together with `perturb`."""
+step (docs/LAB_NOTEBOOK.md §12) and the 0-dim fp32 state on an fp64 grid together with `perturb` (docs/LAB_NOTEBOOK.md §8)."""
 import os
 import random
 import sys

@@ -1,4 +1,4 @@
-"""Feasibility probe for DESIGN §12's GEMM / combine overlap, run on the MI355X through gpurun.
+"""Feasibility probe for docs/LAB_NOTEBOOK.md §12's GEMM / combine overlap, run on the MI355X through gpurun.
 
 The dopri5 trial step of cfg2 is serial by data dependence: combine_i -> func_i (a 65536x128x128 fp32 GEMM) -> ...;
 the combines are HBM-bound, the GEMM is the compute-heavier block.  If the batch is split in row blocks, the chain of

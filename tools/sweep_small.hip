@@ -1,6 +1,6 @@
 // sweep_small.hip — the per-kernel floor of the streaming stage-combine at SHARD size (r04b).
 // An 8-GPU strong-scaling shard of cfg2 is 8192 x 128 = 2^20 fp32 elements; there every solver kernel of the captured
-// step costs ~5 us whatever it moves (8 kernels x 5.0-5.7 us, data Infinity-Cache / L2 resident), and that
+// step costs ~5 us whatever it moves (docs/LAB_NOTEBOOK.md §7: 8 kernels x 5.0-5.7 us, data Infinity-Cache / L2 resident), and that
 // floor — not bandwidth — is what caps strong scaling at 4.2x.  This sweeps what could move the floor for
 // out = y0 + sum_{j<NT} c_j k_j (NT = 1: 3 words, NT = 5: 7 words per element):
 //   * elements per lane E = 1 / 2 / 4 / 8 16-byte vectors (grid = N / (BLOCK * E * 4): 1024 ... 128 workgroups),

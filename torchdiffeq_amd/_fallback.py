@@ -13,7 +13,7 @@ Arithmetic (r04): the REFERENCE's, literally.  Where the HIP kernels have to pic
 over a tableau row, the accumulation of a norm — this path does not pick: it hands ATen the same expression the reference
 evaluates.  A row sum is `torch.sum` over a dense [N, row length] product tensor with the products at their tableau
 positions (`_rowsum`: ATen adds ≤ 7 columns as four interleaved partial sums, more through vector lanes — the result
-depends on the positions); a norm is `x.abs().pow(2).mean().sqrt()` in the state's type per component
+depends on the positions, docs/LAB_NOTEBOOK.md §8); a norm is `x.abs().pow(2).mean().sqrt()` in the state's type per component
 (`HostPlan.rms0 / rms1`, misc.py:22-33), the fp64 sums the kernel interface reports are kept beside it.  Everything else
 follows the operation order of interp.py:17-21,42-47 and rk_common.py:110-157 with coefficients fl_T(fl_T(coef) *
 fl_T(dt)) (rk_common.py:79,89,201-205), and the host scalars round like 0-dim tensors (`_scalars.py`).  Consequence: on
@@ -211,7 +211,7 @@ class HostKernels:
         T = self._T(y0)
         # misc.py:81 `torch.max(y0.abs(), y1.abs())` propagates a NaN of the trial state into the tolerance and the ratio
         # (the step is then rejected with a NaN step size); the kernels' fmax ignores it and leaves the verdict to their
-        # non-finite census — same exception, but not the same number of trial steps before it
+        # non-finite census (docs/LAB_NOTEBOOK.md §8) — same exception, but not the same number of trial steps before it
         larger = torch.maximum if self.literal_norms else torch.fmax
         joint = None
         if self._joint(plan, y0):
@@ -438,7 +438,7 @@ class LowPrecisionHostKernels(HostKernels):
     (products in the state type, fp32 accumulation, one rounding) and `mean()` its own way, and `_scalars.operand` /
     `BFloat16Scalar` / `Float16Scalar` reproduce how it takes Python numbers and 0-dim partners next to a 16-bit tensor
     (tools/lowfloat_semantics.py).  A class of its own only so that the selection (`_native.get_kernels`) and the
-    warning say what runs: no HIP kernels exist for these element types."""
+    warning say what runs: no HIP kernels exist for these element types (docs/LAB_NOTEBOOK.md §10)."""
 
     name = "host-low"
 

@@ -1,5 +1,5 @@
 """Captured trial steps: hipGraph capture, the ping-pong step graphs of the adaptive solvers, their reuse across solves
-and the `hip_graph="auto"` safety machinery (split out of solvers.py).
+and the `hip_graph="auto"` safety machinery (split out of solvers.py; docs/LAB_NOTEBOOK.md §4).
 
   _graph_request                     the `hip_graph` option / TDEQ_HIP_GRAPH -> (wanted, auto)
   _held_tensor_ptrs, _scalar_state   what a captured graph of `func` depends on -> the cache key (_GraphStep._key)
@@ -60,37 +60,35 @@ def _tensors_in(value, _level=0):
     return []
 
 
-def _object_tensor_ptrs(obj):
-    """Storage addresses of the tensors an object's attributes hold (directly or inside a list / tuple / dict)."""
-    return [t.data_ptr() for v in getattr(obj, "__dict__", {}).values() for t in _tensors_in(v)]
+def _object_tensors(obj):
+    """The tensors an object's attributes hold (directly or inside a list / tuple / dict)."""
+    return [t for v in getattr(obj, "__dict__", {}).values() for t in _tensors_in(v)]
 
 
-def _held_tensor_ptrs(fn, _depth=0):
-    """Storage addresses of the tensors a func object visibly holds: an nn.Module's parameters, buffers and plain
-    tensor attributes (all submodules, also inside list / tuple / dict attributes); a function's closure cells,
-    defaults and the module-level tensors its body names; a bound method's owner; an instance with `__call__` (its
-    attributes and what its `__call__` closes over); a functools.partial's arguments.  Part of the captured-step cache
-    key (see _GraphStep._key)."""
-    ptrs = []
+def _held_tensors(fn, _depth=0):
+    """The tensors a func object visibly holds: an nn.Module's parameters, buffers and plain tensor attributes (all
+    submodules, also inside list / tuple / dict attributes); a function's closure cells, defaults and the module-level
+    tensors its body names; a bound method's owner; an instance with `__call__` (its attributes and what its `__call__`
+    closes over); a functools.partial's arguments."""
+    held_t = []
     if isinstance(fn, torch.nn.Module):
-        ptrs += [p.data_ptr() for p in fn.parameters()] + [b.data_ptr() for b in fn.buffers()]
+        held_t += list(fn.parameters()) + list(fn.buffers())
         for m in fn.modules():
-            ptrs += _object_tensor_ptrs(m)
-        return tuple(ptrs)
+            held_t += _object_tensors(m)
+        return held_t
     if _depth > 2:
-        return ()
+        return []
     owner = getattr(fn, "__self__", None)
     if owner is not None and not isinstance(owner, type):
-        ptrs += _held_tensor_ptrs(owner, _depth + 1) if isinstance(owner, torch.nn.Module) else \
-            _object_tensor_ptrs(owner)
+        held_t += _held_tensors(owner, _depth + 1) if isinstance(owner, torch.nn.Module) else _object_tensors(owner)
     is_function = hasattr(fn, "__code__") or hasattr(getattr(fn, "__func__", None), "__code__")
     if not is_function and not isinstance(fn, type) and hasattr(type(fn), "__call__") \
             and not isinstance(fn, functools.partial) and getattr(fn, "__dict__", None) is not None:
         # a callable INSTANCE (class with __call__): what it stores, and what its __call__ is written over
-        ptrs += _object_tensor_ptrs(fn)
+        held_t += _object_tensors(fn)
         call = getattr(type(fn), "__call__", None)
         if call is not None and hasattr(call, "__code__"):
-            ptrs += _held_tensor_ptrs(call, _depth + 1)
+            held_t += _held_tensors(call, _depth + 1)
     inner = getattr(fn, "__func__", fn)
     held = [c.cell_contents for c in (getattr(inner, "__closure__", None) or ()) if _cell_is_set(c)]
     held += list(getattr(inner, "__defaults__", None) or ())
@@ -102,10 +100,25 @@ def _held_tensor_ptrs(fn, _depth=0):
         held.append(fn.func)
     for v in held:
         if isinstance(v, torch.nn.Module) or (callable(v) and not isinstance(v, torch.Tensor)):
-            ptrs += _held_tensor_ptrs(v, _depth + 1)
+            held_t += _held_tensors(v, _depth + 1)
         else:
-            ptrs += [t.data_ptr() for t in _tensors_in(v)]
-    return tuple(ptrs)
+            held_t += _tensors_in(v)
+    return held_t
+
+
+def _held_tensor_ptrs(fn, _depth=0):
+    """Storage addresses of `_held_tensors(fn)` — part of the captured-step cache key (see _GraphStep._key)."""
+    return tuple(t.data_ptr() for t in _held_tensors(fn, _depth))
+
+
+def _holds_a_tensor_that_requires_grad(fn) -> bool:
+    """Whether anything func can be seen to hold is part of an autograd graph or a leaf that wants a gradient — decided
+    from what func HOLDS, without evaluating it (advisor r04: a probe evaluation is visible to the user — RNG state,
+    counters, one more NFE — and looks at one time only)."""
+    try:
+        return any(t.requires_grad for t in _held_tensors(fn))
+    except Exception:       # an exotic callable: be safe, take the path that records a graph
+        return True
 
 
 def _reusable_across_solves(fn) -> bool:

@@ -44,7 +44,7 @@ class LowPrecisionHipKernels(LowPrecisionHostKernels):
     name = "hip-low"
     device_controller = True     # tdeq_error_norm_partial_ctrl on the WHOLE error row + tdeq_stage_combine_sel (look-ahead)
     whole_row_controller = True  # ... i.e. without the fused error split the fp32 / fp64 controller launch continues
-    literal_row_sums = False     # the kernels skip structural zeros of a row, like the fp32 / fp64 ones
+    literal_row_sums = False     # the kernels skip structural zeros of a row, like the fp32 / fp64 ones (docs/LAB_NOTEBOOK.md §8)
     split_row_sums = False       # ... but a row is never split over two launches (it is rounded ONCE): no fused error split
     literal_norms = True         # plan.rms0 / rms1 / abs0 hold the norm values in the state's type (read_norms)
 

@@ -1,7 +1,7 @@
 """Host-side scalar types: the time-like 0-dim tensors of the reference as host numbers that round like them.
 
 The reference keeps t0, t1, dt, tolerances and controller constants as 0-dim tensors on the state's device; this
-package keeps them on the host.  For that to be invisible every host operation has to round as the
+package keeps them on the host (docs/LAB_NOTEBOOK.md §2).  For that to be invisible every host operation has to round as the
 tensor operation it stands for:
 
 * fp64 / fp32 (`y0.abs().dtype` of real and complex states, and the solver option `dtype`,

@@ -9,7 +9,7 @@
 // 16-byte store.  A trial step that costs the torch-op host path ~220 launches and dense [N, row] product tensors is
 // the same handful of launches as for fp32 — at half the bytes per element.
 //
-// What is NOT mirrored (as for fp32 / fp64): structural zeros of a tableau row are skipped, and the norm
+// What is NOT mirrored (as for fp32 / fp64, docs/LAB_NOTEBOOK.md §8): structural zeros of a tableau row are skipped, and the norm
 // accumulates the rounded squares in fp64 per chunk (ATen: float32 cascade) — both far below the 2^-8 / 2^-11 storage
 // rounding that sets the result's precision.
 #pragma once

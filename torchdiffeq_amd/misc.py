@@ -85,7 +85,10 @@ class FuncOutputTypeError(TypeError, AttributeError):
 
 
 class UnsupportedStateDtype(TypeError, NotImplementedError):
-    """An integer / bool state (the reference: NotImplementedError from `nextafter`, misc.py:185-196)."""
+    """An integer / bool state.  The reference raises NotImplementedError from `nextafter` (misc.py:185-196) for the adaptive
+    methods and for `perturb=True`; its fixed-grid methods WITHOUT perturbation accept such a state and let type promotion
+    turn `y0 + dt * f` into floats.  Deviation: this package refuses integer / bool states for every
+    method — there is no kernel for them and no ODE whose state is an integer; convert with `y0.float()`."""
 
 
 class StateLayout:
@@ -284,7 +287,7 @@ def vector_tolerances(rtol, atol, layout: "StateLayout", device, dtype=torch.flo
 def empty_solution(ci: "CheckedInputs", like: torch.Tensor):
     """The solution of a state without a single element: `[len(t), *shape]` per component, nothing to integrate (the
     kernels are never asked to run on a null buffer; the reference's fixed-grid solvers return the same, its adaptive
-    ones trip over the NaN norm of nothing — DESIGN.md §8)."""
+    ones trip over the NaN norm of nothing — docs/LAB_NOTEBOOK.md §8)."""
     rows = [torch.empty((len(ci.t), *shape), dtype=like.dtype, device=like.device) for shape in ci.layout.shapes]
     return tuple(rows) if ci.layout.is_tuple else rows[0]
 
@@ -566,11 +569,11 @@ def check_inputs(func, y0, t, rtol, atol, method, options, event_fn, SOLVERS) ->
         first = y0
         dtype = first.dtype
     device = first.device
-    # float32 / float64 (and complex64 / complex128 through their real views) run on the HIP kernels; bfloat16 / float16
-    # states are integrated in their own precision on the host path, as the reference does (misc.py:185-187)
+    # float32 / float64 (and complex64 / complex128 through their real views) and — r05 — bfloat16 / float16 states run on
+    # the HIP kernels, each integrated in its own precision as the reference does (misc.py:185-187)
     if dtype not in SUPPORTED_STATE_DTYPES:
         raise UnsupportedStateDtype("torchdiffeq_amd supports float32 / float64 / complex64 / complex128 states (and "
-                                    f"bfloat16 / float16 on the torch-op host path), got {dtype}")
+                                    f"bfloat16 / float16), got {dtype}; convert an integer state with y0.float()")
 
     if options is None:
         options = {}

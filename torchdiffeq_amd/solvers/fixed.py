@@ -244,12 +244,11 @@ class FixedGridODESolver(FixedGridEvents):
             return False
         # grad mode with neither y0 nor t in the graph: func's own parameters may still be (plain `odeint` training).
         # The replayed kernels write into raw buffers — a solution without an autograd graph — so such a solve has to
-        # take the eager path.  One probe evaluation tells (as RKAdaptiveStepsizeODESolver._graph_step_ok reads f1);
-        # it is not counted.
-        nfe = self.func.nfe
-        probe = self.func.eval(float(t[0].detach()), self.y0, self._first_perturb())
-        self.func.nfe = nfe
-        return not probe.requires_grad
+        # take the eager path.  Decided from what func HOLDS (module parameters / buffers, closure cells, globals its body
+        # names, attributes of a callable object: `_graph._held_tensors`), not by evaluating it: a probe evaluation would
+        # be visible to the user (RNG / dropout state, counters, one more evaluation) and would look at t[0] only.
+        from .._graph import _holds_a_tensor_that_requires_grad
+        return not _holds_a_tensor_that_requires_grad(self.func.base_func)
 
     def _integrate_graph(self, t: torch.Tensor) -> torch.Tensor:
         """`integrate` for small states, where a step costs launch latency, not bandwidth: ONE hipGraph — the method's

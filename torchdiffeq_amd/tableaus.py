@@ -38,7 +38,7 @@ class RowCoefs(tuple):
     values; equality and hashing are the tuple's) — that also remembers WHERE in the dense row they sit (`idx`) and how
     long that row is (`width`).  The torch-op host path needs both: ATen's `torch.sum` over the stage dimension adds the
     products in an order that depends on their positions (four interleaved partial sums, vector lanes from 8 columns on;
-    DESIGN.md §8), and reproducing the reference bit for bit there means handing ATen the same dense row."""
+    docs/LAB_NOTEBOOK.md §8), and reproducing the reference bit for bit there means handing ATen the same dense row."""
 
     def __new__(cls, values, idx, width):
         self = super().__new__(cls, values)
@@ -59,7 +59,7 @@ class SparseRow:
     def literal(values: Sequence[float]) -> "SparseRow":
         """EVERY slot of the dense row, the zero weights too — the row as the reference multiplies it
         (`k * (beta_i * dt)`, rk_common.py:79-89: `inf * 0` is NaN).  For the torch-op host path, which evaluates the
-        reference's expressions literally; the kernels never read a zero-weight stage."""
+        reference's expressions literally; the kernels never read a zero-weight stage (docs/LAB_NOTEBOOK.md §8)."""
         return _literal_row(tuple(float(v) for v in values))
 
 
@@ -404,7 +404,7 @@ def carry_plan(name: str):
 
 
 def row_by_row_words(tab: Tableau) -> int:
-    """Words per element and step of the row-by-row launches with the end-of-step fusion."""
+    """Words per element and step of the row-by-row launches with the end-of-step fusion (docs/LAB_NOTEBOOK.md §3)."""
     rows = tab.beta_rows()
     err = SparseRow.from_dense(tab.c_error)
     last = rows[-1] if tab.fsal_solution else SparseRow.from_dense(tab.c_sol)
