@@ -97,18 +97,7 @@ def test_fixed_grid_pieces_equal_the_reference_bit_for_bit(low):
     assert torch.equal(q0, T(Z[f"init_{low}_q0"], dtype).reshape(-1)) and torch.equal(q1, T(Z[f"init_{low}_q1"], dtype).reshape(-1))
 
 
-class _KernelOrderLow(_fallback.LowPrecisionHostKernels):
-    """The package's torch-op host path with a row summed in the kernels' order (non-zero weights, left to right, float32
-    accumulation of the rounded products) — the only place where `LowPrecisionHostKernels` hands ATen a choice."""
-    literal_row_sums = False
-
-    @staticmethod
-    def _rowsum(ks, cs, start=None, row=None):
-        acc = None if start is None else start.float()
-        for k, c in zip(ks, cs):
-            p = (k * c).float()
-            acc = p if acc is None else acc + p
-        return acc.to(ks[0].dtype)
+_KernelOrderLow = _fallback.KernelOrderLowHostKernels
 
 
 @pytest.mark.parametrize("low", ["bf16", "f16"])

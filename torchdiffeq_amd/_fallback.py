@@ -458,3 +458,37 @@ class KernelOrderHostKernels(HostKernels):
     @staticmethod
     def _rowsum(ks, cs, start=None, row=None):
         return HostKernels._lsum(ks, cs, start)
+
+
+@_no_grad_methods
+class KernelOrderLowHostKernels(LowPrecisionHostKernels):
+    """The 16-bit HIP kernels' arithmetic (csrc/tdeq_kernels_lp.hpp) restated in torch ops: a tableau row summed over its
+    non-zero weights LEFT TO RIGHT with the rounded products accumulated in float32 and ONE rounding of the sum — the only
+    place where `LowPrecisionHostKernels` hands ATen a choice the kernels make themselves.  Not selected for any state:
+    test infrastructure for same-device comparisons with `_lowp.LowPrecisionHipKernels` (tests/test_lowp_oracle.py,
+    tools/fuzz_complex_gpu.py with FUZZ_LOW=1)."""
+
+    name = "host-low-kernel-order"
+    literal_row_sums = False
+    split_row_sums = False       # like the 16-bit kernels: a row is rounded once, never continued by a second launch
+
+    @staticmethod
+    def _rms(r: torch.Tensor) -> float:
+        """sqrt(mean(|x|^2)) as the 16-bit path forms it from the kernels' words: squares rounded to the type (ATen's
+        `pow(2)`), their sum in fp64 (ATen: a float32 cascade — the one difference, far below the type's rounding), float32
+        sum / n rounded once, sqrt rounded (`_lowp.LowPrecisionHipKernels.read_norms`)."""
+        n = r.numel()
+        if n == 0:
+            return float("nan")
+        T = real_np_dtype(r.dtype)
+        total = float(r.abs().pow(2).double().sum())
+        with np.errstate(all="ignore"):
+            return float(T(np.float32(total) / np.float32(n)) ** 0.5)
+
+    @staticmethod
+    def _rowsum(ks, cs, start=None, row=None):
+        acc = None if start is None else start.float()
+        for k, c in zip(ks, cs):
+            p = (k * c).float()
+            acc = p if acc is None else acc + p
+        return acc.to(ks[0].dtype)

@@ -137,6 +137,8 @@ int launch_combine_err(void* out, void* err_out, const void* y0, const void* con
     constexpr int L = VecOf<T>::L;
     if (vec) {
         const dim3 g(stream_grid(n / L, kBlock)), b(kBlock);
+        // (r05, tried: non-temporal loads for the k streams of THIS launch only — their last use in a dopri5 step — with the
+        //  default policy elsewhere: 0.3357 vs 0.3336 ms per cfg2 step, loads + stores 0.3323: noise; not kept)
         switch (stream_policy((int64_t)(NT + 3) * n * (int64_t)sizeof(T))) {
             case 1: hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 1>), g, b, 0, s, a); break;
             case 2: hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 2>), g, b, 0, s, a); break;
