@@ -200,7 +200,7 @@ def test_low_precision_state_warns_and_selects_the_low_backend(monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter("error", _fallback.HostPathWarning)
         k16 = _native.get_kernels(torch.device("cuda:0"), torch.float16)
-    assert isinstance(k16, _lowp.LowPrecisionHipKernels) and k16.name == "hip-low" and not k16.device_controller
+    assert isinstance(k16, _lowp.LowPrecisionHipKernels) and k16.name == "hip-low" and k16.whole_row_controller
     with pytest.raises(TypeError, match="float8|supports"):
         tda.odeint(lambda t, y: -y, torch.ones(2).to(torch.float8_e4m3fn), torch.tensor([0.0, 1.0]))
 
