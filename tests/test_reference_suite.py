@@ -8,6 +8,8 @@ import warnings
 from functools import partial
 
 import numpy as np
+import os
+
 import pytest
 import scipy.linalg
 import torch
@@ -469,6 +471,11 @@ def test_seminorm_backward_evaluation_counts(dev, method, dtype):
     reference's test is checked for the low-order methods only."""
     if dtype == torch.float32 and method in ("tsit5", "dopri5", "dopri8"):
         pytest.skip("fp32 at tol 1e-6: the step decisions of the high-order pairs are rounding noise")
+    if method == "adaptive_heun" and dev == "cpu" and os.environ.get("TDEQ_SLOW_TESTS") != "1":
+        # 2 x 12.5 k backward evaluations of a width-1024 MLP with autograd: minutes of one CPU core (a quarter of the whole
+        # CPU suite's time).  Passed with exactly the reference's counts in r03 / r04 / r05 (TDEQ_SLOW_TESTS=1 runs it); the
+        # order-2 pair's kernels and controller are the same code the other five methods exercise here.
+        pytest.skip("slow (25 k autograd evaluations on the CPU): set TDEQ_SLOW_TESTS=1")
     tol = 1e-8 if dtype == torch.float64 else 1e-6
     x0 = torch.tensor([1.0, 2.0], dtype=dtype)
     t = torch.tensor([0.0, 1.0], dtype=torch.float64)
