@@ -1,7 +1,7 @@
 /*
  * A plain C client of libtdeq_hip.so: no Python, no torch — only include/tdeq_hip.h and the HIP runtime for device
  * memory.  Built and run by tests/test_abi_c_client.py.  It performs one dopri5-style stage combine, one Adams
- * predictor step and a carried-partial-sum pair (tdeq_stage_combine_multi) on 1000003 fp32 elements and checks every element against the same arithmetic done on the host with
+ * predictor step, a carried-partial-sum pair (tdeq_stage_combine_multi) and — r05 — a bfloat16 stage combine on 1000003 elements and checks every element against the same arithmetic done on the host with
  * the documented rounding sequence (coefficient = fl(fl(coef) * fl(dt)), products and sums rounded separately).
  * Exit code 0 = all elements bit-identical.
  */
@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "tdeq_hip.h"
 
@@ -100,9 +101,58 @@ int main(void) {
         if (tdeq_stage_combine_multi(outs, TDEQ_MAX_MULTI_OUT + 1, d[0], NULL, k, 3, dt, n, TDEQ_F32, stream) != TDEQ_EINVAL) ++bad;
         free(hy); free(hz);
     }
+    /* bfloat16 state (ABI 18, dtype TDEQ_BF16): the same stage combine on 16-bit storage.  The reference integrates a bf16
+     * state with ATen ops that compute in float32 and round every result to bf16 (misc.py:185-187, rk_common.py:61-65), a
+     * row's torch.sum accumulates the rounded products in float32 and rounds once — restated here in plain C:
+     * c_j = bf(bf(coef_j) * bf(dt)); p_j = bf(k_j * c_j); s = bf(p_0 + p_1 + p_2 in float32); y = bf(y0 + s). */
+    {
+        uint16_t* hb[5];
+        uint16_t* db[5];
+        for (int j = 0; j < 5; ++j) { hb[j] = (uint16_t*)malloc(2 * n); CHECK(hipMalloc((void**)&db[j], 2 * n)); }
+#define F2BF(dst, src) do { uint32_t u_; volatile float f_ = (src); memcpy(&u_, (const void*)&f_, 4); \
+                            (dst) = (uint16_t)((u_ + 0x7fffu + ((u_ >> 16) & 1u)) >> 16); } while (0)
+#define BF2F(dst, src) do { uint32_t u_ = (uint32_t)(src) << 16; float f_; memcpy(&f_, &u_, 4); (dst) = f_; } while (0)
+        for (int j = 0; j < 4; ++j)
+            for (int64_t i = 0; i < n; ++i) F2BF(hb[j][i], h[j][i]);
+        for (int j = 0; j < 4; ++j) CHECK(hipMemcpy(db[j], hb[j], 2 * n, hipMemcpyHostToDevice));
+        const void* kb[3] = {db[1], db[2], db[3]};
+        CHECK(tdeq_stage_combine(db[4], db[0], kb, coef, nt, dt, n, TDEQ_BF16, stream));
+        CHECK(hipStreamSynchronize(stream));
+        CHECK(hipMemcpy(hb[4], db[4], 2 * n, hipMemcpyDeviceToHost));
+        float cbf[3];
+        {
+            uint16_t t_; float dtb;
+            F2BF(t_, (float)dt); BF2F(dtb, t_);
+            for (int j = 0; j < nt; ++j) {
+                float cj;
+                F2BF(t_, (float)coef[j]); BF2F(cj, t_);
+                volatile float prod = cj * dtb;
+                F2BF(t_, prod); BF2F(cbf[j], t_);
+            }
+        }
+        for (int64_t i = 0; i < n; ++i) {
+            volatile float acc = 0.0f;
+            for (int j = 0; j < nt; ++j) {
+                float kj, pj; uint16_t t_;
+                BF2F(kj, hb[j + 1][i]);
+                volatile float prod = kj * cbf[j];
+                F2BF(t_, prod); BF2F(pj, t_);
+                acc = (j == 0) ? pj : acc + pj;
+            }
+            uint16_t t_, yb; float sb, y0f;
+            F2BF(t_, acc); BF2F(sb, t_);
+            BF2F(y0f, hb[0][i]);
+            volatile float ysum = y0f + sb;
+            F2BF(yb, ysum);
+            if (yb != hb[4][i]) ++bad;
+        }
+        /* an entry point without 16-bit kernels says so instead of misreading the buffers */
+        if (tdeq_adams_predict(db[4], NULL, NULL, db[0], kb, cb, NULL, nt, 0.0, n, TDEQ_BF16, stream) != TDEQ_EINVAL) ++bad;
+        for (int j = 0; j < 5; ++j) { free(hb[j]); hipFree(db[j]); }
+    }
     /* argument errors are reported, not crashed on */
     if (tdeq_stage_combine(NULL, d[0], k, coef, nt, dt, n, TDEQ_F32, stream) != TDEQ_EINVAL) ++bad;
     if (tdeq_stage_combine(d[4], d[0], k, coef, TDEQ_MAX_TERMS + 1, dt, n, TDEQ_F32, stream) != TDEQ_EINVAL) ++bad;
-    printf("abi_client: %ld mismatching elements of %ld\n", bad, (long)(3 * n));
+    printf("abi_client: %ld mismatching elements of %ld\n", bad, (long)(4 * n));
     return bad ? 1 : 0;
 }

@@ -215,3 +215,37 @@ def test_implicit_rk_full_size_matrix_free():
     exact = y0.double() @ torch.linalg.matrix_exp(A.double()).T
     assert rel_err(y, exact) < 1e-5
     assert calls[0] < 8 * (1 + 2 * 12)          # a handful of Broyden iterations per step, not max_iters = 100
+
+
+@pytest.mark.parametrize("method", ["dopri5", "rk4"])
+def test_bf16_state_at_full_size_equals_the_torch_twin_bit_for_bit(method):
+    """r05, BASELINE.json's size with a bfloat16 STATE (65536 x 128 = 8.4 M elements, 16-byte lane accesses of 8 elements,
+    chunk 2048, the device controller and the look-ahead stage in bf16): the HIP kernels of csrc/tdeq_kernels_lp.hpp against
+    the same arithmetic in torch ops on the same device (`_fallback.KernelOrderLowHostKernels`, host-driven) — a
+    size-independent property: every output row bit-identical, equal evaluation counts."""
+    from torchdiffeq_amd import _fallback, _native
+    A, y0 = _linear(65536, 128, torch.float32)
+    A = (A + 0.1 * torch.eye(128, device=A.device)).to(torch.bfloat16)      # the skew-symmetric part: |y| stays O(1)
+    y0 = y0.to(torch.bfloat16)
+    At = A.T.contiguous()
+    t = torch.linspace(0.0, 2.0, 4, device="cuda")
+    nfe = [0]
+
+    def f(tt, y):
+        nfe[0] += 1
+        return y @ At
+    kw = dict(rtol=1e-2, atol=1e-3) if method == "dopri5" else dict(options=dict(step_size=0.125))
+    with torch.no_grad():
+        y_hip = tda.odeint(f, y0, t, method=method, **kw)
+    n_hip, nfe[0] = nfe[0], 0
+    twin = _fallback.KernelOrderLowHostKernels()
+    orig = _native.get_kernels
+    _native.get_kernels = lambda device, dtype=None: twin if dtype == torch.bfloat16 else orig(device, dtype)
+    try:
+        with torch.no_grad():
+            y_twin = tda.odeint(f, y0, t, method=method, **kw)
+    finally:
+        _native.get_kernels = orig
+    assert n_hip == nfe[0] and n_hip > 10
+    assert y_hip.dtype == torch.bfloat16 and torch.isfinite(y_hip.float()).all()
+    assert torch.equal(y_hip.view(torch.int16), y_twin.view(torch.int16))
