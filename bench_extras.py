@@ -306,8 +306,8 @@ def vector_tolerance_regime(field, y0, device, steps=60, warmup=10):
     for label, kw, fused in (("scalar_tolerances", {}, None), ("vector_rtol_fused", dict(rtol=rtol_vec), True),
                              ("vector_rtol_torch_ops", dict(rtol=rtol_vec), False)):
         solver = make_stepper(field, y0, **kw)
-        if fused is False:
-            solver._vec_fused = None
+        if fused is False:          # the r04 route: raw error materialised, scaling + norm as fp64 torch ops, host-driven steps
+            solver._vec_fused, solver._vec_ctrl, solver._lookahead = None, False, False
         with torch.no_grad():
             for _ in range(warmup):
                 solver._trial_step()
@@ -320,7 +320,7 @@ def vector_tolerance_regime(field, y0, device, steps=60, warmup=10):
         out[label] = {"ms_per_step": ms, "lookahead": bool(solver._lookahead), "fused_norm": solver._vec_fused is not None}
     out["extra_ms_fused"] = out["vector_rtol_fused"]["ms_per_step"] - out["scalar_tolerances"]["ms_per_step"]
     out["extra_ms_torch_ops"] = out["vector_rtol_torch_ops"]["ms_per_step"] - out["scalar_tolerances"]["ms_per_step"]
-    out["note"] = "per-element tolerances run host-driven steps (no look-ahead); the scalar line is the default path"
+    out["note"] = "fused = tdeq_error_norm_vec_ctrl (norm + device controller, look-ahead kept); torch_ops = the r04 route"
     return out
 
 

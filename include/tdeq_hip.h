@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 18
+#define TDEQ_ABI_VERSION 19
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 /* interleaved (re, im) complex states — accepted by the NORM entry points only (tdeq_error_norm, tdeq_error_norm_partial[_ctrl],
@@ -171,6 +171,19 @@ int tdeq_error_norm_vec(const void* y0, const void* y1, const void* const* k, co
                         const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
                         double* out_sumsq, double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
                         void* stream);
+
+/*
+ * tdeq_error_norm_vec whose finalize step also runs the step controller on the device (as tdeq_error_norm_partial_ctrl
+ * does for scalar tolerances): the error ratio in fp64 — the promoted type of the reference's quotient and norm when a
+ * tolerance is dimensioned —, accept flag, next step size, and the next trial step's stage times in T; `out_ctrl`,
+ * `ctrl_dev`, `next_times` as there.  Lets the look-ahead first stage (tdeq_stage_combine_sel) follow.
+ */
+int tdeq_error_norm_vec_ctrl(const void* y0, const void* y1, const void* const* k, const double* coef, int n_terms, double dt,
+                             const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
+                             const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
+                             double* out_sumsq, double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl,
+                             double* ctrl_dev, void* next_times, void* workspace, size_t workspace_bytes, int dtype,
+                             void* stream);
 
 /*
  * Fused pair for the END of a trial step (same results as tdeq_stage_combine + tdeq_error_norm, fewer bytes):

@@ -49,7 +49,7 @@ def test_kernel_equals_the_references_broadcast_expression(dtype, n, form):
 
 
 def test_solve_with_vector_tolerances_takes_the_fused_kernel(monkeypatch):
-    """A no-grad dopri5 solve with a per-element rtol: every trial step's error ratio comes from tdeq_error_norm_vec (the
+    """A no-grad dopri5 solve with a per-element rtol: every trial step's error ratio comes from tdeq_error_norm_vec[_ctrl] (the
     raw-error route `error_scaled` is never taken), and the steps are those of the torch-op evaluation of the same
     formula (TDEQ-internal switch off) — equal evaluation counts, solutions equal to fp64 rounding."""
     from torchdiffeq_amd import solvers
@@ -60,8 +60,9 @@ def test_solve_with_vector_tolerances_takes_the_fused_kernel(monkeypatch):
     rtol = torch.logspace(-8, -4, 12, dtype=torch.float64, device="cuda").expand(300, 12)
     kern = _native.get_kernels(torch.device("cuda:0"), torch.float64)
     calls = {"vec": 0, "scaled": 0}
-    real_vec, real_scaled = kern.error_norm_vec, kern.error_scaled
+    real_vec, real_scaled, real_ctrl = kern.error_norm_vec, kern.error_scaled, kern.error_norm_vec_ctrl
     monkeypatch.setattr(kern, "error_norm_vec", lambda *a, **k: (calls.__setitem__("vec", calls["vec"] + 1), real_vec(*a, **k))[1])
+    monkeypatch.setattr(kern, "error_norm_vec_ctrl", lambda *a, **k: (calls.__setitem__("vec", calls["vec"] + 1), real_ctrl(*a, **k))[1])
     monkeypatch.setattr(kern, "error_scaled", lambda *a, **k: (calls.__setitem__("scaled", calls["scaled"] + 1), real_scaled(*a, **k))[1])
     nfe = [0]
 
@@ -77,9 +78,59 @@ def test_solve_with_vector_tolerances_takes_the_fused_kernel(monkeypatch):
 
     def init_without(self, *a, **k):
         orig_init(self, *a, **k)
-        self._vec_fused = None
+        self._vec_fused, self._vec_ctrl, self._lookahead = None, False, False
     monkeypatch.setattr(solvers.RKAdaptiveStepsizeODESolver, "__init__", init_without)
     with torch.no_grad():
         y_ref = tda.odeint(f, y0, t, rtol=rtol, atol=1e-9, method="dopri5")
     assert calls["scaled"] > 0 and nfe[0] == n_fused
     assert float((y - y_ref).abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_vector_tolerances_keep_the_look_ahead_controller(monkeypatch, dtype):
+    """r05: with per-element tolerances the norm launch's finalize step still runs the step controller on the device
+    (tdeq_error_norm_vec_ctrl: ratio in fp64 — the promoted type —, step size and stage times in T) and the next trial
+    step's first stage is enqueued ahead.  Same solve with TDEQ_LOOKAHEAD=0 (every decision by the host from the read-back
+    sums): equal evaluation counts, accepted / rejected counts, identical solutions (fp32 bit for bit)."""
+    from torchdiffeq_amd import solvers
+    g = torch.Generator().manual_seed(2)
+    A = (torch.randn(12, 12, generator=g, dtype=torch.float64) / 3 - 0.2 * torch.eye(12, dtype=torch.float64)).to(dtype).cuda()
+    y0 = torch.randn(500, 12, generator=g, dtype=torch.float64).to(dtype).cuda()
+    rtol = torch.logspace(-7, -3, 12, dtype=torch.float64, device="cuda").expand(500, 12)
+    atol = torch.full((500, 12), 1e-8, dtype=torch.float64, device="cuda")
+    kern = _native.get_kernels(torch.device("cuda:0"), dtype)
+    calls = {"vec_ctrl": 0}
+    real = kern.error_norm_vec_ctrl
+    monkeypatch.setattr(kern, "error_norm_vec_ctrl", lambda *a, **k: (calls.__setitem__("vec_ctrl", calls["vec_ctrl"] + 1), real(*a, **k))[1])
+    nfe = [0]
+
+    def f(t_, y_):
+        nfe[0] += 1
+        return (y_ @ A.T) * (1.5 + torch.sin(4 * t_))
+    out = {}
+    for t in (torch.tensor([0.0, 0.7, 2.0], dtype=torch.float64, device="cuda"),
+              torch.tensor([1.5, 0.2], dtype=torch.float64, device="cuda")):
+        for la in ("1", "0"):
+            monkeypatch.setenv("TDEQ_LOOKAHEAD", la)
+            made = []
+            orig = solvers.RKAdaptiveStepsizeODESolver.__init__
+
+            def spy(self, *a, **k):
+                orig(self, *a, **k)
+                made.append(self)
+            monkeypatch.setattr(solvers.RKAdaptiveStepsizeODESolver, "__init__", spy)
+            nfe[0] = 0
+            before = calls["vec_ctrl"]
+            with torch.no_grad():
+                y = tda.odeint(f, y0, t, rtol=rtol, atol=atol, method="dopri5", options=dict(first_step=0.8))
+            monkeypatch.setattr(solvers.RKAdaptiveStepsizeODESolver, "__init__", orig)
+            s = made[-1]
+            assert bool(s._lookahead) == (la == "1") and s._vec_fused is not None
+            assert (calls["vec_ctrl"] > before) == (la == "1")
+            out[la] = (y, nfe[0], s.n_accepted, s.n_rejected)
+        assert out["1"][1:] == out["0"][1:], (out["1"][1:], out["0"][1:])
+        if dtype == torch.float32:
+            assert torch.equal(out["1"][0], out["0"][0])
+        else:       # the device's `pow` is within 2 ulp of libm's (DESIGN.md §10): step sizes agree to 1e-16, so do fp64 rows
+            assert float((out["1"][0] - out["0"][0]).abs().max() / out["0"][0].abs().max()) < 1e-13
+        assert out["1"][3] > 0          # the large first step is rejected: that path is compared too

@@ -18,7 +18,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 18
+TDEQ_ABI_VERSION = 19
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_C64, TDEQ_C128 = 2, 3        # interleaved complex: the norm entry points only (include/tdeq_hip.h)
 TDEQ_BF16, TDEQ_F16 = 4, 5        # reduced-precision states: the entry points of the host-driven step (LowPrecisionHipKernels)
@@ -80,6 +80,12 @@ ABI_SIGNATURES = {
                                            ctypes.c_double, ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int,
                                            ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_error_norm_vec_ctrl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
+                                                ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p,
+                                                ctypes.c_double, ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.POINTER(StepCtrl), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_stage_combine_err": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
                                               _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_double,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
@@ -402,6 +408,20 @@ class HipKernels:
                                             plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
                                             plan.workspace.data_ptr(), plan.workspace_bytes, dtype_code(y0.dtype),
                                             self._stream()), "tdeq_error_norm_vec")
+
+    def error_norm_vec_ctrl(self, plan: NormPlan, y0, y1, ks, coefs, dt: float, rtol, atol, ctrl: StepCtrl, next_times) -> None:
+        """`error_norm_vec` whose finalize step also runs the step controller on the device (tdeq_error_norm_vec_ctrl) —
+        read with `read_ctrl`."""
+        ptrs, cf, n = self._terms(ks, coefs)
+        dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
+        rv, rs = (rtol.data_ptr(), 0.0) if isinstance(rtol, torch.Tensor) else (None, float(rtol))
+        av, as_ = (atol.data_ptr(), 0.0) if isinstance(atol, torch.Tensor) else (None, float(atol))
+        self._arm(plan, 1, ctrl=True)
+        _check(self.lib.tdeq_error_norm_vec_ctrl(y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, rv, rs, av, as_, plan.segs,
+                                                 dev, plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
+                                                 ctypes.byref(ctrl), plan.ctrl_ptr, plan.ctrl_dev.data_ptr(),
+                                                 next_times.data_ptr(), plan.workspace.data_ptr(), plan.workspace_bytes,
+                                                 dtype_code(y0.dtype), self._stream()), "tdeq_error_norm_vec_ctrl")
 
     def stage_combine_err(self, out, err_out, y0, ks, coefs, err_coefs, dt: float) -> None:
         """Last combine of a step + partial embedded error over the same stages (tdeq_stage_combine_err)."""

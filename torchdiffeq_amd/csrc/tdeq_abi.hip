@@ -302,10 +302,14 @@ int launch_error(void* scaled, const void* y0, const void* y1, const void* const
     return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
 }
 
+struct CtrlBundle;      // (defined with the controller launch below)
+int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, double* out_bad, const CtrlBundle& cb,
+                         int tkind, hipStream_t s, int ratio_kind);
+
 template <typename T, int NT>
 int launch_error_vec(const void* y0, const void* y1, const void* const* k, const double* coef, double dt,
                      const double* rtol_v, double rtol_s, const double* atol_v, double atol_s, const SegTable& st,
-                     double* out_sumsq, double* out_bad, double* ws, hipStream_t s) {
+                     double* out_sumsq, double* out_bad, double* ws, hipStream_t s, const CtrlBundle* cb = nullptr) {
     ErrVecArgs<T, NT> a;
     a.y0 = static_cast<const T*>(y0);
     a.y1 = static_cast<const T*>(y1);
@@ -324,15 +328,17 @@ int launch_error_vec(const void* y0, const void* y1, const void* const* k, const
     hipLaunchKernelGGL((error_norm_vec_kernel<T, NT>), dim3((unsigned)st.n_chunks), dim3(kBlock), 0, s, a);
     const int e = check_launch();
     if (e) return e;
+    // with a controller bundle: the ratio in fp64 (the promoted type), the step size and the stage times in T
+    if (cb) return launch_finalize_ctrl(st, ws, out_sumsq, out_bad, *cb, sizeof(T) == 4 ? 1 : 0, s, 0);
     return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
 }
 
 template <typename T>
 int dispatch_error_vec(const void* y0, const void* y1, const void* const* k, const double* coef, int nt, double dt,
                        const double* rtol_v, double rtol_s, const double* atol_v, double atol_s, const SegTable& st,
-                       double* out_sumsq, double* out_bad, double* ws, hipStream_t s) {
+                       double* out_sumsq, double* out_bad, double* ws, hipStream_t s, const CtrlBundle* cb = nullptr) {
     switch (nt) {
-#define TDEQ_CASE(N) case N: return launch_error_vec<T, N>(y0, y1, k, coef, dt, rtol_v, rtol_s, atol_v, atol_s, st, out_sumsq, out_bad, ws, s);
+#define TDEQ_CASE(N) case N: return launch_error_vec<T, N>(y0, y1, k, coef, dt, rtol_v, rtol_s, atol_v, atol_s, st, out_sumsq, out_bad, ws, s, cb);
         TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
         TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
 #undef TDEQ_CASE
@@ -364,13 +370,14 @@ struct CtrlBundle {
 
 // tkind: the state's real type — 0 fp64, 1 fp32 (callers pass `sizeof(T) == 4`), 2 bfloat16, 3 float16
 int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, double* out_bad, const CtrlBundle& cb,
-                         int tkind, hipStream_t s) {
+                         int tkind, hipStream_t s, int ratio_kind) {
     CtrlArgs a;
     a.part_sumsq = ws;
     a.part_bad = ws + 2 * st.n_chunks;
     a.st = st;
     a.c = *cb.ctrl;
     a.is_f32 = tkind;
+    a.ratio_kind = ratio_kind < 0 ? tkind : ratio_kind;
     a.out_sumsq = out_sumsq;
     a.out_bad = out_bad;
     a.out_ctrl = cb.out_ctrl;
@@ -423,7 +430,7 @@ int launch_error_partial(const void* partial, const void* y0, const void* y1, co
     else hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, false>), g, b, 0, s, a);
     const int e = check_launch();
     if (e) return e;
-    if (cb) return launch_finalize_ctrl(st, ws, out_sumsq, out_bad, *cb, sizeof(T) == 4, s);
+    if (cb) return launch_finalize_ctrl(st, ws, out_sumsq, out_bad, *cb, sizeof(T) == 4 ? 1 : 0, s, -1);
     return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
 }
 
@@ -608,7 +615,7 @@ int launch_cplx_error(const void* partial, void* scaled, const void* y0, const v
     }
     const int e = check_launch();
     if (e) return e;
-    if (cb) return launch_finalize_ctrl(st, ws, out_sumsq, out_bad, *cb, sizeof(T) == 4, s);
+    if (cb) return launch_finalize_ctrl(st, ws, out_sumsq, out_bad, *cb, sizeof(T) == 4 ? 1 : 0, s, -1);
     return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
 }
 
@@ -1126,6 +1133,32 @@ int tdeq_error_norm_vec(const void* y0, const void* y1, const void* const* k, co
                                             out_sumsq, out_nonfinite, ws, s);
 }
 
+int tdeq_error_norm_vec_ctrl(const void* y0, const void* y1, const void* const* k, const double* coef, int n_terms, double dt,
+                             const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
+                             const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
+                             double* out_sumsq, double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl,
+                             double* ctrl_dev, void* next_times, void* workspace, size_t workspace_bytes, int dtype,
+                             void* stream) {
+    if (!y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if ((!rtol_vec && !atol_vec) || !ctrl || !out_ctrl || !ctrl_dev || !next_times) return TDEQ_EINVAL;
+    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (ctrl->n_times < 1 || ctrl->n_times > TDEQ_MAX_STAGE_TIMES || ctrl->n_norm_seg < 0 || ctrl->n_norm_seg > n_seg)
+        return TDEQ_EINVAL;
+    SegTable st;
+    const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
+    if (e) return e;
+    if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times, 0};
+    return dtype == TDEQ_F32
+               ? dispatch_error_vec<float>(y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
+                                           out_sumsq, out_nonfinite, ws, s, &cb)
+               : dispatch_error_vec<double>(y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
+                                            out_sumsq, out_nonfinite, ws, s, &cb);
+}
+
 int tdeq_stage_combine_err(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
                            const double* err_coef, int n_terms, double dt, int64_t n, int dtype, void* stream) {
     if (!out || !err_out || !y0 || !k || !coef || !err_coef || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
@@ -1266,6 +1299,7 @@ int tdeq_step_controller(const double* sums, const double* nonfinite, const tdeq
     a.st = st;
     a.c = *ctrl;
     a.is_f32 = dtype == TDEQ_F32 ? 1 : 0;
+    a.ratio_kind = a.is_f32;
     a.out_sumsq = out_sumsq;
     a.out_bad = out_nonfinite;
     a.out_ctrl = out_ctrl;

@@ -107,7 +107,7 @@ int lp_launch_error(void* scaled, const void* y0, const void* y1, const void* co
     const int e = check_launch();
     if (e) return e;
     // with a controller bundle: finalize + the step controller in the state's type (tkind 2 / 3), as for fp32 / fp64
-    if (cb) return launch_finalize_ctrl(st, ws, out_sumsq, out_bad, *cb, S::code == TDEQ_BF16 ? 2 : 3, s);
+    if (cb) return launch_finalize_ctrl(st, ws, out_sumsq, out_bad, *cb, S::code == TDEQ_BF16 ? 2 : 3, s, -1);
     return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
 }
 

@@ -697,6 +697,8 @@ struct CtrlArgs {
     SegTable st;              // n_seg <= TDEQ_INLINE_SEGMENTS
     tdeq_step_ctrl c;
     int is_f32;               // kind of T: 0 = fp64, 1 = fp32, 2 = bfloat16, 3 = float16 (ctl_seg_norm / ctl_round_T)
+    int ratio_kind;           // the type the error ratio is formed in: = is_f32, except per-element tolerances (fp64 = 0: the
+                              // reference's quotient and norm promote to the tolerances' type, misc.py:80-82)
     double* out_sumsq;        // [n_seg]   device or pinned host
     double* out_bad;          // [n_seg]
     double* out_ctrl;         // [4] = {accept, dt_next, ratio, t0_next}
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         for (int s = threadIdx.x; s < a.c.n_norm_seg && s < n_seg; s += kBlock) {
             const int64_t numel = get_segment(a.st, s).numel;
             if (numel == 0) continue;
-            const double v = ctl_seg_norm(sums[s], numel, a.is_f32);
+            const double v = ctl_seg_norm(sums[s], numel, a.ratio_kind);
             if (v != v) part[1] = 1.0;
             else part[0] = v > part[0] ? v : part[0];
         }
@@ -918,9 +920,9 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         for (int s = 0; s < c.n_norm_seg && s < n_seg && !a.presummed; ++s) {
             const int64_t numel = a.st.inl[s].numel;
             if (numel == 0) continue;
-            val = ctl_nan_max(val, ctl_seg_norm(seg_val[0][s], numel, a.is_f32));
+            val = ctl_nan_max(val, ctl_seg_norm(seg_val[0][s], numel, a.ratio_kind));
         }
-        const double ratio = a.is_f32 == 1 ? (double)(float)val : val;      // (16-bit kinds: rounded per segment already)
+        const double ratio = a.ratio_kind == 1 ? (double)(float)val : val;      // (16-bit kinds: rounded per segment already)
         // accept / reject (rk_common.py:324-330)
         bool accept = ratio <= 1.0;
         if (step_dt > c.max_step) accept = false;

@@ -260,7 +260,11 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         # Device-resident controller + look-ahead first stage (tdeq_error_norm_partial_ctrl / tdeq_stage_combine_sel):
         # the loop stays here, but the scalar decision of a trial step is also taken on the device so that the next
         # trial step's first stage and func evaluation are enqueued before the decision has been read back.
-        n_norm_seg = self.layout.n_seg - (self.norm.n_skip_tail if isinstance(self.norm, BuiltinNorm) else 0)
+        # (per-element tolerances under the built-in norm, `_vec_fused`: tdeq_error_norm_vec_ctrl forms the fp64 ratio and runs
+        #  the controller in the same finalize launch — the look-ahead stage follows as for scalar tolerances)
+        self._vec_ctrl = self._vec_fused is not None and hasattr(self.kernels, "error_norm_vec_ctrl")
+        n_norm_seg = self.layout.n_seg - (self.norm.n_skip_tail if isinstance(self.norm, BuiltinNorm) else
+                                          (self._vec_fused[2] if self._vec_ctrl else 0))
         # (lock-step sharding: only when the collective runs on device buffers — backend nccl = RCCL —, where the sums
         # are all-reduced between the norm's finalize and the controller kernel without leaving the GPU)
         sync_dev = self._sync is not None and self._sync.on_device and y0.device.type == "cuda" \
@@ -271,7 +275,8 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         self._whole_row_ctrl = bool(getattr(self.kernels, "whole_row_controller", False)) and self._fuse is None \
             and not getattr(self.norm, "leading_scalar", False) and func.time_dtype == y0.dtype and dist_sync is None
         device_ctrl = (getattr(self.kernels, "device_controller", True)
-                       and (self._fuse is not None or self._whole_row_ctrl) and isinstance(self.norm, BuiltinNorm)
+                       and (self._fuse is not None or self._whole_row_ctrl or self._vec_ctrl)
+                       and (isinstance(self.norm, BuiltinNorm) or self._vec_ctrl)
                        and len(self._beta) <= _native.TDEQ_MAX_STAGE_TIMES and n_norm_seg >= 0
                        and self.step_t is None and self.jump_t is None and (self._sync is None or sync_dev)
                        and self._wide)          # the device controller computes in fp64: W = fp64 only
@@ -292,7 +297,7 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         self._auto = None           # auto mode: this solve's policy ("now" / "later" / "never", _GraphStep.auto_policy)
         self._auto_steps = 0
         self._hold_pre = False      # auto mode: the eager step before the switch to replays enqueues no look-ahead stage
-        self.hip_graph = wanted and device_ctrl and self._sync is None and y0.device.type == "cuda" \
+        self.hip_graph = wanted and device_ctrl and self._sync is None and y0.device.type == "cuda" and not self._vec_ctrl \
             and hasattr(self.kernels, "stage_combine_dev") \
             and self.layout.total <= (_GRAPH_AUTO_MAX_ELEMENTS if auto else _GRAPH_MODE_MAX_ELEMENTS)
         if wanted and not auto and not self.hip_graph and hip_graph is not None:
@@ -808,12 +813,16 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
 
         # ---- error ratio (misc.py:80-82) ----
         err = self._c_err
-        use_ctrl = lookahead and (err_partial is not None or (self._whole_row_ctrl and builtin_norm))
+        vec_ctrl = self._vec_ctrl and err_partial is None and not builtin_norm
+        use_ctrl = lookahead and (err_partial is not None or (self._whole_row_ctrl and builtin_norm) or vec_ctrl)
         if use_ctrl:
             ctrl = self._ctrl
             ctrl.t0, ctrl.dt = t0, dt
             tnext = torch.empty(ctrl.n_times, dtype=func.time_dtype, device=y0.device)
-            if err_partial is None:
+            if vec_ctrl:
+                kern.error_norm_vec_ctrl(self.plan, y0, y1, [k[j] for j in err.idx], err.coef, dt_signed,
+                                         self._vec_fused[0], self._vec_fused[1], ctrl, tnext)
+            elif err_partial is None:
                 kern.error_norm_ctrl(self.plan, y0, y1, [k[j] for j in err.idx], err.coef, dt_signed, ctrl, tnext)
             elif self._sync is None:
                 kern.error_norm_partial_ctrl(self.plan, err_partial, y0, y1, [k[j] for j in err_rem[0]],
