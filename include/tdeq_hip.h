@@ -100,7 +100,9 @@ typedef struct tdeq_step_ctrl {
     uint32_t alpha_is_one;                /* bit i set: stage i is evaluated at t1 with Perturb.PREV (rk_common.py:72-75) */
     int32_t n_times;    /* number of stages (func evaluations per step), 1..TDEQ_MAX_STAGE_TIMES               */
     int32_t n_norm_seg; /* leading segments that enter the max of the mixed norm (seminorm: adjoint.py:267-270) */
-    int32_t reserved;
+    int32_t leading_abs; /* 16-bit states only: segment 0, if it holds ONE element, enters the max as |x| itself instead of
+                            its rms — the adjoint norms take their time component as `t.abs()` (adjoint.py:250, 273); for
+                            fp32 / fp64 the two are the same number and the field is ignored */
 } tdeq_step_ctrl;
 
 /* ABI version of the loaded library (== TDEQ_ABI_VERSION). */

@@ -570,7 +570,7 @@ typedef struct oracle_step_ctrl {
     uint32_t alpha_is_one;
     int32_t n_times;
     int32_t n_norm_seg;
-    int32_t reserved;
+    int32_t leading_abs;
 } oracle_step_ctrl;
 
 static double o_nan_max(double a, double b) { return (isnan(a) || isnan(b)) ? NAN : (a > b ? a : b); }

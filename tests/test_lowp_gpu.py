@@ -268,3 +268,43 @@ def test_device_controller_and_look_ahead_take_the_host_loops_steps(monkeypatch,
         assert torch.equal(out["1"][0].view(torch.int16), out["0"][0].view(torch.int16))
         seen[float(t[-1])] = out["1"][1:]
     assert any(v[2] > 0 for v in seen.values())      # the large first step is rejected: that path is compared too
+
+
+@pytest.mark.parametrize("norm", [None, "seminorm"])
+def test_bf16_adjoint_backward_keeps_the_device_controller(monkeypatch, norm):
+    """odeint_adjoint on a bf16 state and bf16 parameters — the mainstream reduced-precision use.  The backward solve's
+    augmented state [vjp_t | y | adj_y | θ…] has a ONE-element first segment that enters the adjoint norm as |t|
+    (adjoint.py:250, 273), not as an rms: the 16-bit device controller takes it that way (`leading_abs`), so the backward
+    solve keeps the controller + look-ahead.  Against TDEQ_LOOKAHEAD=0 (host-driven decisions): equal evaluation counts,
+    bit-identical solution and gradients."""
+    torch.manual_seed(0)
+    lin1 = torch.nn.Linear(8, 32).to(torch.bfloat16).cuda()
+    lin2 = torch.nn.Linear(32, 8).to(torch.bfloat16).cuda()
+
+    class Field(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.nfe = lin1, lin2, 0
+
+        def forward(self, t, y):
+            self.nfe += 1
+            return self.b(torch.tanh(self.a(y))) * (1 + torch.sin(2 * t))
+    field = Field()
+    x0 = torch.randn(64, 8, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+    t = torch.tensor([0.0, 0.5, 1.5], device="cuda")
+    res = {}
+    for la in ("1", "0"):
+        monkeypatch.setenv("TDEQ_LOOKAHEAD", la)
+        field.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        field.nfe = 0
+        kw = dict(adjoint_options=dict(norm=norm)) if norm else {}
+        y = tda.odeint_adjoint(field, x, t, method="dopri5", rtol=2e-2, atol=2e-3, **kw)
+        n_fwd, field.nfe = field.nfe, 0
+        (y[-1].float().pow(2).sum() + y[1].float().sum()).backward()
+        res[la] = (n_fwd, field.nfe, y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in field.parameters()])
+    assert res["1"][:2] == res["0"][:2], (res["1"][:2], res["0"][:2])
+    assert torch.equal(res["1"][2].view(torch.int16), res["0"][2].view(torch.int16))
+    assert torch.equal(res["1"][3].view(torch.int16), res["0"][3].view(torch.int16))
+    for a, b in zip(res["1"][4], res["0"][4]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)) and float(a.float().abs().max()) > 0

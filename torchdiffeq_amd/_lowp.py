@@ -28,6 +28,7 @@ import torch
 
 from . import _fallback
 from ._fallback import HostPlan, LowPrecisionHostKernels, _no_grad_methods
+from ._native import _check, dtype_code
 
 
 class LowPlan(HostPlan):
@@ -77,7 +78,6 @@ class LowPrecisionHipKernels(LowPrecisionHostKernels):
         ptrs, cf, n = hip._terms(ks, coefs)
         dev = p.segs_dev.data_ptr() if p.segs_dev is not None else None
         hip._arm(p, 1)
-        from ._native import _check, dtype_code
         _check(hip.lib.tdeq_error_norm(None if scaled_out is None else scaled_out.data_ptr(), y0.data_ptr(),
                                        y1.data_ptr(), ptrs, cf, n, dt, p.segs, dev, p.n_seg, p.chunk, p.n_chunks,
                                        p.out_ptr, p.bad_ptr, p.workspace.data_ptr(), p.workspace_bytes,
@@ -91,7 +91,6 @@ class LowPrecisionHipKernels(LowPrecisionHostKernels):
         hip, p = self._hip, plan.hip
         ptrs, cf, n = hip._terms(ks, coefs)
         hip._arm(p, 1, ctrl=True)
-        from ._native import _check, dtype_code
         _check(hip.lib.tdeq_error_norm_partial_ctrl(
             None, y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, p.segs,
             p.segs_dev.data_ptr() if p.segs_dev is not None else None, p.n_seg, p.chunk, p.n_chunks, p.out_ptr, p.bad_ptr,

@@ -48,7 +48,7 @@ class StepCtrl(ctypes.Structure):
                 ("ifactor", ctypes.c_double), ("dfactor", ctypes.c_double), ("exponent", ctypes.c_double),
                 ("min_step", ctypes.c_double), ("max_step", ctypes.c_double), ("time_sign", ctypes.c_double),
                 ("alpha", ctypes.c_double * TDEQ_MAX_STAGE_TIMES), ("alpha_is_one", ctypes.c_uint32),
-                ("n_times", ctypes.c_int32), ("n_norm_seg", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("n_times", ctypes.c_int32), ("n_norm_seg", ctypes.c_int32), ("leading_abs", ctypes.c_int32)]
 
 
 class MultiOut(ctypes.Structure):

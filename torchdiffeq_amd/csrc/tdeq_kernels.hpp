@@ -842,7 +842,9 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         for (int s = threadIdx.x; s < a.c.n_norm_seg && s < n_seg; s += kBlock) {
             const int64_t numel = get_segment(a.st, s).numel;
             if (numel == 0) continue;
-            const double v = ctl_seg_norm(sums[s], numel, a.ratio_kind);
+            const double v = (s == 0 && numel == 1 && a.c.leading_abs && a.ratio_kind >= 2)
+                                 ? (double)ctl_rnd16((float)sums[s], a.ratio_kind)      // |x| itself (16-bit adjoint norm)
+                                 : ctl_seg_norm(sums[s], numel, a.ratio_kind);
             if (v != v) part[1] = 1.0;
             else part[0] = v > part[0] ? v : part[0];
         }
@@ -920,7 +922,10 @@ __global__ __launch_bounds__(kBlock) void norm_finalize_ctrl_kernel(const CtrlAr
         for (int s = 0; s < c.n_norm_seg && s < n_seg && !a.presummed; ++s) {
             const int64_t numel = a.st.inl[s].numel;
             if (numel == 0) continue;
-            val = ctl_nan_max(val, ctl_seg_norm(seg_val[0][s], numel, a.ratio_kind));
+            const double v = (s == 0 && numel == 1 && c.leading_abs && a.ratio_kind >= 2)
+                                 ? (double)ctl_rnd16((float)seg_val[0][s], a.ratio_kind)
+                                 : ctl_seg_norm(seg_val[0][s], numel, a.ratio_kind);
+            val = ctl_nan_max(val, v);
         }
         const double ratio = a.ratio_kind == 1 ? (double)(float)val : val;      // (16-bit kinds: rounded per segment already)
         // accept / reject (rk_common.py:324-330)

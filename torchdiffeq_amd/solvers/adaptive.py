@@ -270,10 +270,9 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         sync_dev = self._sync is not None and self._sync.on_device and y0.device.type == "cuda" \
             and hasattr(self.kernels, "step_controller")
         # (reduced-precision states on the HIP kernels — `whole_row_controller`: the controller launch takes the WHOLE error
-        #  row instead of continuing a fused partial sum; builtin norms without the adjoint's |t| component, stage times in
-        #  the state's type)
+        #  row instead of continuing a fused partial sum; stage times in the state's type)
         self._whole_row_ctrl = bool(getattr(self.kernels, "whole_row_controller", False)) and self._fuse is None \
-            and not getattr(self.norm, "leading_scalar", False) and func.time_dtype == y0.dtype and dist_sync is None
+            and func.time_dtype == y0.dtype and dist_sync is None
         device_ctrl = (getattr(self.kernels, "device_controller", True)
                        and (self._fuse is not None or self._whole_row_ctrl or self._vec_ctrl)
                        and (isinstance(self.norm, BuiltinNorm) or self._vec_ctrl)
@@ -323,6 +322,9 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
             c.alpha_is_one = mask
             c.n_times = len(self._alpha)
             c.n_norm_seg = n_norm_seg
+            # the adjoint norms take their one-element time component as |t|, not as an rms (adjoint.py:250, 273): the
+            # same number for fp32 / fp64, one rounding apart for 16-bit states (include/tdeq_hip.h `leading_abs`)
+            c.leading_abs = 1 if (getattr(self.norm, "leading_scalar", False) and self.plan.numels[0] == 1) else 0
             self._ctrl = c
         self._max_rows = _native.TDEQ_MAX_DENSE_OUTPUTS if os.environ.get("TDEQ_DENSE_MULTI", "1") != "0" else 1
         self._t_end = -math.inf     # last output time of the running `integrate` (look-ahead only before it)
