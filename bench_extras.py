@@ -281,6 +281,50 @@ def lowp_combine_rate(dtype, device, nt=5, n=BATCH * DIM, sets=8, launches=48):
     return out
 
 
+def lowp_adjoint_pass(backend, device, passes=3):
+    """cfg3's shape with a bf16 STATE and bf16 parameters (MLP 64-256-256-64, 65536 x 64, loss sum(y(1)^2), rtol 1e-2 / atol
+    1e-3): one forward + backward pass of odeint_adjoint on the 16-bit HIP kernels (device controller + look-ahead in both
+    solves) or on the torch-op path forced onto the same device."""
+    import torchdiffeq_amd as tda
+    from torchdiffeq_amd import _fallback, _native
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(ADJ_DIM, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(),
+                              torch.nn.Linear(256, ADJ_DIM)).to(torch.bfloat16).to(device)
+
+    class Field(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net, self.nfe = net, 0
+
+        def forward(self, t, y):
+            self.nfe += 1
+            return self.net(y)
+    field = Field()
+    y0 = torch.randn(ADJ_BATCH, ADJ_DIM, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(device)
+    t = torch.tensor([0.0, 1.0], device=device)
+    orig = _native.get_kernels
+    if backend == "torch-op":
+        low = _fallback.LowPrecisionHostKernels()
+        _native.get_kernels = lambda dev_, dt_=None: low if dt_ in (torch.bfloat16, torch.float16) else orig(dev_, dt_)
+    try:
+        times = []
+        for _ in range(passes + 1):
+            field.zero_grad()
+            x = y0.clone().requires_grad_(True)
+            field.nfe = 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            y = tda.odeint_adjoint(field, x, t, method="dopri5", rtol=1e-2, atol=1e-3)
+            n_fwd, field.nfe = field.nfe, 0
+            y[-1].float().pow(2).sum().backward()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    finally:
+        _native.get_kernels = orig
+    return {"ms_per_pass": 1e3 * statistics.median(times[1:]), "nfe_fwd": n_fwd, "nfe_bwd": field.nfe,
+            "grad_finite": bool(torch.isfinite(x.grad.float()).all())}
+
+
 def low_precision_regime(device):
     res = {"workload": "dopri5 trial steps, dy/dt = A y (rotation), 65536 x 128, rtol 1e-2 atol 1e-3, state in bf16 / fp16"}
     for name, dtype in (("bf16", torch.bfloat16), ("f16", torch.float16)):
@@ -294,6 +338,12 @@ def low_precision_regime(device):
             # 0.0", tests/test_brow_golden.py) — adaptive solves of fp16 states do not start; fixed grids do
             entry["adaptive_steps"] = {"error": str(exc)}
         res[name] = entry
+    try:
+        hip, ref = lowp_adjoint_pass("hip", device), lowp_adjoint_pass("torch-op", device, passes=2)
+        res["bf16"]["adjoint_cfg3_shape"] = {"hip_kernels": hip, "torch_op_host_path": ref,
+                                             "speedup": ref["ms_per_pass"] / hip["ms_per_pass"]}
+    except Exception as exc:
+        res["bf16"]["adjoint_cfg3_shape"] = {"error": repr(exc)}
     return res
 
 
