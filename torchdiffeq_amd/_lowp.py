@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import _fallback
-from ._fallback import HostPlan, LowPrecisionHostKernels, _no_grad_methods
+from ._fallback import HostPlan, LowPrecisionHostKernels
 from ._native import _check, dtype_code
 
 
@@ -40,7 +40,9 @@ class LowPlan(HostPlan):
         self.pending = None        # ("err" | "init", n_sums) of the norm launch whose words have not been read yet
 
 
-@_no_grad_methods
+# (no `_no_grad_methods` here: the methods below only launch kernels through ctypes — entering a no_grad context per call
+#  costs ~2.5 us of host time, 20 us per trial step of a loop that is host-bound at 16-bit sizes; the inherited torch-op
+#  methods keep their wrappers)
 class LowPrecisionHipKernels(LowPrecisionHostKernels):
     name = "hip-low"
     device_controller = True     # tdeq_error_norm_partial_ctrl on the WHOLE error row + tdeq_stage_combine_sel (look-ahead)
