@@ -209,7 +209,7 @@ def strong_scaling_prediction(device, full_ms, steps=100, warmup=20):
     return out
 
 
-def lowp_steps(dtype, backend, steps, warmup, device):
+def lowp_steps(dtype, backend, steps, warmup, device, hip_graph=False):
     """dopri5 trial steps of the cfg2-shaped workload with a bf16 / fp16 STATE: `backend` "hip" = the kernels of
     csrc/tdeq_kernels_lp.hpp (what a reduced-precision cuda state selects), "torch-op" = the package's torch-op host path
     forced onto the same device (what r04 ran for such states)."""
@@ -228,7 +228,7 @@ def lowp_steps(dtype, backend, steps, warmup, device):
         blocks = []
         with torch.no_grad():
             for _ in range(3):          # a fresh solve per block (a 16-bit solve of this field lasts ~100 steps)
-                solver = make_stepper(lambda t, y: y @ At, y0, rtol=1e-2, atol=1e-3)
+                solver = make_stepper(lambda t, y: y @ At, y0, rtol=1e-2, atol=1e-3, hip_graph=hip_graph)
                 for _ in range(warmup):
                     solver._trial_step()
                 torch.cuda.synchronize()
@@ -238,14 +238,18 @@ def lowp_steps(dtype, backend, steps, warmup, device):
                 torch.cuda.synchronize()
                 blocks.append((time.perf_counter() - t0) / steps)
             breakdown = None
-            if backend == "hip":
+            if backend == "hip" and not hip_graph:
                 b = kernel_breakdown(solver._trial_step, 10)
                 breakdown = {k: b[k] for k in ("solver_kernel_us", "func_kernel_us", "floor_us", "dispatches_per_call",
                                                "top_kernels")}
+            if solver._g is not None:
+                torch.cuda.synchronize()
+                solver._g.release()
     finally:
         _native.get_kernels = orig
     ms = 1e3 * statistics.median(blocks)
-    return {"backend": solver.kernels.name, "lookahead": bool(solver._lookahead), "ms_per_step": ms,
+    return {"backend": solver.kernels.name, "lookahead": bool(solver._lookahead), "hip_graph": bool(solver.hip_graph),
+            "ms_per_step": ms,
             "rk_stages_per_s": 6e3 / ms, "accepted": solver.n_accepted, "rejected": solver.n_rejected,
             "steps_timed": steps, "breakdown": breakdown}
 
@@ -332,7 +336,12 @@ def low_precision_regime(device):
         try:
             hip = lowp_steps(dtype, "hip", 40, 5, device)
             ref = lowp_steps(dtype, "torch-op", 10, 2, device)
-            entry.update({"hip_kernels": hip, "torch_op_host_path": ref, "speedup": ref["ms_per_step"] / hip["ms_per_step"]})
+            # captured trial steps (options={'hip_graph': True}): at this size the eager loop is HOST-bound — six func
+            # dispatches + eight ctypes launches of Python per step — so one replay per step reaches the kernel floor
+            cap = lowp_steps(dtype, "hip", 40, 8, device, hip_graph=True)
+            entry.update({"hip_kernels": hip, "hip_kernels_captured": cap, "torch_op_host_path": ref,
+                          "speedup": ref["ms_per_step"] / hip["ms_per_step"],
+                          "speedup_captured": ref["ms_per_step"] / cap["ms_per_step"]})
         except AssertionError as exc:
             # float16: the initial-step heuristic underflows the type's range in the reference as well ("underflow in dt
             # 0.0", tests/test_brow_golden.py) — adaptive solves of fp16 states do not start; fixed grids do

@@ -55,7 +55,8 @@ extern "C" {
  * tdeq_lerp, tdeq_fixed_stage, tdeq_weighted_sum — with exactly that rounding (tdeq_kernels_lp.hpp), and by the
  * look-ahead pair tdeq_error_norm_partial_ctrl (err_partial MUST be NULL: the whole error row in `k` / `coef`, 1..14
  * terms — a row is rounded once, there is no partial sum to continue; the controller forms the ratio, the next step and
- * its stage times in the state's type) + tdeq_stage_combine_sel; every other entry point returns TDEQ_EINVAL for them.  Scalars: `dt`, tableau weights, `slope`, tolerances are rounded to the
+ * its stage times in the state's type; `state_in_dev` as for fp32) + tdeq_stage_combine_sel, and by tdeq_stage_combine_dev
+ * (captured steps; err_out must be NULL); every other entry point returns TDEQ_EINVAL for them.  Scalars: `dt`, tableau weights, `slope`, tolerances are rounded to the
  * storage type where the reference holds them as 0-dim tensors of the state's type or as FIRST operands, and taken at
  * float32 where ATen takes a Python number as SECOND operand of `*` (rk4's 1/3, `* dt`; tdeq_init_norms' rtol).
  * The norm entry points report per segment the sum of fl(|q|^2) — for a segment of ONE element |q| itself (the adjoint's

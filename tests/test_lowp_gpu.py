@@ -184,14 +184,15 @@ def test_dense_output_and_fixed_grid_stages_bit_exact(low, n):
 
 
 def test_entry_points_outside_the_step_refuse_reduced_precision():
-    """hipGraph-mode and backward-helper entry points have no 16-bit kernels: TDEQ_EINVAL, not a misread buffer."""
+    """Entry points without 16-bit kernels (backward helpers, the fused partial-error forms): TDEQ_EINVAL, not a misread buffer."""
     import ctypes
     lib = _native.load_library()
     y = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
     ptrs = (ctypes.c_void_p * 1)(y.data_ptr())
     w = (ctypes.c_double * 1)(0.5)
     assert lib.tdeq_scale_many(ptrs, y.data_ptr(), w, 1, 64, _native.TDEQ_BF16, None) == -1
-    assert lib.tdeq_stage_combine_dev(y.data_ptr(), None, y.data_ptr(), ptrs, w, None, 1, y.data_ptr(), 64,
+    # the captured-step combine exists for 16-bit states, but not its fused partial-error output (a row is rounded once)
+    assert lib.tdeq_stage_combine_dev(y.data_ptr(), y.data_ptr(), y.data_ptr(), ptrs, w, w, 1, y.data_ptr(), 64,
                                       _native.TDEQ_F16, None) == -1
 
 
@@ -308,3 +309,38 @@ def test_bf16_adjoint_backward_keeps_the_device_controller(monkeypatch, norm):
     assert torch.equal(res["1"][3].view(torch.int16), res["0"][3].view(torch.int16))
     for a, b in zip(res["1"][4], res["0"][4]):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16)) and float(a.float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("method", ["dopri5", "bosh3", "tsit5", "dopri8"])
+def test_captured_trial_steps_of_a_bf16_state_replay_the_eager_solve(method):
+    """`hip_graph=True` for a bf16 state: one trial step — the S evaluations of func, the 16-bit combines reading the step
+    size from the device controller's words (tdeq_stage_combine_dev), the whole-row error norm + controller with the state on
+    the device — is ONE hipGraph replay.  Same kernels, same decisions: bit-identical to the eager (look-ahead) solve, and
+    really replayed."""
+    tda.clear_graph_cache()
+    g = torch.Generator().manual_seed(4)
+    A = (torch.randn(16, 16, generator=g) / 2 - 0.2 * torch.eye(16)).to(torch.bfloat16).cuda()
+    y0 = (2 * torch.randn(128, 16, generator=g)).to(torch.bfloat16).cuda()
+
+    def f(t_, y_):
+        return (y_ @ A.T) * (2 + 2 * torch.sin(3 * t_))
+    replays = [0]
+    real = torch.cuda.CUDAGraph.replay
+
+    def counting(self):
+        replays[0] += 1
+        return real(self)
+    for t in (torch.linspace(0.0, 3.0, 7, device="cuda"), torch.linspace(2.0, -1.0, 4, device="cuda")):
+        with torch.no_grad():
+            eager = tda.odeint(f, y0, t, method=method, rtol=3e-2, atol=1e-3, options=dict(first_step=2.0))
+            torch.cuda.CUDAGraph.replay = counting
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("error")           # in particular: no "running the eager path"
+                    captured = tda.odeint(f, y0, t, method=method, rtol=3e-2, atol=1e-3,
+                                          options=dict(first_step=2.0, hip_graph=True))
+            finally:
+                torch.cuda.CUDAGraph.replay = real
+        assert torch.equal(captured.view(torch.int16), eager.view(torch.int16))
+    assert replays[0] > 4
+    tda.clear_graph_cache()

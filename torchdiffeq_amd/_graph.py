@@ -435,7 +435,8 @@ class _GraphStep:
     @staticmethod
     def _key(s):
         c = s._ctrl
-        segs = tuple((int(sg.chunk_start), int(sg.numel), float(sg.rtol), float(sg.atol)) for sg in s.plan.segs)
+        segs = tuple((int(sg.chunk_start), int(sg.numel), float(sg.rtol), float(sg.atol))
+                     for sg in getattr(s.plan, "native_segs", s.plan.segs))
         key = (type(s).__name__, str(s.y0.dtype), str(s.y0.device), int(s.layout.total), int(s.plan.chunk), segs,
                c.safety, c.ifactor, c.dfactor, c.exponent, c.min_step, c.max_step, c.time_sign, int(c.n_norm_seg))
         # A captured graph reads the STORAGES it saw: in-place updates are fine, anything re-allocated (module.to(...),
@@ -521,6 +522,23 @@ class _GraphStep:
             assert held.pop(R) is epart and not held
             kern.error_norm_partial_ctrl(plan, epart, y_cur, y1, [k[j] for j in carry.err_idx], carry.err_coef, 0.0,
                                          s._ctrl, self.tbuf, state_in_dev=True)
+            if side == 1:
+                self.f0.copy_(k[-1])
+            self.k[side] = k
+            return
+        if fuse is None:
+            # 16-bit states (csrc/tdeq_kernels_lp.hpp): every row whole and the error row whole — a reduced-precision row sum
+            # is rounded once, so there is no partial error to hand from the last combine to the norm launch
+            for i in range(1, n_rows):
+                row = beta[i]
+                yi = y1 if (i == n_rows - 1 and fsal) else torch.empty_like(y_cur)
+                kern.stage_combine_dev(yi, None, y_cur, [k[j] for j in row.idx], row.coef, None, plan)
+                k.append(func.eval_at(self.ts[i], yi))
+            if not fsal:
+                kern.stage_combine_dev(y1, None, y_cur, [k[j] for j in s._c_sol.idx], s._c_sol.coef, None, plan)
+            err = s._c_err
+            kern.error_norm_ctrl(plan, y_cur, y1, [k[j] for j in err.idx], err.coef, 0.0, s._ctrl, self.tbuf,
+                                 state_in_dev=True)
             if side == 1:
                 self.f0.copy_(k[-1])
             self.k[side] = k

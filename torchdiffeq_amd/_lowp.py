@@ -13,9 +13,9 @@ from the torch-op class — same numbers, more launches.
 
 Selection: `_native.get_kernels` for a bf16 / fp16 state on a `cuda` device; a missing libtdeq_hip.so raises there.
 The loop is the fp32 one: the norm launch's finalize step also runs the step controller on the device in the state's type
-and the next trial step's first stage + func evaluation are enqueued before the decision is read back (look-ahead).  What
-reduced precision does not get: the fused error split and carried partial sums (a row would be rounded twice) and
-captured graphs.
+and the next trial step's first stage + func evaluation are enqueued before the decision is read back (look-ahead);
+adaptive trial steps can be captured and replayed as hipGraphs like fp32 ones (`hip_graph`).  What reduced precision does
+not get: the fused error split and carried partial sums (a row would be rounded twice) and captured fixed grids.
 """
 from __future__ import annotations
 
@@ -37,7 +37,15 @@ class LowPlan(HostPlan):
     def __init__(self, segments, total, chunk, native):
         super().__init__(segments, total, chunk)
         self.hip = native
-        self.pending = None        # ("err" | "init", n_sums) of the norm launch whose words have not been read yet
+        self.pending = None        # (kind, dtype) of the norm launch whose words have not been read yet
+
+    @property
+    def ctrl_dev(self):            # the device-resident controller words {accept, sign * T(dt'), t0', dt'} (captured steps)
+        return self.hip.ctrl_dev
+
+    @property
+    def native_segs(self):         # the ctypes segment table (chunk_start, numel, rtol, atol) the kernels were given
+        return self.hip.segs
 
 
 # (no `_no_grad_methods` here: the methods below only launch kernels through ctypes — entering a no_grad context per call
@@ -86,7 +94,15 @@ class LowPrecisionHipKernels(LowPrecisionHostKernels):
                                        dtype_code(y0.dtype), hip._stream()), "tdeq_error_norm")
         plan.pending = ("err", y0.dtype)
 
-    def error_norm_ctrl(self, plan: LowPlan, y0, y1, ks, coefs, dt: float, ctrl, next_times) -> None:
+    def stage_combine_dev(self, out, err_out, y0, ks, coefs, err_coefs, plan: LowPlan) -> None:
+        """`stage_combine` with the step size read on the device from the controller words (captured steps)."""
+        assert err_out is None, "a 16-bit row is rounded once: no partial error sum"
+        self._hip.stage_combine_dev(out, None, y0, ks, coefs, None, plan.hip)
+
+    def arm_readback(self, plan: LowPlan) -> None:
+        self._hip.arm_readback(plan.hip)
+
+    def error_norm_ctrl(self, plan: LowPlan, y0, y1, ks, coefs, dt: float, ctrl, next_times, state_in_dev: bool = False) -> None:
         """`error_norm` whose finalize step also runs the step controller on the device (tdeq_error_norm_partial_ctrl
         with err_partial = NULL: the whole error row in one launch): accept flag, next step size and the next trial
         step's stage times, all in the state's type — read with `read_ctrl`."""
@@ -96,8 +112,8 @@ class LowPrecisionHipKernels(LowPrecisionHostKernels):
         _check(hip.lib.tdeq_error_norm_partial_ctrl(
             None, y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, p.segs,
             p.segs_dev.data_ptr() if p.segs_dev is not None else None, p.n_seg, p.chunk, p.n_chunks, p.out_ptr, p.bad_ptr,
-            ctypes.byref(ctrl), p.ctrl_ptr, p.ctrl_dev.data_ptr(), next_times.data_ptr(), 0, p.workspace.data_ptr(),
-            p.workspace_bytes, dtype_code(y0.dtype), hip._stream()), "tdeq_error_norm_partial_ctrl")
+            ctypes.byref(ctrl), p.ctrl_ptr, p.ctrl_dev.data_ptr(), next_times.data_ptr(), 1 if state_in_dev else 0,
+            p.workspace.data_ptr(), p.workspace_bytes, dtype_code(y0.dtype), hip._stream()), "tdeq_error_norm_partial_ctrl")
         plan.pending = None
 
     def read_ctrl(self, plan: LowPlan):

@@ -1240,9 +1240,8 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
                                  int dtype, void* stream) {
     if (lp_dtype(dtype)) {
         // bf16 / fp16: the WHOLE error row in one launch (a row is rounded once: no partial sum to continue — err_partial
-        // must be NULL), then finalize + controller in the state's type; not in hipGraph mode
-        if (err_partial || !y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || state_in_dev)
-            return TDEQ_EINVAL;
+        // must be NULL), then finalize + controller in the state's type
+        if (err_partial || !y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace) return TDEQ_EINVAL;
         if (!ctrl || !out_ctrl || !ctrl_dev || !next_times || n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
         for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
         if (ctrl->n_times < 1 || ctrl->n_times > TDEQ_MAX_STAGE_TIMES || ctrl->n_norm_seg < 0 || ctrl->n_norm_seg > n_seg)
@@ -1253,7 +1252,7 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
         if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
         hipStream_t s = static_cast<hipStream_t>(stream);
         double* ws = static_cast<double*>(workspace);
-        const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times, 0};
+        const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times, state_in_dev ? 1 : 0};
         return dtype == TDEQ_BF16
                    ? lp_dispatch_error<lp::BF16>(nullptr, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s, &cb)
                    : lp_dispatch_error<lp::F16>(nullptr, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s, &cb);
@@ -1316,11 +1315,16 @@ int tdeq_step_controller(const double* sums, const double* nonfinite, const tdeq
 int tdeq_stage_combine_dev(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
                            const double* err_coef, int n_terms, const double* ctrl_dev, int64_t n, int dtype,
                            void* stream) {
-    if (!out || !y0 || !k || !coef || !ctrl_dev || n < 0 || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!out || !y0 || !k || !coef || !ctrl_dev || n < 0 || (bad_dtype(dtype) && !lp_dtype(dtype))) return TDEQ_EINVAL;
     if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS || (err_out && !err_coef)) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
+    if (lp_dtype(dtype) && err_out) return TDEQ_EINVAL;      // a 16-bit row is rounded once: no partial error to continue
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == TDEQ_BF16)
+        return lp_dispatch_combine<lp::BF16, 1>(out, nullptr, y0, k, coef, nullptr, n_terms, 0.0, n, nullptr, nullptr, 0, s, ctrl_dev);
+    if (dtype == TDEQ_F16)
+        return lp_dispatch_combine<lp::F16, 1>(out, nullptr, y0, k, coef, nullptr, n_terms, 0.0, n, nullptr, nullptr, 0, s, ctrl_dev);
     return dtype == TDEQ_F32
                ? launch_combine_dev<float>(out, err_out, y0, k, coef, err_coef, n_terms, ctrl_dev + 1, n, s)
                : launch_combine_dev<double>(out, err_out, y0, k, coef, err_coef, n_terms, ctrl_dev + 1, n, s);

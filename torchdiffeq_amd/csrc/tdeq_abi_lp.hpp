@@ -42,7 +42,7 @@ inline void lp_no_fill(lp::MapArgs<NIN, NOUT>& a, int64_t n) {
 template <typename S, int NT, int NOUT>
 int lp_launch_combine(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
                       const double* err_coef, double dt, int64_t n, void* fill_dst, const double* fill_vals, int n_fill,
-                      hipStream_t s) {
+                      hipStream_t s, const double* ctrl_dev = nullptr) {
     lp::MapArgs<NT + 1, NOUT> a;
     lp_no_fill(a, n);
     lp::CombineF<S, NT, NOUT> f;
@@ -50,12 +50,14 @@ int lp_launch_combine(void* out, void* err_out, const void* y0, const void* cons
     a.in[0] = static_cast<const uint16_t*>(y0);
     for (int j = 0; j < NT; ++j) {
         a.in[1 + j] = static_cast<const uint16_t*>(k[j]);
-        f.c[0][j] = S::rnd(rs<S>(coef[j]) * dtS);      // fl_S(fl_S(coef) * fl_S(dt)) — rk_common.py:79,201-205
-        if (NOUT == 2) f.c[NOUT - 1][j] = S::rnd(rs<S>(err_coef[j]) * dtS);
+        // fl_S(fl_S(coef) * fl_S(dt)) — rk_common.py:79,201-205; with ctrl_dev the kernel multiplies by the device's dt
+        f.c[0][j] = ctrl_dev ? rs<S>(coef[j]) : S::rnd(rs<S>(coef[j]) * dtS);
+        if (NOUT == 2) f.c[NOUT - 1][j] = ctrl_dev ? rs<S>(err_coef[j]) : S::rnd(rs<S>(err_coef[j]) * dtS);
     }
     a.out[0] = static_cast<uint16_t*>(out);
     if (NOUT == 2) a.out[NOUT - 1] = static_cast<uint16_t*>(err_out);
     f.add_y0 = 1u;
+    f.ctrl_dev = ctrl_dev;
     if (fill_dst) {
         a.fill_dst = static_cast<uint16_t*>(fill_dst);
         a.n_fill = n_fill;
@@ -67,9 +69,9 @@ int lp_launch_combine(void* out, void* err_out, const void* y0, const void* cons
 template <typename S, int NOUT>
 int lp_dispatch_combine(void* out, void* err_out, const void* y0, const void* const* k, const double* coef,
                         const double* err_coef, int nt, double dt, int64_t n, void* fill_dst, const double* fill_vals,
-                        int n_fill, hipStream_t s) {
+                        int n_fill, hipStream_t s, const double* ctrl_dev = nullptr) {
     switch (nt) {
-#define TDEQ_CASE(N) case N: return lp_launch_combine<S, N, NOUT>(out, err_out, y0, k, coef, err_coef, dt, n, fill_dst, fill_vals, n_fill, s);
+#define TDEQ_CASE(N) case N: return lp_launch_combine<S, N, NOUT>(out, err_out, y0, k, coef, err_coef, dt, n, fill_dst, fill_vals, n_fill, s, ctrl_dev);
         TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
         TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
 #undef TDEQ_CASE
@@ -90,9 +92,11 @@ int lp_launch_error(void* scaled, const void* y0, const void* y1, const void* co
     const float dtS = rs<S>(dt);
     for (int j = 0; j < NT; ++j) {
         a.k[j] = static_cast<const uint16_t*>(k[j]);
-        a.c[j] = S::rnd(rs<S>(coef[j]) * dtS);         // dt * c_error — rk_common.py:89
+        // dt * c_error — rk_common.py:89 (captured steps: the kernel multiplies by the device's dt)
+        a.c[j] = (cb && cb->state_in_dev) ? rs<S>(coef[j]) : S::rnd(rs<S>(coef[j]) * dtS);
         vec = vec && aligned16(k[j]);
     }
+    a.ctrl_dev = (cb && cb->state_in_dev) ? cb->ctrl_dev : nullptr;
     a.st = st;
     a.part_sumsq = ws;
     a.part_bad = ws + 2 * st.n_chunks;

@@ -146,8 +146,10 @@ struct MapArgs {
 };
 
 template <typename S, int NIN, int NOUT, bool VEC, typename F>
-__global__ __launch_bounds__(kBlock) void map_kernel(const MapArgs<NIN, NOUT> a, const F f) {
+__global__ __launch_bounds__(kBlock) void map_kernel(const MapArgs<NIN, NOUT> a, const F f_arg) {
     constexpr int L = VEC ? kVec : 1;
+    F f = f_arg;
+    f.prepare();          // (captured steps: coefficients times the step size the device controller left in memory)
     if (blockIdx.x == 0 && (int)threadIdx.x < a.n_fill) a.fill_dst[threadIdx.x] = a.fill_v[threadIdx.x];
     const int64_t ne = a.n / L;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -183,6 +185,10 @@ __global__ __launch_bounds__(kBlock) void map_kernel(const MapArgs<NIN, NOUT> a,
     }
 }
 
+struct NoPrepare {
+    __device__ __forceinline__ void prepare() {}
+};
+
 // A tableau row's sum, as `torch.sum(k[..., :n] * c, dim=-1)` evaluates it for a reduced-precision tensor: products
 // rounded to the storage type, accumulated in float32, ONE rounding of the sum (rk_common.py:79,89,366).
 template <typename S, int NT>
@@ -196,8 +202,18 @@ __device__ __forceinline__ float row_sum(const float* k, const float (&c)[NT]) {
 // in = {y0, k_0 .. k_{NT-1}};  out_o = [y0 +] row_sum(c_o)          (rk_common.py:79, 83-85, 89; misc.py:65)
 template <typename S, int NT, int NOUT>
 struct CombineF {
-    float c[NOUT][NT];     // fl_S(fl_S(coef) * fl_S(dt))
+    float c[NOUT][NT];     // fl_S(fl_S(coef) * fl_S(dt)) — or fl_S(coef) when the step size comes from device memory:
+    const double* ctrl_dev;   // non-null (captured steps): ctrl_dev[1] = sign * fl_S(dt) of the device-resident controller
     uint32_t add_y0;
+    __device__ __forceinline__ void prepare() {
+        if (ctrl_dev) {
+            const float dt = (float)ctrl_dev[1];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) c[o][j] = S::rnd(c[o][j] * dt);
+        }
+    }
     __device__ __forceinline__ void operator()(const float (&in)[NT + 1], float (&out)[NOUT]) const {
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
@@ -230,7 +246,7 @@ __device__ __forceinline__ QuarticF quartic(const float* in, const float (&cm)[N
 }
 
 template <typename S, int NT, int M>      // M evaluation points (x, x^2, x^3, x^4 pre-rounded by the host side)
-struct DenseEvalF {
+struct DenseEvalF : NoPrepare {
     float cm[NT];
     float dt, two_dt;
     float xp[M][4];
@@ -247,7 +263,7 @@ struct DenseEvalF {
 };
 
 template <typename S, int NT>
-struct DenseFitF {
+struct DenseFitF : NoPrepare {
     float cm[NT];
     float dt, two_dt;
     __device__ __forceinline__ void operator()(const float (&in)[NT + 4], float (&out)[5]) const {
@@ -259,7 +275,7 @@ struct DenseFitF {
 // 3/8-rule stages (rk_common.py:110-118): dt as FIRST operand is rounded to the storage type, `* _one_third` and
 // `* dt` as second operands are taken at float32, 0.125 and 3 are exact.   in = {y0, k1 .. k_STAGE}
 template <typename S, int STAGE>
-struct Rk4F {
+struct Rk4F : NoPrepare {
     float dt_first, dt_second, third;
     __device__ __forceinline__ void operator()(const float (&in)[STAGE + 1], float (&out)[1]) const {
         float r;
@@ -274,7 +290,7 @@ struct Rk4F {
 // Generic fixed-grid stages (rk_common.py:121-157): MODE 1 = y0 + (k0 * dt) * w0; MODE 0 = y0 + (w0 k0 + w1 k1 ...) * dt
 // with the sum a CHAIN of elementwise additions (each rounded), not a torch.sum.      in = {y0, k_0 .. k_{NT-1}}
 template <typename S, int NT, int MODE>
-struct FixedF {
+struct FixedF : NoPrepare {
     float w[NT];      // float32 (second operands)
     float dt;         // rounded to the storage type
     __device__ __forceinline__ void operator()(const float (&in)[NT + 1], float (&out)[1]) const {
@@ -291,7 +307,7 @@ struct FixedF {
 
 // out = x_0 w_0 + x_1 w_1 + ... (a chain, each step rounded)        in = {x_0 .. x_{NT-1}}
 template <typename S, int NT>
-struct WeightedF {
+struct WeightedF : NoPrepare {
     float w[NT];
     __device__ __forceinline__ void operator()(const float (&in)[NT], float (&out)[1]) const {
         float acc = S::rnd(in[0] * w[0]);
@@ -303,7 +319,7 @@ struct WeightedF {
 
 // out = y0 + slope * (y1 - y0)   (solvers.py:175-181)          in = {y0, y1}
 template <typename S>
-struct LerpF {
+struct LerpF : NoPrepare {
     float slope;
     __device__ __forceinline__ void operator()(const float (&in)[2], float (&out)[1]) const {
         out[0] = S::rnd(in[0] + S::rnd(slope * S::rnd(in[1] - in[0])));
@@ -355,7 +371,8 @@ struct ErrArgs {
     const uint16_t* y0;
     const uint16_t* y1;
     const uint16_t* k[NT];
-    float c[NT];           // fl_S(fl_S(c_error_j) * fl_S(dt))
+    float c[NT];           // fl_S(fl_S(c_error_j) * fl_S(dt)) — or fl_S(c_error_j) with ctrl_dev (captured steps)
+    const double* ctrl_dev;
     SegTable st;
     double* part_sumsq;    // [n_chunks]  sum of fl_S(|r|^2) — for a ONE-element segment |r| itself (see norm_term)
     double* part_bad;      // [n_chunks]
@@ -385,8 +402,14 @@ __global__ __launch_bounds__(kBlock) void error_norm_kernel(const ErrArgs<NT> a)
     const float rtol = S::rnd((float)seg.rtol), atol = S::rnd((float)seg.atol);
     const bool one = seg.numel == 1;
     double acc[2] = {0.0, 0.0};
+    float cc[NT];
+    {
+        const float dtd = a.ctrl_dev ? (float)a.ctrl_dev[1] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) cc[j] = a.ctrl_dev ? S::rnd(a.c[j] * dtd) : a.c[j];
+    }
     auto elem = [&](const float* kk, float y0, float y1) -> float {
-        const float e = row_sum<S, NT>(kk, a.c);
+        const float e = row_sum<S, NT>(kk, cc);
         const float tol = S::rnd(S::rnd(__builtin_fmaxf(__builtin_fabsf(y0), __builtin_fabsf(y1)) * rtol) + atol);
         const float r = S::rnd(e / tol);
         acc[0] += norm_term<S>(r, one);

@@ -298,7 +298,9 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         self._hold_pre = False      # auto mode: the eager step before the switch to replays enqueues no look-ahead stage
         self.hip_graph = wanted and device_ctrl and self._sync is None and y0.device.type == "cuda" and not self._vec_ctrl \
             and hasattr(self.kernels, "stage_combine_dev") \
-            and self.layout.total <= (_GRAPH_AUTO_MAX_ELEMENTS if auto else _GRAPH_MODE_MAX_ELEMENTS)
+            and self.layout.total <= (_GRAPH_AUTO_MAX_ELEMENTS if auto else _GRAPH_MODE_MAX_ELEMENTS) * \
+            (2 if (y0.element_size() == 2 and not auto) else 1)      # (16-bit states: the same bytes; at 2^23 elements the
+        #                                                               eager loop is still host-bound — six func dispatches)
         if wanted and not auto and not self.hip_graph and hip_graph is not None:
             # (asked for by option; a process-wide TDEQ_HIP_GRAPH=1 default applies where it can and stays silent)
             warnings.warn("{}: hip_graph=True needs a builtin norm, no step_t / jump_t, a tableau with a fused error "
