@@ -82,7 +82,6 @@ for case in range(n_cases):
     rtol, atol = (1e-5, 1e-7) if cdt == torch.complex64 else (1e-8, 1e-10)
     if LOW:
         rtol, atol = 2e-2, 2e-3
-        opts.pop("hip_graph", None)         # no captured steps for 16-bit states
         if "step_t" in opts:
             opts["step_t"] = opts["step_t"].float()
     lookahead = rng.random() < 0.7
