@@ -210,12 +210,23 @@ int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, 
 #define TDEQ_MULTI(P)                                                                                                   \
     if (timed) hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, P>), g, b, 0, s, ev_start, ev_stop, 0, a); \
     else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, P>), g, b, 0, s, a);
+#define TDEQ_MULTI_SHAPE(NO, AC)                                                                                              \
+    if (timed) hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, 0, NO, AC>), g, b, 0, s, ev_start, ev_stop, 0, a); \
+    else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, 0, NO, AC>), g, b, 0, s, a);
         switch (stream_policy(streams * n * (int64_t)sizeof(T))) {
             case 1: TDEQ_MULTI(1) break;
             case 2: TDEQ_MULTI(2) break;
             case 3: TDEQ_MULTI(3) break;
-            default: TDEQ_MULTI(0)
+            default:
+                // the in-cache regime (every dopri5 launch at cfg2): output count and prefix continuation as compile-time
+                // constants for the one- and two-output launches (tdeq_kernels.hpp multi_elem)
+                if (n_out == 1 && acc_in) { TDEQ_MULTI_SHAPE(1, 1) }
+                else if (n_out == 1) { TDEQ_MULTI_SHAPE(1, 0) }
+                else if (n_out == 2 && acc_in) { TDEQ_MULTI_SHAPE(2, 1) }
+                else if (n_out == 2) { TDEQ_MULTI_SHAPE(2, 0) }
+                else { TDEQ_MULTI(0) }
         }
+#undef TDEQ_MULTI_SHAPE
 #undef TDEQ_MULTI
     } else {
         hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);

@@ -219,7 +219,11 @@ struct MultiArgs {
     const double* dt_dev;             // non-null (hipGraph mode): c[][] holds fl_T(coef) and is multiplied by T(dt_dev[1]) here
 };
 
-template <typename T, int NT, typename E, int POLICY = 0>
+// NOUTC / ACCC: the launch's output count (1 or 2; 0 = read a.n_out) and whether it continues a carried prefix (1 / 0;
+// -1 = test a.acc_in) as COMPILE-TIME constants.  A wave of these kernels handles one 16-byte element per lane and lives
+// ~1 us; the scalar branches of the generic form (four output slots, the acc_in tests) are a measurable share of that.
+// (Also tried: the masks' bit tests compiled away for launches without structural zeros — no further gain, not kept.)
+template <typename T, int NT, typename E, int POLICY = 0, int NOUTC = 0, int ACCC = -1>
 __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int64_t i) {
     const E* __restrict__ y0 = reinterpret_cast<const E*>(a.y0);
     E kk[NT];
@@ -227,12 +231,14 @@ __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int
     for (int j = 0; j < NT; ++j) kk[j] = ld_stream<POLICY>(reinterpret_cast<const E*>(a.k[j]) + i);
     const E y = ld_stream<POLICY>(y0 + i);
     E acc0 = y;                       // placeholder when there is no acc_in (never read then)
-    if (a.acc_in) acc0 = ld_stream<POLICY>(reinterpret_cast<const E*>(a.acc_in) + i);
+    const bool has_acc = ACCC < 0 ? (a.acc_in != nullptr) : (ACCC == 1);
+    if (has_acc) acc0 = ld_stream<POLICY>(reinterpret_cast<const E*>(a.acc_in) + i);
+    constexpr int kOuts = NOUTC > 0 ? NOUTC : kMaxMultiOut;
 #pragma unroll
-    for (int o = 0; o < kMaxMultiOut; ++o) {
-        if (o < a.n_out) {
+    for (int o = 0; o < kOuts; ++o) {
+        if (NOUTC > 0 || o < a.n_out) {
             const uint32_t m = a.mask[o];
-            bool started = (o == 0) && a.acc_in;
+            bool started = (o == 0) && has_acc;
             E s = acc0;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -250,14 +256,15 @@ __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int
 
 // POLICY (VEC only): cache policy of the streams, see ld_stream / st_stream — chosen per launch by the host side
 // (tdeq_abi.hip stream_policy(): non-temporal for launches whose streams exceed the 256 MiB Infinity Cache).
-template <typename T, int NT, bool VEC, int POLICY = 0>
+template <typename T, int NT, bool VEC, int POLICY = 0, int NOUTC = 0, int ACCC = -1>
 __global__ __launch_bounds__(kBlock) void stage_combine_multi_kernel(const MultiArgs<T, NT> a) {
     using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
     constexpr int L = VEC ? VecOf<T>::L : 1;
     const int64_t ne = a.n / L;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const T dtT = a.dt_dev ? (T)a.dt_dev[1] : (T)1;          // ctrl_dev[1] = sign * T(dt) of the device-resident controller
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) multi_elem<T, NT, E, POLICY>(a, dtT, i);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
+        multi_elem<T, NT, E, POLICY, NOUTC, ACCC>(a, dtT, i);
     if (VEC) {   // scalar tail (n % L elements)
         const int64_t t = ne * L + threadIdx.x;
         if (blockIdx.x == 0 && t < a.n) multi_elem<T, NT, T>(a, dtT, t);
@@ -1133,16 +1140,33 @@ template <typename T, bool VEC, int POLICY = 0>
 __global__ __launch_bounds__(kBlock) void stage_combine_sel_kernel(const SelArgs<T> a) {
     using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
     constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    E* __restrict__ out = reinterpret_cast<E*>(a.out);
+    // The ACCEPTED pair is loaded before the controller's words are looked at: a wave of this kernel lives ~1 us, and
+    // waiting for the (scalar) load of {accept, dt'} before the first vector load can be issued was a serial third of it.
+    // Steps are accepted in the overwhelming majority; a rejected one re-loads from the other pair (one more read of 2 N
+    // words, then).  Same arithmetic either way.
+    const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    E y_spec{}, f_spec{};
+    if (i0 < ne) {
+        y_spec = ld_stream<POLICY>(reinterpret_cast<const E*>(a.y_acc) + i0);
+        f_spec = ld_stream<POLICY>(reinterpret_cast<const E*>(a.f_acc) + i0);
+    }
     const bool accept = a.ctrl_dev[0] != 0.0;
     const T c = a.coef * (T)a.ctrl_dev[1];
     const T* ys = accept ? a.y_acc : a.y_rej;
     const T* fs = accept ? a.f_acc : a.f_rej;
-    const int64_t ne = a.n / L;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
     const E* __restrict__ y = reinterpret_cast<const E*>(ys);
     const E* __restrict__ f = reinterpret_cast<const E*>(fs);
-    E* __restrict__ out = reinterpret_cast<E*>(a.out);
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
+    if (i0 < ne) {
+        if (!accept) {
+            y_spec = ld_stream<POLICY>(y + i0);
+            f_spec = ld_stream<POLICY>(f + i0);
+        }
+        st_stream<POLICY>(out + i0, y_spec + f_spec * c);
+    }
+    for (int64_t i = i0 + stride; i < ne; i += stride)      // (only beyond 65536 workgroups)
         st_stream<POLICY>(out + i, ld_stream<POLICY>(y + i) + ld_stream<POLICY>(f + i) * c);
     if (VEC) {
         const int64_t t = ne * L + threadIdx.x;
