@@ -85,7 +85,10 @@ int launch_combine(void* out, const void* y0, const void* const* k, const double
             case 1: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 1>), dim3(g), dim3(kBlock), 0, s, a); break;
             case 2: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 2>), dim3(g), dim3(kBlock), 0, s, a); break;
             case 3: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 3>), dim3(g), dim3(kBlock), 0, s, a); break;
-            default: hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 0>), dim3(g), dim3(kBlock), 0, s, a);
+            default:
+                if ((int64_t)g * kBlock * U >= n / L)
+                    hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 0, true>), dim3(g), dim3(kBlock), 0, s, a);
+                else hipLaunchKernelGGL((stage_combine_kernel<T, NT, U, true, 0>), dim3(g), dim3(kBlock), 0, s, a);
         }
     } else {
         const unsigned g = stream_grid(n, kBlock * U);
@@ -143,7 +146,10 @@ int launch_combine_err(void* out, void* err_out, const void* y0, const void* con
             case 1: hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 1>), g, b, 0, s, a); break;
             case 2: hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 2>), g, b, 0, s, a); break;
             case 3: hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 3>), g, b, 0, s, a); break;
-            default: hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 0>), g, b, 0, s, a);
+            default:
+                if ((int64_t)g.x * kBlock >= n / L)
+                    hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 0, true>), g, b, 0, s, a);
+                else hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, true, 0>), g, b, 0, s, a);
         }
     } else {
         hipLaunchKernelGGL((stage_combine_err_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
@@ -210,9 +216,11 @@ int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, 
 #define TDEQ_MULTI(P)                                                                                                   \
     if (timed) hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, P>), g, b, 0, s, ev_start, ev_stop, 0, a); \
     else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, P>), g, b, 0, s, a);
+        const bool one_pass = (int64_t)g.x * kBlock >= n / L;      // exact cover (always, up to 2^24 16-byte elements)
 #define TDEQ_MULTI_SHAPE(NO, AC)                                                                                              \
-    if (timed) hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, 0, NO, AC>), g, b, 0, s, ev_start, ev_stop, 0, a); \
-    else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, 0, NO, AC>), g, b, 0, s, a);
+    if (dt_dev || !one_pass) { TDEQ_MULTI(0) }                                                                                 \
+    else if (timed) hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, 0, NO, AC, false, true>), g, b, 0, s, ev_start, ev_stop, 0, a); \
+    else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, 0, NO, AC, false, true>), g, b, 0, s, a);
         switch (stream_policy(streams * n * (int64_t)sizeof(T))) {
             case 1: TDEQ_MULTI(1) break;
             case 2: TDEQ_MULTI(2) break;
@@ -435,8 +443,12 @@ int launch_error_partial(const void* partial, const void* y0, const void* y1, co
     a.part_sumsq = ws;
     a.part_bad = ws + 2 * st.n_chunks;
     const dim3 g((unsigned)st.n_chunks), b(kBlock);
+    // the common shape — one segment whose chunk_start is 0, dt folded by the host — has its own lean instantiation
+    const bool single = st.n_seg == 1 && st.inl[0].chunk_start == 0, lean = single && !dev_dt;
     if (vec && (stream_policy((int64_t)(NT + 3) * st.n_chunks * st.chunk * (int64_t)sizeof(T)) & 1))
         hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 1>), g, b, 0, s, a);
+    else if (vec && lean) hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 0, true, false>), g, b, 0, s, a);
+    else if (vec && single) hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 0, true, true>), g, b, 0, s, a);
     else if (vec) hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 0>), g, b, 0, s, a);
     else hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, false>), g, b, 0, s, a);
     const int e = check_launch();

@@ -121,12 +121,14 @@ struct CombineErrArgs {
     T e[NT];
 };
 
-template <typename T, int NT, bool VEC, int POLICY = 0>
+// ONEPASS (host: the grid covers the tensor once — every launch below kMaxGrid workgroups): no grid-stride loop, so no
+// gridDim read and no loop-carried 64-bit index — the first stream load issues ~20 instructions into the wave.
+template <typename T, int NT, bool VEC, int POLICY = 0, bool ONEPASS = false>
 __global__ __launch_bounds__(kBlock) void stage_combine_err_kernel(const CombineErrArgs<T, NT> a) {
     using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
     constexpr int L = VEC ? VecOf<T>::L : 1;
     const int64_t ne = a.c.n / L;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t stride = ONEPASS ? ne : (int64_t)gridDim.x * kBlock;
     const E* __restrict__ y0 = reinterpret_cast<const E*>(a.c.y0);
     E* __restrict__ out = reinterpret_cast<E*>(a.c.out);
     E* __restrict__ eo = reinterpret_cast<E*>(a.err_out);
@@ -156,11 +158,31 @@ __global__ __launch_bounds__(kBlock) void stage_combine_err_kernel(const Combine
 }
 
 // U independent 16-byte elements per lane and iteration => (NT+1)*U loads in flight per lane.
-template <typename T, int NT, int U, bool VEC, int POLICY = 0>
+template <typename T, int NT, int U, bool VEC, int POLICY = 0, bool ONEPASS = false>
 __global__ __launch_bounds__(kBlock) void stage_combine_kernel(const CombineArgs<T, NT> a) {
     using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
     constexpr int L = VEC ? VecOf<T>::L : 1;
     const int64_t ne = a.n / L;
+    if constexpr (ONEPASS && U == 1) {      // see stage_combine_err_kernel
+        const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (i < ne) {
+            E kk[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kk[j] = ld_stream<POLICY>(reinterpret_cast<const E*>(a.k[j]) + i);
+            st_stream<POLICY>(reinterpret_cast<E*>(a.out) + i,
+                              combine_one<T, NT, E>(a, ld_stream<POLICY>(reinterpret_cast<const E*>(a.y0) + i), kk));
+        }
+        if (VEC) {
+            const int64_t t = ne * L + threadIdx.x;
+            if (blockIdx.x == 0 && t < a.n) {
+                T kk[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) kk[j] = a.k[j][t];
+                a.out[t] = combine_one<T, NT, T>(a, a.y0[t], kk);
+            }
+        }
+        return;
+    }
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const E* __restrict__ y0 = reinterpret_cast<const E*>(a.y0);
     E* __restrict__ out = reinterpret_cast<E*>(a.out);
@@ -223,7 +245,9 @@ struct MultiArgs {
 // -1 = test a.acc_in) as COMPILE-TIME constants.  A wave of these kernels handles one 16-byte element per lane and lives
 // ~1 us; the scalar branches of the generic form (four output slots, the acc_in tests) are a measurable share of that.
 // (Also tried: the masks' bit tests compiled away for launches without structural zeros — no further gain, not kept.)
-template <typename T, int NT, typename E, int POLICY = 0, int NOUTC = 0, int ACCC = -1>
+// DEVDT: the step size comes from device memory (captured steps, a.dt_dev) — a compile-time property as well: the host
+// launches never pay for the dependent scalar load and the per-coefficient selects in their prologue.
+template <typename T, int NT, typename E, int POLICY = 0, int NOUTC = 0, int ACCC = -1, bool DEVDT = true>
 __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int64_t i) {
     const E* __restrict__ y0 = reinterpret_cast<const E*>(a.y0);
     E kk[NT];
@@ -243,7 +267,7 @@ __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if ((m >> j) & 1u) {
-                    const T cj = a.dt_dev ? a.c[o][j] * dtT : a.c[o][j];     // fl_T(fl_T(coef) * T(dt)) either way
+                    const T cj = (DEVDT && a.dt_dev) ? a.c[o][j] * dtT : a.c[o][j];     // fl_T(fl_T(coef) * T(dt)) either way
                     const E p = kk[j] * cj;
                     s = started ? s + p : p;
                     started = true;
@@ -256,15 +280,23 @@ __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int
 
 // POLICY (VEC only): cache policy of the streams, see ld_stream / st_stream — chosen per launch by the host side
 // (tdeq_abi.hip stream_policy(): non-temporal for launches whose streams exceed the 256 MiB Infinity Cache).
-template <typename T, int NT, bool VEC, int POLICY = 0, int NOUTC = 0, int ACCC = -1>
+// ONEPASS: the grid covers the tensor exactly once (always, up to 2^24 16-byte elements): no grid-stride loop, hence no
+// loop-carried pointers / masks in SGPRs (the generic form spilled them to VGPR lanes) and the loads are issued ~100
+// instructions earlier in a wave's life.
+template <typename T, int NT, bool VEC, int POLICY = 0, int NOUTC = 0, int ACCC = -1, bool DEVDT = true, bool ONEPASS = false>
 __global__ __launch_bounds__(kBlock) void stage_combine_multi_kernel(const MultiArgs<T, NT> a) {
     using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
     constexpr int L = VEC ? VecOf<T>::L : 1;
     const int64_t ne = a.n / L;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const T dtT = a.dt_dev ? (T)a.dt_dev[1] : (T)1;          // ctrl_dev[1] = sign * T(dt) of the device-resident controller
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
-        multi_elem<T, NT, E, POLICY, NOUTC, ACCC>(a, dtT, i);
+    const T dtT = (DEVDT && a.dt_dev) ? (T)a.dt_dev[1] : (T)1;      // ctrl_dev[1] = sign * T(dt) of the device-resident controller
+    if constexpr (ONEPASS) {
+        const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (i < ne) multi_elem<T, NT, E, POLICY, NOUTC, ACCC, DEVDT>(a, dtT, i);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
+            multi_elem<T, NT, E, POLICY, NOUTC, ACCC, DEVDT>(a, dtT, i);
+    }
     if (VEC) {   // scalar tail (n % L elements)
         const int64_t t = ne * L + threadIdx.x;
         if (blockIdx.x == 0 && t < a.n) multi_elem<T, NT, T>(a, dtT, t);
@@ -503,22 +535,38 @@ __device__ __forceinline__ void tol_accumulate(T e, T y0, T y1, T rtol, T atol, 
     bad += (__builtin_isfinite(y0) && __builtin_isfinite(y1)) ? 0.0 : 1.0;
 }
 
-template <typename T, int NT, bool VEC, int POLICY = 0>
+// SINGLE (host: st.n_seg == 1) reads the one segment's fields straight from the kernel arguments — scalar loads issued with
+// the rest of the kernarg.  The general path picks the segment by address (inline table or device table), which the compiler
+// turns into a VECTOR load from a generic pointer: one full memory latency in front of every wave's first stream load.
+// DEVDT = false (host-driven steps: dt folded into c[] by the host) drops the load of *dt_dev and its dependent multiplies.
+template <typename T, int NT, bool VEC, int POLICY = 0, bool SINGLE = false, bool DEVDT = true>
 __global__ __launch_bounds__(kBlock) void error_norm_partial_kernel(const ErrPartialArgs<T, NT> a) {
     using V = typename VecOf<T>::type;
     constexpr int L = VecOf<T>::L;
     __shared__ double red[2 * (kBlock / kWave)];
     const int64_t b = blockIdx.x;
-    const tdeq_segment seg = find_segment(a.st, b);
     const int64_t base = b * a.st.chunk;
-    int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+    int64_t valid;
+    T rtol, atol;
+    if constexpr (SINGLE) {
+        valid = a.st.inl[0].numel - b * a.st.chunk;
+        rtol = (T)a.st.inl[0].rtol;
+        atol = (T)a.st.inl[0].atol;
+    } else {
+        const tdeq_segment seg = find_segment(a.st, b);
+        valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+        rtol = (T)seg.rtol;
+        atol = (T)seg.atol;
+    }
     valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
-    const T rtol = (T)seg.rtol, atol = (T)seg.atol;
     T cc[NT > 0 ? NT : 1];
-    {
+    if constexpr (DEVDT) {
         const T dtT = a.dt_dev ? (T)*a.dt_dev : (T)1;
 #pragma unroll
         for (int j = 0; j < NT; ++j) cc[j] = a.dt_dev ? a.c[j] * dtT : a.c[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) cc[j] = a.c[j];
     }
     double acc[2] = {0.0, 0.0};
     int64_t t0 = 0;
