@@ -105,7 +105,10 @@ int lp_launch_error(void* scaled, const void* y0, const void* y1, const void* co
         if (vec) hipLaunchKernelGGL((lp::error_norm_kernel<S, NT, true, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((lp::error_norm_kernel<S, NT, false, true>), g, b, 0, s, a);
     } else {
-        if (vec) hipLaunchKernelGGL((lp::error_norm_kernel<S, NT, true, false>), g, b, 0, s, a);
+        const bool single = st.n_seg == 1 && st.inl[0].chunk_start == 0;
+        if (vec && single && !a.ctrl_dev) hipLaunchKernelGGL((lp::error_norm_kernel<S, NT, true, false, true, false>), g, b, 0, s, a);
+        else if (vec && single) hipLaunchKernelGGL((lp::error_norm_kernel<S, NT, true, false, true, true>), g, b, 0, s, a);
+        else if (vec) hipLaunchKernelGGL((lp::error_norm_kernel<S, NT, true, false>), g, b, 0, s, a);
         else hipLaunchKernelGGL((lp::error_norm_kernel<S, NT, false, false>), g, b, 0, s, a);
     }
     const int e = check_launch();

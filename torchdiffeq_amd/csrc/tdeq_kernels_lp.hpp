@@ -390,30 +390,49 @@ __device__ __forceinline__ double norm_term(float q, bool one) {
 
 // err = row_sum(c_error * dt); tol = atol + rtol * max(|y0|, |y1|) with rtol, atol rounded to the storage type and the
 // product and the sum rounded (misc.py:81); r = err / tol rounded (misc.py:82); norm term = fl_S(|r|^2) (misc.py:22).
-template <typename S, int NT, bool VEC, bool WRITE>
+// SINGLE (host: one segment starting at chunk 0): the segment's fields are scalar loads from the kernel arguments;
+// DEVDT = false (coefficients already multiplied by dt): no dependent load of the device's dt — see error_norm_partial_kernel.  A wave runs
+// two 8-element iterations, so what precedes the first stream load is a sizeable part of its life.
+template <typename S, int NT, bool VEC, bool WRITE, bool SINGLE = false, bool DEVDT = true>
 __global__ __launch_bounds__(kBlock) void error_norm_kernel(const ErrArgs<NT> a) {
     constexpr int L = VEC ? kVec : 1;
     __shared__ double red[2 * (kBlock / kWave)];
     const int64_t b = blockIdx.x;
-    const tdeq_segment seg = find_segment(a.st, b);
     const int64_t base = b * a.st.chunk;
-    int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+    int64_t valid;
+    float rtol, atol;
+    bool one;
+    if constexpr (SINGLE) {
+        valid = a.st.inl[0].numel - b * a.st.chunk;
+        rtol = S::rnd((float)a.st.inl[0].rtol);
+        atol = S::rnd((float)a.st.inl[0].atol);
+        one = a.st.inl[0].numel == 1;
+    } else {
+        const tdeq_segment seg = find_segment(a.st, b);
+        valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+        rtol = S::rnd((float)seg.rtol);
+        atol = S::rnd((float)seg.atol);
+        one = seg.numel == 1;
+    }
     valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
-    const float rtol = S::rnd((float)seg.rtol), atol = S::rnd((float)seg.atol);
-    const bool one = seg.numel == 1;
-    double acc[2] = {0.0, 0.0};
+    double acc = 0.0;
+    uint32_t n_bad = 0;          // at most chunk / kBlock per lane
     float cc[NT];
-    {
+    if constexpr (!DEVDT) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) cc[j] = a.c[j];
+    } else {
         const float dtd = a.ctrl_dev ? (float)a.ctrl_dev[1] : 1.0f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) cc[j] = a.ctrl_dev ? S::rnd(a.c[j] * dtd) : a.c[j];
     }
-    auto elem = [&](const float* kk, float y0, float y1) -> float {
+    // `single` = the segment is ONE element: only ever true in the scalar tail (such a segment has no 8-element group)
+    auto elem = [&](const float* kk, float y0, float y1, bool single) -> float {
         const float e = row_sum<S, NT>(kk, cc);
         const float tol = S::rnd(S::rnd(__builtin_fmaxf(__builtin_fabsf(y0), __builtin_fabsf(y1)) * rtol) + atol);
         const float r = S::rnd(e / tol);
-        acc[0] += norm_term<S>(r, one);
-        acc[1] += (__builtin_isfinite(y0) && __builtin_isfinite(y1)) ? 0.0 : 1.0;
+        acc += norm_term<S>(r, single);
+        n_bad += (__builtin_isfinite(y0) && __builtin_isfinite(y1)) ? 0u : 1u;
         return r;
     };
     const int64_t nv = valid / L;
@@ -428,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void error_norm_kernel(const ErrArgs<NT> a)
             float kq[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) kq[j] = kk[j][q];
-            r[q] = elem(kq, y0[q], y1[q]);
+            r[q] = elem(kq, y0[q], y1[q], VEC ? false : one);
         }
         if (WRITE) store_elems<S, L>(a.scaled + base, i, r);
     }
@@ -438,16 +457,17 @@ __global__ __launch_bounds__(kBlock) void error_norm_kernel(const ErrArgs<NT> a)
             float kq[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) kq[j] = S::ld(a.k[j][base + t]);
-            const float r = elem(kq, S::ld(a.y0[base + t]), S::ld(a.y1[base + t]));
+            const float r = elem(kq, S::ld(a.y0[base + t]), S::ld(a.y1[base + t]), one);
             if (WRITE) a.scaled[base + t] = (uint16_t)S::st(r);
         }
     }
     if (WRITE && a.st.n_seg > 1)   // zero the padding of a segmented layout
         for (int64_t t = valid + threadIdx.x; t < a.st.chunk; t += kBlock) a.scaled[base + t] = 0;
-    block_sum<2>(acc, red);
+    double sums[2] = {acc, (double)n_bad};
+    block_sum<2>(sums, red);
     if (threadIdx.x == 0) {
-        a.part_sumsq[b] = acc[0];
-        a.part_bad[b] = acc[1];
+        a.part_sumsq[b] = sums[0];
+        a.part_bad[b] = sums[1];
     }
 }
 
