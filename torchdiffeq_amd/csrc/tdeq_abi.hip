@@ -217,10 +217,14 @@ int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, 
     if (timed) hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, P>), g, b, 0, s, ev_start, ev_stop, 0, a); \
     else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, P>), g, b, 0, s, a);
         const bool one_pass = (int64_t)g.x * kBlock >= n / L;      // exact cover (always, up to 2^24 16-byte elements)
-#define TDEQ_MULTI_SHAPE(NO, AC)                                                                                              \
-    if (dt_dev || !one_pass) { TDEQ_MULTI(0) }                                                                                 \
-    else if (timed) hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, 0, NO, AC, false, true>), g, b, 0, s, ev_start, ev_stop, 0, a); \
-    else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, 0, NO, AC, false, true>), g, b, 0, s, a);
+#define TDEQ_MULTI_LAUNCH(...)                                                                                                \
+    if (timed) hipExtLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, 0, __VA_ARGS__>), g, b, 0, s, ev_start, ev_stop, 0, a); \
+    else hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, true, 0, __VA_ARGS__>), g, b, 0, s, a);
+        // (output count, prefix continuation, dt from device memory — captured steps —, one pass)
+#define TDEQ_MULTI_SHAPE(NO, AC)                                       \
+    if (!one_pass) { TDEQ_MULTI_LAUNCH(NO, AC) }                       \
+    else if (dt_dev) { TDEQ_MULTI_LAUNCH(NO, AC, true, true) }         \
+    else { TDEQ_MULTI_LAUNCH(NO, AC, false, true) }
         switch (stream_policy(streams * n * (int64_t)sizeof(T))) {
             case 1: TDEQ_MULTI(1) break;
             case 2: TDEQ_MULTI(2) break;
@@ -235,6 +239,7 @@ int launch_combine_multi(const tdeq_multi_out* outs, int n_out, const void* y0, 
                 else { TDEQ_MULTI(0) }
         }
 #undef TDEQ_MULTI_SHAPE
+#undef TDEQ_MULTI_LAUNCH
 #undef TDEQ_MULTI
     } else {
         hipLaunchKernelGGL((stage_combine_multi_kernel<T, NT, false>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a);
