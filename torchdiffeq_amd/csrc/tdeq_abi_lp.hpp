@@ -20,12 +20,22 @@ inline bool lp_aligned(const lp::MapArgs<NIN, NOUT>& a) {
     return vec;
 }
 
-template <typename S, int NIN, int NOUT, typename F>
-int lp_launch_map(lp::MapArgs<NIN, NOUT>& a, const F& f, hipStream_t s) {
-    if (lp_aligned(a))
-        hipLaunchKernelGGL((lp::map_kernel<S, NIN, NOUT, true, F>), dim3(stream_grid(a.n / lp::kVec, kBlock)), dim3(kBlock), 0, s, a, f);
-    else
+// LEANABLE (the stage combines): the common launch shapes get map_kernel's LEAN instantiations — see there.
+template <typename S, int NIN, int NOUT, typename F, bool LEANABLE = false>
+int lp_launch_map(lp::MapArgs<NIN, NOUT>& a, const F& f, hipStream_t s, bool needs_prepare = true) {
+    if (lp_aligned(a)) {
+        const dim3 g(stream_grid(a.n / lp::kVec, kBlock)), b(kBlock);
+        if constexpr (LEANABLE) {
+            if ((int64_t)g.x * kBlock >= a.n / lp::kVec && a.n_fill == 0 && a.n_live == NOUT) {
+                if (needs_prepare) hipLaunchKernelGGL((lp::map_kernel<S, NIN, NOUT, true, F, true, true>), g, b, 0, s, a, f);
+                else hipLaunchKernelGGL((lp::map_kernel<S, NIN, NOUT, true, F, true, false>), g, b, 0, s, a, f);
+                return check_launch();
+            }
+        }
+        hipLaunchKernelGGL((lp::map_kernel<S, NIN, NOUT, true, F>), g, b, 0, s, a, f);
+    } else {
         hipLaunchKernelGGL((lp::map_kernel<S, NIN, NOUT, false, F>), dim3(stream_grid(a.n, kBlock)), dim3(kBlock), 0, s, a, f);
+    }
     return check_launch();
 }
 
@@ -56,14 +66,13 @@ int lp_launch_combine(void* out, void* err_out, const void* y0, const void* cons
     }
     a.out[0] = static_cast<uint16_t*>(out);
     if (NOUT == 2) a.out[NOUT - 1] = static_cast<uint16_t*>(err_out);
-    f.add_y0 = 1u;
     f.ctrl_dev = ctrl_dev;
     if (fill_dst) {
         a.fill_dst = static_cast<uint16_t*>(fill_dst);
         a.n_fill = n_fill;
         for (int i = 0; i < n_fill; ++i) a.fill_v[i] = (uint16_t)S::st((float)fill_vals[i]);
     }
-    return lp_launch_map<S, NT + 1, NOUT>(a, f, s);
+    return lp_launch_map<S, NT + 1, NOUT, lp::CombineF<S, NT, NOUT>, true>(a, f, s, ctrl_dev != nullptr);
 }
 
 template <typename S, int NOUT>

@@ -103,13 +103,21 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kVec = 8;      // storage elements per 16-byte lane access
 
 template <typename S, int L>
-__device__ __forceinline__ void load_elems(const uint16_t* __restrict__ p, int64_t i, float (&v)[L]) {
+__device__ __forceinline__ void unpack_elems(const u32x4& w, float (&v)[L]) {
     if constexpr (L == kVec) {
-        const u32x4 w = reinterpret_cast<const u32x4*>(p)[i];
         S::unpack2(w.x, v[0], v[1]);
         S::unpack2(w.y, v[2], v[3]);
         S::unpack2(w.z, v[4], v[5]);
         S::unpack2(w.w, v[6], v[7]);
+    } else {
+        v[0] = S::ld(w.x & 0xffffu);
+    }
+}
+
+template <typename S, int L>
+__device__ __forceinline__ void load_elems(const uint16_t* __restrict__ p, int64_t i, float (&v)[L]) {
+    if constexpr (L == kVec) {
+        unpack_elems<S, L>(reinterpret_cast<const u32x4*>(p)[i], v);
     } else {
         v[0] = S::ld(p[i]);
     }
@@ -145,18 +153,16 @@ struct MapArgs {
     int n_fill;
 };
 
-template <typename S, int NIN, int NOUT, bool VEC, typename F>
+// LEAN (host: the grid covers the tensor once, no side fill, every output live) and PREP = false (the functor's
+// prepare() is a no-op for this launch: coefficients already hold the step size) are compile-time properties of the common
+// launches: the generic kernel reads its arguments in four dependent rounds of scalar loads before the first stream load —
+// a sizeable part of a wave that handles one 16-byte access per stream.
+template <typename S, int NIN, int NOUT, bool VEC, typename F, bool LEAN = false, bool PREP = true>
 __global__ __launch_bounds__(kBlock) void map_kernel(const MapArgs<NIN, NOUT> a, const F f_arg) {
     constexpr int L = VEC ? kVec : 1;
     F f = f_arg;
-    f.prepare();          // (captured steps: coefficients times the step size the device controller left in memory)
-    if (blockIdx.x == 0 && (int)threadIdx.x < a.n_fill) a.fill_dst[threadIdx.x] = a.fill_v[threadIdx.x];
     const int64_t ne = a.n / L;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
-        float v[NIN][L];
-#pragma unroll
-        for (int j = 0; j < NIN; ++j) load_elems<S, L>(a.in[j], i, v[j]);
+    auto compute_store = [&](int64_t i, const float (&v)[NIN][L]) {
         float r[NOUT][L];
 #pragma unroll
         for (int q = 0; q < L; ++q) {
@@ -169,7 +175,34 @@ __global__ __launch_bounds__(kBlock) void map_kernel(const MapArgs<NIN, NOUT> a,
         }
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
-            if (o < a.n_live) store_elems<S, L>(a.out[o], i, r[o]);
+            if (LEAN || o < a.n_live) store_elems<S, L>(a.out[o], i, r[o]);
+    };
+    if constexpr (LEAN) {
+        // stream loads first; the functor's own (dependent, scalar) load of the device's step size overlaps them
+        static_assert(!LEAN || VEC, "the lean instantiations are 16-byte launches");
+        const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        u32x4 w[NIN];        // (lanes past the end never read theirs)
+        if (i < ne) {
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) w[j] = reinterpret_cast<const u32x4*>(a.in[j])[i];
+        }
+        if constexpr (PREP) f.prepare();
+        if (i < ne) {
+            float v[NIN][L];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) unpack_elems<S, L>(w[j], v[j]);
+            compute_store(i, v);
+        }
+    } else {
+        if constexpr (PREP) f.prepare();   // (captured steps: coefficients times the step size the device controller left in memory)
+        if (blockIdx.x == 0 && (int)threadIdx.x < a.n_fill) a.fill_dst[threadIdx.x] = a.fill_v[threadIdx.x];
+        const int64_t stride = (int64_t)gridDim.x * kBlock;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
+            float v[NIN][L];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) load_elems<S, L>(a.in[j], i, v[j]);
+            compute_store(i, v);
+        }
     }
     if (VEC) {   // scalar tail (n % 8 elements)
         const int64_t t = ne * L + threadIdx.x;
@@ -180,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void map_kernel(const MapArgs<NIN, NOUT> a,
             f(x, y);
 #pragma unroll
             for (int o = 0; o < NOUT; ++o)
-                if (o < a.n_live) a.out[o][t] = (uint16_t)S::st(y[o]);
+                if (LEAN || o < a.n_live) a.out[o][t] = (uint16_t)S::st(y[o]);
         }
     }
 }
@@ -204,7 +237,6 @@ template <typename S, int NT, int NOUT>
 struct CombineF {
     float c[NOUT][NT];     // fl_S(fl_S(coef) * fl_S(dt)) — or fl_S(coef) when the step size comes from device memory:
     const double* ctrl_dev;   // non-null (captured steps): ctrl_dev[1] = sign * fl_S(dt) of the device-resident controller
-    uint32_t add_y0;
     __device__ __forceinline__ void prepare() {
         if (ctrl_dev) {
             const float dt = (float)ctrl_dev[1];
@@ -218,7 +250,7 @@ struct CombineF {
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
             const float s = row_sum<S, NT>(in + 1, c[o]);
-            out[o] = ((add_y0 >> o) & 1u) ? S::rnd(in[0] + s) : s;
+            out[o] = o == 0 ? S::rnd(in[0] + s) : s;      // output 0 = the stage input / y1, output 1 = the partial error row
         }
     }
 };
@@ -342,14 +374,30 @@ struct SelArgs {
 template <typename S, bool VEC>
 __global__ __launch_bounds__(kBlock) void sel_kernel(const SelArgs a) {
     constexpr int L = VEC ? kVec : 1;
+    const int64_t ne = a.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    // the ACCEPTED pair is loaded before the controller's words are looked at (stage_combine_sel_kernel, tdeq_kernels.hpp);
+    // a rejected step re-loads from the other pair
+    const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float y[L], f[L], r[L];
+    if (i0 < ne) {
+        load_elems<S, L>(a.y_acc, i0, y);
+        load_elems<S, L>(a.f_acc, i0, f);
+    }
     const bool accept = a.ctrl_dev[0] != 0.0;
     const float c = S::rnd(a.coef * (float)a.ctrl_dev[1]);
     const uint16_t* ys = accept ? a.y_acc : a.y_rej;
     const uint16_t* fs = accept ? a.f_acc : a.f_rej;
-    const int64_t ne = a.n / L;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
-        float y[L], f[L], r[L];
+    if (i0 < ne) {
+        if (!accept) {
+            load_elems<S, L>(ys, i0, y);
+            load_elems<S, L>(fs, i0, f);
+        }
+#pragma unroll
+        for (int q = 0; q < L; ++q) r[q] = S::rnd(y[q] + S::rnd(f[q] * c));
+        store_elems<S, L>(a.out, i0, r);
+    }
+    for (int64_t i = i0 + stride; i < ne; i += stride) {      // (only beyond 65536 workgroups)
         load_elems<S, L>(ys, i, y);
         load_elems<S, L>(fs, i, f);
 #pragma unroll
