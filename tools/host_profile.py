@@ -1,68 +1,52 @@
-"""Where does the HOST time of one dopri5 trial step go?  (run on the GPU box)
-Wraps the kernel interface and func with perf_counter timers; prints per-step averages in microseconds."""
+#!/usr/bin/env python
+"""Where the HOST time of an eager trial step goes (GPU box): cProfile of dopri5 trial steps on a state small enough
+(8192 x 128 fp32, or the bf16 headline shape) that the loop is host-bound.
+
+    python tools/host_profile.py [fp32|bf16] [steps]"""
+import cProfile
+import io
 import os
+import pstats
 import sys
 import time
-from collections import defaultdict
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from torchdiffeq_amd.misc import OdeFunc, StateLayout, rms_norm  # noqa: E402
-from torchdiffeq_amd.solvers import Dopri5Solver  # noqa: E402
-
-acc = defaultdict(float)
-
-
-def timed(name, fn):
-    def w(*a, **k):
-        t = time.perf_counter()
-        r = fn(*a, **k)
-        acc[name] += time.perf_counter() - t
-        return r
-    return w
-
-
-def main():
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    dev = torch.device("cuda:0")
-    A, y0 = bench.make_problem(dev)
-    At = A.T.contiguous()
-    field = timed("func(matmul dispatch)", lambda t, y: y @ At)
-    func = OdeFunc(field, StateLayout([y0.shape], False), 1.0, y0.dtype, dev)
-    solver = Dopri5Solver(func=func, y0=y0.reshape(-1), rtol=1e-7, atol=1e-9, norm=rms_norm)
-    k = solver.kernels
-
-    class K:
-        pass
-    kk = K()
-    for name in dir(k):       # every kernel entry (incl. the look-ahead pair and read_ctrl) gets a timer
-        if name.startswith("_"):
-            continue
-        attr = getattr(k, name)
-        setattr(kk, name, timed(name, attr) if callable(attr) else attr)
-    solver.kernels = kk
-    solver.ops.k = kk
-    with torch.no_grad():
-        solver._before_integrate([0.0])
-        solver._t_end = float("inf")          # mid-solve steps: look-ahead first stage active (as in bench.py)
-        for _ in range(20):
-            solver._adaptive_step()
-        torch.cuda.synchronize()
-        acc.clear()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            solver._adaptive_step()
-        torch.cuda.synchronize()
-        total = time.perf_counter() - t0
-    print(f"step wall: {1e6*total/steps:.1f} us")
-    s = 0.0
-    for name, v in sorted(acc.items(), key=lambda kv: -kv[1]):
-        print(f"  {name:28s} {1e6*v/steps:8.1f} us/step")
-        s += v
-    print(f"  {'other python in the step':28s} {1e6*(total-s)/steps:8.1f} us/step")
-
 
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    dev = torch.device("cuda", 0)
+    A, y0 = bench.make_problem(dev)
+    if which == "bf16":
+        A = (A + 0.1 * torch.eye(A.shape[0], device=dev)).to(torch.bfloat16)
+        y0 = y0.to(torch.bfloat16)
+        kw = dict(rtol=1e-2, atol=1e-3)
+    else:
+        y0 = y0[:8192].contiguous()
+        kw = {}
+    At = A.T.contiguous()
+    with torch.no_grad():
+        solver = bench.make_stepper(lambda t, y: y @ At, y0, **kw)
+        for _ in range(20):
+            solver._trial_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            solver._trial_step()
+        torch.cuda.synchronize()
+        print("ms_per_step", 1e3 * (time.perf_counter() - t0) / steps)
+        solver = bench.make_stepper(lambda t, y: y @ At, y0, **kw)
+        for _ in range(20):
+            solver._trial_step()
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(steps):
+            solver._trial_step()
+        pr.disable()
+        torch.cuda.synchronize()
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
+    print(s.getvalue()[:6000])
