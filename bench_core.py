@@ -127,7 +127,11 @@ class EventTimedKernels:
         if self.armed and acc_in is None and len(ks) + 1 + len(outs) == self._nt + 2:
             ev = self._take()
             if ev is not None:
-                self.kernel = f"stage_combine_multi_kernel<float, {len(ks)}, true> ({len(outs)} outputs)"
+                # the instantiation this launch resolves to (csrc/tdeq_abi.hip launch_combine_multi: default cache policy,
+                # output count / no prefix / dt folded by the host / one pass as compile-time constants) — the name the
+                # rocprofv3 summary under profiles/ lists
+                shape = f", 0, {len(outs)}, 0, false, true" if len(outs) <= 2 else ""
+                self.kernel = f"stage_combine_multi_kernel<float, {len(ks)}, true{shape}> ({len(outs)} outputs)"
                 return self._inner.stage_combine_multi(outs, rows, y0, acc_in, ks, dt, events=ev)
         return self._inner.stage_combine_multi(outs, rows, y0, acc_in, ks, dt)
 
@@ -284,7 +288,7 @@ def cold_dominant_kernel(kern, n, device, sets=4, launches=24, carried=False):
     ach = bytes_per_launch / (avg * 1e-3) / 1e9
     return {"achieved": ach, "frac": ach / HBM_PEAK_GBPS, "avg_launch_ms": avg, "launches_timed": len(ms),
             "buffer_sets": sets, "working_set_bytes": sets * 7 * n * 4,
-            "kernel": "stage_combine_multi_kernel<float, 4, true> (2 outputs)" if carried
+            "kernel": "stage_combine_multi_kernel<float, 4, true, 0, 2, 0, false, true> (2 outputs)" if carried
                       else "stage_combine_kernel<float, 5, 1, true>",
             "note": "same kernel, rotating buffer sets larger than the 256 MiB Infinity Cache: all reads from HBM"}
 
