@@ -121,7 +121,7 @@ def contract_line(out, extras_path=None):
     if isinstance(rf, dict):
         cold = rf.get("cold") if isinstance(rf.get("cold"), dict) else {}
         line["roofline"] = {
-            "bound": rf.get("bound"), "kernel": _short(rf.get("kernel"), 72), "achieved": _num(rf.get("achieved")),
+            "bound": rf.get("bound"), "kernel": _short(rf.get("kernel"), 112), "achieved": _num(rf.get("achieved")),
             "peak": rf.get("peak"), "unit": rf.get("unit"),
             # frac = IN SITU: algorithmic bytes / this kernel's average launch duration inside the timed region (the
             # figure the committed rocprofv3 --stats summary must agree with; the launch's inputs were just written by
