@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 19
+#define TDEQ_ABI_VERSION 20
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 /* interleaved (re, im) complex states — accepted by the NORM entry points only (tdeq_error_norm, tdeq_error_norm_partial[_ctrl],
@@ -168,9 +168,12 @@ int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void
  * the other one may be 0-dim (`*_vec` NULL, value in `*_scalar`); at least one must be dimensioned.  Promotion as ATen
  * does it: rtol[i] * max(|y0|,|y1|) in fp64 when rtol is dimensioned, in T (rtol cast to T) when it is 0-dim; the sum
  * with atol, err / tol and the sum of squares in fp64.  The segment table's rtol / atol are ignored.
+ * `err_partial` (nullable, ABI 20): the error row's leading run as tdeq_stage_combine_err summed it —
+ * err = (err_partial + c_0 k_0) + ... over the n_terms >= 0 remaining stages, as tdeq_error_norm_partial; NULL: the whole row
+ * from k (n_terms >= 1).
  */
-int tdeq_error_norm_vec(const void* y0, const void* y1, const void* const* k, const double* coef, int n_terms, double dt,
-                        const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
+int tdeq_error_norm_vec(const void* err_partial, const void* y0, const void* y1, const void* const* k, const double* coef,
+                        int n_terms, double dt, const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
                         const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
                         double* out_sumsq, double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
                         void* stream);
@@ -181,7 +184,8 @@ int tdeq_error_norm_vec(const void* y0, const void* y1, const void* const* k, co
  * tolerance is dimensioned —, accept flag, next step size, and the next trial step's stage times in T; `out_ctrl`,
  * `ctrl_dev`, `next_times` as there.  Lets the look-ahead first stage (tdeq_stage_combine_sel) follow.
  */
-int tdeq_error_norm_vec_ctrl(const void* y0, const void* y1, const void* const* k, const double* coef, int n_terms, double dt,
+int tdeq_error_norm_vec_ctrl(const void* err_partial, const void* y0, const void* y1, const void* const* k,
+                             const double* coef, int n_terms, double dt,
                              const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
                              const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
                              double* out_sumsq, double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl,

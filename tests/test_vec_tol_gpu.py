@@ -48,6 +48,34 @@ def test_kernel_equals_the_references_broadcast_expression(dtype, n, form):
     assert sumsq[0] == pytest.approx(float(q.abs().pow(2).sum()), rel=1e-12) and bad == [0.0]
 
 
+@pytest.mark.parametrize("n_lead", [6, 5, 4])
+@pytest.mark.parametrize("n", [1031, 5000])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_kernel_continues_a_partial_error_row(dtype, n, n_lead):
+    """ABI 20: `err_partial` — the leading run of the error row as tdeq_stage_combine_err sums it — continued by the vector-
+    tolerance kernel over the remaining 0 / 1 / 2 stages: the same left-to-right sum, so the per-segment sums equal those of
+    the whole-row launch to the last bit, with and without the device controller."""
+    g = torch.Generator().manual_seed(n + n_lead)
+    r = lambda: torch.randn(n, generator=g, dtype=torch.float64).to(dtype).cuda()
+    y0, ks = r(), [r() for _ in range(6)]
+    rtol_v = (torch.rand(n, generator=g, dtype=torch.float64) * 1e-3 + 1e-6).cuda()
+    atol_v = (torch.rand(n, generator=g, dtype=torch.float64) * 1e-5 + 1e-8).cuda()
+    kern = _native.get_kernels(torch.device("cuda:0"), dtype)
+    plan = kern.make_plan([(0, n, 0.0, 1.0)], n, 1024, torch.device("cuda:0"))
+    dt = 0.0371
+    y1, part = torch.empty_like(y0), torch.empty_like(y0)
+    kern.stage_combine_err(y1, part, y0, ks[:n_lead], COEFS[:n_lead], COEFS[1:n_lead + 1], dt)
+    err_coefs = COEFS[1:7]
+    kern.error_norm_vec(plan, y0, y1, ks, err_coefs, dt, rtol_v, atol_v)
+    whole = kern.read_norms(plan)
+    kern.error_norm_vec(plan, y0, y1, ks[n_lead:], err_coefs[n_lead:], dt, rtol_v, atol_v, partial=part)
+    split = kern.read_norms(plan)
+    assert split[0] == whole[0] and split[2] == whole[2] == [0.0]
+    y1[n // 2] = float("nan")
+    kern.error_norm_vec(plan, y0, y1, ks[n_lead:], err_coefs[n_lead:], dt, 3e-4, atol_v, partial=part)
+    assert kern.read_norms(plan)[2] == [1.0]
+
+
 def test_solve_with_vector_tolerances_takes_the_fused_kernel(monkeypatch):
     """A no-grad dopri5 solve with a per-element rtol: every trial step's error ratio comes from tdeq_error_norm_vec[_ctrl] (the
     raw-error route `error_scaled` is never taken), and the steps are those of the torch-op evaluation of the same

@@ -18,7 +18,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 19
+TDEQ_ABI_VERSION = 20
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_C64, TDEQ_C128 = 2, 3        # interleaved complex: the norm entry points only (include/tdeq_hip.h)
 TDEQ_BF16, TDEQ_F16 = 4, 5        # reduced-precision states: the entry points of the host-driven step (LowPrecisionHipKernels)
@@ -75,12 +75,12 @@ ABI_SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
-    "tdeq_error_norm_vec": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
+    "tdeq_error_norm_vec": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
                                            ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p,
                                            ctypes.c_double, ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int,
                                            ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
-    "tdeq_error_norm_vec_ctrl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
+    "tdeq_error_norm_vec_ctrl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp, _c_double_p, ctypes.c_int,
                                                 ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p,
                                                 ctypes.c_double, ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int,
                                                 ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
@@ -396,20 +396,25 @@ class HipKernels:
                                         plan.workspace.data_ptr(), plan.workspace_bytes,
                                         dtype_code(y0.dtype), self._stream()), "tdeq_error_norm")
 
-    def error_norm_vec(self, plan: NormPlan, y0, y1, ks, coefs, dt: float, rtol, atol) -> None:
+    vec_partial = True      # error_norm_vec[_ctrl] continue a partial error row (`partial=`) like error_norm_partial
+
+    def error_norm_vec(self, plan: NormPlan, y0, y1, ks, coefs, dt: float, rtol, atol, partial=None) -> None:
         """`error_norm` with per-element tolerances (tdeq_error_norm_vec): `rtol` / `atol` = an fp64 device vector over the
-        flat padded state, or a host float for a 0-dim tolerance (at least one vector)."""
+        flat padded state, or a host float for a 0-dim tolerance (at least one vector).  `partial`: the error row's leading
+        run from `stage_combine_err`; `ks` / `coefs` are the remaining stages then."""
         ptrs, cf, n = self._terms(ks, coefs)
         dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
         rv, rs = (rtol.data_ptr(), 0.0) if isinstance(rtol, torch.Tensor) else (None, float(rtol))
         av, as_ = (atol.data_ptr(), 0.0) if isinstance(atol, torch.Tensor) else (None, float(atol))
         self._arm(plan, 1)
-        _check(self.lib.tdeq_error_norm_vec(y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, rv, rs, av, as_, plan.segs, dev,
+        pp = None if partial is None else partial.data_ptr()
+        _check(self.lib.tdeq_error_norm_vec(pp, y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, rv, rs, av, as_, plan.segs, dev,
                                             plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
                                             plan.workspace.data_ptr(), plan.workspace_bytes, dtype_code(y0.dtype),
                                             self._stream()), "tdeq_error_norm_vec")
 
-    def error_norm_vec_ctrl(self, plan: NormPlan, y0, y1, ks, coefs, dt: float, rtol, atol, ctrl: StepCtrl, next_times) -> None:
+    def error_norm_vec_ctrl(self, plan: NormPlan, y0, y1, ks, coefs, dt: float, rtol, atol, ctrl: StepCtrl, next_times,
+                            partial=None) -> None:
         """`error_norm_vec` whose finalize step also runs the step controller on the device (tdeq_error_norm_vec_ctrl) —
         read with `read_ctrl`."""
         ptrs, cf, n = self._terms(ks, coefs)
@@ -417,7 +422,8 @@ class HipKernels:
         rv, rs = (rtol.data_ptr(), 0.0) if isinstance(rtol, torch.Tensor) else (None, float(rtol))
         av, as_ = (atol.data_ptr(), 0.0) if isinstance(atol, torch.Tensor) else (None, float(atol))
         self._arm(plan, 1, ctrl=True)
-        _check(self.lib.tdeq_error_norm_vec_ctrl(y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, rv, rs, av, as_, plan.segs,
+        pp = None if partial is None else partial.data_ptr()
+        _check(self.lib.tdeq_error_norm_vec_ctrl(pp, y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, rv, rs, av, as_, plan.segs,
                                                  dev, plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
                                                  ctypes.byref(ctrl), plan.ctrl_ptr, plan.ctrl_dev.data_ptr(),
                                                  next_times.data_ptr(), plan.workspace.data_ptr(), plan.workspace_bytes,

@@ -331,12 +331,15 @@ int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, doub
                          int tkind, hipStream_t s, int ratio_kind);
 
 template <typename T, int NT>
-int launch_error_vec(const void* y0, const void* y1, const void* const* k, const double* coef, double dt,
+int launch_error_vec(const void* partial, const void* y0, const void* y1, const void* const* k, const double* coef, double dt,
                      const double* rtol_v, double rtol_s, const double* atol_v, double atol_s, const SegTable& st,
                      double* out_sumsq, double* out_bad, double* ws, hipStream_t s, const CtrlBundle* cb = nullptr) {
     ErrVecArgs<T, NT> a;
     a.y0 = static_cast<const T*>(y0);
     a.y1 = static_cast<const T*>(y1);
+    a.partial = static_cast<const T*>(partial);
+    a.k[0] = nullptr;
+    a.c[0] = (T)0;
     const T dtT = (T)dt;
     for (int j = 0; j < NT; ++j) {
         a.k[j] = static_cast<const T*>(k[j]);
@@ -349,7 +352,10 @@ int launch_error_vec(const void* y0, const void* y1, const void* const* k, const
     a.st = st;
     a.part_sumsq = ws;
     a.part_bad = ws + 2 * st.n_chunks;
-    hipLaunchKernelGGL((error_norm_vec_kernel<T, NT>), dim3((unsigned)st.n_chunks), dim3(kBlock), 0, s, a);
+    const dim3 g((unsigned)st.n_chunks), b(kBlock);
+    if (partial) hipLaunchKernelGGL((error_norm_vec_kernel<T, NT, true>), g, b, 0, s, a);
+    else if constexpr (NT > 0) hipLaunchKernelGGL((error_norm_vec_kernel<T, NT, false>), g, b, 0, s, a);
+    else return TDEQ_EINVAL;
     const int e = check_launch();
     if (e) return e;
     // with a controller bundle: the ratio in fp64 (the promoted type), the step size and the stage times in T
@@ -358,12 +364,12 @@ int launch_error_vec(const void* y0, const void* y1, const void* const* k, const
 }
 
 template <typename T>
-int dispatch_error_vec(const void* y0, const void* y1, const void* const* k, const double* coef, int nt, double dt,
-                       const double* rtol_v, double rtol_s, const double* atol_v, double atol_s, const SegTable& st,
+int dispatch_error_vec(const void* partial, const void* y0, const void* y1, const void* const* k, const double* coef, int nt,
+                       double dt, const double* rtol_v, double rtol_s, const double* atol_v, double atol_s, const SegTable& st,
                        double* out_sumsq, double* out_bad, double* ws, hipStream_t s, const CtrlBundle* cb = nullptr) {
     switch (nt) {
-#define TDEQ_CASE(N) case N: return launch_error_vec<T, N>(y0, y1, k, coef, dt, rtol_v, rtol_s, atol_v, atol_s, st, out_sumsq, out_bad, ws, s, cb);
-        TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
+#define TDEQ_CASE(N) case N: return launch_error_vec<T, N>(partial, y0, y1, k, coef, dt, rtol_v, rtol_s, atol_v, atol_s, st, out_sumsq, out_bad, ws, s, cb);
+        TDEQ_CASE(0) TDEQ_CASE(1) TDEQ_CASE(2) TDEQ_CASE(3) TDEQ_CASE(4) TDEQ_CASE(5) TDEQ_CASE(6) TDEQ_CASE(7)
         TDEQ_CASE(8) TDEQ_CASE(9) TDEQ_CASE(10) TDEQ_CASE(11) TDEQ_CASE(12) TDEQ_CASE(13) TDEQ_CASE(14)
 #undef TDEQ_CASE
     }
@@ -1139,14 +1145,14 @@ int tdeq_error_norm(void* scaled_out, const void* y0, const void* y1, const void
                : dispatch_error<double>(scaled_out, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, s);
 }
 
-int tdeq_error_norm_vec(const void* y0, const void* y1, const void* const* k, const double* coef, int n_terms, double dt,
-                        const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
+int tdeq_error_norm_vec(const void* err_partial, const void* y0, const void* y1, const void* const* k, const double* coef,
+                        int n_terms, double dt, const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
                         const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
                         double* out_sumsq, double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype,
                         void* stream) {
-    if (!y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype)) return TDEQ_EINVAL;
     if (!rtol_vec && !atol_vec) return TDEQ_EINVAL;      // two 0-dim tolerances: tdeq_error_norm (a different promotion)
-    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    if (n_terms < (err_partial ? 0 : 1) || n_terms > TDEQ_MAX_TERMS || (n_terms > 0 && (!k || !coef))) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
     SegTable st;
     const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
@@ -1155,21 +1161,21 @@ int tdeq_error_norm_vec(const void* y0, const void* y1, const void* const* k, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
     return dtype == TDEQ_F32
-               ? dispatch_error_vec<float>(y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
+               ? dispatch_error_vec<float>(err_partial, y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
                                            out_sumsq, out_nonfinite, ws, s)
-               : dispatch_error_vec<double>(y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
+               : dispatch_error_vec<double>(err_partial, y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
                                             out_sumsq, out_nonfinite, ws, s);
 }
 
-int tdeq_error_norm_vec_ctrl(const void* y0, const void* y1, const void* const* k, const double* coef, int n_terms, double dt,
-                             const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
+int tdeq_error_norm_vec_ctrl(const void* err_partial, const void* y0, const void* y1, const void* const* k,
+                             const double* coef, int n_terms, double dt, const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
                              const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
                              double* out_sumsq, double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl,
                              double* ctrl_dev, void* next_times, void* workspace, size_t workspace_bytes, int dtype,
                              void* stream) {
-    if (!y0 || !y1 || !k || !coef || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype)) return TDEQ_EINVAL;
+    if (!y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype)) return TDEQ_EINVAL;
     if ((!rtol_vec && !atol_vec) || !ctrl || !out_ctrl || !ctrl_dev || !next_times) return TDEQ_EINVAL;
-    if (n_terms < 1 || n_terms > TDEQ_MAX_TERMS) return TDEQ_EINVAL;
+    if (n_terms < (err_partial ? 0 : 1) || n_terms > TDEQ_MAX_TERMS || (n_terms > 0 && (!k || !coef))) return TDEQ_EINVAL;
     for (int j = 0; j < n_terms; ++j) if (!k[j]) return TDEQ_EINVAL;
     if (ctrl->n_times < 1 || ctrl->n_times > TDEQ_MAX_STAGE_TIMES || ctrl->n_norm_seg < 0 || ctrl->n_norm_seg > n_seg)
         return TDEQ_EINVAL;
@@ -1181,9 +1187,9 @@ int tdeq_error_norm_vec_ctrl(const void* y0, const void* y1, const void* const* 
     double* ws = static_cast<double*>(workspace);
     const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times, 0};
     return dtype == TDEQ_F32
-               ? dispatch_error_vec<float>(y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
+               ? dispatch_error_vec<float>(err_partial, y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
                                            out_sumsq, out_nonfinite, ws, s, &cb)
-               : dispatch_error_vec<double>(y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
+               : dispatch_error_vec<double>(err_partial, y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
                                             out_sumsq, out_nonfinite, ws, s, &cb);
 }
 

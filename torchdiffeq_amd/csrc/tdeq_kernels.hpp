@@ -469,8 +469,9 @@ template <typename T, int NT>
 struct ErrVecArgs {
     const T* y0;
     const T* y1;
-    const T* k[NT];
-    T c[NT];
+    const T* partial;       // PARTIAL: the error row's leading run, summed by stage_combine_err_kernel (else unused)
+    const T* k[NT > 0 ? NT : 1];
+    T c[NT > 0 ? NT : 1];
     const double* rtol_v;   // per element of the flat (padded) state, or null: rtol_s
     const double* atol_v;
     double rtol_s, atol_s;
@@ -479,7 +480,10 @@ struct ErrVecArgs {
     double* part_bad;
 };
 
-template <typename T, int NT>
+// PARTIAL: err = (partial + c_0 k_0) + ... over the NT >= 0 remaining stages, as error_norm_partial_kernel continues the
+// sum stage_combine_err_kernel started — per-element tolerances keep the step's launch sequence (carried partial sums, the
+// end-of-step error split) and pay exactly their own two fp64 streams.
+template <typename T, int NT, bool PARTIAL = false>
 __global__ __launch_bounds__(kBlock) void error_norm_vec_kernel(const ErrVecArgs<T, NT> a) {
     __shared__ double red[2 * (kBlock / kWave)];
     const int64_t b = blockIdx.x;
@@ -494,9 +498,9 @@ __global__ __launch_bounds__(kBlock) void error_norm_vec_kernel(const ErrVecArgs
 #pragma unroll 2
     for (int64_t t = threadIdx.x; t < valid; t += kBlock) {
         const int64_t i = base + t;
-        T e = a.k[0][i] * a.c[0];
+        T e = PARTIAL ? a.partial[i] : a.k[0][i] * a.c[0];
 #pragma unroll
-        for (int j = 1; j < NT; ++j) e = e + a.k[j][i] * a.c[j];
+        for (int j = PARTIAL ? 0 : 1; j < NT; ++j) e = e + a.k[j][i] * a.c[j];
         const T y0 = a.y0[i], y1 = a.y1[i];
         const T m = smax(sabs(y0), sabs(y1));
         const double prod = a.rtol_v ? a.rtol_v[i] * (double)m : (double)(rtolT * m);

@@ -756,10 +756,15 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         n_rows = len(self._beta)
         fsal = self.tableau.fsal_solution
         builtin_norm = isinstance(self.norm, BuiltinNorm)
+        # a norm LAUNCH that can continue the partial error row of the step's last combine: the built-in norm, and per-element
+        # tolerances on the fused vector-tolerance kernel (tdeq_error_norm_vec's `err_partial`) — same launch sequence, the
+        # tolerance vectors are the only extra streams
+        vec_fused = self._vec_fused is not None and not builtin_norm and getattr(kern, "vec_partial", False)
+        fused_norm = builtin_norm or vec_fused
         err_partial = None
         err_rem = self._fuse[1:] if self._fuse is not None else None     # (stages, weights) left to the norm kernel
         nograd = not torch.is_grad_enabled()      # no-grad solves (the adjoint's two solves, inference): no graph checks
-        carry = self._carry if (builtin_norm and (nograd or (plain and not k1.requires_grad))) else None
+        carry = self._carry if (fused_norm and (nograd or (plain and not k1.requires_grad))) else None
         y1_planned = None
         if carry is not None:
             # planned launches (tableaus.carry_plan): a launch may also emit the left-to-right prefixes of later rows'
@@ -792,7 +797,7 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
             err_partial, err_rem = held.pop(R), (carry.err_idx, carry.err_coef)
         for i in range(1, n_rows if carry is None else 0):
             row = self._beta[i]
-            if i == n_rows - 1 and fsal and self._fuse is not None and builtin_norm and \
+            if i == n_rows - 1 and fsal and self._fuse is not None and fused_norm and \
                     (nograd or not (y0.requires_grad or k[-1].requires_grad)):
                 yi, err_partial = torch.empty_like(y0), torch.empty_like(y0)
                 kern.stage_combine_err(yi, err_partial, y0, [k[j] for j in row.idx], row.coef, self._fuse[0], dt_signed)
@@ -806,7 +811,7 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
             y1 = yi
         elif y1_planned is not None:
             y1 = y1_planned
-        elif self._fuse is not None and builtin_norm and \
+        elif self._fuse is not None and fused_norm and \
                 not (torch.is_grad_enabled() and (y0.requires_grad or k[-1].requires_grad)):
             sol = self._c_sol
             y1, err_partial = torch.empty_like(y0), torch.empty_like(y0)
@@ -817,13 +822,17 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
 
         # ---- error ratio (misc.py:80-82) ----
         err = self._c_err
-        vec_ctrl = self._vec_ctrl and err_partial is None and not builtin_norm
-        use_ctrl = lookahead and (err_partial is not None or (self._whole_row_ctrl and builtin_norm) or vec_ctrl)
+        vec_ctrl = self._vec_ctrl and not builtin_norm and (err_partial is None or vec_fused)
+        use_ctrl = lookahead and ((err_partial is not None and (builtin_norm or vec_ctrl))
+                                  or (self._whole_row_ctrl and builtin_norm) or vec_ctrl)
         if use_ctrl:
             ctrl = self._ctrl
             ctrl.t0, ctrl.dt = t0, dt
             tnext = torch.empty(ctrl.n_times, dtype=func.time_dtype, device=y0.device)
-            if vec_ctrl:
+            if vec_ctrl and err_partial is not None:
+                kern.error_norm_vec_ctrl(self.plan, y0, y1, [k[j] for j in err_rem[0]], err_rem[1], dt_signed,
+                                         self._vec_fused[0], self._vec_fused[1], ctrl, tnext, partial=err_partial)
+            elif vec_ctrl:
                 kern.error_norm_vec_ctrl(self.plan, y0, y1, [k[j] for j in err.idx], err.coef, dt_signed,
                                          self._vec_fused[0], self._vec_fused[1], ctrl, tnext)
             elif err_partial is None:
@@ -846,7 +855,7 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
                 self._pre = (yi_n, tn, func.eval_at(tn[0], yi_n))
             accept_dev, dt_next_dev, error_ratio, bad = kern.read_ctrl(self.plan)
             y1_nonfinite = any(b != 0 for b in bad)
-        elif err_partial is not None:
+        elif err_partial is not None and builtin_norm:
             kern.error_norm_partial(self.plan, err_partial, y0, y1, [k[j] for j in err_rem[0]], err_rem[1],
                                     dt_signed)
             sumsq, _, bad = self._read_norms()
@@ -858,7 +867,7 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
             error_ratio = self._segment_norm(sumsq, bad)
             y1_nonfinite = any(b != 0 for b in bad)
         else:
-            error_ratio, y1_nonfinite = self._user_norm_ratio(y0, y1, k, dt_signed)
+            error_ratio, y1_nonfinite = self._user_norm_ratio(y0, y1, k, dt_signed, err_partial, err_rem)
         if use_ctrl:
             accept_step = accept_dev      # the device's decision is the one its look-ahead stage was built on
         else:
@@ -961,7 +970,7 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
             self._g = None
             self._hold_pre = False
 
-    def _user_norm_ratio(self, y0, y1, k, dt_signed):
+    def _user_norm_ratio(self, y0, y1, k, dt_signed, err_partial=None, err_rem=None):
         """User-supplied `norm` callable (misc.py:80-82 with a custom norm): the kernel materialises
         err/tol (padding zero-filled) and the user's own function reduces it."""
         err = self._c_err
@@ -970,8 +979,12 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
             # per-element tolerances under the built-in norm: err / tol and the per-segment sums in one launch, in the
             # reference's promoted precision (fp64); max over the components of sqrt(mean) as misc.py:22-33
             rtol_v, atol_v, n_skip = self._vec_fused
-            self.kernels.error_norm_vec(self.plan, y0, y1, [k[j].detach() for j in err.idx], err.coef, dt_signed,
-                                        rtol_v, atol_v)
+            if err_partial is not None:       # (the step's last combine already summed the row's leading run)
+                self.kernels.error_norm_vec(self.plan, y0, y1, [k[j].detach() for j in err_rem[0]], err_rem[1], dt_signed,
+                                            rtol_v, atol_v, partial=err_partial)
+            else:
+                self.kernels.error_norm_vec(self.plan, y0, y1, [k[j].detach() for j in err.idx], err.coef, dt_signed,
+                                            rtol_v, atol_v)
             sumsq, _, bad = self.kernels.read_norms(self.plan)
             ratio = 0.0
             for s_, n_ in list(zip(sumsq, self._numels))[:len(self._numels) - n_skip]:
