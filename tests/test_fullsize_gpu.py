@@ -47,6 +47,30 @@ def test_cfg4_full_size_dopri8_fp64():
     assert f.nfe == 2 + 13 * (len(f.accept) + len(f.reject))
 
 
+def test_cfg2_full_size_per_element_tolerances_equal_scalar_ones():
+    """cfg2 with the reference-default rtol as a CONSTANT per-element vector (ABI 20: tdeq_error_norm_vec_ctrl continuing the
+    partial error row, carried partial sums, look-ahead): the same steps as the scalar-tolerance solve — only the quotient's
+    precision differs (fp64 when a tolerance is dimensioned, misc.py:80-82) — and a row-wise vector that is tighter on half of
+    the columns costs more steps and lands closer to the closed form there."""
+    A, y0 = _linear(65536, 128, torch.float32)
+    At = A.T.contiguous()
+    t = torch.tensor([0.0, 1.0]).cuda()
+    exact = (y0.double() @ torch.linalg.matrix_exp(A.double()).T)
+    runs = {}
+    for name, rtol in (("scalar", 1e-7), ("vector", torch.full((65536, 128), 1e-7, dtype=torch.float64, device="cuda")),
+                       ("tight_half", torch.cat([torch.full((64,), 1e-9, dtype=torch.float64),
+                                                 torch.full((64,), 1e-7, dtype=torch.float64)]).cuda())):
+        f = StatFunc(lambda t_, y: y @ At)
+        with torch.no_grad():
+            y = tda.odeint(f, y0, t, method="dopri5", rtol=rtol, atol=1e-9)[-1]
+        runs[name] = (y, f.nfe, len(f.accept), len(f.reject))
+    assert runs["vector"][1:] == runs["scalar"][1:]
+    assert rel_err(runs["vector"][0], runs["scalar"][0]) < 1e-5      # (fp32 rounding level: a step size that differs in its last bits)
+    assert runs["tight_half"][1] > runs["scalar"][1]
+    err = lambda y: float((y.double() - exact).abs().max() / exact.abs().max())
+    assert err(runs["tight_half"][0]) <= err(runs["scalar"][0]) * 1.05 and err(runs["scalar"][0]) < 1e-5
+
+
 def test_cfg2_full_size_round_trip():
     """0 -> 1 -> 0 returns to y0 (exercises the folded time reversal at full size)."""
     A, y0 = _linear(65536, 128, torch.float32)
