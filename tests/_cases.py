@@ -136,3 +136,14 @@ FUNC_SHAPE_CASES = {
     "tuple_reshaped": (((2, 3), (3,)), lambda y: (-y[0].T, -y[1].reshape(3, 1))),
 }
 FUNC_SHAPE_METHODS = ("dopri5", "dopri8", "bosh3", "adaptive_heun", "rk4", "euler", "midpoint")
+
+
+# r06: tuple tolerances whose vector ENTRIES are not tensors — `torch.as_tensor(entry).expand(numel)` in the reference
+# (torchdiffeq/_impl/misc.py:113-123) takes lists, tuples and numpy arrays alike.  Inputs of tests/golden/tuple_tol.npz
+# (`ttl_*`, generated by make_golden.py from the imported reference) and of the tests that replay them.
+TUPLE_TOL_LIST_FORMS = {
+    "rtol_list": (([1e-5, 1e-4, 1e-6], 1e-4), (1e-8, 1e-8)),
+    "atol_list": ((1e-5, 1e-4), ([1e-8, 1e-7, 1e-9], 1e-8)),
+    "both": (([1e-5, 1e-4, 1e-6], [1e-4, 1e-5]), ([1e-8, 1e-7, 1e-9], 1e-8)),
+    "numpy_and_tuple": ((np.array([1e-5, 1e-4, 1e-6]), 1e-4), (1e-8, (1e-8, 1e-7))),
+}

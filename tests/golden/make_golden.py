@@ -514,6 +514,10 @@ def gen_backprop():
     save("backprop.npz", **arrays)
 
 
+sys.path.insert(0, os.path.join(HERE, ".."))
+from _cases import TUPLE_TOL_LIST_FORMS  # noqa: E402  (inputs only: the tolerance forms of the r06 list-entry cases)
+
+
 def gen_tuple_tolerances():
     """Tuple states with PER-COMPONENT tolerances (misc.py:115-123 `_tuple_tol`: rtol / atol become per-element
     vectors, fp32 values widened to fp64, so the reference forms the error ratio in fp64 there)."""
@@ -534,6 +538,37 @@ def gen_tuple_tolerances():
             arrays[f"tt_{dname}_{tag}_ya"], arrays[f"tt_{dname}_{tag}_yb"] = sa, sb
             arrays[f"tt_{dname}_{tag}_nfe"] = count[0]
         arrays[f"tt_{dname}_A"], arrays[f"tt_{dname}_y0a"], arrays[f"tt_{dname}_y0b"] = A, ya, yb
+    # r06: an ENTRY of a tuple tolerance may be any array-like `torch.as_tensor` takes (misc.py:121) —
+    # a Python list, a tuple of numbers, a numpy array — not only a tensor.  Forms: list entry in rtol / in atol / in
+    # both / numpy + tuple entries; fp32 and fp64 states; one odeint_adjoint forward + backward.
+    for dname, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        x0, b0 = rand(3, seed=31).to(dtype), rand(2, seed=32).to(dtype)
+        w = torch.tensor([1.0, 3.0, 0.3], dtype=dtype)
+        t = torch.tensor([0.0, 0.4, 1.1], dtype=dtype)
+        arrays[f"ttl_{dname}_x0"], arrays[f"ttl_{dname}_b0"] = x0, b0
+        for form, (rtol, atol) in TUPLE_TOL_LIST_FORMS.items():
+            count, accepted = [0], []
+
+            class F(torch.nn.Module):
+                def forward(self, t_, y_):
+                    count[0] += 1
+                    return -y_[0] * w * (1 + 0.2 * t_) + 0.1 * torch.sin(y_[0]), -0.4 * y_[1]
+
+                def callback_accept_step(self, t0, y_, dt):
+                    accepted.append(float(dt))
+            with torch.no_grad():
+                sa, sb = torchdiffeq.odeint(F(), (x0, b0), t, rtol=rtol, atol=atol, method="dopri5")
+            arrays[f"ttl_{dname}_{form}_ya"], arrays[f"ttl_{dname}_{form}_yb"] = sa, sb
+            arrays[f"ttl_{dname}_{form}_nfe"] = count[0]
+            arrays[f"ttl_{dname}_{form}_accept_dt"] = np.array(accepted)
+    x = rand(3, seed=31).requires_grad_(True)
+    wp = torch.tensor([1.0, 3.0, 0.3], dtype=torch.float64, requires_grad=True)
+    rtol, atol = TUPLE_TOL_LIST_FORMS["both"]
+    out = torchdiffeq.odeint_adjoint(lambda t_, y_: (-y_[0] * wp * (1 + 0.2 * t_) + 0.1 * torch.sin(y_[0]), -0.4 * y_[1]),
+                                     (x, rand(2, seed=32)), torch.tensor([0.0, 0.4, 1.1], dtype=torch.float64),
+                                     rtol=rtol, atol=atol, adjoint_rtol=1e-8, adjoint_atol=1e-10, adjoint_params=(wp,))
+    out[0][-1].pow(2).sum().backward()
+    arrays["ttl_adj_ya"], arrays["ttl_adj_gx"], arrays["ttl_adj_gw"] = out[0], x.grad, wp.grad
     save("tuple_tol.npz", **arrays)
 
 

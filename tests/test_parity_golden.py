@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import torchdiffeq_amd as tda
-from _cases import SOLVE_CASES, PlanarCNF, StatFunc, T, linear_case, load, make_mlp, rel_err
+from _cases import SOLVE_CASES, TUPLE_TOL_LIST_FORMS, PlanarCNF, StatFunc, T, linear_case, load, make_mlp, rel_err
 
 
 
@@ -333,6 +333,44 @@ def test_tuple_state_with_per_component_tolerances(dev, dname, tag):
     tol = 1e-12 if dname == "f64" else 2e-6
     assert rel_err(sa, z[f"tt_{dname}_{tag}_ya"]) < tol
     assert rel_err(sb, z[f"tt_{dname}_{tag}_yb"]) < tol
+
+
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+@pytest.mark.parametrize("form", sorted(TUPLE_TOL_LIST_FORMS))
+def test_tuple_tolerance_entries_that_are_lists_or_arrays(dev, dname, form):
+    """misc.py:113-123 (`torch.as_tensor(tol_).expand(shape.numel())`): an entry of a tuple tolerance may be a Python list,
+    a tuple of numbers or a numpy array — r05's kernel path recognised only tensors and raised ValueError (VERDICT r05,
+    `tools/fuzz_vs_reference.py vectol 9157`).  Same evaluation count and accepted steps as the reference."""
+    z = load("tuple_tol.npz")
+    dtype = torch.float32 if dname == "f32" else torch.float64
+    x0, b0 = T(z[f"ttl_{dname}_x0"], dev), T(z[f"ttl_{dname}_b0"], dev)
+    w = torch.tensor([1.0, 3.0, 0.3], dtype=dtype, device=dev)
+    t = torch.tensor([0.0, 0.4, 1.1], dtype=dtype, device=dev)
+    rtol, atol = TUPLE_TOL_LIST_FORMS[form]
+    f = StatFunc(lambda t_, y_: (-y_[0] * w * (1 + 0.2 * t_) + 0.1 * torch.sin(y_[0]), -0.4 * y_[1]))
+    with torch.no_grad():
+        sa, sb = tda.odeint(f, (x0, b0), t, rtol=rtol, atol=atol, method="dopri5")
+    key = f"ttl_{dname}_{form}"
+    tol = 1e-11 if dname == "f64" else 2e-5
+    assert rel_err(sa, z[f"{key}_ya"]) < tol and rel_err(sb, z[f"{key}_yb"]) < tol
+    if dname == "f64":
+        assert f.nfe == int(z[f"{key}_nfe"])
+        np.testing.assert_allclose(f.accept, z[f"{key}_accept_dt"], rtol=1e-9)
+
+
+def test_tuple_tolerance_list_entries_through_odeint_adjoint(dev):
+    """The same forms through `odeint_adjoint`'s forward solve (adjoint.py:156-223 hands rtol / atol on untouched), with
+    the gradients of the reference's backward solve."""
+    z = load("tuple_tol.npz")
+    x = T(z["ttl_f64_x0"], dev).requires_grad_(True)
+    wp = torch.tensor([1.0, 3.0, 0.3], dtype=torch.float64, device=dev, requires_grad=True)
+    rtol, atol = TUPLE_TOL_LIST_FORMS["both"]
+    out = tda.odeint_adjoint(lambda t_, y_: (-y_[0] * wp * (1 + 0.2 * t_) + 0.1 * torch.sin(y_[0]), -0.4 * y_[1]),
+                             (x, T(z["ttl_f64_b0"], dev)), torch.tensor([0.0, 0.4, 1.1], dtype=torch.float64, device=dev),
+                             rtol=rtol, atol=atol, adjoint_rtol=1e-8, adjoint_atol=1e-10, adjoint_params=(wp,))
+    out[0][-1].pow(2).sum().backward()
+    assert rel_err(out[0], z["ttl_adj_ya"]) < 1e-11
+    assert rel_err(x.grad, z["ttl_adj_gx"]) < 1e-7 and rel_err(wp.grad, z["ttl_adj_gw"]) < 1e-7
 
 
 @pytest.mark.parametrize("tup", [False, True], ids=["tensor", "tuple"])

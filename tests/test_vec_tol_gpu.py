@@ -162,3 +162,40 @@ def test_vector_tolerances_keep_the_look_ahead_controller(monkeypatch, dtype):
         else:       # the device's `pow` is within 2 ulp of libm's: step sizes agree to 1e-16, so do fp64 rows
             assert float((out["1"][0] - out["0"][0]).abs().max() / out["0"][0].abs().max()) < 1e-13
         assert out["1"][3] > 0          # the large first step is rejected: that path is compared too
+
+
+@pytest.mark.parametrize("form", ["rtol_list", "atol_list", "both", "numpy_and_tuple"])
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+def test_tuple_tolerance_with_list_entries_takes_the_fused_kernel(monkeypatch, dname, form):
+    """r06: an ENTRY of a tuple tolerance that is a Python list / tuple / numpy array is a vector over
+    its component exactly like a tensor entry (torchdiffeq/_impl/misc.py:113-123: `torch.as_tensor(tol_).expand(...)`):
+    the solve runs (r05 raised ValueError from `_per_segment`), every trial step's ratio comes from tdeq_error_norm_vec[_ctrl],
+    and the result is the reference's (tests/golden/tuple_tol.npz `ttl_*`, generated from the imported reference)."""
+    import numpy as np
+    from _cases import TUPLE_TOL_LIST_FORMS, T, load, rel_err
+    z = load("tuple_tol.npz")
+    dtype = torch.float32 if dname == "f32" else torch.float64
+    x0, b0 = T(z[f"ttl_{dname}_x0"], "cuda"), T(z[f"ttl_{dname}_b0"], "cuda")
+    w = torch.tensor([1.0, 3.0, 0.3], dtype=dtype, device="cuda")
+    t = torch.tensor([0.0, 0.4, 1.1], dtype=dtype, device="cuda")
+    rtol, atol = TUPLE_TOL_LIST_FORMS[form]
+    kern = _native.get_kernels(torch.device("cuda:0"), dtype)
+    calls = {"vec": 0, "scaled": 0}
+    real_vec, real_scaled, real_ctrl = kern.error_norm_vec, kern.error_scaled, kern.error_norm_vec_ctrl
+    monkeypatch.setattr(kern, "error_norm_vec", lambda *a, **k: (calls.__setitem__("vec", calls["vec"] + 1), real_vec(*a, **k))[1])
+    monkeypatch.setattr(kern, "error_norm_vec_ctrl", lambda *a, **k: (calls.__setitem__("vec", calls["vec"] + 1), real_ctrl(*a, **k))[1])
+    monkeypatch.setattr(kern, "error_scaled", lambda *a, **k: (calls.__setitem__("scaled", calls["scaled"] + 1), real_scaled(*a, **k))[1])
+    nfe, accepted = [0], []
+
+    class F(torch.nn.Module):
+        def forward(self, t_, y_):
+            nfe[0] += 1
+            return -y_[0] * w * (1 + 0.2 * t_) + 0.1 * torch.sin(y_[0]), -0.4 * y_[1]
+    with torch.no_grad():
+        sa, sb = tda.odeint(F(), (x0, b0), t, rtol=rtol, atol=atol, method="dopri5")
+    key = f"ttl_{dname}_{form}"
+    assert calls["vec"] == (nfe[0] - 2) // 6 and calls["scaled"] == 0
+    tol = 1e-11 if dname == "f64" else 2e-5
+    assert rel_err(sa, z[f"{key}_ya"]) < tol and rel_err(sb, z[f"{key}_yb"]) < tol
+    if dname == "f64":
+        assert nfe[0] == int(z[f"{key}_nfe"])

@@ -258,13 +258,29 @@ def vector_tolerances(rtol, atol, layout: "StateLayout", device, dtype=torch.flo
     # tuple state: a sequence with one entry per component is the ordinary case (scalars: handled per segment by the
     # kernels); only vector ENTRIES need the per-element form
     def entries(tol):
-        if isinstance(tol, torch.Tensor) and tol.dim() == 1 and len(tol) == layout.n_seg:
-            return list(tol)
-        if isinstance(tol, (list, tuple)) and len(tol) == layout.n_seg:
-            return list(tol)
-        return None
+        # `iter(tol)` then `tuple(tol)` (misc.py:113-118): ANY iterable with one entry per component — list, tuple,
+        # 1-D tensor, numpy array —; a 0-dim tensor / number is not iterable and stays a scalar
+        if isinstance(tol, (str, bytes)) or (isinstance(tol, torch.Tensor) and tol.dim() == 0):
+            return None
+        try:
+            ent = list(tol)
+        except TypeError:
+            return None
+        return ent if len(ent) == layout.n_seg else None
+
+    def is_vector(v):
+        # an entry goes through `torch.as_tensor(v)` there (misc.py:121): a tensor, a Python list / tuple of numbers, a
+        # numpy array are all vectors over their component when they hold more than one number
+        if isinstance(v, torch.Tensor):
+            return v.numel() > 1
+        if isinstance(v, (int, float)):
+            return False
+        try:
+            return torch.as_tensor(v).numel() > 1
+        except Exception:
+            return False
     er, ea = entries(rtol), entries(atol)
-    has_vec = any(e is not None and any(isinstance(v, torch.Tensor) and v.numel() > 1 for v in e) for e in (er, ea))
+    has_vec = any(e is not None and any(is_vector(v) for v in e) for e in (er, ea))
     if not (has_vec or (tuple_entries_too and (er is not None or ea is not None))):
         return None
     out = []
