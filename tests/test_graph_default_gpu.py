@@ -1,0 +1,269 @@
+"""r06: `hip_graph='auto'` is the BUILT-IN default (torchdiffeq_amd/_graph.py `_DEFAULT_REQUEST`) — the reference has no such
+switch (torchdiffeq/_impl/odeint.py:49-108), so a drop-in user gets captured trial steps without asking, and gets the eager
+path, silently, wherever a replay could differ from re-running `func`'s Python.  What makes that safe is pinned here:
+
+  * nothing is captured that the static look at func or the first evaluations show to be part of an autograd graph
+    (advisor r05: callable objects holding Modules, bound methods, globals, hidden parameters);
+  * a func with per-evaluation side effects stays eager WITHOUT a warning under the default (with one when asked for);
+  * a cached graph is re-checked against one eager evaluation at the start of every later solve, so a Python value func
+    hides from the cache key cannot be replayed stale;
+  * results are bit-identical to the eager path throughout."""
+import types
+import warnings
+
+import pytest
+import torch
+
+import torchdiffeq_amd as tda
+from torchdiffeq_amd import _graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _builtin_default(monkeypatch):
+    monkeypatch.delenv("TDEQ_HIP_GRAPH", raising=False)
+    yield
+    _graph.clear_graph_cache()
+
+
+def _problem(n=64, d=8):
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(n, d, generator=g).cuda(), torch.tensor([0.0, 0.5, 1.0], device="cuda")
+
+
+class _Pure(torch.nn.Module):
+    def __init__(self, d=8):
+        super().__init__()
+        torch.manual_seed(3)
+        self.lin = torch.nn.Linear(d, d).cuda()
+        self._calls = [0]
+        self.lin.register_forward_pre_hook(lambda m, a: self._calls.__setitem__(0, self._calls[0] + 1))
+
+    def forward(self, t, y):
+        return torch.tanh(self.lin(y)) * torch.cos(t) - 0.3 * y
+
+
+def test_default_request_is_auto_and_env_opts_out(monkeypatch):
+    assert _graph._graph_request(None) == (True, True) and not _graph._request_is_explicit(None)
+    monkeypatch.setenv("TDEQ_HIP_GRAPH", "0")
+    assert _graph._graph_request(None) == (False, False) and _graph._request_is_explicit(None)
+    assert _graph._graph_request("auto") == (True, True) and _graph._request_is_explicit("auto")
+
+
+def test_default_captures_a_pure_field_from_its_second_solve_on_bit_identically():
+    """No option, no environment variable: the second solve of a training-loop-like sequence is captured, the third is
+    replays only (a handful of Python calls), every solution equals the eager one to the last bit, nothing warns."""
+    y0, t = _problem()
+    f = _Pure()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        y_eager = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph=False))
+        nfe = f._calls[0]
+        counts, ys = [], []
+        for _ in range(4):
+            f._calls[0] = 0
+            ys.append(tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8))
+            counts.append(f._calls[0])
+    assert all(torch.equal(y, y_eager) for y in ys)
+    assert counts[0] == nfe                       # first sight: eager
+    # later solves: the two initial-step evaluations + the one-evaluation re-check (+ at most a side-1 capture)
+    assert counts[3] <= 3 + 6, (counts, nfe)
+    assert f in _graph._GraphStep._cache and f not in _graph._GraphStep._refused
+
+
+def test_default_is_silent_about_a_counting_field_and_keeps_its_counts():
+    """The reference's examples count evaluations in `forward`; such a field cannot be replayed.  Under the built-in
+    default that costs nothing and says nothing: eager solves, exact counts, no warning.  Asked for explicitly
+    (`options={'hip_graph': 'auto'}`) the same refusal is reported once."""
+    y0, t = _problem()
+
+    class Counting(_Pure):
+        nfe = 0
+
+        def forward(self, t_, y_):
+            self.nfe += 1
+            return super().forward(t_, y_)
+    f = Counting()
+    with torch.no_grad():
+        y_eager = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph=False))
+        n = f.nfe
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            for _ in range(3):
+                f.nfe = 0
+                y = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8)
+                assert f.nfe == n and torch.equal(y, y_eager)
+    assert f in _graph._GraphStep._refused
+    g = Counting()
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            tda.odeint(g, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph="auto"))
+    assert len([x for x in w if "hip_graph='auto'" in str(x.message)]) == 1
+
+
+def test_cached_graph_is_rechecked_against_python_state_the_key_cannot_see():
+    """A number func reads through a property of a `__slots__` object is invisible to the cache key and baked into the
+    captured kernels.  The first replay of every later solve is compared with one eager evaluation: after the change the
+    stale graph is dropped, the solve is the eager one's bit for bit, and func is not replayed again."""
+    y0, t = _problem()
+    lin = torch.nn.Linear(8, 8).cuda()
+
+    class Hidden:
+        __slots__ = ("_v",)
+
+        def __init__(self):
+            self._v = 0.5
+    h = Hidden()
+
+    def f(t_, y_):
+        return torch.tanh(lin(y_)) * h._v
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for v in (0.5, 0.5, 0.5, 1.5, 1.5):
+            h._v = v
+            y_auto = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8)
+            y_eager = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph=False))
+            assert torch.equal(y_auto, y_eager), v
+    assert f in _graph._GraphStep._refused
+
+
+def test_module_level_numbers_are_part_of_the_cache_key():
+    y0, t = _problem()
+    lin = torch.nn.Linear(8, 8).cuda()
+    ns = {"torch": torch, "lin": lin, "ALPHA": 0.5}
+    exec("def f(t_, y_):\n    return torch.tanh(lin(y_)) * ALPHA\n", ns)
+    f = ns["f"]
+    k1 = _graph._scalar_state(f)
+    ns["ALPHA"] = 1.5
+    assert _graph._scalar_state(f) != k1
+    with torch.no_grad():
+        for v in (0.5, 0.5, 0.5, 1.5, 1.5, 1.5):
+            ns["ALPHA"] = v
+            y_auto = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8)
+            y_eager = tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph=False))
+            assert torch.equal(y_auto, y_eager), v
+    assert f not in _graph._GraphStep._refused       # seen through the key: recaptured, not refused
+
+
+# -- advisor r05 (medium): fixed grids in grad mode must keep parameter gradients ---------------------------------------
+class _Holder:                                   # a plain callable object holding a Module
+    def __init__(self):
+        torch.manual_seed(1)
+        self.net = torch.nn.Linear(2, 2).cuda()
+
+    def __call__(self, t, y):
+        return torch.tanh(self.net(y))
+
+    def rhs(self, t, y):
+        return torch.tanh(self.net(y))
+
+
+_CFG = types.SimpleNamespace(w=None)
+_LAYERS = []
+
+
+def _f_cfg(t, y):
+    return torch.tanh(y @ _CFG.w)
+
+
+def _f_layers(t, y):
+    return torch.tanh(_LAYERS[0](y))
+
+
+@pytest.mark.parametrize("kind", ["callable_object", "bound_method", "global_object", "global_list"])
+@pytest.mark.parametrize("mode", [None, True, "auto"])
+def test_fixed_grid_keeps_parameter_gradients_for_funcs_the_r05_walk_missed(kind, mode):
+    torch.manual_seed(0)
+    if kind == "callable_object":
+        f = _Holder()
+        params = list(f.net.parameters())
+    elif kind == "bound_method":
+        o = _Holder()
+        f, params = o.rhs, list(o.net.parameters())
+    elif kind == "global_object":
+        _CFG.w = torch.randn(2, 2, device="cuda", requires_grad=True)
+        f, params = _f_cfg, [_CFG.w]
+    else:
+        _LAYERS[:] = [torch.nn.Linear(2, 2).cuda()]
+        f, params = _f_layers, list(_LAYERS[0].parameters())
+    assert _graph._holds_a_tensor_that_requires_grad(f)
+    y0 = torch.tensor([[1.0, -0.5]], device="cuda")
+    t = torch.linspace(0.0, 1.0, 60, device="cuda")
+    opts = {} if mode is None else dict(hip_graph=mode)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = tda.odeint(f, y0, t, method="rk4", options=dict(opts))
+    assert y.requires_grad
+    grads = torch.autograd.grad(y[-1].pow(2).sum(), params)
+    y_ref = tda.odeint(f, y0, t, method="rk4", options=dict(hip_graph=False))
+    grads_ref = torch.autograd.grad(y_ref[-1].pow(2).sum(), params)
+    assert all(torch.equal(a, b) for a, b in zip(grads, grads_ref))
+
+
+@pytest.mark.parametrize("mode", [None, True])
+def test_fixed_grid_dynamic_guard_catches_a_parameter_nothing_static_can_see(mode):
+    """A parameter behind `__slots__` with a `hip_graph_token` (so the object counts as inspectable and the static look
+    answers "holds nothing that requires grad"): the captured-grid path starts, its first evaluation returns a tensor that
+    requires grad, the step is discarded and the eager, differentiable path runs — gradients equal the eager ones."""
+    torch.manual_seed(2)
+    w = torch.randn(2, 2, device="cuda", requires_grad=True)
+
+    class Opaque:
+        __slots__ = ("_w", "hip_graph_token")
+
+        def __init__(self):
+            self._w, self.hip_graph_token = w, 1
+
+        def __call__(self, t, y):
+            return torch.tanh(y @ self._w)
+    f = Opaque()
+    assert not _graph._holds_a_tensor_that_requires_grad(f)
+    y0 = torch.tensor([[1.0, -0.5]], device="cuda")
+    t = torch.linspace(0.0, 1.0, 60, device="cuda")
+    y = tda.odeint(f, y0, t, method="rk4", options={} if mode is None else dict(hip_graph=mode))
+    assert y.requires_grad
+    g, = torch.autograd.grad(y[-1].pow(2).sum(), [w])
+    y_ref = tda.odeint(f, y0, t, method="rk4", options=dict(hip_graph=False))
+    g_ref, = torch.autograd.grad(y_ref[-1].pow(2).sum(), [w])
+    assert torch.equal(g, g_ref) and torch.equal(y.detach(), y_ref.detach())
+
+
+def test_default_adjoint_training_loop_is_captured_and_bit_identical():
+    """`odeint_adjoint` with no option: iteration 1 eager, iteration 2 captures forward and backward solves, later ones
+    replay — gradients equal the eager ones to the last bit in every iteration, nothing warns."""
+    y0, t = _problem()
+    f = _Pure()
+
+    def one(options):
+        x = y0.clone().requires_grad_(True)
+        f.zero_grad()
+        f._calls[0] = 0
+        y = tda.odeint_adjoint(f, x, t, method="dopri5", rtol=1e-6, atol=1e-8, options=options)
+        y[-1].pow(2).sum().backward()
+        return f._calls[0], x.grad.clone(), f.lin.weight.grad.clone()
+    n_eager, gx, gw = one(dict(hip_graph=False))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        counts = []
+        for _ in range(4):
+            n, gx_a, gw_a = one(None)
+            counts.append(n)
+            assert torch.equal(gx_a, gx) and torch.equal(gw_a, gw)
+    assert counts[0] == n_eager and counts[3] < n_eager // 2, (counts, n_eager)
+
+
+def test_no_nested_capture_inside_a_callers_stream_capture(monkeypatch):
+    """A solve issued while the caller's own stream capture is running must not open a second capture."""
+    monkeypatch.setattr(_graph, "_stream_is_capturing", lambda: True)
+    from torchdiffeq_amd import solvers
+    monkeypatch.setattr(solvers.adaptive, "_stream_is_capturing", lambda: True)
+    monkeypatch.setattr(solvers.fixed, "_stream_is_capturing", lambda: True)
+    y0, t = _problem()
+    f = _Pure()
+    with torch.no_grad():
+        for _ in range(3):
+            tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8)
+            tda.odeint(f, y0, torch.linspace(0, 1, 50, device="cuda"), method="rk4")
+    assert f not in _graph._GraphStep._cache

@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _no_process_wide_graph_default(monkeypatch):
     """These tests choose the step path per call (`options={'hip_graph': ...}`) and assert on cache entries and Python
-    call counts: a process-wide TDEQ_HIP_GRAPH default (the suite is also run under TDEQ_HIP_GRAPH=auto) must not turn
+    call counts: the process-wide default ("auto" since r06; tests/test_graph_default_gpu.py covers it) must not turn
     their eager baselines into captured solves."""
-    monkeypatch.delenv("TDEQ_HIP_GRAPH", raising=False)
+    monkeypatch.setenv("TDEQ_HIP_GRAPH", "0")
 
 
 def _spiral():

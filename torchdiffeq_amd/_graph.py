@@ -17,6 +17,7 @@ import functools
 import gc
 import os
 import threading
+import types
 import warnings
 import weakref
 from typing import List, Optional
@@ -35,11 +36,21 @@ _GRAPH_MODE_MAX_ELEMENTS = 1 << 22
 _GRAPH_AUTO_MAX_ELEMENTS = 1 << 21
 
 
+# r06: the built-in default of the `hip_graph` solver option.  "auto" — captured trial steps wherever the safety net below
+# lets them through (states up to _GRAPH_AUTO_MAX_ELEMENTS, a func without visible per-evaluation side effects, a replay
+# that reproduces the eager step bit for bit, a func evaluation re-checked at the start of every later solve), silently
+# eager everywhere else.  The reference has no such switch (torchdiffeq/_impl/odeint.py:49-108): a drop-in user never sets
+# one, so the fast path has to be the one they get.  TDEQ_HIP_GRAPH=0 opts out process-wide, options={'hip_graph': False}
+# per solve.
+_DEFAULT_REQUEST = "auto"
+
+
 def _graph_request(hip_graph):
     """(wanted, auto) from the `hip_graph` solver option: True / False, "auto", or None = the process-wide default
-    taken from the environment variable TDEQ_HIP_GRAPH ("0" — the default —, "1" or "auto")."""
+    taken from the environment variable TDEQ_HIP_GRAPH ("auto" — the default since r06 —, "0" or "1")."""
     if hip_graph is None:
-        hip_graph = {"0": False, "": False, "1": True, "auto": "auto"}.get(os.environ.get("TDEQ_HIP_GRAPH", "0").lower())
+        hip_graph = {"0": False, "": False, "1": True, "auto": "auto"}.get(
+            os.environ.get("TDEQ_HIP_GRAPH", _DEFAULT_REQUEST).lower())
         if hip_graph is None:
             raise ValueError("TDEQ_HIP_GRAPH must be 0, 1 or auto")
     if isinstance(hip_graph, str):
@@ -49,60 +60,148 @@ def _graph_request(hip_graph):
     return bool(hip_graph), False
 
 
-def _tensors_in(value, _level=0):
-    """Tensors directly in `value` or one container level down (list / tuple / dict / set attribute values)."""
+_WALK_DEPTH = 4                  # containers / plain objects nested deeper than this are not searched
+_WALK_ITEMS = 4096               # ... nor are the items of a container beyond this many
+_PLAIN = (bool, int, float, complex, str, bytes, type(None))
+
+
+def _is_plain_object(value) -> bool:
+    """An INSTANCE that merely stores things (a config namespace, a dataclass, a hand-written parameter holder): has a
+    `__dict__`, is not a class, a Python module, a function or any other callable code object."""
+    return (getattr(value, "__dict__", None) is not None and not isinstance(value, (type, types.ModuleType))
+            and not hasattr(value, "__code__") and not hasattr(getattr(value, "__func__", None), "__code__")
+            and not isinstance(value, (functools.partial, types.BuiltinFunctionType)))
+
+
+def _request_is_explicit(hip_graph) -> bool:
+    """Whether captured steps were ASKED for — by the solver option or by the environment variable — rather than being
+    the built-in default: only then is a refusal worth a warning (the reference's user never heard of hipGraphs)."""
+    return hip_graph is not None or "TDEQ_HIP_GRAPH" in os.environ
+
+
+def _stream_is_capturing() -> bool:
+    """The caller is inside a stream capture of its own (`torch.cuda.graph(...)` around the solve): the solver must not
+    open a second one — its kernels simply become nodes of the caller's graph on the eager path."""
+    try:
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    except Exception:
+        return False
+
+
+def _tensors_in(value, _level=0, _seen=None):
+    """Every tensor reachable from `value` through containers (list / tuple / set / dict / deque), nn.Modules (parameters,
+    buffers, plain attributes of every submodule) and plain objects' attributes — bounded in depth and width, each
+    object visited once.  (r06, advisor r05: r05 stopped one container level down and never entered a Module or an
+    object found in an attribute, so `self.net = nn.Linear(...)` on a plain callable object was invisible.)"""
     if isinstance(value, torch.Tensor):
         return [value]
-    if _level == 0 and isinstance(value, (list, tuple, set, frozenset)):
-        return [t for v in value for t in _tensors_in(v, 1)]
-    if _level == 0 and isinstance(value, dict):
-        return [t for v in value.values() for t in _tensors_in(v, 1)]
+    if isinstance(value, _PLAIN) or _level > _WALK_DEPTH:
+        return []
+    seen = set() if _seen is None else _seen
+    if id(value) in seen:
+        return []
+    seen.add(id(value))
+    if isinstance(value, torch.nn.Module):
+        out = list(value.parameters()) + list(value.buffers())
+        for m in value.modules():
+            seen.add(id(m))
+            for name, v in list(m.__dict__.items()):
+                if name not in ("_parameters", "_buffers", "_modules"):
+                    out += _tensors_in(v, _level + 1, seen)
+        return out
+    if isinstance(value, (list, tuple, set, frozenset, collections.deque)):
+        out = []
+        for i, v in enumerate(value):
+            if i >= _WALK_ITEMS:
+                break
+            out += _tensors_in(v, _level + 1, seen)
+        return out
+    if isinstance(value, dict):
+        out = []
+        for i, v in enumerate(list(value.values())):
+            if i >= _WALK_ITEMS:
+                break
+            out += _tensors_in(v, _level + 1, seen)
+        return out
+    if _is_plain_object(value):
+        out = []
+        for v in list(value.__dict__.values()):
+            out += _tensors_in(v, _level + 1, seen)
+        return out
     return []
 
 
-def _object_tensors(obj):
-    """The tensors an object's attributes hold (directly or inside a list / tuple / dict)."""
-    return [t for v in getattr(obj, "__dict__", {}).values() for t in _tensors_in(v)]
+def _object_tensors(obj, _seen=None):
+    """The tensors an object's attributes hold (directly, inside containers, Modules or nested plain objects)."""
+    out = []
+    seen = set() if _seen is None else _seen
+    for v in list((getattr(obj, "__dict__", None) or {}).values()):
+        out += _tensors_in(v, 1, seen)
+    return out
 
 
-def _held_tensors(fn, _depth=0):
-    """The tensors a func object visibly holds: an nn.Module's parameters, buffers and plain tensor attributes (all
-    submodules, also inside list / tuple / dict attributes); a function's closure cells, defaults and the module-level
-    tensors its body names; a bound method's owner; an instance with `__call__` (its attributes and what its `__call__`
-    closes over); a functools.partial's arguments."""
-    held_t = []
-    if isinstance(fn, torch.nn.Module):
-        held_t += list(fn.parameters()) + list(fn.buffers())
-        for m in fn.modules():
-            held_t += _object_tensors(m)
-        return held_t
-    if _depth > 2:
+def _named_globals(inner):
+    """The module-level objects a function's body (and the lambdas / inner functions defined in it) names."""
+    code, glob = getattr(inner, "__code__", None), getattr(inner, "__globals__", None)
+    if code is None or glob is None:
         return []
+    names, stack = [], [code]
+    while stack:
+        c = stack.pop()
+        names += [n for n in c.co_names if n in glob]
+        stack += [k for k in c.co_consts if isinstance(k, types.CodeType)]
+    out, done = [], set()
+    for n in names:
+        if n not in done:
+            done.add(n)
+            out.append(glob[n])
+    return out
+
+
+def _held_tensors(fn, _depth=0, _seen=None):
+    """The tensors a func object visibly holds: an nn.Module's parameters, buffers and plain attributes (all submodules,
+    nested containers / objects / Modules inside them); a function's closure cells, defaults and the module-level
+    tensors, Modules, containers, plain objects and helper functions its body names; a bound method's owner; an instance
+    with `__call__` (its attributes and what its `__call__` closes over); a functools.partial's arguments."""
+    seen = set() if _seen is None else _seen
+    if isinstance(fn, torch.nn.Module):
+        return _tensors_in(fn, 0, seen)
+    if _depth > 2 or id(fn) in seen:
+        return []
+    seen.add(id(fn))
+    held_t = []
     owner = getattr(fn, "__self__", None)
-    if owner is not None and not isinstance(owner, type):
-        held_t += _held_tensors(owner, _depth + 1) if isinstance(owner, torch.nn.Module) else _object_tensors(owner)
+    if owner is not None and not isinstance(owner, (type, types.ModuleType)):
+        held_t += _tensors_in(owner, 0, seen) if isinstance(owner, torch.nn.Module) else _object_tensors(owner, seen)
     is_function = hasattr(fn, "__code__") or hasattr(getattr(fn, "__func__", None), "__code__")
     if not is_function and not isinstance(fn, type) and hasattr(type(fn), "__call__") \
             and not isinstance(fn, functools.partial) and getattr(fn, "__dict__", None) is not None:
         # a callable INSTANCE (class with __call__): what it stores, and what its __call__ is written over
-        held_t += _object_tensors(fn)
+        held_t += _object_tensors(fn, seen)
         call = getattr(type(fn), "__call__", None)
         if call is not None and hasattr(call, "__code__"):
-            held_t += _held_tensors(call, _depth + 1)
+            held_t += _held_tensors(call, _depth + 1, seen)
     inner = getattr(fn, "__func__", fn)
     held = [c.cell_contents for c in (getattr(inner, "__closure__", None) or ()) if _cell_is_set(c)]
     held += list(getattr(inner, "__defaults__", None) or ())
-    code, glob = getattr(inner, "__code__", None), getattr(inner, "__globals__", None)
-    if code is not None and glob is not None:        # module-level tensors / modules the body names
-        held += [glob[n] for n in code.co_names if isinstance(glob.get(n), (torch.Tensor, torch.nn.Module))]
+    held += list((getattr(inner, "__kwdefaults__", None) or {}).values())
+    # module-level things the body names: tensors, Modules, containers (a global list of layers), plain objects (`cfg.w`),
+    # helper FUNCTIONS of the user's own (not classes, not imported library modules / functions)
+    for g in _named_globals(inner):
+        if isinstance(g, (torch.Tensor, torch.nn.Module, list, tuple, dict, set, collections.deque)) or _is_plain_object(g):
+            held.append(g)
+        elif hasattr(g, "__code__") and getattr(g, "__module__", None) == getattr(inner, "__module__", None):
+            held.append(g)
     held += list(getattr(fn, "args", ())) + list((getattr(fn, "keywords", None) or {}).values())     # functools.partial
     if getattr(fn, "func", None) is not None and callable(fn.func):
         held.append(fn.func)
     for v in held:
-        if isinstance(v, torch.nn.Module) or (callable(v) and not isinstance(v, torch.Tensor)):
-            held_t += _held_tensors(v, _depth + 1)
+        if isinstance(v, (torch.Tensor, torch.nn.Module)):
+            held_t += _tensors_in(v, 0, seen)
+        elif callable(v) and not isinstance(v, type):
+            held_t += _held_tensors(v, _depth + 1, seen)
         else:
-            held_t += _tensors_in(v)
+            held_t += _tensors_in(v, 0, seen)
     return held_t
 
 
@@ -114,9 +213,14 @@ def _held_tensor_ptrs(fn, _depth=0):
 def _holds_a_tensor_that_requires_grad(fn) -> bool:
     """Whether anything func can be seen to hold is part of an autograd graph or a leaf that wants a gradient — decided
     from what func HOLDS, without evaluating it (advisor r04: a probe evaluation is visible to the user — RNG state,
-    counters, one more NFE — and looks at one time only)."""
+    counters, one more NFE — and looks at one time only).  A func in which NOTHING can be inspected (state behind
+    `__slots__`, properties, a C extension object) counts as holding one: the eager path, which records a graph, is the
+    safe answer (advisor r05).  What this static look misses is caught after the first evaluation by the solvers' dynamic
+    guard (`OdeFunc.grad_output_seen`)."""
     try:
-        return any(t.requires_grad for t in _held_tensors(fn))
+        if any(t.requires_grad for t in _held_tensors(fn)):
+            return True
+        return not _reusable_across_solves(fn)
     except Exception:       # an exotic callable: be safe, take the path that records a graph
         return True
 
@@ -152,6 +256,59 @@ _AUTO_CAPTURE_AFTER_STEPS = 96
 _AUTO_MIN_GRID_STEPS = 24           # fixed grids: intervals below which "auto" does not capture (one capture ≈ 1 ms there)
 
 
+def _global_state(inner, versions=False, _depth=0):
+    """Identity of the module-level PLAIN values a function body names — numbers, flags, strings, small containers of
+    them, the plain attributes of a config-like object, and (one level) the same for the user's own helper functions it
+    calls.  A captured graph bakes such values into its kernel arguments exactly like an attribute `self.scale` (r06: a
+    module-level `alpha = 2.0` changed between two solves must lead to a new capture, not to a replay of the old value;
+    `global NFE; NFE += 1` inside func is a per-evaluation side effect).  `versions`: also the storage address and in-place
+    version counter of module-level tensors (the side-effect fingerprint; the cache key has their addresses already)."""
+    if inner is None or not hasattr(inner, "__code__"):
+        return ()
+    out = []
+    code, glob = inner.__code__, inner.__globals__
+    names, stack = [], [code]
+    while stack:
+        c = stack.pop()
+        names += [n for n in c.co_names if n in glob]
+        stack += [k for k in c.co_consts if isinstance(k, types.CodeType)]
+    for n in dict.fromkeys(names):
+        v = glob[n]
+        if isinstance(v, _PLAIN):
+            out.append((n, v))
+        elif isinstance(v, torch.Tensor):
+            if versions:
+                out.append((n, v.data_ptr(), v._version))
+        elif isinstance(v, (list, tuple, collections.deque)):
+            out.append((n, len(v), tuple(x for x in list(v)[:64] if isinstance(x, _PLAIN))))
+        elif isinstance(v, dict):
+            out.append((n, len(v), tuple(x for x in list(v.values())[:64] if isinstance(x, _PLAIN))))
+        elif isinstance(v, torch.nn.Module):
+            out.append((n, _scalar_state(v)))
+        elif _is_plain_object(v):
+            sub = []
+            _visible_state(v, sub, 1)
+            out.append((n, tuple(x for x in sub if versions or not (len(x) == 3 and isinstance(x[1], int) and isinstance(x[2], int)))))
+        elif _depth < 1 and hasattr(v, "__code__") and getattr(v, "__module__", None) == getattr(inner, "__module__", None):
+            out.append((n, _global_state(v, versions, _depth + 1)))
+    return tuple(out)
+
+
+def _module_global_state(module, versions=False):
+    """`_global_state` of the `forward` of every user-defined class among a Module's submodules (torch.nn's own layers
+    name no module-level state of the user's)."""
+    out, done = [], set()
+    for m in module.modules():
+        cls = type(m)
+        if cls in done or (cls.__module__ or "").startswith("torch."):
+            continue
+        done.add(cls)
+        fwd = getattr(cls, "forward", None)
+        if fwd is not None and hasattr(fwd, "__code__"):
+            out.append(_global_state(fwd, versions))
+    return tuple(out)
+
+
 def _visible_state(obj, out, depth=0):
     """Cheap identity of what `obj` visibly holds — plain numbers, flags, strings, container lengths, tensor storages
     with their in-place version counters — appended to `out`."""
@@ -161,9 +318,19 @@ def _visible_state(obj, out, depth=0):
         elif isinstance(v, (bool, int, float, complex, str, bytes, type(None))):
             out.append((name, v))
         elif isinstance(v, (list, tuple, set, frozenset, collections.deque)):
-            out.append((name, len(v), tuple((t.data_ptr(), t._version) for t in v if isinstance(t, torch.Tensor))))
+            out.append((name, len(v), tuple((t.data_ptr(), t._version) for t in v if isinstance(t, torch.Tensor)),
+                        tuple(x for x in list(v)[:64] if isinstance(x, (bool, int, float)))))
         elif isinstance(v, dict) and name not in ("_parameters", "_buffers", "_modules"):
-            out.append((name, len(v), tuple((t.data_ptr(), t._version) for t in v.values() if isinstance(t, torch.Tensor))))
+            out.append((name, len(v), tuple((t.data_ptr(), t._version) for t in v.values() if isinstance(t, torch.Tensor)),
+                        tuple(x for x in list(v.values())[:64] if isinstance(x, (bool, int, float)))))
+        elif isinstance(v, torch.nn.Module):
+            if not isinstance(obj, torch.nn.Module) and depth < 2:     # (a Module's submodules are walked by the caller)
+                out.append((name, _side_effect_fingerprint(v, None)))
+        elif depth < 2 and _is_plain_object(v):
+            # r06: a counter kept one object down (`self.stats.nfe += 1`)
+            sub = []
+            _visible_state(v, sub, depth + 1)
+            out.append((name, tuple(sub)))
 
 
 def _side_effect_fingerprint(fn, device):
@@ -178,6 +345,7 @@ def _side_effect_fingerprint(fn, device):
             _visible_state(m, out)
         out += [(n, t.data_ptr(), t._version) for n, t in fn.named_parameters()]
         out += [(n, t.data_ptr(), t._version) for n, t in fn.named_buffers()]
+        out.append(_module_global_state(fn, versions=True))
     else:
         _visible_state(fn, out)
         owner = getattr(fn, "__self__", None)
@@ -200,6 +368,8 @@ def _side_effect_fingerprint(fn, device):
                         out.append(tuple(x for x in v if isinstance(x, (bool, int, float))))
                 elif hasattr(v, "__dict__") and not callable(v):
                     _visible_state(v, out)
+        call = getattr(type(fn), "__call__", None) if not hasattr(inner, "__code__") else None
+        out.append(_global_state(inner if hasattr(inner, "__code__") else call, versions=True))
     if device is not None and torch.device(device).type == "cuda":
         try:
             idx = torch.device(device).index
@@ -215,17 +385,26 @@ def _scalar_state(fn):
     the key by storage address).  A captured graph bakes such values into its kernel arguments, so they are part of the
     captured-step cache key: `self.scale = 0.5` changed between two solves leads to a new capture, not to a replay
     with the old value."""
-    def plain(obj, out):
-        for name, v in list(getattr(obj, "__dict__", {}).items()):
+    def plain(obj, out, depth=0):
+        for name, v in list((getattr(obj, "__dict__", None) or {}).items()):
             if isinstance(v, (bool, int, float, complex, str, bytes, type(None))):
                 out.append((name, v))
             elif isinstance(v, (list, tuple)) and len(v) <= 64 and all(isinstance(x, (bool, int, float, str)) for x in v):
                 out.append((name, tuple(v)))
+            elif isinstance(v, dict) and name not in ("_parameters", "_buffers", "_modules") and len(v) <= 64:
+                out.append((name, tuple((k, x) for k, x in v.items() if isinstance(k, str) and isinstance(x, (bool, int, float, str)))))
+            elif depth < 2 and isinstance(v, torch.nn.Module) and not isinstance(obj, torch.nn.Module):
+                out.append((name, _scalar_state(v)))
+            elif depth < 2 and _is_plain_object(v) and not isinstance(v, torch.nn.Module):
+                sub = []
+                plain(v, sub, depth + 1)        # (`self.cfg.scale`)
+                out.append((name, tuple(sub)))
     out = []
     if isinstance(fn, torch.nn.Module):
         for m in fn.modules():
             plain(m, out)
             out.append(m.training)
+        out.append(_module_global_state(fn))
         return tuple(out)
     plain(fn, out)
     owner = getattr(fn, "__self__", None)
@@ -233,6 +412,7 @@ def _scalar_state(fn):
         out.append(_scalar_state(owner) if isinstance(owner, torch.nn.Module) else None)
         plain(owner, out)
     inner = getattr(fn, "__func__", fn)
+    out.append(_global_state(inner if hasattr(inner, "__code__") else getattr(type(fn), "__call__", None)))
     for c in (getattr(inner, "__closure__", None) or ()):
         if _cell_is_set(c):
             v = c.cell_contents
@@ -346,6 +526,7 @@ class _GraphStep:
         self.in_use = True
         self.auto = bool(getattr(s, "_graph_auto", False))    # `hip_graph="auto"`: verify before trusting replays
         self.probed = False         # a replayed step has reproduced an eager one bit for bit
+        self.recheck = False        # re-used in a LATER solve (auto mode): verify the first replay, see _recheck
         self.refused = None         # why this func must not be replayed (auto mode)
         self.reset(s, t0, dt)
 
@@ -418,7 +599,9 @@ class _GraphStep:
                     del per_func[k]
         except TypeError:
             first = True
-        if first:
+        if first and getattr(s, "_graph_explicit", True):
+            # (only where captured steps were asked for: under the built-in default a refusal is silent — the reference's
+            #  user never heard of hipGraphs and gets the eager path, which is what the reference is)
             warnings.warn("hip_graph='auto': {} is not captured into a hipGraph — {}; its solves run on the eager "
                           "path (pass hip_graph=True to capture it regardless)".format(type(base).__name__, reason))
 
@@ -462,6 +645,8 @@ class _GraphStep:
         g = per_func.get(key) if per_func is not None else None
         if g is not None and not g.in_use:
             g.in_use = True
+            g.auto = bool(getattr(s, "_graph_auto", False))
+            g.recheck = g.auto      # "auto": the first replay of this solve is checked against one eager evaluation
             s.plan = g.plan         # read-backs must poll the buffers the captured kernels write
             g.reset(s, t0, dt)
             return g
@@ -595,9 +780,45 @@ class _GraphStep:
                 self._probe(s, side, graph)
                 func.nfe += len(s._beta)
                 return
-        kern.arm_readback(s.plan)
-        self.graphs[side].replay()
+        if self.recheck:
+            self.recheck = False
+            if not self._recheck(s, side):
+                func.nfe += len(s._beta)
+                return
+        else:
+            kern.arm_readback(s.plan)
+            self.graphs[side].replay()
         func.nfe += len(s._beta)
+
+    def _recheck(self, s, side: int) -> bool:
+        """Auto mode, first replay of a LATER solve with a cached graph (r06, the price of being the default): the cache key
+        holds every tensor storage and every plain value `func` can be SEEN to hold, but a Python number behind a property,
+        in a C-extension object or in another module is baked into the captured kernels' arguments all the same.  So the
+        step's first stage is also evaluated eagerly — one combine launch and ONE evaluation of func, with the Python body
+        as it is NOW — and must equal the graph's own first evaluation bit for bit.  If not, the graph is stale: the full
+        probe puts the eagerly evaluated step in place and func is not replayed again.  Returns whether the replay stands."""
+        kern, func, plan = s.kernels, s.func, s.plan
+        graph = self.graphs[side]
+        ctrl0, times0 = plan.ctrl_dev.clone(), self.tbuf.clone()
+        y_cur, f_cur = self.y[side], self.f_in(side)
+        nfe = func.nfe
+        yi = torch.empty_like(y_cur)
+        kern.stage_combine_dev(yi, None, y_cur, [f_cur], s._beta[0].coef, None, plan)
+        k1 = func.eval_at(self.ts[0], yi)
+        func.nfe = nfe
+        kern.arm_readback(plan)
+        graph.replay()
+        if torch.equal(k1, self.k[side][1]):
+            return True
+        plan.ctrl_dev.copy_(ctrl0)
+        self.tbuf.copy_(times0)
+        self.probed = False
+        self._probe(s, side, graph)
+        if self.refused is None:
+            # (the full probe agrees although the single evaluation did not: a func that is not deterministic from call to
+            #  call — nothing a replay could be trusted with either)
+            self.refuse(s, "two evaluations of it at the same (t, y) differ")
+        return False
 
     def _eager_body(self, s, side: int) -> None:
         current = torch.cuda.current_stream(s.y0.device)

@@ -72,6 +72,8 @@ class _AliasParams(torch.overrides.TorchFunctionMode):
             return self._alias.get(id(x), x)
         if type(x) in (list, tuple):
             return type(x)(self._sub(v) for v in x)
+        if type(x) is dict:
+            return {k: self._sub(v) for k, v in x.items()}
         return x
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
@@ -153,7 +155,7 @@ class _AugmentedDynamics(OdeFunc):
                 grads = (None,) * len(wrt)
         return f_list, grads
 
-    def proxy_is_faithful(self, t_user: torch.Tensor, aug: torch.Tensor) -> bool:
+    def proxy_is_faithful(self, t_user: torch.Tensor, aug: torch.Tensor, t_other: Optional[torch.Tensor] = None) -> bool:
         """Captured evaluations differentiate func through `functional_call` on leaf aliases of the parameters.  A
         forward that reaches a registered parameter some other way than by attribute lookup on the module (a Python
         list or an alias holding the same Parameter objects, a pre-bound closure) is not re-routed by functional_call:
@@ -174,14 +176,23 @@ class _AugmentedDynamics(OdeFunc):
         for v in self.layout.unpack(aug, lo=1 + n_y, hi=1 + 2 * n_y):
             flat = v.reshape(-1)
             flat.copy_(torch.cos(torch.arange(flat.numel(), device=flat.device, dtype=torch.float64) * 1.618).to(flat.dtype))
-        _, direct = self._vjps(t_user, aug, False)
-        _, proxied = self._vjps(t_user, aug, True)
         ok = True
-        for a, b in zip(direct[1 + n_y:], proxied[1 + n_y:]):
-            if (a is None) != (b is None):
-                ok = False
-            elif a is not None and not torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(a.abs().max()) + 1e-30):
-                ok = False
+        # two evaluation points (advisor r05: a parameter whose use is gated by time or state may be idle at one of them):
+        # the end of the backward interval at hand and, if given, its other end with a different state
+        points = [(t_user, aug)]
+        if t_other is not None:
+            aug2 = aug.clone()
+            for v in self.layout.unpack(aug2, lo=1, hi=1 + n_y):
+                v.mul_(-0.5).add_(0.25)
+            points.append((t_other, aug2))
+        for t_p, aug_p in points:
+            _, direct = self._vjps(t_p, aug_p, False)
+            _, proxied = self._vjps(t_p, aug_p, True)
+            for a, b in zip(direct[1 + n_y:], proxied[1 + n_y:]):
+                if (a is None) != (b is None):
+                    ok = False
+                elif a is not None and not torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(a.abs().max()) + 1e-30):
+                    ok = False
         try:
             _PROXY_CHECKED[self.fwd.base_func] = (key, ok)
         except TypeError:
@@ -310,7 +321,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
             # evaluation all-reduce does not belong in a graph.
             if sync is not None:
                 options["hip_graph"] = False
-            from .solvers import _graph_request
+            from .solvers import _graph_request, _request_is_explicit
             wanted, auto = _graph_request(options.get("hip_graph"))
             auto_second_sight = False
             if wanted and auto and not _auto_backward_due(fwd.base_func, aug_layout.total):
@@ -323,15 +334,18 @@ class OdeintAdjointMethod(torch.autograd.Function):
                 # the forward solve's SOLVER time of the last output: `_vjps` turns it into the user's time itself (a
                 # sign-corrected value here would evaluate a reversed-time func at -t, possibly outside its domain)
                 t_end_user = torch.full((), float(fwd.np_dtype(float(t[-1]))), dtype=fwd.time_dtype, device=device)
-                if aug_func.proxy_is_faithful(t_end_user, aug):
+                t_start_user = torch.full((), float(fwd.np_dtype(float(t[0]))), dtype=fwd.time_dtype, device=device)
+                if aug_func.proxy_is_faithful(t_end_user, aug, t_start_user):
                     aug_func.use_proxy = True
                     auto_second_sight = auto    # (the first backward solve of func ran with the option off)
-                else:
+                elif _request_is_explicit(options.get("hip_graph")):
+                    options["hip_graph"] = False
                     warnings.warn("hip_graph: func reaches some of its adjoint parameters in a way that cannot be re-routed to "
                                   "leaf aliases (a module parameter used other than by attribute lookup, a pre-computed "
                                   "view of a parameter held by a closure), so the backward solve cannot be captured with "
                                   "correct parameter gradients; running it eagerly")
-                    options["hip_graph"] = False
+                else:
+                    options["hip_graph"] = False        # (built-in default: silently the eager backward solve)
             if sync is not None:
                 # lock-step backward solve: [vjp_t | θ-adjoints] replicated (all-reduced per evaluation), y / adj_y
                 # sharded; the norm sums are added over ranks (solvers._LockStep)

@@ -358,6 +358,7 @@ class OdeFunc:
         self.np_dtype = scalar_type(dtype)          # host stand-in for 0-dim tensors of that type (_scalars.py)
         self.time_dtype = real_dtype(dtype)
         self.nfe = 0
+        self.grad_output_seen = False   # an evaluation in grad mode returned a tensor that is part of an autograd graph
         self._kernels = None
         self._anchor_user = None     # user-time t[0] when `t` requires grad (adaptive solvers)
         self.strict_numel = False    # see _conform; set by check_inputs from the solver class
@@ -481,8 +482,13 @@ class OdeFunc:
             out = f.reshape(-1)
             if not out.is_contiguous():
                 out = out.contiguous()
-        if out.requires_grad and not grad:
-            out = out.detach()      # func built its own graph internally (e.g. a Jacobian trace): drop it
+        if out.requires_grad:
+            if not grad:
+                out = out.detach()      # func built its own graph internally (e.g. a Jacobian trace): drop it
+            else:
+                # the solve is part of an autograd graph through func's own parameters — seen by the captured-step paths,
+                # which write raw buffers (fixed.py `_integrate_graph`: the dynamic guard behind the static look at func)
+                self.grad_output_seen = True
         return out
 
     def __call__(self, t, y_flat, *, perturb: Perturb = Perturb.NONE):

@@ -24,7 +24,7 @@ with time-like scalars (t0, t1, dt, rtol, ...) as host doubles instead of 0-dim 
 from .._graph import (_AUTO_CAPTURE_AFTER_STEPS, _AUTO_MIN_GRID_STEPS, _GRAPH_AUTO_MAX_ELEMENTS,  # noqa: F401
                       _GRAPH_MODE_MAX_ELEMENTS, _CaptureFailed, _DtCell, _GraphStep, _capture, _graph_request,
                       _held_tensor_ptrs, _reusable_across_solves, _scalar_state, _side_effect_fingerprint, _side_stream,
-                      clear_graph_cache)
+                      _request_is_explicit, _stream_is_capturing, clear_graph_cache)
 from ._common import (_nan_max, _nan_min, _clamp, _norm_value, _as_float, optimal_step_size, optimal_step_size_in, _StepShadow, _NoShadow, _NO_SHADOW)  # noqa: F401
 from .adaptive import (AdaptiveHeunSolver, Bosh3Solver, Dopri5Solver, Dopri8Solver, Fehlberg2,  # noqa: F401
                        RKAdaptiveStepsizeODESolver, Tsit5Solver, _DenseRecord, _InitialStepShadow, _LockStep)

@@ -18,7 +18,7 @@ from .. import _native
 from .._graph import (_AUTO_CAPTURE_AFTER_STEPS, _AUTO_MIN_GRID_STEPS, _GRAPH_AUTO_MAX_ELEMENTS,  # noqa: F401
                      _GRAPH_MODE_MAX_ELEMENTS, _CaptureFailed, _DtCell, _GraphStep, _capture, _graph_request,
                      _held_tensor_ptrs, _reusable_across_solves, _scalar_state, _side_effect_fingerprint, _side_stream,
-                     clear_graph_cache)
+                     _request_is_explicit, _stream_is_capturing, clear_graph_cache)
 from .._scalars import is_low, power, rdiv, scalar_type  # noqa: F401
 from ..autodiff import Ops, stitch  # noqa: F401
 from ..misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, component_norm, find_event, handle_unused_kwargs, rms_norm,  # noqa: F401
@@ -288,11 +288,17 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
                                                      self.layout.chunk, y0.device)
         self._lookahead = device_ctrl and os.environ.get("TDEQ_LOOKAHEAD", "1") != "0"
         # `hip_graph=True` (an extension, not a reference option): one captured hipGraph per trial step, see _GraphStep
-        # "auto" = only where it pays (states up to _GRAPH_AUTO_MAX_ELEMENTS) and silently; never the built-in default,
-        # because a captured func runs in Python only while the graph is being built: per-evaluation Python side
-        # effects (an evaluation counter, data-dependent branches) are not replayed — the user has to vouch for that
+        # "auto" = only where it pays (states up to _GRAPH_AUTO_MAX_ELEMENTS) and silently; the built-in default since r06
+        # (_graph._DEFAULT_REQUEST).  A captured func runs in Python only while the graph is being built; what makes that
+        # safe without the user vouching for it is `auto`'s net: the side-effect fingerprint around the first eager
+        # evaluation, the replay-vs-eager probe of the first captured step, the cache key over every tensor storage and
+        # plain value func can be seen to hold, and the one-evaluation re-check of a cached graph at the start of every
+        # later solve (_GraphStep._recheck)
         wanted, auto = _graph_request(hip_graph)
         self._graph_auto = auto
+        self._graph_explicit = _request_is_explicit(hip_graph)    # refusals warn only where captured steps were asked for
+        if wanted and _stream_is_capturing():
+            wanted = False          # the caller is capturing a graph of its own around this solve: no nested capture
         self._auto = None           # auto mode: this solve's policy ("now" / "later" / "never", _GraphStep.auto_policy)
         self._auto_steps = 0
         self._hold_pre = False      # auto mode: the eager step before the switch to replays enqueues no look-ahead stage

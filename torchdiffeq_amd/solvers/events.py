@@ -18,7 +18,7 @@ from .. import _native
 from .._graph import (_AUTO_CAPTURE_AFTER_STEPS, _AUTO_MIN_GRID_STEPS, _GRAPH_AUTO_MAX_ELEMENTS,  # noqa: F401
                      _GRAPH_MODE_MAX_ELEMENTS, _CaptureFailed, _DtCell, _GraphStep, _capture, _graph_request,
                      _held_tensor_ptrs, _reusable_across_solves, _scalar_state, _side_effect_fingerprint, _side_stream,
-                     clear_graph_cache)
+                     _request_is_explicit, _stream_is_capturing, clear_graph_cache)
 from .._scalars import is_low, power, rdiv, scalar_type  # noqa: F401
 from ..autodiff import Ops, stitch  # noqa: F401
 from ..misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, component_norm, find_event, handle_unused_kwargs, rms_norm,  # noqa: F401

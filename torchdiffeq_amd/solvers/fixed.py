@@ -18,7 +18,7 @@ from .. import _native
 from .._graph import (_AUTO_CAPTURE_AFTER_STEPS, _AUTO_MIN_GRID_STEPS, _GRAPH_AUTO_MAX_ELEMENTS,  # noqa: F401
                      _GRAPH_MODE_MAX_ELEMENTS, _CaptureFailed, _DtCell, _GraphStep, _capture, _graph_request,
                      _held_tensor_ptrs, _reusable_across_solves, _scalar_state, _side_effect_fingerprint, _side_stream,
-                     clear_graph_cache)
+                     _request_is_explicit, _stream_is_capturing, clear_graph_cache)
 from .._scalars import is_low, power, rdiv, scalar_type  # noqa: F401
 from ..autodiff import Ops, stitch  # noqa: F401
 from ..misc import (BuiltinNorm, OdeFunc, Perturb, StateLayout, component_norm, find_event, handle_unused_kwargs, rms_norm,  # noqa: F401
@@ -71,6 +71,7 @@ class FixedGridODESolver(FixedGridEvents):
         # (rk4, small states), without the warning otherwise.
         self.hip_graph, self._graph_auto = _graph_request(hip_graph)
         self._graph_explicit = hip_graph is not None
+        self._graph_warn = _request_is_explicit(hip_graph)       # refusals warn only where captured steps were asked for
         unused_kwargs.pop("rtol", None)
         unused_kwargs.pop("norm", None)
         unused_kwargs.pop("dist_sync", None)          # fixed grids are in lock step by construction
@@ -160,8 +161,12 @@ class FixedGridODESolver(FixedGridEvents):
         if self.hip_graph:
             if self._graph_capable(t, time_grid) and not (self._graph_auto and
                                                           self.layout.total > _GRAPH_AUTO_MAX_ELEMENTS):
-                return self._integrate_graph(t)
-            if not self._graph_auto and self._graph_explicit:
+                solution = self._integrate_graph(t)
+                if solution is not None:
+                    return solution
+                # (None: the first evaluations showed func's outputs to be part of an autograd graph the static look at
+                #  func had not found — the solve starts over on the eager, differentiable path below)
+            elif not self._graph_auto and self._graph_explicit:
                 # (asked for by option; a process-wide TDEQ_HIP_GRAPH=1 default applies where it can and stays silent)
                 warnings.warn("{}: hip_graph=True needs an explicit Runge-Kutta fixed-grid method (euler, midpoint, "
                               "heun2, heun3, rk4), the output times as the grid, linear interpolation, no callback, no "
@@ -238,6 +243,8 @@ class FixedGridODESolver(FixedGridEvents):
                 and self.func.callback_step is _null and self.device.type == "cuda"
                 and hasattr(self.kernels, "grid_advance_stages")):
             return False
+        if _stream_is_capturing():
+            return False            # the caller is capturing a graph of its own around this solve: no nested capture
         if not torch.is_grad_enabled():
             return True
         if t.requires_grad or self.y0.requires_grad:
@@ -288,9 +295,19 @@ class FixedGridODESolver(FixedGridEvents):
         side.wait_stream(current)
         auto = self._graph_auto
         before = _side_effect_fingerprint(func.base_func, self.device) if auto else None
+        func.grad_output_seen = False
+        nfe_first = func.nfe
         with torch.cuda.stream(side):
             step()
         current.wait_stream(side)
+        if func.grad_output_seen and torch.is_grad_enabled():
+            # Dynamic guard (advisor r05): func's output requires grad although nothing `_held_tensors` could see does — a
+            # parameter behind a property, a C-extension object, a weak reference ...  The kernels of this path write raw
+            # buffers, the solution would carry no graph and the parameter gradients would be lost silently.  The step
+            # just taken is discarded; `integrate` runs the eager path, which records one node per kernel call.  (Its
+            # evaluations have happened: a func that counts its own calls sees `n_eval` more than the reference's.)
+            func.nfe = nfe_first
+            return None
         if auto and n_t > 2:
             # "auto": replay only what is safe and worth it — a func whose evaluation visibly changed its own state (a
             # counter, a cache, random numbers) is not captured; nor is a grid too short to pay for the capture
@@ -307,8 +324,9 @@ class FixedGridODESolver(FixedGridEvents):
                     _GraphStep._refused[base] = reason
                 except TypeError:
                     pass
-                warnings.warn("hip_graph='auto': {} is not captured into a hipGraph — {}; its solves run on the eager "
-                              "path (pass hip_graph=True to capture it regardless)".format(type(base).__name__, reason))
+                if self._graph_warn:
+                    warnings.warn("hip_graph='auto': {} is not captured into a hipGraph — {}; its solves run on the eager "
+                                  "path (pass hip_graph=True to capture it regardless)".format(type(base).__name__, reason))
             if reason is not None or n_t - 2 < _AUTO_MIN_GRID_STEPS:
                 for _ in range(n_t - 2):
                     step()
@@ -322,8 +340,15 @@ class FixedGridODESolver(FixedGridEvents):
                     step()
             except Exception as exc:      # func is not capturable: nothing has run, the same body works eagerly
                 func.nfe = nfe_before
-                warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({!r}); continuing with "
-                              "the eager path".format(exc))
+                if auto:
+                    # remembered per func object: the next solve of a training loop does not try again
+                    try:
+                        _GraphStep._refused[func.base_func] = "capturing it failed ({!r})".format(exc)
+                    except TypeError:
+                        pass
+                if self._graph_warn:
+                    warnings.warn("hip_graph=True: func could not be captured into a hipGraph ({!r}); continuing with "
+                                  "the eager path".format(exc))
                 for _ in range(n_t - 2):
                     step()
                 return solution
