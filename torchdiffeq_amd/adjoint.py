@@ -321,8 +321,10 @@ class OdeintAdjointMethod(torch.autograd.Function):
             # evaluation all-reduce does not belong in a graph.
             if sync is not None:
                 options["hip_graph"] = False
-            from .solvers import _graph_request, _request_is_explicit
+            from .solvers import _graph_request, _request_is_explicit, _stream_is_capturing
             wanted, auto = _graph_request(options.get("hip_graph"))
+            if device.type != "cuda" or _stream_is_capturing():
+                wanted = False      # nothing can be captured here: no proxy check (its evaluations of func would be visible)
             auto_second_sight = False
             if wanted and auto and not _auto_backward_due(fwd.base_func, aug_layout.total):
                 # "auto": nothing would be captured in this backward solve (state too large, func refused, or first sight
