@@ -77,6 +77,42 @@ def test_bench_self_launches_two_ranks_gloo(tmp_path):
     assert "extras_timed_out" not in out and set(out["extras_s"]) >= {"weak", "lockstep", "adjoint"}
 
 
+@pytest.mark.skipif(torch.cuda.device_count() >= 8, reason="on an 8-GPU node the driver's own run covers N = 8 over RCCL")
+def test_bench_self_launches_eight_ranks_gloo(tmp_path):
+    """r06: the N = 8 control flow — the command the driver runs on an 8-GPU node, `python bench.py
+    --gpus 8` — executed once on the 1-GPU lease with the ranks sharing the device over gloo: 8 self-launched ranks, the
+    strong split at 8192 rows per rank, weak / lock-step / adjoint regimes, the watchdog, ONE stdout line < 4 KB.  Nothing
+    here measures scaling (one GPU serves all ranks); it shows that the N = 8 path cannot fail on the day an 8-GPU node
+    exists for a reason findable today."""
+    import json
+    import time
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TDEQ_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r, lines, out = _run_bench(["--gpus", "8", "--steps", "5", "--warmup", "2"], env, tmp_path, 900)
+    elapsed = time.time() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["value"] > 0 and line["steps"] == 5
+    assert line["config"]["global_batch"] == 65536 and line["config"]["rows_per_gpu"] == 8192
+    assert line["backend"] == "gloo" and line["rccl_ranks"] is None
+    assert not any(isinstance(v, list) for v in line.values())
+    hung = (out or {}).get("extras_hung_in") or line.get("extras_hung_in")
+    for regime in ("strong", "weak", "lockstep"):
+        assert (regime in line and line[regime]["value"] > 0) or (hung and regime in str(hung)), (regime, hung)
+    assert "adjoint" in line or (hung and "adjoint" in str(hung))
+    if "adjoint" in line:
+        for mode in ("strong", "weak"):
+            assert line["adjoint"][mode]["allreduce_calls"] == 1
+    assert out is not None and line["extras_file"].endswith("bench_extras_n8.json")
+    assert out["comm"]["comm_ranks"] == 8 and [d["rank"] for d in out["comm"]["devices"]] == list(range(8))
+    assert [r_["rank"] for r_ in out["breakdown"]["per_rank"]] == list(range(8))
+    print("bench.py --gpus 8 over gloo on one GPU: {:.1f} s".format(elapsed))
+    assert elapsed < 300, elapsed
+
+
 def test_bench_census_through_rccl_at_world_size_one(tmp_path):
     """bench.py's communicator census — the all-reduce of ones ON THE DEVICE and the gather of the ranks' GPU identities
     that every N > 1 run performs before timing anything — executed through RCCL itself: TDEQ_DIST_FORCE_INIT=1 creates

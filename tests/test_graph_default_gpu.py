@@ -104,6 +104,38 @@ def test_default_is_silent_about_a_counting_field_and_keeps_its_counts():
         for _ in range(3):
             tda.odeint(g, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph="auto"))
     assert len([x for x in w if "hip_graph='auto'" in str(x.message)]) == 1
+    assert g.nfe == 3 * n                         # (the counter kept running across the solves: still every evaluation)
+
+
+def test_default_adjoint_never_adds_evaluations_a_counting_field_could_see():
+    """`odeint_adjoint` with the reference's counting field and NO option: forward and backward counts of every iteration
+    equal the eager ones — the field is recognised at the first evaluation of its first solve, so neither a capture nor the
+    backward solve's proxy check (which evaluates func) is ever attempted."""
+    y0, t = _problem()
+
+    class Counting(_Pure):
+        nfe = 0
+
+        def forward(self, t_, y_):
+            self.nfe += 1
+            return super().forward(t_, y_)
+    f = Counting()
+
+    def one(options):
+        x = y0.clone().requires_grad_(True)
+        f.zero_grad()
+        f.nfe = 0
+        y = tda.odeint_adjoint(f, x, t, method="dopri5", rtol=1e-6, atol=1e-8, options=options)
+        fwd, f.nfe = f.nfe, 0
+        y[-1].pow(2).sum().backward()
+        return fwd, f.nfe, x.grad.clone(), f.lin.weight.grad.clone()
+    ref = one(dict(hip_graph=False))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for _ in range(4):
+            got = one(None)
+            assert got[:2] == ref[:2], (got[:2], ref[:2])
+            assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
 
 
 def test_cached_graph_is_rechecked_against_python_state_the_key_cannot_see():

@@ -1,5 +1,5 @@
 """Run one of BASELINE.json's configurations at full size on the GPU a few times (the command profiled by
-tools/profile_cmd.sh).  Usage: run_config.py <cfg2|cfg4|cfg3|cfg3_shard|cfg5> [reps]"""
+tools/profile_cmd.sh).  Usage: run_config.py <cfg2|cfg2_shard|cfg4|cfg3|cfg3_shard|cfg5> [reps]"""
 import os
 import sys
 import time
@@ -57,8 +57,9 @@ def cfg5():
 
 fn = {"cfg2": lambda: linear(65536, 128, torch.float32, "dopri5", 1e-7, 1e-9),
       "cfg4": lambda: linear(16384, 512, torch.float64, "dopri8", 1e-9, 1e-11),
+      "cfg2_shard": lambda: linear(8192, 128, torch.float32, "dopri5", 1e-7, 1e-9),      # the 1/8 strong-scaling shard
       "cfg3": lambda: cfg3(None), "cfg3_shard": lambda: cfg3(slice(0, 8192)), "cfg5": cfg5}[case]()
-no_grad = case in ("cfg2", "cfg4")
+no_grad = case in ("cfg2", "cfg4", "cfg2_shard")
 ctx = torch.no_grad() if no_grad else torch.enable_grad()
 with ctx:
     fn()

@@ -586,6 +586,30 @@ class _GraphStep:
             pass
         return "later"
 
+    @classmethod
+    def status_known(cls, base) -> bool:
+        """Whether `auto` has already made up its mind about this func object: refused, or captured and probed."""
+        try:
+            return base in cls._refused or base in cls._cache
+        except TypeError:
+            return False
+
+    @classmethod
+    def refuse_func(cls, s, reason: str) -> None:
+        """Auto mode, before anything was captured (r06): the FIRST evaluation of a solve — f(t0, y0), which every solve
+        makes anyway — changed what the side-effect fingerprint sees.  Remembered per func object; nothing is ever
+        captured for it, and the adjoint's proxy check (evaluations a counting func would see) is not run either."""
+        base = s.func.base_func
+        try:
+            first = base not in cls._refused
+            cls._refused[base] = reason
+            cls._cache.pop(base, None)
+        except TypeError:
+            first = True
+        if first and getattr(s, "_graph_explicit", True):
+            warnings.warn("hip_graph='auto': {} is not captured into a hipGraph — {}; its solves run on the eager "
+                          "path (pass hip_graph=True to capture it regardless)".format(type(base).__name__, reason))
+
     def refuse(self, s, reason: str) -> None:
         """Auto mode found `func` unfit for replay: remember it (per func object), drop the cached graphs, say so once."""
         self.refused = reason

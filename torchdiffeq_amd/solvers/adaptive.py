@@ -463,7 +463,16 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
     def _before_integrate(self, t_host: List[float]) -> None:
         t0 = t_host[0]
         self._dt_shadow = None
+        # "auto" (the default): while nothing is known about func yet, the evaluation every solve starts with doubles as the
+        # side-effect test — an evaluation counter, a cache, dropout show up HERE, before any capture is attempted and
+        # before the adjoint's proxy check would evaluate func on its own account
+        watch = self.hip_graph and self._graph_auto and not _GraphStep.status_known(self.func.base_func)
+        before = _side_effect_fingerprint(self.func.base_func, self.y0.device) if watch else None
         f0 = self.func.eval(t0, self.y0)
+        if watch and _side_effect_fingerprint(self.func.base_func, self.y0.device) != before:
+            _GraphStep.refuse_func(self, "evaluating it changed its own attributes, buffers or the device's random-number "
+                                         "state (an evaluation counter, a cache, dropout ...), which a replay would not repeat")
+            self.hip_graph = False
         if self.first_step is None:
             first_step = self._select_initial_step(t0, self.y0, f0)
         else:
