@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TDEQ_ABI_VERSION 20
+#define TDEQ_ABI_VERSION 21
 #define TDEQ_F32 0
 #define TDEQ_F64 1
 /* interleaved (re, im) complex states — accepted by the NORM entry points only (tdeq_error_norm, tdeq_error_norm_partial[_ctrl],
@@ -183,14 +183,17 @@ int tdeq_error_norm_vec(const void* err_partial, const void* y0, const void* y1,
  * does for scalar tolerances): the error ratio in fp64 — the promoted type of the reference's quotient and norm when a
  * tolerance is dimensioned —, accept flag, next step size, and the next trial step's stage times in T; `out_ctrl`,
  * `ctrl_dev`, `next_times` as there.  Lets the look-ahead first stage (tdeq_stage_combine_sel) follow.
+ * state_in_dev != 0 (ABI 21, hipGraph mode, as for tdeq_error_norm_partial_ctrl): the trial step's (t0, dt) and the step
+ * size the error row's coefficients are multiplied by live in ctrl_dev; `dt` is ignored and c = fl_T(fl_T(coef) * T(dt))
+ * is formed on the device — captured trial steps with per-element tolerances.
  */
 int tdeq_error_norm_vec_ctrl(const void* err_partial, const void* y0, const void* y1, const void* const* k,
                              const double* coef, int n_terms, double dt,
                              const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
                              const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
                              double* out_sumsq, double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl,
-                             double* ctrl_dev, void* next_times, void* workspace, size_t workspace_bytes, int dtype,
-                             void* stream);
+                             double* ctrl_dev, void* next_times, int state_in_dev, void* workspace, size_t workspace_bytes,
+                             int dtype, void* stream);
 
 /*
  * Fused pair for the END of a trial step (same results as tdeq_stage_combine + tdeq_error_norm, fewer bytes):
@@ -346,6 +349,18 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale,
                     const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk,
                     int64_t n_chunks, double* out_sumsq, double* out_nonfinite, void* workspace, size_t workspace_bytes,
                     int dtype, void* stream);
+
+/*
+ * tdeq_init_norms with PER-ELEMENT tolerances (ABI 21): `rtol_vec` / `atol_vec` = fp64 device vectors over the flat (padded)
+ * state, or NULL with the 0-dim value in `rtol_scalar` / `atol_scalar` (at least one vector) — what misc.py:50-56,68
+ * computes by broadcasting when the caller's tolerances are tensors (rk_common.py:186-187 makes them W = fp64 tensors).
+ * Promotion as ATen applies it: |y| * rtol[i] in fp64 for a dimensioned rtol, in T for a 0-dim one; the sum with atol,
+ * the quotients and the sums of squares in fp64; (a - b) of mode 1 in T.  fp32 / fp64 states; outputs as tdeq_init_norms.
+ */
+int tdeq_init_norms_vec(int mode, const void* a, const void* b, const void* yscale, const double* rtol_vec,
+                        double rtol_scalar, const double* atol_vec, double atol_scalar, const tdeq_segment* segs,
+                        const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
+                        double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /*
  * The quotients of tdeq_init_norms MATERIALISED, for a user-supplied norm callable (the reference hands its `norm`

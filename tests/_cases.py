@@ -147,3 +147,21 @@ TUPLE_TOL_LIST_FORMS = {
     "both": (([1e-5, 1e-4, 1e-6], [1e-4, 1e-5]), ([1e-8, 1e-7, 1e-9], 1e-8)),
     "numpy_and_tuple": ((np.array([1e-5, 1e-4, 1e-6]), 1e-4), (1e-8, (1e-8, 1e-7))),
 }
+
+
+# r06: small-state dopri8 cases of tests/golden/dopri8_small.npz — name: (field kind, rows, dim, seed, end time)
+DOPRI8_SMALL_CASES = {
+    "tanh": ("tanh", 4, 3, 41, 1.3),
+    "linear_t": ("linear_t", 1, 5, 43, 0.9),
+    "cubic": ("cubic", 9, 2, 47, 1.7),
+}
+
+
+def dopri8_small_field(kind, W):
+    def f(t, y):
+        if kind == "tanh":
+            return torch.tanh(y @ W.T) * torch.cos(t)
+        if kind == "linear_t":
+            return y @ W.T * (1 + 0.3 * t) - 0.2 * y
+        return -0.3 * y ** 3 + torch.sin(3 * t) * (y @ W.T)
+    return f

@@ -53,6 +53,15 @@ _GPU_ELSEWHERE_FILES = ("test_reference_suite.py", "test_events_golden.py", "tes
 
 
 def pytest_collection_modifyitems(config, items):
+    # (advisor r05) a plain `pytest tests/` on a box without a GPU: everything that carries the `gpu` marker is skipped
+    # instead of failing with "No HIP GPUs are available"; an explicit `-m gpu` still runs (and fails) them
+    markexpr = (config.getoption("markexpr", "") or "").replace(" ", "")
+    asked_for_gpu = "gpu" in markexpr and "notgpu" not in markexpr      # `-m gpu`: a box without a GPU must fail loudly
+    if not torch.cuda.is_available() and not asked_for_gpu:
+        no_gpu = pytest.mark.skip(reason="needs a real MI355X (no GPU visible here)")
+        for item in items:
+            if item.get_closest_marker("gpu") is not None:
+                item.add_marker(no_gpu)
     if os.environ.get("TDEQ_FULL_GPU_MATRIX") == "1":
         return
     seen = set()

@@ -266,6 +266,27 @@ def gen_solves():
     save("solves.npz", **arrays)
 
 
+def gen_dopri8_small():
+    """r06: dopri8 on SMALL states, fp32 at rtol 1e-5 and fp64 at rtol 1e-9, with the accepted
+    step sequence stored.  The first step of such a solve is tiny, its 13-stage error row cancels to rounding noise and the
+    second step size depends on the association of the row sums (the reference: ATen's `torch.sum` order, rk_common.py:79,
+    89; this package: non-zeros left to right) — the one place where "identical results" is a bound, not
+    bits.  tests/test_dopri8_small_golden.py asserts the measured bounds so that a regression is visible."""
+    from _cases import DOPRI8_SMALL_CASES, dopri8_small_field
+    arrays = {}
+    for name, (kind, n, d, seed, t1) in DOPRI8_SMALL_CASES.items():
+        for dname, dtype, rtol, atol in (("f32", torch.float32, 1e-5, 1e-7), ("f64", torch.float64, 1e-9, 1e-11)):
+            W = (rand(d, d, seed=seed) * 0.6).to(dtype)
+            y0 = rand(n, d, seed=seed + 1).to(dtype)
+            t = torch.tensor([0.0, t1], dtype=dtype)
+            y, nfe, c = solve(dopri8_small_field(kind, W), y0, t, rtol=rtol, atol=atol, method="dopri8")
+            key = f"d8_{name}_{dname}"
+            arrays[f"{key}_W"], arrays[f"{key}_y0"], arrays[f"{key}_t"] = W, y0, t
+            arrays[f"{key}_y"], arrays[f"{key}_nfe"] = y, nfe
+            arrays[f"{key}_accept_dt"], arrays[f"{key}_reject_dt"] = np.array(c.accept), np.array(c.reject)
+    save("dopri8_small.npz", **arrays)
+
+
 def gen_adjoint():
     """cfg3 (reduced): odeint_adjoint through a tanh MLP, loss = sum(y(T)^2) (+ intermediate outputs)."""
     arrays = {}
@@ -1465,7 +1486,7 @@ def gen_programs():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
-                     ("solves", gen_solves), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
+                     ("solves", gen_solves), ("dopri8_small", gen_dopri8_small), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
                      ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin), ("dropin", gen_dropin), ("brow", gen_brow), ("r4b", gen_r4b), ("programs", gen_programs)]:
         if not only or name in only:
             fn()

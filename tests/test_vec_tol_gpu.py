@@ -199,3 +199,121 @@ def test_tuple_tolerance_with_list_entries_takes_the_fused_kernel(monkeypatch, d
     assert rel_err(sa, z[f"{key}_ya"]) < tol and rel_err(sb, z[f"{key}_yb"]) < tol
     if dname == "f64":
         assert nfe[0] == int(z[f"{key}_nfe"])
+
+
+@pytest.mark.parametrize("form", ["both", "rtol_only", "atol_only"])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("n", [1, 1031, 5000])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_init_norms_vec_equals_the_references_broadcast_expression(dtype, n, mode, form):
+    """r06, tdeq_init_norms_vec (ABI 21): misc.py:50-56,68 evaluated literally by ATen on the same device — `scale = atol +
+    |y0| * rtol` with W = fp64 tolerance tensors, type promotion included (a dimensioned fp64 tolerance promotes, a 0-dim one
+    does not), `(f1 - f0)` formed in T — against the kernel's fp64 sums of squares."""
+    g = torch.Generator().manual_seed(7 * n + mode)
+    r = lambda: torch.randn(n, generator=g, dtype=torch.float64).to(dtype).cuda()
+    a, b, y = r(), r(), r()
+    rtol_v = (torch.rand(n, generator=g, dtype=torch.float64) * 1e-3 + 1e-6).cuda()
+    atol_v = (torch.rand(n, generator=g, dtype=torch.float64) * 1e-5 + 1e-8).cuda()
+    rtol = rtol_v if form != "atol_only" else torch.tensor(3e-4, dtype=torch.float64, device="cuda")
+    atol = atol_v if form != "rtol_only" else torch.tensor(2e-6, dtype=torch.float64, device="cuda")
+    kern = _native.get_kernels(torch.device("cuda:0"), dtype)
+    plan = kern.make_plan([(0, n, 0.0, 1.0)], n, 1024, torch.device("cuda:0"))
+    kern.init_norms_vec(plan, mode, a, b, y, rtol if rtol.dim() else float(rtol), atol if atol.dim() else float(atol))
+    s0, s1, bad = kern.read_norms(plan)
+    scale = atol + torch.abs(y) * rtol                      # misc.py:50
+    assert scale.dtype == torch.float64
+    if mode == 0:
+        q0, q1 = a / scale, b / scale                       # misc.py:55-56
+        assert s0[0] == pytest.approx(float(q0.abs().pow(2).sum()), rel=1e-12)
+        assert s1[0] == pytest.approx(float(q1.abs().pow(2).sum()), rel=1e-12)
+    else:
+        q = (a - b) / scale                                 # misc.py:68
+        assert q.dtype == torch.float64
+        assert s0[0] == pytest.approx(float(q.abs().pow(2).sum()), rel=1e-12)
+    assert bad == [0.0]
+    y[n // 2] = float("inf")
+    kern.init_norms_vec(plan, mode, a, b, y, rtol if rtol.dim() else float(rtol), atol if atol.dim() else float(atol))
+    assert kern.read_norms(plan)[2] == [1.0]
+
+
+@pytest.mark.parametrize("tuple_state", [False, True], ids=["tensor", "tuple"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_initial_step_with_vector_tolerances_runs_on_the_kernel_and_keeps_its_value(monkeypatch, dtype, tuple_state):
+    """The once-per-solve heuristic (misc.py:36-77) with per-element tolerances: three tdeq_init_norms_vec launches, no
+    `init_scaled` + torch-op scaling (the r05 route) — and the first step size it returns equals the r05 route's to fp64
+    rounding (sums of ≤ 5000 fp64 squares in a different order), the evaluation counts of the whole solve are equal."""
+    from torchdiffeq_amd import solvers
+    g = torch.Generator().manual_seed(11)
+    A = (torch.randn(12, 12, generator=g, dtype=torch.float64) / 4 - 0.2 * torch.eye(12, dtype=torch.float64)).to(dtype).cuda()
+    ya = torch.randn(300, 12, generator=g, dtype=torch.float64).to(dtype).cuda()
+    yb = torch.randn(7, generator=g, dtype=torch.float64).to(dtype).cuda()
+    t = torch.tensor([0.0, 0.7, 2.0], dtype=torch.float64, device="cuda")
+    rt = torch.logspace(-7, -4, 12, dtype=torch.float64, device="cuda").expand(300, 12)
+    if tuple_state:
+        y0, rtol, atol = (ya, yb), (rt.reshape(-1), 1e-5), (1e-9, torch.full((7,), 1e-8, dtype=torch.float64, device="cuda"))
+        f = lambda t_, y_: (y_[0] @ A.T * torch.cos(t_), -0.5 * y_[1])
+    else:
+        y0, rtol, atol = ya, rt, 1e-9
+        f = lambda t_, y_: y_ @ A.T * torch.cos(t_)
+    kern = _native.get_kernels(torch.device("cuda:0"), dtype)
+    calls = {"vec": 0, "scaled": 0}
+    real_vec, real_scaled = kern.init_norms_vec, kern.init_scaled
+    monkeypatch.setattr(kern, "init_norms_vec", lambda *a, **k: (calls.__setitem__("vec", calls["vec"] + 1), real_vec(*a, **k))[1])
+    monkeypatch.setattr(kern, "init_scaled", lambda *a, **k: (calls.__setitem__("scaled", calls["scaled"] + 1), real_scaled(*a, **k))[1])
+    made = []
+    orig = solvers.RKAdaptiveStepsizeODESolver._select_initial_step
+
+    def spy(self, *a, **k):
+        dt0 = orig(self, *a, **k)
+        made.append(dt0)
+        return dt0
+    monkeypatch.setattr(solvers.RKAdaptiveStepsizeODESolver, "_select_initial_step", spy)
+    nfe = [0]
+
+    def counted(t_, y_):
+        nfe[0] += 1
+        return f(t_, y_)
+    with torch.no_grad():
+        y_new = tda.odeint(counted, y0, t, rtol=rtol, atol=atol, method="dopri5", options=dict(hip_graph=False))
+    n_new, nfe[0] = nfe[0], 0
+    assert calls == {"vec": 2, "scaled": 0}
+    # the r05 route: hide the entry point
+    monkeypatch.delattr(type(kern), "init_norms_vec", raising=False)
+    monkeypatch.delattr(kern, "init_norms_vec", raising=False)
+    assert not hasattr(kern, "init_norms_vec")
+    with torch.no_grad():
+        y_old = tda.odeint(counted, y0, t, rtol=rtol, atol=atol, method="dopri5", options=dict(hip_graph=False))
+    assert calls["scaled"] == 2 and nfe[0] == n_new
+    assert made[0] == pytest.approx(made[1], rel=1e-12)
+    ya_new, ya_old = (y_new[0], y_old[0]) if tuple_state else (y_new, y_old)
+    assert float((ya_new - ya_old).abs().max()) <= (1e-12 if dtype == torch.float64 else 2e-5) * float(ya_old.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_captured_steps_with_vector_tolerances_equal_the_eager_solve(dtype):
+    """r06 (ABI 21: `state_in_dev` on tdeq_error_norm_vec_ctrl): per-element tolerances no longer switch captured trial steps
+    off.  hip_graph=True against the eager look-ahead solve: identical bits, fewer Python evaluations; a second solve with
+    OTHER tolerance values re-uses the captured step (its static tolerance buffers are refreshed) and is again identical."""
+    from torchdiffeq_amd import _graph
+    g = torch.Generator().manual_seed(2)
+    lin = torch.nn.Linear(12, 12).to(dtype).cuda()
+    y0 = torch.randn(500, 12, generator=g, dtype=torch.float64).to(dtype).cuda()
+    t = torch.tensor([0.0, 0.7, 2.0], dtype=torch.float64, device="cuda")
+    calls = [0]
+    lin.register_forward_pre_hook(lambda m, a: calls.__setitem__(0, calls[0] + 1))
+    f = lambda t_, y_: torch.tanh(lin(y_)) * (1.5 + torch.sin(4 * t_))
+    try:
+        for scale in (1.0, 0.1):
+            rtol = (torch.logspace(-7, -3, 12, dtype=torch.float64, device="cuda") * scale).expand(500, 12)
+            atol = torch.full((500, 12), 1e-8 * scale, dtype=torch.float64, device="cuda")
+            with torch.no_grad():
+                calls[0] = 0
+                y_e = tda.odeint(f, y0, t, rtol=rtol, atol=atol, method="dopri5", options=dict(hip_graph=False))
+                n_e, calls[0] = calls[0], 0
+                y_g = tda.odeint(f, y0, t, rtol=rtol, atol=atol, method="dopri5", options=dict(hip_graph=True))
+                n_g = calls[0]
+            assert torch.equal(y_g, y_e), scale
+            assert n_g < n_e, (n_g, n_e)
+        assert f in _graph._GraphStep._cache
+    finally:
+        _graph.clear_graph_cache()

@@ -21,8 +21,8 @@ def linear(B, D, dtype, method, rtol, atol):
     A, y0 = fs.linear_problem(B, D, dtype)
     At, y0 = A.T.contiguous().to(dev), y0.to(dev)
     t = torch.tensor([0.0, 1.0], dtype=dtype, device=dev)
-    with torch.no_grad():
-        return lambda: tda.odeint(lambda tt, y: y @ At, y0, t, rtol=rtol, atol=atol, method=method)
+    field = lambda tt, y: y @ At         # ONE func object: a fresh lambda per call would be a first sight for 'auto' every time
+    return lambda: tda.odeint(field, y0, t, rtol=rtol, atol=atol, method=method)
 
 
 def cfg3(rows):

@@ -1,7 +1,8 @@
 #!/bin/bash
 # r06: are the re-reads of k_0..k_4 by successive stage rows of a SHARD-sized trial step L2 hits or
 # fabric traffic?  Run on the GPU box (through gpurun):
-#   tools/shard_l2.sh <tag> "<command>"        e.g.  tools/shard_l2.sh cfg2_shard_graph "python tools/run_config.py cfg2_shard 20"
+#   tools/shard_l2.sh <tag> "<command>"        e.g.  tools/shard_l2.sh cfg2_shard_graph "python $PWD/tools/run_config.py cfg2_shard 20"
+# (the command runs from /tmp: give absolute paths)
 # Passes (PMC never combined with tracing domains other than --kernel-trace): kernel trace + stats; TCC_HIT_sum + TCC_MISS_sum;
 # FETCH_SIZE; WRITE_SIZE; TCC_REQ_sum + TCC_READ_sum.  tools/shard_l2_summary.py condenses them per kernel.
 set -u

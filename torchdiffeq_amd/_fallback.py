@@ -70,6 +70,9 @@ class HostPlan:
         self.sums0 = [0.0] * self.n_seg
         self.sums1 = [0.0] * self.n_seg
         self.bad = [0.0] * self.n_seg
+        # the fp64 sums of squares are consumed by lock-step sharding only (dist_sync all-reduces them); an unsharded solve
+        # on this path reads rms0 / rms1, so the extra fp64 reduction per norm is skipped unless asked for (advisor r05)
+        self.want_sums = False
         # the reference's own norm of the same quotients, per segment: sqrt(mean(|x|^2)) evaluated by ATen in the state's
         # type (what the solver drivers use on this path — `literal_norms`)
         self.rms0 = [0.0] * self.n_seg
@@ -229,7 +232,7 @@ class HostKernels:
                 r = e[sl] / tol
             plan.rms0[s] = rms = self._rms(r)
             plan.abs0[s] = float(r.abs()) if n == 1 else math.nan
-            plan.sums0[s] = self._sumsq(r)      # the fp64 sum itself: lock-step sharding (dist_sync) all-reduces it
+            plan.sums0[s] = self._sumsq(r) if plan.want_sums else math.nan    # the fp64 sum itself: lock-step sharding (dist_sync) all-reduces it
             plan.bad[s] = _nonfinite(y0[sl], y1[sl])
             if scaled_out is not None:
                 scaled_out[sl] = r
@@ -277,11 +280,11 @@ class HostKernels:
             n = q0.numel()
             plan.rms0[s] = rms = self._rms(q0)
             plan.abs0[s] = float(q0.abs()) if n == 1 else math.nan
-            plan.sums0[s] = self._sumsq(q0)
+            plan.sums0[s] = self._sumsq(q0) if plan.want_sums else math.nan
             if q1 is not None:
                 plan.rms1[s] = rms = self._rms(q1)
                 plan.abs1[s] = float(q1.abs()) if n == 1 else math.nan
-                plan.sums1[s] = self._sumsq(q1)
+                plan.sums1[s] = self._sumsq(q1) if plan.want_sums else math.nan
             plan.bad[s] = _nonfinite(yscale[sl])
 
     def init_scaled(self, plan, mode: int, a, b, yscale, out0, out1=None) -> None:

@@ -524,6 +524,11 @@ class _GraphStep:
         self.calls = 0
         self.plan = s.plan          # the graphs' norm kernels write into THIS plan's buffers
         self.in_use = True
+        # per-element tolerances (r06): the solver's tolerance vectors are new tensors in every solve — the captured norm
+        # launch reads static copies, refreshed by `reset`; 0-dim tolerances are baked in and therefore part of the key
+        self.vec_tol = None
+        if getattr(s, "_vec_ctrl", False):
+            self.vec_tol = [v.clone() if isinstance(v, torch.Tensor) else v for v in s._vec_fused[:2]]
         self.auto = bool(getattr(s, "_graph_auto", False))    # `hip_graph="auto"`: verify before trusting replays
         self.probed = False         # a replayed step has reproduced an eager one bit for bit
         self.recheck = False        # re-used in a LATER solve (auto mode): verify the first replay, see _recheck
@@ -541,6 +546,10 @@ class _GraphStep:
         self.side = 0
         self.y[0].copy_(s.y1.detach())
         self.f0.copy_(s.f1.detach())
+        if self.vec_tol is not None:
+            for dst, src in zip(self.vec_tol, s._vec_fused[:2]):
+                if isinstance(dst, torch.Tensor):
+                    dst.copy_(src)
         t0_T, dt_T, t1_T = T(t0), T(dt), T(t0 + dt)
         self.plan.ctrl_dev.copy_(torch.tensor([0.0, float(dt_T) * func.sign, t0, dt], dtype=torch.float64))
         times = [(t1_T, Perturb.PREV) if s._alpha_is_one[i] else (t0_T + s._alpha[i] * dt_T, Perturb.NONE)
@@ -586,13 +595,30 @@ class _GraphStep:
             pass
         return "later"
 
+    _pure = weakref.WeakSet()                   # auto mode: funcs whose first evaluation of a solve left the fingerprint alone
+
     @classmethod
     def status_known(cls, base) -> bool:
-        """Whether `auto` has already made up its mind about this func object: refused, or captured and probed."""
+        """Whether `auto` has already made up its mind about this func object: refused, or seen to evaluate without a
+        visible side effect."""
         try:
-            return base in cls._refused or base in cls._cache
+            return base in cls._refused or base in cls._pure
         except TypeError:
             return False
+
+    @classmethod
+    def passed_side_effect_test(cls, base) -> bool:
+        try:
+            return base in cls._pure and base not in cls._refused
+        except TypeError:
+            return False
+
+    @classmethod
+    def mark_pure(cls, base) -> None:
+        try:
+            cls._pure.add(base)
+        except TypeError:
+            pass
 
     @classmethod
     def refuse_func(cls, s, reason: str) -> None:
@@ -650,6 +676,10 @@ class _GraphStep:
         # a re-built layer, a closure variable bound to a new tensor) must lead to a new capture — so every tensor the
         # func object can be seen to hold goes into the key; a user-supplied `hip_graph_token` attribute of func (any
         # hashable: bump it when func changes what it computes) does too.
+        if getattr(s, "_vec_ctrl", False):
+            # which tolerance is a vector (its VALUES are copied into the captured step's static buffers by `reset`), the
+            # baked value of a 0-dim one
+            key += tuple(("vec", int(v.numel())) if isinstance(v, torch.Tensor) else float(v) for v in s._vec_fused[:2])
         key += (_held_tensor_ptrs(s.func.base_func), getattr(s.func.base_func, "hip_graph_token", None),
                 type(s.func).__name__, s.func.graph_key(),
                 # ("auto" only: with hip_graph=True the user vouches for func, and an evaluation counter among its
@@ -729,8 +759,7 @@ class _GraphStep:
                 if i < n_rows:
                     k.append(func.eval_at(self.ts[i], yi))
             assert held.pop(R) is epart and not held
-            kern.error_norm_partial_ctrl(plan, epart, y_cur, y1, [k[j] for j in carry.err_idx], carry.err_coef, 0.0,
-                                         s._ctrl, self.tbuf, state_in_dev=True)
+            self._norm_ctrl(s, epart, y_cur, y1, [k[j] for j in carry.err_idx], carry.err_coef)
             if side == 1:
                 self.f0.copy_(k[-1])
             self.k[side] = k
@@ -765,11 +794,20 @@ class _GraphStep:
         if not fsal:
             sol = s._c_sol
             kern.stage_combine_dev(y1, epart, y_cur, [k[j] for j in sol.idx], sol.coef, fuse[0], plan)
-        kern.error_norm_partial_ctrl(plan, epart, y_cur, y1, [k[j] for j in fuse[1]], fuse[2], 0.0,
-                                     s._ctrl, self.tbuf, state_in_dev=True)
+        self._norm_ctrl(s, epart, y_cur, y1, [k[j] for j in fuse[1]], fuse[2])
         if side == 1:
             self.f0.copy_(k[-1])          # side 0 reads its derivative from a buffer of its own (see the class text)
         self.k[side] = k
+
+    def _norm_ctrl(self, s, epart, y_cur, y1, ks, coefs) -> None:
+        """The step's last launch pair: the error norm continuing `epart` + the device controller, step state in device
+        memory — with scalar tolerances (tdeq_error_norm_partial_ctrl) or per-element ones (tdeq_error_norm_vec_ctrl)."""
+        if self.vec_tol is not None:
+            s.kernels.error_norm_vec_ctrl(s.plan, y_cur, y1, ks, coefs, 0.0, self.vec_tol[0], self.vec_tol[1], s._ctrl,
+                                          self.tbuf, partial=epart, state_in_dev=True)
+        else:
+            s.kernels.error_norm_partial_ctrl(s.plan, epart, y_cur, y1, ks, coefs, 0.0, s._ctrl, self.tbuf,
+                                              state_in_dev=True)
 
     def run(self, s) -> None:
         """One trial step from the current side's pair.  The caller flips `side` when the step was accepted."""

@@ -18,7 +18,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-TDEQ_ABI_VERSION = 20
+TDEQ_ABI_VERSION = 21
 TDEQ_F32, TDEQ_F64 = 0, 1
 TDEQ_C64, TDEQ_C128 = 2, 3        # interleaved complex: the norm entry points only (include/tdeq_hip.h)
 TDEQ_BF16, TDEQ_F16 = 4, 5        # reduced-precision states: the entry points of the host-driven step (LowPrecisionHipKernels)
@@ -85,7 +85,11 @@ ABI_SIGNATURES = {
                                                 ctypes.c_double, ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int,
                                                 ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.POINTER(StepCtrl), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                                ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+                                                ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "tdeq_init_norms_vec": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(Segment),
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "tdeq_stage_combine_err": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_void_pp,
                                               _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_double,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
@@ -398,6 +402,8 @@ class HipKernels:
 
     vec_partial = True      # error_norm_vec[_ctrl] continue a partial error row (`partial=`) like error_norm_partial
 
+    vec_ctrl_in_graph = True     # tdeq_error_norm_vec_ctrl takes `state_in_dev` (ABI 21): captured steps with per-element tolerances
+
     def error_norm_vec(self, plan: NormPlan, y0, y1, ks, coefs, dt: float, rtol, atol, partial=None) -> None:
         """`error_norm` with per-element tolerances (tdeq_error_norm_vec): `rtol` / `atol` = an fp64 device vector over the
         flat padded state, or a host float for a 0-dim tolerance (at least one vector).  `partial`: the error row's leading
@@ -414,9 +420,9 @@ class HipKernels:
                                             self._stream()), "tdeq_error_norm_vec")
 
     def error_norm_vec_ctrl(self, plan: NormPlan, y0, y1, ks, coefs, dt: float, rtol, atol, ctrl: StepCtrl, next_times,
-                            partial=None) -> None:
+                            partial=None, state_in_dev: bool = False) -> None:
         """`error_norm_vec` whose finalize step also runs the step controller on the device (tdeq_error_norm_vec_ctrl) —
-        read with `read_ctrl`."""
+        read with `read_ctrl`.  `state_in_dev` (captured steps): the step size comes from `plan.ctrl_dev`, `dt` is ignored."""
         ptrs, cf, n = self._terms(ks, coefs)
         dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
         rv, rs = (rtol.data_ptr(), 0.0) if isinstance(rtol, torch.Tensor) else (None, float(rtol))
@@ -426,8 +432,21 @@ class HipKernels:
         _check(self.lib.tdeq_error_norm_vec_ctrl(pp, y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, rv, rs, av, as_, plan.segs,
                                                  dev, plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
                                                  ctypes.byref(ctrl), plan.ctrl_ptr, plan.ctrl_dev.data_ptr(),
-                                                 next_times.data_ptr(), plan.workspace.data_ptr(), plan.workspace_bytes,
-                                                 dtype_code(y0.dtype), self._stream()), "tdeq_error_norm_vec_ctrl")
+                                                 next_times.data_ptr(), 1 if state_in_dev else 0, plan.workspace.data_ptr(),
+                                                 plan.workspace_bytes, dtype_code(y0.dtype), self._stream()),
+               "tdeq_error_norm_vec_ctrl")
+
+    def init_norms_vec(self, plan: NormPlan, mode: int, a, b, yscale, rtol, atol) -> None:
+        """`init_norms` with per-element tolerances (tdeq_init_norms_vec): `rtol` / `atol` = an fp64 device vector over the
+        flat padded state, or a host float for a 0-dim tolerance (at least one vector); sums in fp64, the promoted type."""
+        dev = plan.segs_dev.data_ptr() if plan.segs_dev is not None else None
+        rv, rs = (rtol.data_ptr(), 0.0) if isinstance(rtol, torch.Tensor) else (None, float(rtol))
+        av, as_ = (atol.data_ptr(), 0.0) if isinstance(atol, torch.Tensor) else (None, float(atol))
+        self._arm(plan, 2 if mode == 0 else 1)
+        _check(self.lib.tdeq_init_norms_vec(mode, a.data_ptr(), b.data_ptr(), yscale.data_ptr(), rv, rs, av, as_, plan.segs, dev,
+                                            plan.n_seg, plan.chunk, plan.n_chunks, plan.out_ptr, plan.bad_ptr,
+                                            plan.workspace.data_ptr(), plan.workspace_bytes, dtype_code(yscale.dtype),
+                                            self._stream()), "tdeq_init_norms_vec")
 
     def stage_combine_err(self, out, err_out, y0, ks, coefs, err_coefs, dt: float) -> None:
         """Last combine of a step + partial embedded error over the same stages (tdeq_stage_combine_err)."""

@@ -42,6 +42,10 @@ def _auto_backward_due(base_func, total: int) -> bool:
     from .solvers import _GRAPH_AUTO_MAX_ELEMENTS, _GraphStep
     if total > _GRAPH_AUTO_MAX_ELEMENTS:
         return False
+    # (r06) only a func that has been SEEN to evaluate without a visible side effect — the forward solve's first
+    # evaluation is that test, whatever its method — is evaluated for the proxy check; a counting field never is
+    if not _GraphStep.passed_side_effect_test(base_func):
+        return False
     try:
         if base_func in _GraphStep._refused:
             return False

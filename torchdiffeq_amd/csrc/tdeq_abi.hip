@@ -326,7 +326,13 @@ int launch_error(void* scaled, const void* y0, const void* y1, const void* const
     return launch_finalize(st, ws, 1, out_sumsq, out_bad, s);
 }
 
-struct CtrlBundle;      // (defined with the controller launch below)
+struct CtrlBundle {
+    const tdeq_step_ctrl* ctrl;
+    double* out_ctrl;
+    double* ctrl_dev;
+    void* next_times;
+    int state_in_dev;     // hipGraph mode: (t0, dt) of the trial step and the kernels' dt live in ctrl_dev
+};
 int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, double* out_bad, const CtrlBundle& cb,
                          int tkind, hipStream_t s, int ratio_kind);
 
@@ -340,11 +346,13 @@ int launch_error_vec(const void* partial, const void* y0, const void* y1, const 
     a.partial = static_cast<const T*>(partial);
     a.k[0] = nullptr;
     a.c[0] = (T)0;
+    const bool dev_dt = cb && cb->state_in_dev;      // hipGraph mode: dt = ctrl_dev[1] on the device
     const T dtT = (T)dt;
     for (int j = 0; j < NT; ++j) {
         a.k[j] = static_cast<const T*>(k[j]);
-        a.c[j] = (T)coef[j] * dtT;
+        a.c[j] = dev_dt ? (T)coef[j] : (T)coef[j] * dtT;
     }
+    a.dt_dev = dev_dt ? cb->ctrl_dev + 1 : nullptr;
     a.rtol_v = rtol_v;
     a.atol_v = atol_v;
     a.rtol_s = rtol_s;
@@ -353,7 +361,11 @@ int launch_error_vec(const void* partial, const void* y0, const void* y1, const 
     a.part_sumsq = ws;
     a.part_bad = ws + 2 * st.n_chunks;
     const dim3 g((unsigned)st.n_chunks), b(kBlock);
-    if (partial) hipLaunchKernelGGL((error_norm_vec_kernel<T, NT, true>), g, b, 0, s, a);
+    if (dev_dt) {
+        if (partial) hipLaunchKernelGGL((error_norm_vec_kernel<T, NT, true, true>), g, b, 0, s, a);
+        else if constexpr (NT > 0) hipLaunchKernelGGL((error_norm_vec_kernel<T, NT, false, true>), g, b, 0, s, a);
+        else return TDEQ_EINVAL;
+    } else if (partial) hipLaunchKernelGGL((error_norm_vec_kernel<T, NT, true>), g, b, 0, s, a);
     else if constexpr (NT > 0) hipLaunchKernelGGL((error_norm_vec_kernel<T, NT, false>), g, b, 0, s, a);
     else return TDEQ_EINVAL;
     const int e = check_launch();
@@ -390,13 +402,6 @@ int dispatch_error(void* scaled, const void* y0, const void* y1, const void* con
 }
 
 // Optional controller bundle of the *_ctrl entry point (null ctrl => plain finalize).
-struct CtrlBundle {
-    const tdeq_step_ctrl* ctrl;
-    double* out_ctrl;
-    double* ctrl_dev;
-    void* next_times;
-    int state_in_dev;     // hipGraph mode: (t0, dt) of the trial step and the kernels' dt live in ctrl_dev
-};
 
 // tkind: the state's real type — 0 fp64, 1 fp32 (callers pass `sizeof(T) == 4`), 2 bfloat16, 3 float16
 int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, double* out_bad, const CtrlBundle& cb,
@@ -610,6 +615,30 @@ int launch_init(int mode, const void* a_, const void* b_, const void* y_, const 
         if (vec) hipLaunchKernelGGL((init_norms_kernel<T, 1, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((init_norms_kernel<T, 1, false>), g, b, 0, s, a);
     }
+    const int e = check_launch();
+    if (e) return e;
+    return launch_finalize(st, ws, mode == 0 ? 2 : 1, out_sumsq, out_bad, s);
+}
+
+template <typename T>
+int launch_init_vec(int mode, const void* a_, const void* b_, const void* y_, const double* rtol_v, double rtol_s,
+                    const double* atol_v, double atol_s, const SegTable& st, double* out_sumsq, double* out_bad, double* ws,
+                    hipStream_t s) {
+    InitVecArgs<T> a;
+    a.a = static_cast<const T*>(a_);
+    a.b = static_cast<const T*>(b_);
+    a.y = static_cast<const T*>(y_);
+    a.rtol_v = rtol_v;
+    a.atol_v = atol_v;
+    a.rtol_s = rtol_s;
+    a.atol_s = atol_s;
+    a.st = st;
+    a.part0 = ws;
+    a.part1 = ws + st.n_chunks;
+    a.part_bad = ws + 2 * st.n_chunks;
+    const dim3 g((unsigned)st.n_chunks), b(kBlock);
+    if (mode == 0) hipLaunchKernelGGL((init_norms_vec_kernel<T, 0>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((init_norms_vec_kernel<T, 1>), g, b, 0, s, a);
     const int e = check_launch();
     if (e) return e;
     return launch_finalize(st, ws, mode == 0 ? 2 : 1, out_sumsq, out_bad, s);
@@ -1171,8 +1200,8 @@ int tdeq_error_norm_vec_ctrl(const void* err_partial, const void* y0, const void
                              const double* coef, int n_terms, double dt, const double* rtol_vec, double rtol_scalar, const double* atol_vec, double atol_scalar,
                              const tdeq_segment* segs, const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks,
                              double* out_sumsq, double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl,
-                             double* ctrl_dev, void* next_times, void* workspace, size_t workspace_bytes, int dtype,
-                             void* stream) {
+                             double* ctrl_dev, void* next_times, int state_in_dev, void* workspace, size_t workspace_bytes,
+                             int dtype, void* stream) {
     if (!y0 || !y1 || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype)) return TDEQ_EINVAL;
     if ((!rtol_vec && !atol_vec) || !ctrl || !out_ctrl || !ctrl_dev || !next_times) return TDEQ_EINVAL;
     if (n_terms < (err_partial ? 0 : 1) || n_terms > TDEQ_MAX_TERMS || (n_terms > 0 && (!k || !coef))) return TDEQ_EINVAL;
@@ -1185,7 +1214,7 @@ int tdeq_error_norm_vec_ctrl(const void* err_partial, const void* y0, const void
     if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
-    const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times, 0};
+    const CtrlBundle cb{ctrl, out_ctrl, ctrl_dev, next_times, state_in_dev ? 1 : 0};
     return dtype == TDEQ_F32
                ? dispatch_error_vec<float>(err_partial, y0, y1, k, coef, n_terms, dt, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st,
                                            out_sumsq, out_nonfinite, ws, s, &cb)
@@ -1404,6 +1433,26 @@ int tdeq_init_norms(int mode, const void* a, const void* b, const void* yscale, 
     if (dtype == TDEQ_C128) return launch_cplx_init<double>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, nullptr, nullptr, s);
     return dtype == TDEQ_F32 ? launch_init<float>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, s)
                              : launch_init<double>(mode, a, b, yscale, st, out_sumsq, out_nonfinite, ws, s);
+}
+
+int tdeq_init_norms_vec(int mode, const void* a, const void* b, const void* yscale, const double* rtol_vec,
+                        double rtol_scalar, const double* atol_vec, double atol_scalar, const tdeq_segment* segs,
+                        const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
+                        double* out_nonfinite, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    if ((mode != 0 && mode != 1) || !a || !b || !yscale || !out_sumsq || !out_nonfinite || !workspace || bad_dtype(dtype))
+        return TDEQ_EINVAL;
+    if (!rtol_vec && !atol_vec) return TDEQ_EINVAL;      // two 0-dim tolerances: tdeq_init_norms (a different promotion)
+    SegTable st;
+    const int e = fill_segtable(st, segs, segs_dev, n_seg, chunk, n_chunks);
+    if (e) return e;
+    if (workspace_bytes < tdeq_workspace_bytes(n_chunks)) return TDEQ_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    return dtype == TDEQ_F32
+               ? launch_init_vec<float>(mode, a, b, yscale, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st, out_sumsq,
+                                        out_nonfinite, ws, s)
+               : launch_init_vec<double>(mode, a, b, yscale, rtol_vec, rtol_scalar, atol_vec, atol_scalar, st, out_sumsq,
+                                         out_nonfinite, ws, s);
 }
 
 int tdeq_init_scaled(int mode, const void* a, const void* b, const void* yscale, const tdeq_segment* segs,

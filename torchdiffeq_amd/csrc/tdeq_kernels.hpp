@@ -248,7 +248,7 @@ struct MultiArgs {
 // DEVDT: the step size comes from device memory (captured steps, a.dt_dev) — a compile-time property as well: the host
 // launches never pay for the dependent scalar load and the per-coefficient selects in their prologue.
 template <typename T, int NT, typename E, int POLICY = 0, int NOUTC = 0, int ACCC = -1, bool DEVDT = true>
-__device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int64_t i) {
+__device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, int64_t i) {
     const E* __restrict__ y0 = reinterpret_cast<const E*>(a.y0);
     E kk[NT];
 #pragma unroll
@@ -257,6 +257,8 @@ __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, T dtT, int
     E acc0 = y;                       // placeholder when there is no acc_in (never read then)
     const bool has_acc = ACCC < 0 ? (a.acc_in != nullptr) : (ACCC == 1);
     if (has_acc) acc0 = ld_stream<POLICY>(reinterpret_cast<const E*>(a.acc_in) + i);
+    // (r06: fetched AFTER the stream loads are in flight — a dependent scalar load of a word another CU just wrote)
+    const T dtT = (DEVDT && a.dt_dev) ? (T)a.dt_dev[1] : (T)1;      // ctrl_dev[1] = sign * T(dt) of the device-resident controller
     constexpr int kOuts = NOUTC > 0 ? NOUTC : kMaxMultiOut;
 #pragma unroll
     for (int o = 0; o < kOuts; ++o) {
@@ -289,17 +291,18 @@ __global__ __launch_bounds__(kBlock) void stage_combine_multi_kernel(const Multi
     constexpr int L = VEC ? VecOf<T>::L : 1;
     const int64_t ne = a.n / L;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const T dtT = (DEVDT && a.dt_dev) ? (T)a.dt_dev[1] : (T)1;      // ctrl_dev[1] = sign * T(dt) of the device-resident controller
     if constexpr (ONEPASS) {
         const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-        if (i < ne) multi_elem<T, NT, E, POLICY, NOUTC, ACCC, DEVDT>(a, dtT, i);
+        if (i < ne) multi_elem<T, NT, E, POLICY, NOUTC, ACCC, DEVDT>(a, i);
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride)
-            multi_elem<T, NT, E, POLICY, NOUTC, ACCC, DEVDT>(a, dtT, i);
+        const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (i0 < ne) multi_elem<T, NT, E, POLICY, NOUTC, ACCC, DEVDT>(a, i0);
+        for (int64_t i = i0 + stride; i < ne; i += stride)      // (only beyond 65536 workgroups)
+            multi_elem<T, NT, E, POLICY, NOUTC, ACCC, DEVDT>(a, i);
     }
     if (VEC) {   // scalar tail (n % L elements)
         const int64_t t = ne * L + threadIdx.x;
-        if (blockIdx.x == 0 && t < a.n) multi_elem<T, NT, T>(a, dtT, t);
+        if (blockIdx.x == 0 && t < a.n) multi_elem<T, NT, T>(a, t);
     }
 }
 
@@ -478,12 +481,13 @@ struct ErrVecArgs {
     SegTable st;
     double* part_sumsq;
     double* part_bad;
+    const double* dt_dev;   // DEVDT (hipGraph mode, r06): c[] holds fl_T(coef) and is multiplied by T(*dt_dev) here
 };
 
 // PARTIAL: err = (partial + c_0 k_0) + ... over the NT >= 0 remaining stages, as error_norm_partial_kernel continues the
 // sum stage_combine_err_kernel started — per-element tolerances keep the step's launch sequence (carried partial sums, the
 // end-of-step error split) and pay exactly their own two fp64 streams.
-template <typename T, int NT, bool PARTIAL = false>
+template <typename T, int NT, bool PARTIAL = false, bool DEVDT = false>
 __global__ __launch_bounds__(kBlock) void error_norm_vec_kernel(const ErrVecArgs<T, NT> a) {
     __shared__ double red[2 * (kBlock / kWave)];
     const int64_t b = blockIdx.x;
@@ -492,15 +496,24 @@ __global__ __launch_bounds__(kBlock) void error_norm_vec_kernel(const ErrVecArgs
     int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
     valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
     const T rtolT = (T)a.rtol_s;
+    T cc[NT > 0 ? NT : 1];
+    if constexpr (DEVDT) {
+        const T dtT = (T)*a.dt_dev;         // the same product the host forms: fl_T(fl_T(coef) * T(dt))
+#pragma unroll
+        for (int j = 0; j < NT; ++j) cc[j] = a.c[j] * dtT;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) cc[j] = a.c[j];
+    }
     double acc[2] = {0.0, 0.0};
     // consecutive lanes read consecutive elements: 4- / 8-byte state loads and 8-byte tolerance loads, all coalesced;
     // two elements per lane and iteration keep 2 (NT + 4) loads in flight
 #pragma unroll 2
     for (int64_t t = threadIdx.x; t < valid; t += kBlock) {
         const int64_t i = base + t;
-        T e = PARTIAL ? a.partial[i] : a.k[0][i] * a.c[0];
+        T e = PARTIAL ? a.partial[i] : a.k[0][i] * cc[0];
 #pragma unroll
-        for (int j = PARTIAL ? 0 : 1; j < NT; ++j) e = e + a.k[j][i] * a.c[j];
+        for (int j = PARTIAL ? 0 : 1; j < NT; ++j) e = e + a.k[j][i] * cc[j];
         const T y0 = a.y0[i], y1 = a.y1[i];
         const T m = smax(sabs(y0), sabs(y1));
         const double prod = a.rtol_v ? a.rtol_v[i] * (double)m : (double)(rtolT * m);
@@ -659,6 +672,60 @@ __global__ __launch_bounds__(kBlock) void init_norms_kernel(const InitArgs<T> a)
     } else {
         for (int64_t t = threadIdx.x; t < valid; t += kBlock)
             init_elem<T, MODE>(rtol, atol, a.a[base + t], a.b[base + t], a.y[base + t], acc);
+    }
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        a.part0[b] = acc[0];
+        if (MODE == 0) a.part1[b] = acc[1];
+        a.part_bad[b] = acc[2];
+    }
+}
+
+// Initial-step norms with PER-ELEMENT tolerances (r06; misc.py:50-56,68 on W = fp64 tolerance tensors that broadcast against
+// the state).  Type promotion as ATen applies it, operation by operation (the same rules as error_norm_vec_kernel):
+//   scale = atol + |y| * rtol :  |y| * rtol[i] is an fp64 product for a dimensioned rtol, a T product (rtol cast to T) for
+//                                a 0-dim one; the sum with atol is fp64 whenever either tolerance is dimensioned
+//   MODE 0: (a / scale)^2, (b / scale)^2     MODE 1: ((a - b) / scale)^2 with a - b formed in T; quotients and sums in fp64
+template <typename T>
+struct InitVecArgs {
+    const T* a;
+    const T* b;
+    const T* y;
+    const double* rtol_v;   // per element of the flat (padded) state, or null: rtol_s
+    const double* atol_v;
+    double rtol_s, atol_s;
+    SegTable st;
+    double* part0;
+    double* part1;
+    double* part_bad;
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(kBlock) void init_norms_vec_kernel(const InitVecArgs<T> a) {
+    __shared__ double red[3 * (kBlock / kWave)];
+    const int64_t b = blockIdx.x;
+    const tdeq_segment seg = find_segment(a.st, b);
+    const int64_t base = b * a.st.chunk;
+    int64_t valid = seg.numel - (b - seg.chunk_start) * a.st.chunk;
+    valid = valid < 0 ? 0 : (valid > a.st.chunk ? a.st.chunk : valid);
+    const T rtolT = (T)a.rtol_s;
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll 2
+    for (int64_t t = threadIdx.x; t < valid; t += kBlock) {
+        const int64_t i = base + t;
+        const T yv = a.y[i];
+        const T m = sabs(yv);
+        const double prod = a.rtol_v ? (double)m * a.rtol_v[i] : (double)(m * rtolT);
+        const double scale = (a.atol_v ? a.atol_v[i] : a.atol_s) + prod;
+        if (MODE == 0) {
+            const double r0 = (double)a.a[i] / scale, r1 = (double)a.b[i] / scale;
+            acc[0] += r0 * r0;
+            acc[1] += r1 * r1;
+        } else {
+            const double r0 = (double)(a.a[i] - a.b[i]) / scale;
+            acc[0] += r0 * r0;
+        }
+        acc[2] += __builtin_isfinite(yv) ? 0.0 : 1.0;
     }
     block_sum<3>(acc, red);
     if (threadIdx.x == 0) {
@@ -1088,6 +1155,23 @@ template <typename T, int NT, bool VEC, bool ERR>
 __global__ __launch_bounds__(kBlock) void combine_devdt_kernel(const CombineDevTArgs<T, NT> a) {
     using E = typename std::conditional<VEC, typename VecOf<T>::type, T>::type;
     constexpr int L = VEC ? VecOf<T>::L : 1;
+    const int64_t ne = a.c.n / L;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const E* __restrict__ y0 = reinterpret_cast<const E*>(a.c.y0);
+    E* __restrict__ out = reinterpret_cast<E*>(a.c.out);
+    E* __restrict__ eo = reinterpret_cast<E*>(a.err_out);
+    // r06: the first pass's stream loads are issued BEFORE the step size is fetched.  *dt_dev was written by the previous
+    // launch's controller on another CU: a scalar load that misses the scalar cache and the L2 — ~1.5 us during which a
+    // wave of the r05 form (dt first, coefficients, then the loads) had nothing in flight; a wave of this kernel lives ~1 us
+    // otherwise (profiles/r06_shard_l2.json: 5.1-5.7 us per captured combine against 3.4-3.8 us for the host-dt kernels).
+    const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    E kk[NT];
+    E yv{};
+    if (i0 < ne) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.c.k[j])[i0];
+        yv = y0[i0];
+    }
     const T dtT = (T)*a.dt_dev;
     T c[NT], e[NT];
 #pragma unroll
@@ -1095,13 +1179,19 @@ __global__ __launch_bounds__(kBlock) void combine_devdt_kernel(const CombineDevT
         c[j] = a.c.c[j] * dtT;
         e[j] = ERR ? a.e[j] * dtT : (T)0;
     }
-    const int64_t ne = a.c.n / L;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const E* __restrict__ y0 = reinterpret_cast<const E*>(a.c.y0);
-    E* __restrict__ out = reinterpret_cast<E*>(a.c.out);
-    E* __restrict__ eo = reinterpret_cast<E*>(a.err_out);
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ne; i += stride) {
-        E kk[NT];
+    if (i0 < ne) {
+        E acc = kk[0] * c[0];
+#pragma unroll
+        for (int j = 1; j < NT; ++j) acc = acc + kk[j] * c[j];
+        out[i0] = yv + acc;
+        if (ERR) {
+            E err = kk[0] * e[0];
+#pragma unroll
+            for (int j = 1; j < NT; ++j) err = err + kk[j] * e[j];
+            eo[i0] = err;
+        }
+    }
+    for (int64_t i = i0 + stride; i < ne; i += stride) {        // (only beyond 65536 workgroups)
 #pragma unroll
         for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.c.k[j])[i];
         E acc = kk[0] * c[0];

@@ -216,6 +216,8 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         self.ops = Ops(self.kernels, self.np_dtype)      # elementwise kernels, differentiable when grad is needed
         self.plan = self.kernels.make_plan(self.layout.segments(rtol, atol), self.layout.total,
                                            self.layout.chunk, y0.device)
+        if self._sync is not None and hasattr(self.plan, "want_sums"):
+            self.plan.want_sums = True      # (torch-op host path: the fp64 sums are formed only for lock-step sharding)
         # element counts behind the per-segment sums (global counts in lock-step mode)
         self._numels = list(self.plan.numels) if self._sync is None else self._sync.global_numels(self.plan.numels,
                                                                                                   y0.device)
@@ -299,10 +301,15 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         self._graph_explicit = _request_is_explicit(hip_graph)    # refusals warn only where captured steps were asked for
         if wanted and _stream_is_capturing():
             wanted = False          # the caller is capturing a graph of its own around this solve: no nested capture
+        # "auto": the side-effect test of a not-yet-known func rides on the solve's first evaluation whether or not THIS
+        # solver can capture (a method without a fused error row, a large state): the adjoint's backward solve, which may,
+        # asks for the verdict before it evaluates func on its own account (_GraphStep.passed_side_effect_test)
+        self._graph_watch = wanted and auto and y0.device.type == "cuda"
         self._auto = None           # auto mode: this solve's policy ("now" / "later" / "never", _GraphStep.auto_policy)
         self._auto_steps = 0
         self._hold_pre = False      # auto mode: the eager step before the switch to replays enqueues no look-ahead stage
-        self.hip_graph = wanted and device_ctrl and self._sync is None and y0.device.type == "cuda" and not self._vec_ctrl \
+        self.hip_graph = wanted and device_ctrl and self._sync is None and y0.device.type == "cuda" \
+            and (not self._vec_ctrl or getattr(self.kernels, "vec_ctrl_in_graph", False)) \
             and hasattr(self.kernels, "stage_combine_dev") \
             and self.layout.total <= (_GRAPH_AUTO_MAX_ELEMENTS if auto else _GRAPH_MODE_MAX_ELEMENTS) * \
             (2 if (y0.element_size() == 2 and not auto) else 1)      # (16-bit states: the same bytes; at 2^23 elements the
@@ -466,13 +473,17 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         # "auto" (the default): while nothing is known about func yet, the evaluation every solve starts with doubles as the
         # side-effect test — an evaluation counter, a cache, dropout show up HERE, before any capture is attempted and
         # before the adjoint's proxy check would evaluate func on its own account
-        watch = self.hip_graph and self._graph_auto and not _GraphStep.status_known(self.func.base_func)
+        watch = self._graph_watch and not _GraphStep.status_known(self.func.base_func)
         before = _side_effect_fingerprint(self.func.base_func, self.y0.device) if watch else None
         f0 = self.func.eval(t0, self.y0)
-        if watch and _side_effect_fingerprint(self.func.base_func, self.y0.device) != before:
-            _GraphStep.refuse_func(self, "evaluating it changed its own attributes, buffers or the device's random-number "
-                                         "state (an evaluation counter, a cache, dropout ...), which a replay would not repeat")
-            self.hip_graph = False
+        if watch:
+            if _side_effect_fingerprint(self.func.base_func, self.y0.device) != before:
+                _GraphStep.refuse_func(self, "evaluating it changed its own attributes, buffers or the device's random-"
+                                             "number state (an evaluation counter, a cache, dropout ...), which a replay "
+                                             "would not repeat")
+                self.hip_graph = False
+            else:
+                _GraphStep.mark_pure(self.func.base_func)
         if self.first_step is None:
             first_step = self._select_initial_step(t0, self.y0, f0)
         else:
@@ -516,10 +527,26 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         y0_g, f0_g = y0, f0
         y0, f0 = y0.detach(), f0.detach()
         user_norm = not isinstance(self.norm, BuiltinNorm)
-        kern.init_norms(plan, 0, y0, f0, y0)
+        # r06: per-element tolerances under the built-in norm — the heuristic's three norms are tdeq_init_norms_vec launches
+        # (the tolerance vectors as two fp64 streams, ATen's promotion per operation), not ~10 fp64 torch ops each
+        vec_init = self._vec_fused is not None and hasattr(kern, "init_norms_vec")
+
+        def vec_norm(sums):
+            # max over the components of sqrt(mean) in W = fp64 (misc.py:22-33 on the promoted quotients)
+            val = 0.0
+            for s_, n_ in list(zip(sums, self._numels))[:len(self._numels) - self._vec_fused[2]]:
+                if n_:
+                    val = _nan_max(val, math.sqrt(s_ / n_))
+            return val
+        if vec_init:
+            kern.init_norms_vec(plan, 0, y0, f0, y0, self._vec_fused[0], self._vec_fused[1])
+        else:
+            kern.init_norms(plan, 0, y0, f0, y0)
         s0, s1, bad = self._read_norms()
         self._y_nonfinite = any(b != 0 for b in bad)
-        if user_norm:
+        if vec_init:
+            d0, d1 = S(vec_norm(s0)), S(vec_norm(s1))
+        elif user_norm:
             # the reference hands ITS norm to the heuristic (rk_common.py:217): materialise the quotients and let the
             # user's callable reduce them
             q0, q1 = torch.empty_like(y0), torch.empty_like(y0)
@@ -548,7 +575,11 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
             kern.stage_combine(y1, y0, [f0], [1.0], float(h0) * self.func.sign)
             with torch.no_grad():
                 f1 = self.func.eval(self._w(t0 + float(h0)), y1)
-        if user_norm:
+        if vec_init:
+            kern.init_norms_vec(plan, 1, f1, f0, y0, self._vec_fused[0], self._vec_fused[1])
+            s2, _, bad = self._read_norms()
+            d2_num = S(vec_norm(s2))
+        elif user_norm:
             q0 = torch.empty_like(y0)
             kern.init_scaled(plan, 1, f1, f0, y0, q0)
             if self._vec_tol is not None:
