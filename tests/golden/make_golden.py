@@ -287,6 +287,26 @@ def gen_dopri8_small():
     save("dopri8_small.npz", **arrays)
 
 
+def gen_int_state():
+    """What the reference does with an INTEGER state (advisor r05): its fixed-grid methods run — `y0 + dt * f` promotes
+    every step to float, the solution buffer keeps y0's dtype, so each output row is TRUNCATED back to int64 —, its adaptive
+    methods fail inside `nextafter` (NotImplementedError).  This package refuses integer / bool states for every method
+    (`UnsupportedStateDtype`, a TypeError and a NotImplementedError); tests/test_api_corners_r4.py pins the refusal next to
+    these recorded results, so the deviation is a decision on record, not an accident."""
+    arrays = {}
+    y0, t = torch.tensor([4, 8]), torch.tensor([0.0, 1.0, 2.0])
+    for m in ("euler", "midpoint", "rk4"):
+        y = torchdiffeq.odeint(lambda t_, y_: -0.5 * y_, y0, t, method=m)
+        assert y.dtype == torch.int64
+        arrays[f"int_{m}_y"] = y
+    try:
+        torchdiffeq.odeint(lambda t_, y_: -0.5 * y_, y0, t, method="dopri5")
+        arrays["int_dopri5_error"] = np.array("none")
+    except Exception as exc:      # noqa: BLE001
+        arrays["int_dopri5_error"] = np.array(type(exc).__name__)
+    save("int_state.npz", **arrays)
+
+
 def gen_adjoint():
     """cfg3 (reduced): odeint_adjoint through a tanh MLP, loss = sum(y(T)^2) (+ intermediate outputs)."""
     arrays = {}
@@ -1486,7 +1506,7 @@ def gen_programs():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in [("tableaus", gen_tableaus), ("kernels", gen_kernel_vectors), ("controller", gen_controller_vectors),
-                     ("solves", gen_solves), ("dopri8_small", gen_dopri8_small), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
+                     ("solves", gen_solves), ("dopri8_small", gen_dopri8_small), ("int_state", gen_int_state), ("adjoint", gen_adjoint), ("cnf", gen_cnf), ("methods", gen_methods), ("events", gen_events), ("backprop", gen_backprop), ("tuple_tol", gen_tuple_tolerances), ("adjoint_tdep", gen_adjoint_time_dependent),
                      ("adams", gen_adams), ("implicit", gen_implicit), ("detest", gen_detest), ("hostpath", gen_hostpath), ("eager_pin", gen_eager_pin), ("dropin", gen_dropin), ("brow", gen_brow), ("r4b", gen_r4b), ("programs", gen_programs)]:
         if not only or name in only:
             fn()

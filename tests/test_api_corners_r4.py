@@ -3,6 +3,7 @@
 test pins what the reference does, cited."""
 import warnings
 
+import numpy as np
 import pytest
 import torch
 
@@ -85,6 +86,24 @@ def test_integer_state_is_refused_with_the_references_exception_class(on):
     with pytest.raises(NotImplementedError) as exc:
         tda.odeint(lambda t, y: y, torch.tensor([1, 2]), T, method="dopri5")
     assert isinstance(exc.value, TypeError)
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_integer_state_on_a_fixed_grid_is_refused_where_the_reference_truncates(on, method):
+    """Advisor r05: the one documented drop-in DEVIATION for a call the reference completes.  Its fixed-grid methods
+    accept an int64 state — every step is promoted to float by `y0 + dt * f` and TRUNCATED back into the int64 solution
+    buffer (tests/golden/int_state.npz holds what it returns: e.g. midpoint [4, 8] -> [2, 5] -> [1, 3]) —, its adaptive ones
+    raise NotImplementedError (recorded there too).  No ODE has an integer state; this package refuses both with one
+    exception that is a TypeError and a NotImplementedError, and says how to convert."""
+    from _cases import load
+    from torchdiffeq_amd.misc import UnsupportedStateDtype
+    z = load("int_state.npz")
+    assert z[f"int_{method}_y"].dtype == np.int64 and str(z["int_dopri5_error"]) == "NotImplementedError"
+    with pytest.raises(UnsupportedStateDtype, match=r"y0\.float\(\)"):
+        tda.odeint(lambda t, y: -0.5 * y, torch.tensor([4, 8]), torch.tensor([0.0, 1.0, 2.0]), method=method)
+    # the conversion the message recommends gives the un-truncated solution the reference's arithmetic was heading for
+    y = tda.odeint(lambda t, y: -0.5 * y, torch.tensor([4.0, 8.0]), torch.tensor([0.0, 1.0, 2.0]), method=method)
+    assert torch.equal(y[1].to(torch.int64), torch.from_numpy(z[f"int_{method}_y"][1]).to(y.device))
 
 
 def test_zero_tolerances_fail_like_the_reference_without_numpy_warnings(on):

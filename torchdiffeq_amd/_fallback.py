@@ -176,7 +176,11 @@ class HostKernels:
         return float(r.abs().pow(2).mean().sqrt()) if r.numel() else float("nan")
 
     def make_plan(self, segments, total, chunk, device) -> HostPlan:
-        return HostPlan(segments, total, chunk)
+        plan = HostPlan(segments, total, chunk)
+        # who reads the fp64 sums: the variant whose norms ARE those sums (KernelOrderHostKernels), and lock-step sharding
+        # (the solver sets the flag then); the literal path reads rms0 / rms1
+        plan.want_sums = not self.literal_norms
+        return plan
 
     # -- stage combines ------------------------------------------------------------------------------------
     def stage_combine(self, out, y0, ks, coefs, dt: float) -> None:
