@@ -250,6 +250,10 @@ struct MultiArgs {
 template <typename T, int NT, typename E, int POLICY = 0, int NOUTC = 0, int ACCC = -1, bool DEVDT = true>
 __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, int64_t i) {
     const E* __restrict__ y0 = reinterpret_cast<const E*>(a.y0);
+    // (r06) captured steps: ctrl_dev[1] = sign * T(dt) of the device-resident controller, fetched as a VECTOR load issued
+    // ahead of the stream loads — one in-order queue, one wait (see combine_devdt_kernel)
+    double dtd = 1.0;
+    if (DEVDT && a.dt_dev) dtd = __hip_atomic_load(a.dt_dev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     E kk[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) kk[j] = ld_stream<POLICY>(reinterpret_cast<const E*>(a.k[j]) + i);
@@ -257,8 +261,7 @@ __device__ __forceinline__ void multi_elem(const MultiArgs<T, NT>& a, int64_t i)
     E acc0 = y;                       // placeholder when there is no acc_in (never read then)
     const bool has_acc = ACCC < 0 ? (a.acc_in != nullptr) : (ACCC == 1);
     if (has_acc) acc0 = ld_stream<POLICY>(reinterpret_cast<const E*>(a.acc_in) + i);
-    // (r06: fetched AFTER the stream loads are in flight — a dependent scalar load of a word another CU just wrote)
-    const T dtT = (DEVDT && a.dt_dev) ? (T)a.dt_dev[1] : (T)1;      // ctrl_dev[1] = sign * T(dt) of the device-resident controller
+    const T dtT = (T)dtd;
     constexpr int kOuts = NOUTC > 0 ? NOUTC : kMaxMultiOut;
 #pragma unroll
     for (int o = 0; o < kOuts; ++o) {
@@ -1164,6 +1167,11 @@ __global__ __launch_bounds__(kBlock) void combine_devdt_kernel(const CombineDevT
     // launch's controller on another CU: a scalar load that misses the scalar cache and the L2 — ~1.5 us during which a
     // wave of the r05 form (dt first, coefficients, then the loads) had nothing in flight; a wave of this kernel lives ~1 us
     // otherwise (profiles/r06_shard_l2.json: 5.1-5.7 us per captured combine against 3.4-3.8 us for the host-dt kernels).
+    // The step size itself travels as a VECTOR load (an agent-scope relaxed atomic load is never selected as a scalar
+    // load): issued first, it shares the in-order vmcnt queue with the stream loads behind it, so the one wait before the
+    // arithmetic covers both — a scalar load would put its own full round trip (kernarg pointer, then the value) in series
+    // with them, and every later kernarg wait would wait for it too (lgkmcnt counts out-of-order returns).
+    const double dtd = __hip_atomic_load(a.dt_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     E kk[NT];
     E yv{};
@@ -1172,7 +1180,7 @@ __global__ __launch_bounds__(kBlock) void combine_devdt_kernel(const CombineDevT
         for (int j = 0; j < NT; ++j) kk[j] = reinterpret_cast<const E*>(a.c.k[j])[i0];
         yv = y0[i0];
     }
-    const T dtT = (T)*a.dt_dev;
+    const T dtT = (T)dtd;
     T c[NT], e[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
