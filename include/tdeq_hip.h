@@ -284,6 +284,10 @@ int tdeq_stage_combine_multi_timed(const tdeq_multi_out* outs, int n_out, const 
  *       more; same sums, same decision).  state_in_dev != 0 (hipGraph mode, below): ctrl->t0 / ctrl->dt and
  *       the `dt` argument are ignored — the trial step's (t0, dt) are ctrl_dev[2..3] and the error coefficients are
  *       scaled by ctrl_dev[1], all left there by the previous call (or by the host before the first one).
+ *       copy_last_k (ABI 21, nullable; fp32 / fp64 states, n_terms >= 1): the last remaining stage k[n_terms - 1] — the
+ *       step's f1 = f(t1, y1) for an FSAL pair — is ALSO written to this buffer by the norm launch, which has the
+ *       stream in registers: a captured trial step whose next step must read f1 from a buffer of its own (func's output
+ *       buffer cannot be chosen) saves the N-word copy node.
  *
  *   tdeq_stage_combine_sel   first stage of the next trial step, launched before the host knows `accept`:
  *         (y, f) = accept ? (y_acc, f_acc) : (y_rej, f_rej) ;  out = y + fl_T(fl_T(coef) * T(dt')) * f
@@ -295,8 +299,8 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
                                  const double* coef, int n_terms, double dt, const tdeq_segment* segs,
                                  const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
                                  double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev,
-                                 void* next_times, int state_in_dev, void* workspace, size_t workspace_bytes,
-                                 int dtype, void* stream);
+                                 void* next_times, int state_in_dev, void* copy_last_k, void* workspace,
+                                 size_t workspace_bytes, int dtype, void* stream);
 int tdeq_stage_combine_sel(void* out, const void* y_acc, const void* f_acc, const void* y_rej, const void* f_rej,
                            double coef, const double* ctrl_dev, int64_t n, int dtype, void* stream);
 

@@ -383,3 +383,51 @@ def test_max_num_steps_is_exceeded_after_the_references_number_of_evaluations(cp
                        method="dopri5", rtol=1e-3, atol=1e-9, options=dict(max_num_steps=20))
     assert f.nfe == 122
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("layout", ["single", "single_unaligned", "segmented"])
+@pytest.mark.parametrize("n_terms", [1, 2])
+def test_norm_launch_also_writes_the_last_stage_for_captured_steps(hip_kernels, dtype, layout, n_terms):
+    """r06, ABI 21 `copy_last_k`: the captured step's norm launch (state in device memory) writes the last remaining stage
+    — the step's f1 — into a second buffer, replacing the N-word copy node.  Same sums and controller words as without the
+    copy, the buffer an exact copy (alignment padding of a segmented layout included), neighbours untouched."""
+    g = torch.Generator().manual_seed(3)
+    chunk = 1024
+    if layout == "segmented":
+        numels = [1, 1500, 4099]
+        offs, total = [], 0
+        for m in numels:
+            offs.append(total)
+            total += -(-m // chunk) * chunk
+        segs = [(o, m, 1e-6, 1e-8) for o, m in zip(offs, numels)]
+    else:
+        total = 5003
+        segs = [(0, total, 1e-6, 1e-8)]
+    pad = 3 if layout == "single_unaligned" else 0          # views at an odd offset: the scalar path
+
+    def buf():
+        return torch.randn(total + pad + 8, generator=g, dtype=torch.float64).to(dtype).cuda()[pad:pad + total]
+    y0, y1, part = buf(), buf(), buf() * 1e-7
+    ks = [buf() * 1e-7 for _ in range(n_terms)]
+    y1 = y0 + 0.01 * y1
+    plan = hip_kernels.make_plan(segs, total, chunk, torch.device("cuda:0"))
+    np_dtype = np.float32 if dtype == torch.float32 else np.float64
+    c = _ctrl(0.37, 0.0123, 5, DOPRI5, 1.0, 0.0, math.inf, np_dtype=np_dtype, n_norm_seg=len(segs))
+    tn = torch.empty(c.n_times, dtype=dtype, device="cuda")
+    coefs = [0.025, -0.0125][:n_terms]
+
+    def run(copy_to):
+        plan.ctrl_dev.copy_(torch.tensor([0.0, float(np_dtype(0.0123)), 0.37, 0.0123], dtype=torch.float64))
+        hip_kernels.error_norm_partial_ctrl(plan, part, y0, y1, ks, coefs, 0.0, c, tn, state_in_dev=True, copy_last_to=copy_to)
+        words = hip_kernels.read_ctrl(plan)
+        return words, list(hip_kernels._read_out(plan)), tn.clone(), plan.ctrl_dev.clone()
+    ref = run(None)
+    whole = torch.full((total + pad + 16,), 7.0, dtype=dtype, device="cuda")
+    dst = whole[pad + 8:pad + 8 + total]
+    got = run(dst)
+    assert got[0] == ref[0] and np.array_equal(np.array(got[1]), np.array(ref[1]), equal_nan=True)
+    assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
+    assert torch.equal(dst, ks[-1])
+    assert bool((whole[:pad + 8] == 7.0).all()) and bool((whole[pad + 8 + total:] == 7.0).all())

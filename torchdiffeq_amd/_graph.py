@@ -759,8 +759,9 @@ class _GraphStep:
                 if i < n_rows:
                     k.append(func.eval_at(self.ts[i], yi))
             assert held.pop(R) is epart and not held
-            self._norm_ctrl(s, epart, y_cur, y1, [k[j] for j in carry.err_idx], carry.err_coef)
-            if side == 1:
+            if not self._norm_ctrl(s, epart, y_cur, y1, [k[j] for j in carry.err_idx], carry.err_coef,
+                                   self.f0 if side == 1 and carry.err_idx and carry.err_idx[-1] == len(k) - 1 else None) \
+                    and side == 1:
                 self.f0.copy_(k[-1])
             self.k[side] = k
             return
@@ -794,20 +795,30 @@ class _GraphStep:
         if not fsal:
             sol = s._c_sol
             kern.stage_combine_dev(y1, epart, y_cur, [k[j] for j in sol.idx], sol.coef, fuse[0], plan)
-        self._norm_ctrl(s, epart, y_cur, y1, [k[j] for j in fuse[1]], fuse[2])
-        if side == 1:
-            self.f0.copy_(k[-1])          # side 0 reads its derivative from a buffer of its own (see the class text)
+        # side 0 reads its derivative from a buffer of its own (see the class text): side 1's last evaluation goes there —
+        # written by the norm launch itself where that launch reads the stream anyway (r06), else by a copy node
+        if not self._norm_ctrl(s, epart, y_cur, y1, [k[j] for j in fuse[1]], fuse[2],
+                               self.f0 if side == 1 and fuse[1] and fuse[1][-1] == len(k) - 1 else None) and side == 1:
+            self.f0.copy_(k[-1])
         self.k[side] = k
 
-    def _norm_ctrl(self, s, epart, y_cur, y1, ks, coefs) -> None:
+    def _norm_ctrl(self, s, epart, y_cur, y1, ks, coefs, copy_last_to=None) -> bool:
         """The step's last launch pair: the error norm continuing `epart` + the device controller, step state in device
-        memory — with scalar tolerances (tdeq_error_norm_partial_ctrl) or per-element ones (tdeq_error_norm_vec_ctrl)."""
+        memory — with scalar tolerances (tdeq_error_norm_partial_ctrl) or per-element ones (tdeq_error_norm_vec_ctrl).
+        `copy_last_to`: also write ks[-1] there; returns whether that was done."""
         if self.vec_tol is not None:
             s.kernels.error_norm_vec_ctrl(s.plan, y_cur, y1, ks, coefs, 0.0, self.vec_tol[0], self.vec_tol[1], s._ctrl,
                                           self.tbuf, partial=epart, state_in_dev=True)
+            return False
+        fused = copy_last_to is not None and getattr(s.kernels, "norm_copies_last_stage", False) \
+            and not y_cur.is_complex() and os.environ.get("TDEQ_NORM_COPY", "1") != "0"
+        if fused:
+            s.kernels.error_norm_partial_ctrl(s.plan, epart, y_cur, y1, ks, coefs, 0.0, s._ctrl, self.tbuf,
+                                              state_in_dev=True, copy_last_to=copy_last_to)
         else:
             s.kernels.error_norm_partial_ctrl(s.plan, epart, y_cur, y1, ks, coefs, 0.0, s._ctrl, self.tbuf,
                                               state_in_dev=True)
+        return fused
 
     def run(self, s) -> None:
         """One trial step from the current side's pair.  The caller flips `side` when the step was accepted."""

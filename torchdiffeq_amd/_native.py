@@ -113,7 +113,7 @@ ABI_SIGNATURES = {
                                                     ctypes.POINTER(Segment), ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                                     ctypes.POINTER(StepCtrl), ctypes.c_void_p, ctypes.c_void_p,
-                                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                                     ctypes.c_int, ctypes.c_void_p]),
     "tdeq_step_controller": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Segment), ctypes.c_void_p,
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -578,10 +578,13 @@ class HipKernels:
             return plan.out_np.tolist()
         return plan.out.tolist()
 
+    norm_copies_last_stage = True       # tdeq_error_norm_partial_ctrl(copy_last_k=...), ABI 21
+
     def error_norm_partial_ctrl(self, plan: NormPlan, err_partial, y0, y1, ks, coefs, dt: float, ctrl: StepCtrl,
-                                next_times, state_in_dev: bool = False) -> None:
+                                next_times, state_in_dev: bool = False, copy_last_to=None) -> None:
         """`error_norm_partial` whose finalize step also runs the step controller on the device: accept flag,
-        next step size and the next trial step's stage times (`next_times`, T[n_times]) — read with `read_ctrl`."""
+        next step size and the next trial step's stage times (`next_times`, T[n_times]) — read with `read_ctrl`.
+        `copy_last_to` (captured steps): the launch also writes `ks[-1]` into this buffer."""
         n = len(ks)
         ptrs = (ctypes.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
         cf = (ctypes.c_double * max(n, 1))(*coefs)
@@ -590,8 +593,9 @@ class HipKernels:
             err_partial.data_ptr(), y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, plan.segs,
             plan.segs_dev.data_ptr() if plan.segs_dev is not None else None, plan.n_seg, plan.chunk,
             plan.n_chunks, plan.out_ptr, plan.bad_ptr, ctypes.byref(ctrl), plan.ctrl_ptr, plan.ctrl_dev.data_ptr(),
-            next_times.data_ptr(), 1 if state_in_dev else 0, plan.workspace.data_ptr(), plan.workspace_bytes,
-            dtype_code(y0.dtype), self._stream()), "tdeq_error_norm_partial_ctrl")
+            next_times.data_ptr(), 1 if state_in_dev else 0, None if copy_last_to is None else copy_last_to.data_ptr(),
+            plan.workspace.data_ptr(), plan.workspace_bytes, dtype_code(y0.dtype), self._stream()),
+            "tdeq_error_norm_partial_ctrl")
 
     def step_controller(self, plan: NormPlan, sums_plan: NormPlan, numel_plan: NormPlan, ctrl: StepCtrl, next_times,
                         dtype: torch.dtype, state_in_dev: bool = False) -> None:

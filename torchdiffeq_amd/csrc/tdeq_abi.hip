@@ -439,8 +439,10 @@ int launch_finalize_ctrl(const SegTable& st, double* ws, double* out_sumsq, doub
 template <typename T, int NT>
 int launch_error_partial(const void* partial, const void* y0, const void* y1, const void* const* k,
                          const double* coef, double dt, const SegTable& st, double* out_sumsq, double* out_bad,
-                         double* ws, const CtrlBundle* cb, hipStream_t s) {
+                         double* ws, const CtrlBundle* cb, hipStream_t s, void* copy_last = nullptr) {
     ErrPartialArgs<T, NT> a;
+    a.copy_out = static_cast<T*>(copy_last);
+    if (copy_last && NT == 0) return TDEQ_EINVAL;        // nothing to copy: the error row ended with the last combine
     a.partial = static_cast<const T*>(partial);
     a.y0 = static_cast<const T*>(y0);
     a.y1 = static_cast<const T*>(y1);
@@ -461,7 +463,15 @@ int launch_error_partial(const void* partial, const void* y0, const void* y1, co
     const dim3 g((unsigned)st.n_chunks), b(kBlock);
     // the common shape — one segment whose chunk_start is 0, dt folded by the host — has its own lean instantiation
     const bool single = st.n_seg == 1 && st.inl[0].chunk_start == 0, lean = single && !dev_dt;
-    if (vec && (stream_policy((int64_t)(NT + 3) * st.n_chunks * st.chunk * (int64_t)sizeof(T)) & 1))
+    if (copy_last) {
+        // (captured steps only: states of at most 2^22 elements, always the default cache policy)
+        if constexpr (NT > 0) {
+            const bool v = vec && aligned16(copy_last);
+            if (v && single) hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 0, true, true, true>), g, b, 0, s, a);
+            else if (v) hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 0, false, true, true>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, false, 0, false, true, true>), g, b, 0, s, a);
+        }
+    } else if (vec && (stream_policy((int64_t)(NT + 3) * st.n_chunks * st.chunk * (int64_t)sizeof(T)) & 1))
         hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 1>), g, b, 0, s, a);
     else if (vec && lean) hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 0, true, false>), g, b, 0, s, a);
     else if (vec && single) hipLaunchKernelGGL((error_norm_partial_kernel<T, NT, true, 0, true, true>), g, b, 0, s, a);
@@ -476,11 +486,11 @@ int launch_error_partial(const void* partial, const void* y0, const void* y1, co
 template <typename T>
 int dispatch_error_partial(const void* partial, const void* y0, const void* y1, const void* const* k,
                            const double* coef, int nt, double dt, const SegTable& st, double* out_sumsq,
-                           double* out_bad, double* ws, const CtrlBundle* cb, hipStream_t s) {
+                           double* out_bad, double* ws, const CtrlBundle* cb, hipStream_t s, void* copy_last = nullptr) {
     switch (nt) {
-        case 0: return launch_error_partial<T, 0>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s);
-        case 1: return launch_error_partial<T, 1>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s);
-        case 2: return launch_error_partial<T, 2>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s);
+        case 0: return launch_error_partial<T, 0>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s, copy_last);
+        case 1: return launch_error_partial<T, 1>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s, copy_last);
+        case 2: return launch_error_partial<T, 2>(partial, y0, y1, k, coef, dt, st, out_sumsq, out_bad, ws, cb, s, copy_last);
     }
     return TDEQ_EINVAL;
 }
@@ -1299,8 +1309,9 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
                                  const double* coef, int n_terms, double dt, const tdeq_segment* segs,
                                  const void* segs_dev, int n_seg, int64_t chunk, int64_t n_chunks, double* out_sumsq,
                                  double* out_nonfinite, const tdeq_step_ctrl* ctrl, double* out_ctrl, double* ctrl_dev,
-                                 void* next_times, int state_in_dev, void* workspace, size_t workspace_bytes,
-                                 int dtype, void* stream) {
+                                 void* next_times, int state_in_dev, void* copy_last_k, void* workspace,
+                                 size_t workspace_bytes, int dtype, void* stream) {
+    if (copy_last_k && (lp_dtype(dtype) || dtype == TDEQ_C64 || dtype == TDEQ_C128 || n_terms < 1)) return TDEQ_EINVAL;
     if (lp_dtype(dtype)) {
         // bf16 / fp16: the WHOLE error row in one launch (a row is rounded once: no partial sum to continue — err_partial
         // must be NULL), then finalize + controller in the state's type
@@ -1339,8 +1350,8 @@ int tdeq_error_norm_partial_ctrl(const void* err_partial, const void* y0, const 
     if (dtype == TDEQ_C128)
         return dispatch_cplx_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s);
     return dtype == TDEQ_F32
-               ? dispatch_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s)
-               : dispatch_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s);
+               ? dispatch_error_partial<float>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s, copy_last_k)
+               : dispatch_error_partial<double>(err_partial, y0, y1, k, coef, n_terms, dt, st, out_sumsq, out_nonfinite, ws, &cb, s, copy_last_k);
 }
 
 int tdeq_step_controller(const double* sums, const double* nonfinite, const tdeq_segment* segs, const void* segs_dev,

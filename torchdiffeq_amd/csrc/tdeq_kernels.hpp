@@ -545,6 +545,8 @@ struct ErrPartialArgs {
     double* part_sumsq;
     double* part_bad;
     const double* dt_dev;   // non-null (hipGraph mode): c[] holds fl_T(coef) and is multiplied by T(*dt_dev) here
+    T* copy_out;            // COPY (r06, captured steps): the LAST remaining stage k[NT-1] — the step's f1 — is also written here,
+                            // which saves the captured step its N-word copy node (the stream is in registers anyway)
 };
 
 template <typename T>
@@ -559,7 +561,7 @@ __device__ __forceinline__ void tol_accumulate(T e, T y0, T y1, T rtol, T atol, 
 // the rest of the kernarg.  The general path picks the segment by address (inline table or device table), which the compiler
 // turns into a VECTOR load from a generic pointer: one full memory latency in front of every wave's first stream load.
 // DEVDT = false (host-driven steps: dt folded into c[] by the host) drops the load of *dt_dev and its dependent multiplies.
-template <typename T, int NT, bool VEC, int POLICY = 0, bool SINGLE = false, bool DEVDT = true>
+template <typename T, int NT, bool VEC, int POLICY = 0, bool SINGLE = false, bool DEVDT = true, bool COPY = false>
 __global__ __launch_bounds__(kBlock) void error_norm_partial_kernel(const ErrPartialArgs<T, NT> a) {
     using V = typename VecOf<T>::type;
     constexpr int L = VecOf<T>::L;
@@ -599,7 +601,11 @@ __global__ __launch_bounds__(kBlock) void error_norm_partial_kernel(const ErrPar
         for (int64_t i = threadIdx.x; i < nv; i += kBlock) {
             V e = ld_stream<POLICY>(pe + i);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) e = e + ld_stream<POLICY>(reinterpret_cast<const V*>(a.k[j] + base) + i) * cc[j];
+            for (int j = 0; j < NT; ++j) {
+                const V kv = ld_stream<POLICY>(reinterpret_cast<const V*>(a.k[j] + base) + i);
+                if (COPY && j == NT - 1) reinterpret_cast<V*>(a.copy_out + base)[i] = kv;
+                e = e + kv * cc[j];
+            }
             const V v0 = ld_stream<POLICY>(y0 + i), v1 = ld_stream<POLICY>(y1 + i);
 #pragma unroll
             for (int q = 0; q < L; ++q) tol_accumulate<T>(e[q], v0[q], v1[q], rtol, atol, acc[0], acc[1]);
@@ -609,8 +615,18 @@ __global__ __launch_bounds__(kBlock) void error_norm_partial_kernel(const ErrPar
     for (int64_t t = t0 + threadIdx.x; t < valid; t += kBlock) {
         T e = a.partial[base + t];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) e = e + a.k[j][base + t] * cc[j];
+        for (int j = 0; j < NT; ++j) {
+            const T kv = a.k[j][base + t];
+            if (COPY && j == NT - 1) a.copy_out[base + t] = kv;
+            e = e + kv * cc[j];
+        }
         tol_accumulate<T>(e, a.y0[base + t], a.y1[base + t], rtol, atol, acc[0], acc[1]);
+    }
+    if constexpr (COPY && NT > 0) {
+        // the alignment padding behind a segment of a segmented layout travels too (what the copy node moved): a chunk of
+        // such a layout lies inside the buffer as a whole
+        if (a.st.n_seg > 1)
+            for (int64_t t = valid + threadIdx.x; t < a.st.chunk; t += kBlock) a.copy_out[base + t] = a.k[NT - 1][base + t];
     }
     block_sum<2>(acc, red);
     if (threadIdx.x == 0) {
