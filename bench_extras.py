@@ -160,16 +160,21 @@ def shard_regime_linear(device, steps=100, warmup=20):
     At = A.T.contiguous()
     field = lambda t, y: y @ At
     out = {"state": f"{BATCH // 8} x {DIM} fp32 (1/8 of cfg2)", "steps_per_block": steps}
+    # "default": no option, no environment variable — what a drop-in user gets (r06: hip_graph='auto' built in);
+    # "lookahead" / "host_driven": the eager loops, asked for explicitly (hip_graph=False)
     for name, kw in (("host_driven", dict(lookahead=False)), ("lookahead", dict(lookahead=True)),
-                     ("hip_graph", dict(hip_graph=True)), ("auto", dict(hip_graph="auto"))):
+                     ("hip_graph", dict(hip_graph=True)), ("auto", dict(hip_graph="auto")), ("default", dict(hip_graph=None))):
         try:
+            if name == "default":
+                field = lambda t, y: y @ At          # a func object "auto" has not seen: the whole default experience
             solver = make_stepper(field, y0, **kw)
-            # ("auto": first sight of this func -> eager until solvers._AUTO_CAPTURE_AFTER_STEPS trial steps, then captured)
-            blocks = time_steps(solver, steps, warmup if name != "auto" else warmup + 110, 1, device, n_blocks=3)
+            # ("auto" / "default": first sight of this func -> eager until solvers._AUTO_CAPTURE_AFTER_STEPS trial steps, then
+            #  captured)
+            blocks = time_steps(solver, steps, warmup if name not in ("auto", "default") else warmup + 110, 1, device, n_blocks=3)
             st = block_stats(blocks, steps)
             out[name] = {"ms_per_step": st["median"], "min": st["min"], "max": st["max"],
                          "stages_per_s_of_the_shard": 6e3 / st["median"]}
-            if name == "auto":
+            if name in ("auto", "default"):
                 out[name]["replaying"] = solver._g is not None
             if name == "hip_graph":
                 solver = make_stepper(field, y0, **kw)
@@ -546,9 +551,10 @@ def cfg5_config(device):
     idx = torch.from_numpy(z["rows"]).to(device)
     out = {"workload": "BASELINE.json configs[4]: CNF (examples/cnf.py model, closed-form trace), dopri5 + adjoint, "
                        "batch=32768 x dim=2, rtol=atol=1e-5"}
-    for name, opts in (("eager", None), ("captured_steps", {"hip_graph": "auto"})):
+    # "default": no option (r06: = 'auto' built in) — must equal "captured_steps"; "eager": asked for with hip_graph=False
+    for name, opts in (("eager", {"hip_graph": False}), ("captured_steps", {"hip_graph": "auto"}), ("default", None)):
         cnf = fs.ExampleCNF([z[f"p{i}"] for i in range(6)], trace="closed").to(device)
-        cnf.counting = opts is None         # "auto" refuses a func with an evaluation counter (it would stop counting)
+        cnf.counting = name == "eager"      # "auto" refuses a func with an evaluation counter (it would stop counting)
         params = list(cnf.parameters())
         best = None
         for rep in range(5):                # (auto: pass 0 eager = first sight, pass 1 captures, passes 2.. replay)
@@ -587,8 +593,9 @@ def cfg1_config(device):
     z = np.load(os.path.join(ROOT, "tests", "golden", "solves.npz"))
     ref = torch.from_numpy(z["cfg1_y"])
     out = {"workload": "BASELINE.json configs[0]: spiral ODE, rk4 fixed step, y0 in R^2, batch=1, fp32, 1000 output times"}
-    for name, dev_, opts in (("gpu_eager", device, None), ("gpu_captured_step", device, {"hip_graph": True}),
-                             ("gpu_auto", device, {"hip_graph": "auto"}), ("cpu_host_path", torch.device("cpu"), None)):
+    for name, dev_, opts in (("gpu_eager", device, {"hip_graph": False}), ("gpu_captured_step", device, {"hip_graph": True}),
+                             ("gpu_auto", device, {"hip_graph": "auto"}), ("gpu_default", device, None),
+                             ("cpu_host_path", torch.device("cpu"), None)):
         try:
             A = torch.from_numpy(z["cfg1_A"]).to(dev_)
             y0 = torch.from_numpy(z["cfg1_y0"]).to(dev_)
