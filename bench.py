@@ -36,7 +36,8 @@ l2_fabric_bytes per launch from the committed PMC summary)}, cpu_baseline{value,
 reference_8core_value}, rel_err_vs_reference, nfe / reference_nfe, rccl_ranks / backend and — N > 1 — one scalar pair per
 regime (weak, strong, lockstep, adjoint.{strong, weak}).  EVERYTHING ELSE goes to `gpurun_out/bench_extras_n{N}.json`
 (TDEQ_BENCH_EXTRAS_DIR overrides the directory; the line names the file):
-  roofline      dominant launch = the step's 7-words-per-element stage combine (234.9 MB; with carried partial sums row 4 +
+  roofline      the launch the north star names = the step's 7-words-per-element stage combine (234.9 MB; the 8-word
+                stage_combine_err launch is marginally heavier by total time; with carried partial sums row 4 +
                 the prefix of row 5: stage_combine_multi_kernel<float, 4>, 2 outputs).  `frac` = IN SITU: its launches inside
                 the timed region, each stamped by the dispatch itself (hipExtLaunchKernelGGL start / stop events) — the stage
                 tensors were written by `func` just before, so part of the reads is served by the 256 MiB Infinity Cache;
@@ -122,6 +123,9 @@ def contract_line(out, extras_path=None):
         cold = rf.get("cold") if isinstance(rf.get("cold"), dict) else {}
         line["roofline"] = {
             "bound": rf.get("bound"), "kernel": _short(rf.get("kernel"), 112), "achieved": _num(rf.get("achieved")),
+            # (r06) which launch this is: the one BASELINE.json's north_star names (its target is quoted on the dopri5 stage
+            # combine) — by total time the step's 8-word stage_combine_err launch is marginally heavier (profiles/ CSV)
+            "kernel_role": "north_star's stage-combine launch, 7 words/element",
             "peak": rf.get("peak"), "unit": rf.get("unit"),
             # frac = IN SITU: algorithmic bytes / this kernel's average launch duration inside the timed region (the
             # figure the committed rocprofv3 --stats summary must agree with; the launch's inputs were just written by

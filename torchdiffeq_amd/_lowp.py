@@ -113,6 +113,7 @@ class LowPrecisionHipKernels(LowPrecisionHostKernels):
             None, y0.data_ptr(), y1.data_ptr(), ptrs, cf, n, dt, p.segs,
             p.segs_dev.data_ptr() if p.segs_dev is not None else None, p.n_seg, p.chunk, p.n_chunks, p.out_ptr, p.bad_ptr,
             ctypes.byref(ctrl), p.ctrl_ptr, p.ctrl_dev.data_ptr(), next_times.data_ptr(), 1 if state_in_dev else 0,
+            None,       # copy_last_k (ABI 21): fp32 / fp64 states only
             p.workspace.data_ptr(), p.workspace_bytes, dtype_code(y0.dtype), hip._stream()), "tdeq_error_norm_partial_ctrl")
         plan.pending = None
 
