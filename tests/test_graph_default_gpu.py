@@ -302,3 +302,30 @@ def test_no_nested_capture_inside_a_callers_stream_capture(monkeypatch):
             tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8)
             tda.odeint(f, y0, torch.linspace(0, 1, 50, device="cuda"), method="rk4")
     assert f not in _graph._GraphStep._cache
+
+
+def test_cached_captured_steps_stay_within_the_global_budget(monkeypatch):
+    """Captured steps are on by default, so what they keep across solves is bounded globally (TDEQ_GRAPH_CACHE_MB): least
+    recently used entries go first, results are unaffected, and a budget of 0 keeps nothing."""
+    y0, t = _problem(n=4096, d=8)
+    fields = [_Pure() for _ in range(4)]
+    with torch.no_grad():
+        y_ref = [tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8, options=dict(hip_graph=False)) for f in fields]
+        for f in fields[:1]:
+            for _ in range(3):
+                tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8)
+        live, total = _graph._GraphStep._cached_steps()
+        assert len(live) == 1 and total == live[0].approx_bytes() > 0
+        one = live[0].approx_bytes()
+        monkeypatch.setenv("TDEQ_GRAPH_CACHE_MB", str(2.5 * one / (1 << 20)))          # room for two cached steps
+        for f, ref in zip(fields, y_ref):
+            for _ in range(3):
+                assert torch.equal(tda.odeint(f, y0, t, method="dopri5", rtol=1e-6, atol=1e-8), ref)
+        live, total = _graph._GraphStep._cached_steps()
+        assert len(live) == 2 and total <= 2.5 * one
+        assert fields[0] not in _graph._GraphStep._cache or not _graph._GraphStep._cache[fields[0]]      # the oldest went first
+        monkeypatch.setenv("TDEQ_GRAPH_CACHE_MB", "0")
+        g = _Pure()
+        for _ in range(3):
+            assert torch.equal(tda.odeint(g, y0, t, method="dopri5", rtol=1e-6, atol=1e-8), y_ref[0])
+        assert not _graph._GraphStep._cache.get(g)

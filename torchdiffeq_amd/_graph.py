@@ -563,6 +563,12 @@ class _GraphStep:
     # same parameter storages — what a captured graph requires anyway; `clear_graph_cache()` drops them.
     _cache = weakref.WeakKeyDictionary()
     _MAX_PER_FUNC = 4
+    # r06 (captured steps are on by default): a global budget over everything kept for reuse.  A captured step owns its
+    # static buffers and, through its graphs' private pool, every stage tensor of both sides — about (2 S + 9) states; a
+    # process with many long-lived funcs must not grow without bound where the reference would not.  Least recently used
+    # entries that no running solve holds are dropped first; TDEQ_GRAPH_CACHE_MB (default 2048) sets the budget, 0 keeps
+    # nothing across solves.
+    _lru = collections.OrderedDict()            # id(step) -> weakref to the cached step, oldest first
     _seen = weakref.WeakKeyDictionary()         # auto mode: func -> keys that have been solved (eagerly) once already
     _refused = weakref.WeakKeyDictionary()      # auto mode: func -> why it is never captured
 
@@ -578,8 +584,8 @@ class _GraphStep:
         try:
             if base in cls._refused:
                 return "never"
-            if not _reusable_across_solves(base):
-                return "later"
+            if not _reusable_across_solves(base) or cls._budget_bytes() <= 0:
+                return "later"          # (nothing can be kept for the next solve: capture only if THIS solve turns out long)
             key = cls._key(s)
             per_func = cls._cache.get(base)
             if per_func is not None and key in per_func:
@@ -699,6 +705,7 @@ class _GraphStep:
         g = per_func.get(key) if per_func is not None else None
         if g is not None and not g.in_use:
             g.in_use = True
+            cls._touch(g)
             g.auto = bool(getattr(s, "_graph_auto", False))
             g.recheck = g.auto      # "auto": the first replay of this solve is checked against one eager evaluation
             s.plan = g.plan         # read-backs must poll the buffers the captured kernels write
@@ -716,12 +723,73 @@ class _GraphStep:
                     if not old.in_use:
                         del per_func[old_key]
                         break
-            if len(per_func) < cls._MAX_PER_FUNC:
+            if len(per_func) < cls._MAX_PER_FUNC and cls._make_room(g):
                 per_func[key] = g
+                cls._touch(g)
         return g
 
     def release(self) -> None:
         self.in_use = False
+
+    # -- the global budget ------------------------------------------------------------------------------------
+    def approx_bytes(self) -> int:
+        """Device memory a cached step pins, roughly: y (2), f0, epart (2), two sides of S + 1 stage tensors and as many
+        stage inputs in the graphs' pool, the tolerance copies of the per-element mode."""
+        state = self.y[0].numel() * self.y[0].element_size()
+        n_stage = len(self.tbuf) + 1
+        extra = sum(v.numel() * v.element_size() for v in (self.vec_tol or ()) if isinstance(v, torch.Tensor))
+        return state * (5 + 4 * n_stage) + extra
+
+    @staticmethod
+    def _budget_bytes() -> int:
+        try:
+            return int(float(os.environ.get("TDEQ_GRAPH_CACHE_MB", "2048")) * (1 << 20))
+        except ValueError:
+            return 2048 << 20
+
+    @classmethod
+    def _touch(cls, g) -> None:
+        cls._lru.pop(id(g), None)
+        cls._lru[id(g)] = weakref.ref(g)
+
+    @classmethod
+    def _cached_steps(cls):
+        """(live cached steps oldest first, total bytes); entries whose step or func has gone are forgotten on the way."""
+        live, total = [], 0
+        for ident, ref in list(cls._lru.items()):
+            g = ref()
+            if g is None or not g._is_cached():
+                del cls._lru[ident]
+                continue
+            live.append(g)
+            total += g.approx_bytes()
+        return live, total
+
+    def _is_cached(self) -> bool:
+        try:
+            return any(g is self for per_func in self._cache.values() for g in per_func.values())
+        except RuntimeError:        # the weak dictionary changed size under the iteration: count it as cached, re-examined later
+            return True
+
+    @classmethod
+    def _make_room(cls, new) -> bool:
+        """Evict least-recently-used cached steps that no solve holds until `new` fits the budget; False: `new` itself does
+        not fit (it then serves its own solve only)."""
+        budget, need = cls._budget_bytes(), new.approx_bytes()
+        if need > budget:
+            return False
+        live, total = cls._cached_steps()
+        for old in live:
+            if total + need <= budget:
+                break
+            if old.in_use:
+                continue
+            for per_func in list(cls._cache.values()):
+                for k in [k for k, g in per_func.items() if g is old]:
+                    del per_func[k]
+            cls._lru.pop(id(old), None)
+            total -= old.approx_bytes()
+        return total + need <= budget
 
     def body(self, s, side: int) -> None:
         func, kern, plan = s.func, s.kernels, s.plan
@@ -959,3 +1027,4 @@ class _GraphStep:
 def clear_graph_cache() -> None:
     """Drop every captured trial-step graph kept for reuse (options={'hip_graph': True})."""
     _GraphStep._cache.clear()
+    _GraphStep._lru.clear()
