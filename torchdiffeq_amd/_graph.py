@@ -586,7 +586,7 @@ class _GraphStep:
                 return "never"
             if not _reusable_across_solves(base) or cls._budget_bytes() <= 0:
                 return "later"          # (nothing can be kept for the next solve: capture only if THIS solve turns out long)
-            key = cls._key(s)
+            key = s._graph_key = cls._key(s)        # (kept for `acquire`: the walk over func is not repeated within a solve)
             per_func = cls._cache.get(base)
             if per_func is not None and key in per_func:
                 return "now"
@@ -701,7 +701,7 @@ class _GraphStep:
             per_func = cls._cache.get(s.func.base_func)
         except TypeError:           # func object cannot be weakly referenced: no reuse
             return cls(s, t0, dt)
-        key = cls._key(s)
+        key = getattr(s, "_graph_key", None) or cls._key(s)
         g = per_func.get(key) if per_func is not None else None
         if g is not None and not g.in_use:
             g.in_use = True

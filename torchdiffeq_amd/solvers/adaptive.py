@@ -498,6 +498,7 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
         self._t_end, self._pre = -math.inf, None    # event mode / direct stepping: no look-ahead
         self._g = None
         self._auto, self._auto_steps, self._hold_pre = None, 0, False
+        self._graph_key = None
         if self.first_step is not None:
             self._dt_shadow = None
 
@@ -658,6 +659,7 @@ class RKAdaptiveStepsizeODESolver(AdaptiveEvents):
             self.hip_graph = False
             return False
         if self._auto == "later":
+            self._graph_key = None      # (the key computed at the first step is not trusted ~100 steps later)
             self._auto_steps += 1
             if self._auto_steps <= _AUTO_CAPTURE_AFTER_STEPS:
                 # (the last eager step enqueues no look-ahead stage, so that the replays start from a clean state)
