@@ -942,13 +942,15 @@ class _GraphStep:
         graph = self.graphs[side]
         ctrl0, times0 = plan.ctrl_dev.clone(), self.tbuf.clone()
         y_cur, f_cur = self.y[side], self.f_in(side)
-        nfe = func.nfe
         yi = torch.empty_like(y_cur)
-        kern.stage_combine_dev(yi, None, y_cur, [f_cur], s._beta[0].coef, None, plan)
-        k1 = func.eval_at(self.ts[0], yi)
-        func.nfe = nfe
+        kern.stage_combine_dev(yi, None, y_cur, [f_cur], s._beta[0].coef, None, plan)     # (reads dt before the replay moves it on)
         kern.arm_readback(plan)
         graph.replay()
+        # the eager evaluation is issued BEHIND the replay: its Python runs while the GPU replays the step (the first stage
+        # time comes from the copy — the replay's controller has moved the live one on by the time these kernels run)
+        nfe = func.nfe
+        k1 = func.eval_at(times0[0], yi)
+        func.nfe = nfe
         if torch.equal(k1, self.k[side][1]):
             return True
         plan.ctrl_dev.copy_(ctrl0)
