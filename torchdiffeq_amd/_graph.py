@@ -63,6 +63,10 @@ def _graph_request(hip_graph):
 _WALK_DEPTH = 4                  # containers / plain objects nested deeper than this are not searched
 _WALK_ITEMS = 4096               # ... nor are the items of a container beyond this many
 _PLAIN = (bool, int, float, complex, str, bytes, type(None))
+# attributes every nn.Module carries for its own bookkeeping (hook dictionaries, `_parameters` ...): never user state, skipped
+# by the per-solve walks (`training` is read explicitly where it matters)
+_MODULE_INTERNALS = frozenset(torch.nn.Module().__dict__.keys())
+_CODE_NAMES = {}                 # code object -> the global names its body (and nested code objects) mention
 
 
 def _is_plain_object(value) -> bool:
@@ -267,12 +271,19 @@ def _global_state(inner, versions=False, _depth=0):
         return ()
     out = []
     code, glob = inner.__code__, inner.__globals__
-    names, stack = [], [code]
-    while stack:
-        c = stack.pop()
-        names += [n for n in c.co_names if n in glob]
-        stack += [k for k in c.co_consts if isinstance(k, types.CodeType)]
-    for n in dict.fromkeys(names):
+    names = _CODE_NAMES.get(code)
+    if names is None:
+        names, stack = [], [code]
+        while stack:
+            c = stack.pop()
+            names += list(c.co_names)
+            stack += [k for k in c.co_consts if isinstance(k, types.CodeType)]
+        names = _CODE_NAMES[code] = tuple(dict.fromkeys(names))
+        if len(_CODE_NAMES) > 4096:
+            _CODE_NAMES.clear()
+    for n in names:
+        if n not in glob:
+            continue
         v = glob[n]
         if isinstance(v, _PLAIN):
             out.append((n, v))
@@ -386,7 +397,10 @@ def _scalar_state(fn):
     captured-step cache key: `self.scale = 0.5` changed between two solves leads to a new capture, not to a replay
     with the old value."""
     def plain(obj, out, depth=0):
+        skip = _MODULE_INTERNALS if isinstance(obj, torch.nn.Module) else ()
         for name, v in list((getattr(obj, "__dict__", None) or {}).items()):
+            if name in skip:
+                continue
             if isinstance(v, (bool, int, float, complex, str, bytes, type(None))):
                 out.append((name, v))
             elif isinstance(v, (list, tuple)) and len(v) <= 64 and all(isinstance(x, (bool, int, float, str)) for x in v):
