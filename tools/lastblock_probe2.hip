@@ -57,10 +57,11 @@ __device__ __forceinline__ double chunk_partial(const float* e, const float* y0,
     return acc;
 }
 
-enum { SPLIT = 0, FENCE = 1, WT = 2, ATOM = 3 };
+enum { SPLIT = 0, FENCE = 1, WT = 2, ATOM = 3, HWT = 4 };
+constexpr int kGroups = 16;     // HWT: workgroup b arrives at ticket[1 + b % kGroups]; the last of a group at ticket[0]
 
 template <int MODE> __device__ __forceinline__ double load_partial(double* part, int i) {
-    if (MODE == WT) return __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (MODE == WT || MODE == HWT) return __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (MODE == ATOM) {
         const unsigned long long u = __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(part) + i, 0ull,
                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -99,15 +100,30 @@ __global__ __launch_bounds__(kBlock) void PF(const float* e, const float* y0, co
         if (MODE == FENCE) {
             part[blockIdx.x] = s;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        } else if (MODE == WT) {
+        } else if (MODE == WT || MODE == HWT) {
             __hip_atomic_store(part + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // global_store_dwordx2 sc1
         } else {
             __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(part) + blockIdx.x,
                                   (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (MODE == HWT) {
+            // two-level arrival: 16 group tickets absorb the same-address serialisation (~9 ns per returning atomic), only
+            // the last arriver of a group touches the top ticket
+            const unsigned grp = blockIdx.x % kGroups;
+            const unsigned in_grp = (gridDim.x - grp + kGroups - 1) / kGroups;
+            const unsigned n_grp = gridDim.x < (unsigned)kGroups ? gridDim.x : (unsigned)kGroups;
+            const unsigned tg = __hip_atomic_fetch_add(ticket + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = 0;
+            if (tg == in_grp - 1) {
+                __hip_atomic_store(ticket + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned tt = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = (tt == n_grp - 1);
+            }
+        } else {
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = (t == gridDim.x - 1);
+        }
         if (last && MODE == FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -146,15 +162,15 @@ int main() {
     printf("{\n \"unit\": \"us per graph replay (X -> norm -> X), median of 5 x 400 replays; stale = wrong words in 2000 tagged launches under load\"");
     for (int64_t n : {131072LL, 1048576LL, 2097152LL, 8388608LL}) {
         float *e, *y0, *y1, *o, *junk;
-        double *part, *out[4];
+        double *part, *out[5];
         unsigned* ticket;
         unsigned long long* bad;
         const int n_part = (int)(n / kChunk);
         CHECK(hipMalloc(&e, n * 4)); CHECK(hipMalloc(&y0, n * 4)); CHECK(hipMalloc(&y1, n * 4)); CHECK(hipMalloc(&o, n * 4));
         CHECK(hipMalloc(&junk, (8 << 20) * 4));
-        CHECK(hipMalloc(&part, n_part * 8)); CHECK(hipMalloc(&ticket, 4)); CHECK(hipMalloc(&bad, 8));
-        for (int v = 0; v < 4; ++v) CHECK(hipMalloc(&out[v], 8));
-        CHECK(hipMemset(ticket, 0, 4)); CHECK(hipMemset(bad, 0, 8)); CHECK(hipMemset(junk, 0, (8 << 20) * 4));
+        CHECK(hipMalloc(&part, n_part * 8)); CHECK(hipMalloc(&ticket, 4 * (1 + kGroups))); CHECK(hipMalloc(&bad, 8));
+        for (int v = 0; v < 5; ++v) CHECK(hipMalloc(&out[v], 8));
+        CHECK(hipMemset(ticket, 0, 4 * (1 + kGroups))); CHECK(hipMemset(bad, 0, 8)); CHECK(hipMemset(junk, 0, (8 << 20) * 4));
         std::vector<float> h(n);
         for (int64_t i = 0; i < n; ++i) h[i] = 1e-7f * (float)((i * 2654435761u) % 1000) / 1000.0f;
         CHECK(hipMemcpy(e, h.data(), n * 4, hipMemcpyHostToDevice));
@@ -162,9 +178,9 @@ int main() {
         CHECK(hipMemcpy(y0, h.data(), n * 4, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(y1, h.data(), n * 4, hipMemcpyHostToDevice));
         const unsigned gx = (unsigned)((n / 4 + kBlock - 1) / kBlock);
-        hipGraph_t g[4];
-        hipGraphExec_t ge[4];
-        for (int v = 0; v < 4; ++v) {
+        hipGraph_t g[5];
+        hipGraphExec_t ge[5];
+        for (int v = 0; v < 5; ++v) {
             CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
             hipLaunchKernelGGL(X, dim3(gx), dim3(kBlock), 0, s, y0, y1, o, n);
             if (v == SPLIT) {
@@ -174,15 +190,17 @@ int main() {
                 launch_pf<FENCE>(s, n_part, e, y0, o, n, part, ticket, out[v], -1, bad);
             } else if (v == WT) {
                 launch_pf<WT>(s, n_part, e, y0, o, n, part, ticket, out[v], -1, bad);
-            } else {
+            } else if (v == ATOM) {
                 launch_pf<ATOM>(s, n_part, e, y0, o, n, part, ticket, out[v], -1, bad);
+            } else {
+                launch_pf<HWT>(s, n_part, e, y0, o, n, part, ticket, out[v], -1, bad);
             }
             hipLaunchKernelGGL(X, dim3(gx), dim3(kBlock), 0, s, y0, o, y1, n);
             CHECK(hipStreamEndCapture(s, &g[v]));
             CHECK(hipGraphInstantiate(&ge[v], g[v], nullptr, nullptr, 0));
         }
-        double med[4], res[4];
-        for (int v = 0; v < 4; ++v) {
+        double med[5], res[5];
+        for (int v = 0; v < 5; ++v) {
             CHECK(hipMemcpy(y1, h.data(), n * 4, hipMemcpyHostToDevice));      // same evolution of y1 for every variant
             std::vector<double> runs;
             for (int rep = 0; rep < 6; ++rep) {
@@ -201,24 +219,27 @@ int main() {
             CHECK(hipMemcpy(&res[v], out[v], 8, hipMemcpyDeviceToHost));
         }
         // staleness: tagged partials, a different generation per launch, a streaming kernel on a second stream as load
-        unsigned long long stale[4] = {0, 0, 0, 0};
-        for (int v = 1; v < 4; ++v) {
+        unsigned long long stale[5] = {0, 0, 0, 0, 0};
+        for (int v = 1; v < 5; ++v) {
             CHECK(hipMemset(bad, 0, 8));
             for (long long gen = 0; gen < 2000; ++gen) {
                 if (gen % 3 == 0) hipLaunchKernelGGL(X, dim3(8192), dim3(kBlock), 0, s2, junk, junk, junk, (int64_t)(8 << 20));
                 if (v == FENCE) launch_pf<FENCE>(s, n_part, e, y0, o, n, part, ticket, out[v], gen, bad);
                 if (v == WT) launch_pf<WT>(s, n_part, e, y0, o, n, part, ticket, out[v], gen, bad);
                 if (v == ATOM) launch_pf<ATOM>(s, n_part, e, y0, o, n, part, ticket, out[v], gen, bad);
+                if (v == HWT) launch_pf<HWT>(s, n_part, e, y0, o, n, part, ticket, out[v], gen, bad);
             }
             CHECK(hipDeviceSynchronize());
             CHECK(hipMemcpy(&stale[v], bad, 8, hipMemcpyDeviceToHost));
         }
         printf(",\n \"%lld\": {\"split_P_then_F\": %.3f, \"fused_release_fence\": %.3f, \"fused_write_through\": %.3f, \"fused_atomics\": %.3f, "
-               "\"gain_write_through_us\": %.3f, \"sums_equal\": %s, \"stale_words\": {\"fence\": %llu, \"write_through\": %llu, \"atomics\": %llu}}",
-               (long long)n, med[0], med[1], med[2], med[3], med[0] - med[2],
-               (res[0] == res[1] && res[0] == res[2] && res[0] == res[3]) ? "true" : "false", stale[1], stale[2], stale[3]);
+               "\"fused_write_through_16_group_tickets\": %.3f, \"gain_write_through_us\": %.3f, \"gain_group_tickets_us\": %.3f, \"sums_equal\": %s, "
+               "\"stale_words\": {\"fence\": %llu, \"write_through\": %llu, \"atomics\": %llu, \"group_tickets\": %llu}}",
+               (long long)n, med[0], med[1], med[2], med[3], med[4], med[0] - med[2], med[0] - med[4],
+               (res[0] == res[1] && res[0] == res[2] && res[0] == res[3] && res[0] == res[4]) ? "true" : "false", stale[1], stale[2],
+               stale[3], stale[4]);
         hipFree(e); hipFree(y0); hipFree(y1); hipFree(o); hipFree(junk); hipFree(part); hipFree(ticket); hipFree(bad);
-        for (int v = 0; v < 4; ++v) hipFree(out[v]);
+        for (int v = 0; v < 5; ++v) hipFree(out[v]);
     }
     printf("\n}\n");
     return 0;
