@@ -106,12 +106,23 @@ def _tensors_in(value, _level=0, _seen=None):
         return []
     seen.add(id(value))
     if isinstance(value, torch.nn.Module):
-        out = list(value.parameters()) + list(value.buffers())
-        for m in value.modules():
+        # one pass over the module tree (registered parameters and buffers in registration order, then each module's own
+        # plain attributes) — `parameters()` + `buffers()` + `modules()` walk it three times with name bookkeeping, which was
+        # most of a solve's cache-key cost
+        out, rest, stack = [], [], [value]
+        while stack:
+            m = stack.pop()
+            if m is not value and id(m) in seen:
+                continue
             seen.add(id(m))
-            for name, v in list(m.__dict__.items()):
-                if name not in ("_parameters", "_buffers", "_modules"):
-                    out += _tensors_in(v, _level + 1, seen)
+            out += [p for p in m._parameters.values() if p is not None]
+            out += [b for b in m._buffers.values() if b is not None]
+            for name, v in m.__dict__.items():
+                if name not in _MODULE_INTERNALS and not isinstance(v, _PLAIN):
+                    rest.append(v)
+            stack += [c for c in reversed(list(m._modules.values())) if c is not None]
+        for v in rest:
+            out += _tensors_in(v, _level + 1, seen)
         return out
     if isinstance(value, (list, tuple, set, frozenset, collections.deque)):
         out = []
