@@ -576,7 +576,8 @@ class _GraphStep:
                 if isinstance(dst, torch.Tensor):
                     dst.copy_(src)
         t0_T, dt_T, t1_T = T(t0), T(dt), T(t0 + dt)
-        self.plan.ctrl_dev.copy_(torch.tensor([0.0, float(dt_T) * func.sign, t0, dt], dtype=torch.float64))
+        # (the four doubles travel in the kernel arguments of one launch: no pageable host-to-device copy per solve)
+        kern.fill_scalars(self.plan.ctrl_dev, [0.0, float(dt_T) * func.sign, t0, dt])
         times = [(t1_T, Perturb.PREV) if s._alpha_is_one[i] else (t0_T + s._alpha[i] * dt_T, Perturb.NONE)
                  for i in range(len(s._beta))]
         kern.fill_scalars(self.tbuf, [func.user_time(t, p) for t, p in times])
